@@ -1,0 +1,647 @@
+/*
+ * cosdata_oracle_hnsw.c — HNSW walk, finalisation and deterministic builder of the oracle.
+ * TEST INFRASTRUCTURE (see cosdata_oracle.h).  Behavioural spec: SURVEY.md Appendix A.
+ */
+#include "cosdata_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define IDX_NONE 0xFFFFFFFFu
+#define KEEP_SEARCH 100 /* vector_store.rs:1194 final_len (search) */
+#define KEEP_INDEX 64   /* vector_store.rs:1194 final_len (indexing) */
+
+typedef struct {
+    uint32_t n, cap, M;
+    uint32_t *node_id; /* internal id per node (COSO_ROOT_ID for the root) */
+    uint32_t *nbr;     /* [n][M] level-local node index, IDX_NONE = null slot */
+    float *nbr_sim;    /* [n][M] */
+    uint32_t *child;   /* [n] node index one level down (levels >= 1) */
+    uint8_t *low_idx;  /* prob_node.rs:108 lowest_index cache */
+    float *low_sim;
+    uint32_t root_idx;
+    int sorted; /* node_id ascending (imported) -> binary search allowed */
+} level_t;
+
+struct coso_index {
+    coso_params p;
+    uint32_t n;
+    const float *raw;
+    size_t cb;
+    uint8_t *codes; /* [n+1][cb] */
+    float *mags;    /* [n+1] */
+    float *root_raw;
+    level_t *lv; /* [num_layers+1] */
+    int has_root;
+};
+
+typedef struct {
+    int32_t key; /* metric-aware order key: larger = better */
+    uint32_t id;
+    uint32_t idx;
+    float sim;
+} hent;
+
+typedef struct {
+    hent *heap;
+    size_t heap_cap;
+    hent *res;
+    size_t res_cap;
+    uint64_t *visited;
+    size_t visited_words;
+    uint32_t *touched; /* EXACT mode: words dirtied by the previous walk (cleared lazily) */
+    size_t ntouched, touched_cap;
+    uint8_t *qcode;
+} scratch_t;
+
+static inline int32_t total_key(float v) {
+    int32_t b;
+    memcpy(&b, &v, 4);
+    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+    return b;
+}
+static inline int32_t order_key(int metric, float v) {
+    int32_t k = total_key(v);
+    return (metric == COSO_METRIC_EUCLIDEAN || metric == COSO_METRIC_HAMMING) ? ~k : k;
+}
+/* strict "a is greater than b": similarity first, then LARGER internal id (documented tie-break) */
+static inline int hent_gt(const hent *a, const hent *b) {
+    return a->key > b->key || (a->key == b->key && a->id > b->id);
+}
+
+static inline uint32_t row_of(const coso_index *ix, uint32_t id) { return id == COSO_ROOT_ID ? ix->n : id; }
+static inline uint32_t level_M(const coso_index *ix, uint32_t level) {
+    return level == 0 ? ix->p.level0_neighbors_count : ix->p.neighbors_count;
+}
+static inline float metric_min(int metric) { return metric == COSO_METRIC_COSINE ? -1.0f : -INFINITY; } /* types.rs:435-446 */
+static inline float metric_max(int metric) { return metric == COSO_METRIC_COSINE ? 2.0f : INFINITY; }   /* types.rs:448-457 */
+
+/* ------------------------------------------------------------------------------------------ */
+coso_index *coso_index_create(const coso_params *p) {
+    if (!p || p->dim == 0) return NULL;
+    uint32_t M = p->neighbors_count, M0 = p->level0_neighbors_count;
+    if (M == 0 || M0 == 0 || (M & (M - 1)) || (M0 & (M0 - 1))) return NULL; /* fixedset.rs needs a power of two */
+    if (M > 256 || M0 > 256) return NULL;                                     /* lowest_index is a u8 */
+    coso_index *ix = (coso_index *)calloc(1, sizeof(*ix));
+    ix->p = *p;
+    ix->cb = coso_code_bytes((int)p->storage, (int)p->resolution, (int)p->dim);
+    if (ix->cb == 0) { free(ix); return NULL; }
+    ix->lv = (level_t *)calloc(p->num_layers + 1, sizeof(level_t));
+    for (uint32_t l = 0; l <= p->num_layers; l++) { ix->lv[l].M = level_M(ix, l); ix->lv[l].root_idx = IDX_NONE; }
+    ix->root_raw = (float *)calloc(p->dim, sizeof(float));
+    return ix;
+}
+
+static void level_free(level_t *L) {
+    free(L->node_id); free(L->nbr); free(L->nbr_sim); free(L->child); free(L->low_idx); free(L->low_sim);
+    uint32_t M = L->M;
+    memset(L, 0, sizeof(*L));
+    L->M = M;
+    L->root_idx = IDX_NONE;
+}
+void coso_index_destroy(coso_index *ix) {
+    if (!ix) return;
+    for (uint32_t l = 0; l <= ix->p.num_layers; l++) level_free(&ix->lv[l]);
+    free(ix->lv); free(ix->codes); free(ix->mags); free(ix->root_raw); free(ix);
+}
+
+int coso_index_set_vectors(coso_index *ix, const float *raw, uint32_t n) {
+    if (!ix || (!raw && n)) return COSO_ERR_INVALID;
+    free(ix->codes); free(ix->mags);
+    ix->n = n;
+    ix->raw = raw;
+    ix->codes = (uint8_t *)calloc((size_t)n + 1, ix->cb);
+    ix->mags = (float *)calloc((size_t)n + 1, sizeof(float));
+    int rc = COSO_OK;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        int r = coso_quantize(raw + (size_t)i * ix->p.dim, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution,
+                              ix->p.range_lo, ix->p.range_hi, ix->codes + (size_t)i * ix->cb, &ix->mags[i]);
+        if (r != COSO_OK) rc = r;
+    }
+    if (ix->has_root) /* re-quantize the root into its row */
+        coso_quantize(ix->root_raw, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo,
+                      ix->p.range_hi, ix->codes + (size_t)n * ix->cb, &ix->mags[n]);
+    return rc;
+}
+
+const float *coso_index_root_raw(const coso_index *ix) { return ix->root_raw; }
+int coso_index_set_root_raw(coso_index *ix, const float *root) {
+    if (!ix->codes) return COSO_ERR_INVALID;
+    memcpy(ix->root_raw, root, (size_t)ix->p.dim * 4);
+    ix->has_root = 1;
+    return coso_quantize(ix->root_raw, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo,
+                         ix->p.range_hi, ix->codes + (size_t)ix->n * ix->cb, &ix->mags[ix->n]);
+}
+const void *coso_index_codes(const coso_index *ix) { return ix->codes; }
+const float *coso_index_mags(const coso_index *ix) { return ix->mags; }
+void coso_index_set_ef_search(coso_index *ix, uint32_t ef) { ix->p.ef_search = ef; }
+void coso_index_set_visited_mode(coso_index *ix, uint32_t mode) { ix->p.visited_mode = mode; }
+uint32_t coso_index_level_count(const coso_index *ix, uint32_t level) { return level <= ix->p.num_layers ? ix->lv[level].n : 0; }
+
+/* ------------------------------------------------------------------------------------------
+ * scratch
+ * ---------------------------------------------------------------------------------------- */
+static scratch_t *scratch_new(const coso_index *ix) {
+    scratch_t *s = (scratch_t *)calloc(1, sizeof(*s));
+    s->heap_cap = 8192;
+    s->heap = (hent *)malloc(s->heap_cap * sizeof(hent));
+    s->res_cap = 1024;
+    s->res = (hent *)malloc(s->res_cap * sizeof(hent));
+    uint32_t Mmax = ix->p.level0_neighbors_count > ix->p.neighbors_count ? ix->p.level0_neighbors_count : ix->p.neighbors_count;
+    s->visited_words = ix->p.visited_mode == COSO_VISITED_EXACT ? ((size_t)ix->n + 64) / 64 + 1 : Mmax;
+    if (s->visited_words < Mmax) s->visited_words = Mmax;
+    s->visited = (uint64_t *)calloc(s->visited_words, 8);
+    s->touched_cap = 4096;
+    s->touched = (uint32_t *)malloc(s->touched_cap * 4);
+    s->qcode = (uint8_t *)malloc(ix->cb);
+    return s;
+}
+static void scratch_free(scratch_t *s) {
+    if (!s) return;
+    free(s->heap); free(s->res); free(s->visited); free(s->touched); free(s->qcode); free(s);
+}
+
+static inline void heap_push(scratch_t *s, size_t *n, hent e) {
+    if (*n == s->heap_cap) { s->heap_cap *= 2; s->heap = (hent *)realloc(s->heap, s->heap_cap * sizeof(hent)); }
+    size_t i = (*n)++;
+    hent *h = s->heap;
+    while (i > 0) {
+        size_t p = (i - 1) / 2;
+        if (!hent_gt(&e, &h[p])) break;
+        h[i] = h[p];
+        i = p;
+    }
+    h[i] = e;
+}
+static inline hent heap_pop(scratch_t *s, size_t *n) {
+    hent *h = s->heap;
+    hent top = h[0];
+    hent last = h[--(*n)];
+    size_t i = 0, cnt = *n;
+    for (;;) {
+        size_t c = 2 * i + 1;
+        if (c >= cnt) break;
+        if (c + 1 < cnt && hent_gt(&h[c + 1], &h[c])) c++;
+        if (!hent_gt(&h[c], &last)) break;
+        h[i] = h[c];
+        i = c;
+    }
+    if (cnt) h[i] = last;
+    return top;
+}
+static int cmp_hent_desc(const void *a, const void *b) {
+    const hent *x = (const hent *)a, *y = (const hent *)b;
+    return hent_gt(x, y) ? -1 : (hent_gt(y, x) ? 1 : 0);
+}
+
+/* visited filter: REF = PerformantFixedSet::new(M_level) (vector_store.rs:266-270), EXACT = bitset over rows */
+static inline int visited_test(const coso_index *ix, const scratch_t *s, uint32_t M, uint32_t id) {
+    if (ix->p.visited_mode == COSO_VISITED_EXACT) {
+        if (id == COSO_QUERY_ID) return 0;
+        uint32_t r = row_of(ix, id);
+        return (int)((s->visited[r >> 6] >> (r & 63)) & 1ull);
+    }
+    return (int)((s->visited[(id >> 6) & (M - 1)] >> (id & 63)) & 1ull);
+}
+static inline void visited_set(const coso_index *ix, scratch_t *s, uint32_t M, uint32_t id) {
+    if (ix->p.visited_mode == COSO_VISITED_EXACT) {
+        if (id == COSO_QUERY_ID) return;
+        uint32_t r = row_of(ix, id);
+        if (s->visited[r >> 6] == 0) {
+            if (s->ntouched == s->touched_cap) { s->touched_cap *= 2; s->touched = (uint32_t *)realloc(s->touched, s->touched_cap * 4); }
+            s->touched[s->ntouched++] = r >> 6;
+        }
+        s->visited[r >> 6] |= 1ull << (r & 63);
+        return;
+    }
+    s->visited[(id >> 6) & (M - 1)] |= 1ull << (id & 63);
+}
+
+static inline int node_distance(const coso_index *ix, const uint8_t *qcode, float qmag, uint32_t row, float *out) {
+    return coso_distance((int)ix->p.metric, (int)ix->p.storage, (int)ix->p.resolution, (int)ix->p.dim, qcode, qmag,
+                         ix->codes + (size_t)row * ix->cb, ix->mags[row], out);
+}
+
+/* traverse_find_nearest (vector_store.rs:1112-1204) on one level.
+ * self_id: id pre-inserted in the visited filter (query id :271, or the new node's id :807).
+ * Returns number of results in s->res (sorted desc), or a negative status. */
+static int walk_level(const coso_index *ix, uint32_t level, uint32_t entry_idx, const uint8_t *qcode, float qmag,
+                      uint32_t self_id, uint32_t ef, uint32_t keep, scratch_t *s, coso_stats *st) {
+    const level_t *L = &ix->lv[level];
+    const uint32_t M = L->M;
+    const int metric = (int)ix->p.metric;
+    uint32_t slots = M < ix->p.shortlist_size ? M : ix->p.shortlist_size; /* .take(shortlist_size) :1164 */
+    if (ix->p.visited_mode == COSO_VISITED_EXACT) {
+        for (size_t t = 0; t < s->ntouched; t++) s->visited[s->touched[t]] = 0;
+        s->ntouched = 0;
+    } else memset(s->visited, 0, (size_t)M * 8);
+    visited_set(ix, s, M, self_id);
+
+    size_t hn = 0, rn = 0;
+    float d0;
+    int rc = node_distance(ix, qcode, qmag, row_of(ix, L->node_id[entry_idx]), &d0);
+    if (st) st->evals++;
+    if (rc != COSO_OK) return -rc;
+    visited_set(ix, s, M, L->node_id[entry_idx]);
+    hent e0 = {order_key(metric, d0), L->node_id[entry_idx], entry_idx, d0};
+    heap_push(s, &hn, e0);
+
+    uint32_t nodes_visited = 0;
+    while (hn > 0) {
+        hent cur = heap_pop(s, &hn);
+        if (nodes_visited >= ef) break; /* the popped element is discarded */
+        nodes_visited++;
+        if (rn == s->res_cap) { s->res_cap *= 2; s->res = (hent *)realloc(s->res, s->res_cap * sizeof(hent)); }
+        s->res[rn++] = cur;
+        if (st) { st->expansions++; st->adj_bytes += (uint64_t)M * 4; }
+        const uint32_t *nb = L->nbr + (size_t)cur.idx * M;
+        for (uint32_t j = 0; j < slots; j++) {
+            uint32_t nidx = nb[j];
+            if (nidx == IDX_NONE) continue;
+            uint32_t nid = L->node_id[nidx];
+            if (visited_test(ix, s, M, nid)) continue;
+            float d;
+            rc = node_distance(ix, qcode, qmag, row_of(ix, nid), &d);
+            if (st) st->evals++;
+            if (rc != COSO_OK) return -rc;
+            visited_set(ix, s, M, nid);
+            hent e = {order_key(metric, d), nid, nidx, d};
+            heap_push(s, &hn, e);
+        }
+    }
+    qsort(s->res, rn, sizeof(hent), cmp_hent_desc); /* select_nth + truncate + sort desc :1194-1201 */
+    if (rn > keep) rn = keep;
+    return (int)rn;
+}
+
+/* ann_search (vector_store.rs:256-402): every level runs the full ef-bounded walk; results of all
+ * levels are concatenated top level first. out must hold (num_layers+1)*KEEP_SEARCH entries. */
+static int ann_search_internal(const coso_index *ix, const uint8_t *qcode, float qmag, scratch_t *s, hent *out,
+                               uint32_t *level_counts, coso_stats *st) {
+    const uint32_t Ltop = ix->p.num_layers;
+    uint32_t entry = ix->lv[Ltop].root_idx;
+    if (entry == IDX_NONE) return -COSO_ERR_INVALID;
+    int total = 0;
+    for (int level = (int)Ltop; level >= 0; level--) {
+        int cnt = walk_level(ix, (uint32_t)level, entry, qcode, qmag, COSO_QUERY_ID, ix->p.ef_search, KEEP_SEARCH, s, st);
+        if (cnt < 0) return cnt;
+        if (cnt == 0) { /* vector_store.rs:329-380 fallback: the entry node's own distance */
+            const level_t *L = &ix->lv[level];
+            float d;
+            int rc = node_distance(ix, qcode, qmag, row_of(ix, L->node_id[entry]), &d);
+            if (rc != COSO_OK) return -rc;
+            hent e = {order_key((int)ix->p.metric, d), L->node_id[entry], entry, d};
+            s->res[0] = e;
+            cnt = 1;
+        }
+        memcpy(out + total, s->res, (size_t)cnt * sizeof(hent));
+        if (level_counts) level_counts[Ltop - (uint32_t)level] = (uint32_t)cnt;
+        total += cnt;
+        if (level > 0) entry = ix->lv[level].child[s->res[0].idx];
+    }
+    return total;
+}
+
+int coso_ann_search(const coso_index *ix, const float *query, uint32_t *out_ids, float *out_sims, uint32_t *level_counts) {
+    scratch_t *s = scratch_new(ix);
+    float qmag;
+    int rc = coso_quantize(query, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo, ix->p.range_hi,
+                           s->qcode, &qmag);
+    if (rc != COSO_OK) { scratch_free(s); return -rc; }
+    hent *all = (hent *)malloc((size_t)(ix->p.num_layers + 1) * KEEP_SEARCH * sizeof(hent));
+    int total = ann_search_internal(ix, s->qcode, qmag, s, all, level_counts, NULL);
+    for (int i = 0; i < total; i++) { out_ids[i] = all[i].id; out_sims[i] = all[i].sim; }
+    free(all);
+    scratch_free(s);
+    return total;
+}
+
+typedef struct { float cs; uint32_t id; } fent;
+static int cmp_fent_desc(const void *a, const void *b) {
+    const fent *x = (const fent *)a, *y = (const fent *)b;
+    int32_t kx = total_key(x->cs), ky = total_key(y->cs);
+    if (kx != ky) return kx > ky ? -1 : 1;
+    return x->id > y->id ? -1 : (x->id < y->id ? 1 : 0);
+}
+
+/* search_internal (indexes/hnsw/mod.rs:390-440) for one query */
+static int search_one(const coso_index *ix, const float *q, uint32_t top_k, scratch_t *s, hent *all, fent *f, uint32_t *out_ids,
+                      float *out_scores, uint32_t *out_count, coso_stats *st) {
+    float qmag;
+    int rc = coso_quantize(q, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo, ix->p.range_hi,
+                           s->qcode, &qmag);
+    if (rc != COSO_OK) return rc;
+    int total = ann_search_internal(ix, s->qcode, qmag, s, all, NULL, st);
+    if (total < 0) return -total;
+    /* remove_duplicates_and_filter (common.rs:381-412): first-seen dedup, drop root, sort desc, keep 5k */
+    int m = 0;
+    for (int i = 0; i < total; i++) {
+        int dup = 0;
+        for (int j = 0; j < m; j++)
+            if (all[j].id == all[i].id) { dup = 1; break; }
+        if (dup) continue;
+        all[m++] = all[i];
+    }
+    int w = 0;
+    for (int i = 0; i < m; i++)
+        if (all[i].id != COSO_ROOT_ID) all[w++] = all[i];
+    m = w;
+    qsort(all, (size_t)m, sizeof(hent), cmp_hent_desc);
+    if ((uint32_t)m > 5 * top_k) m = (int)(5 * top_k);
+    /* finalize_ann_results (vector_store.rs:404-445): exact cosine on RAW f32, norm recomputed per candidate */
+    const int d = (int)ix->p.dim;
+    float mag_query = coso_seq_norm_f32(q, d);
+    for (int i = 0; i < m; i++) {
+        uint32_t id = all[i].id;
+        const float *rv = ix->raw + (size_t)id * d;
+        float dp = coso_dot_f32(q, rv, d);
+        float mag_raw = coso_seq_norm_f32(rv, d);
+        float cs = dp / (mag_query * mag_raw);
+        fent t = {cs, id};
+        f[i] = t;
+    }
+    qsort(f, (size_t)m, sizeof(fent), cmp_fent_desc);
+    if ((uint32_t)m > top_k) m = (int)top_k;
+    for (int i = 0; i < m; i++) { out_ids[i] = f[i].id; out_scores[i] = f[i].cs; }
+    *out_count = (uint32_t)m;
+    return COSO_OK;
+}
+
+int coso_search_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                      float *out_scores, uint32_t *out_counts, int32_t *out_status, coso_stats *stats, int threads) {
+    if (!ix || !ix->raw || top_k == 0) return COSO_ERR_INVALID;
+    int first_err = COSO_OK;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        scratch_t *s = scratch_new(ix);
+        hent *all = (hent *)malloc((size_t)(ix->p.num_layers + 1) * KEEP_SEARCH * sizeof(hent));
+        fent *fbuf = (fent *)malloc((size_t)(ix->p.num_layers + 1) * KEEP_SEARCH * sizeof(fent));
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            coso_stats st = {0, 0, 0};
+            uint32_t cnt = 0;
+            int rc = search_one(ix, queries + (size_t)b * ix->p.dim, top_k, s, all, fbuf, out_ids + (size_t)b * top_k,
+                                out_scores + (size_t)b * top_k, &cnt, &st);
+            out_counts[b] = rc == COSO_OK ? cnt : 0;
+            if (out_status) out_status[b] = rc;
+            if (stats) stats[b] = st;
+            if (rc != COSO_OK) {
+#pragma omp critical
+                if (first_err == COSO_OK) first_err = rc;
+            }
+        }
+        free(all);
+        free(fbuf);
+        scratch_free(s);
+    }
+    return first_err;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * deterministic builder (vector_store.rs:714-1109, prob_node.rs:210-329)
+ * ---------------------------------------------------------------------------------------- */
+static uint64_t splitmix64(uint64_t *st) {
+    uint64_t z = (*st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static float rand_f32(uint64_t *st) { return (float)(splitmix64(st) >> 40) * (1.0f / 16777216.0f); } /* 24-bit U[0,1) like rand::random::<f32>() */
+
+static uint32_t level_append(level_t *L, uint32_t id, int metric) {
+    if (L->n == L->cap) {
+        uint32_t nc = L->cap ? L->cap * 2 : 1024;
+        L->node_id = (uint32_t *)realloc(L->node_id, (size_t)nc * 4);
+        L->nbr = (uint32_t *)realloc(L->nbr, (size_t)nc * L->M * 4);
+        L->nbr_sim = (float *)realloc(L->nbr_sim, (size_t)nc * L->M * 4);
+        L->child = (uint32_t *)realloc(L->child, (size_t)nc * 4);
+        L->low_idx = (uint8_t *)realloc(L->low_idx, nc);
+        L->low_sim = (float *)realloc(L->low_sim, (size_t)nc * 4);
+        L->cap = nc;
+    }
+    uint32_t i = L->n++;
+    L->node_id[i] = id;
+    for (uint32_t j = 0; j < L->M; j++) { L->nbr[(size_t)i * L->M + j] = IDX_NONE; L->nbr_sim[(size_t)i * L->M + j] = 0.0f; }
+    L->child[i] = IDX_NONE;
+    L->low_idx[i] = 0;                    /* prob_node.rs:140 */
+    L->low_sim[i] = metric_min(metric);
+    return i;
+}
+
+static void remove_neighbor_by_idx(level_t *L, uint32_t node, uint32_t target) { /* remove_neighbor_by_id :285-306 */
+    uint32_t *nb = L->nbr + (size_t)node * L->M;
+    for (uint32_t j = 0; j < L->M; j++)
+        if (nb[j] == target) { nb[j] = IDX_NONE; return; }
+}
+
+/* ProbNode::add_neighbor (prob_node.rs:210-283). Returns slot index or -1. */
+static int add_neighbor(level_t *L, int metric, uint32_t self, uint32_t nbr, float dist) {
+    const uint32_t M = L->M;
+    uint32_t lowest_idx = L->low_idx[self];
+    float lowest_sim = L->low_sim[self];
+    if (coso_metric_cmp(metric, dist, lowest_sim) <= 0) return -1;
+    uint32_t *nb = L->nbr + (size_t)self * M;
+    float *ns = L->nbr_sim + (size_t)self * M;
+    int ok = (nb[lowest_idx] == IDX_NONE) || coso_metric_cmp(metric, dist, ns[lowest_idx]) > 0;
+    uint32_t old = IDX_NONE;
+    if (ok) { old = nb[lowest_idx]; nb[lowest_idx] = nbr; ns[lowest_idx] = dist; }
+    uint32_t nl = 0;
+    float nsim = metric_max(metric);
+    for (uint32_t j = 0; j < M; j++) {
+        if (nb[j] == IDX_NONE) { nsim = metric_min(metric); nl = j; break; }
+        if (coso_metric_cmp(metric, ns[j], nsim) < 0) { nsim = ns[j]; nl = j; }
+    }
+    L->low_idx[self] = (uint8_t)nl;
+    L->low_sim[self] = nsim;
+    if (!ok) return -1;
+    if (old != IDX_NONE) remove_neighbor_by_idx(L, old, self); /* evictee drops its back edge; its cache is NOT refreshed */
+    return (int)lowest_idx;
+}
+
+typedef struct { uint32_t idx; float sim; } zent;
+
+static void create_node_edges(coso_index *ix, uint32_t level, uint32_t node, const zent *z, int zn) { /* :976-1074 */
+    level_t *L = &ix->lv[level];
+    const int metric = (int)ix->p.metric;
+    uint32_t succ = 0;
+    for (int i = 0; i < zn; i++) {
+        if (succ >= L->M) break;
+        int r = add_neighbor(L, metric, node, z[i].idx, z[i].sim);
+        if (r >= 0) {
+            int r2 = add_neighbor(L, metric, z[i].idx, node, z[i].sim);
+            if (r2 >= 0) succ++;
+            else if (L->nbr[(size_t)node * L->M + (uint32_t)r] == z[i].idx) L->nbr[(size_t)node * L->M + (uint32_t)r] = IDX_NONE; /* remove_neighbor_by_index_and_id */
+        }
+    }
+}
+
+static int index_embedding(coso_index *ix, uint32_t id, uint32_t parent_idx, uint32_t entry_idx, int level, int max_level,
+                           scratch_t *s) { /* :782-937 */
+    const uint32_t row = row_of(ix, id);
+    const uint8_t *code = ix->codes + (size_t)row * ix->cb;
+    int zn = walk_level(ix, (uint32_t)level, entry_idx, code, ix->mags[row], id, ix->p.ef_construction, KEEP_INDEX, s, NULL);
+    if (zn < 0) return -zn;
+    zent z[KEEP_INDEX];
+    if (zn == 0) {
+        float d;
+        int rc = node_distance(ix, code, ix->mags[row], row_of(ix, ix->lv[level].node_id[entry_idx]), &d);
+        if (rc != COSO_OK) return rc;
+        z[0].idx = entry_idx; z[0].sim = d; zn = 1;
+    } else {
+        for (int i = 0; i < zn; i++) { z[i].idx = s->res[i].idx; z[i].sim = s->res[i].sim; }
+    }
+    uint32_t child = level > 0 ? ix->lv[level].child[z[0].idx] : IDX_NONE;
+    if (level > max_level) {
+        if (level != 0) return index_embedding(ix, id, IDX_NONE, child, level - 1, max_level, s);
+        return COSO_OK;
+    }
+    uint32_t me = level_append(&ix->lv[level], id, (int)ix->p.metric);
+    if (parent_idx != IDX_NONE) ix->lv[level + 1].child[parent_idx] = me;
+    if (level != 0) {
+        int rc = index_embedding(ix, id, me, child, level - 1, max_level, s);
+        if (rc != COSO_OK) return rc;
+    }
+    create_node_edges(ix, (uint32_t)level, me, z, zn);
+    return COSO_OK;
+}
+
+int coso_index_build(coso_index *ix) {
+    if (!ix || !ix->codes) return COSO_ERR_INVALID;
+    const uint32_t Ltop = ix->p.num_layers;
+    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
+    for (uint32_t l = 0; l <= Ltop; l++) level_free(&ix->lv[l]);
+    /* create_root_node (vector_store.rs:44-150): random vector in values_range, id u32::MAX, one node per level */
+    for (uint32_t i = 0; i < ix->p.dim; i++) ix->root_raw[i] = ix->p.range_lo + rand_f32(&rng) * (ix->p.range_hi - ix->p.range_lo);
+    int rc = coso_index_set_root_raw(ix, ix->root_raw);
+    if (rc != COSO_OK) return rc;
+    for (uint32_t l = 0; l <= Ltop; l++) {
+        uint32_t r = level_append(&ix->lv[l], COSO_ROOT_ID, (int)ix->p.metric);
+        ix->lv[l].root_idx = r;
+        if (l > 0) ix->lv[l].child[r] = ix->lv[l - 1].root_idx;
+    }
+    double *pv = (double *)malloc((Ltop + 1) * sizeof(double));
+    uint8_t *pl = (uint8_t *)malloc(Ltop + 1);
+    coso_level_probs(4.0, (int)Ltop, pv, pl); /* api_service.rs:109 */
+    scratch_t *s = scratch_new(ix);
+    for (uint32_t id = 0; id < ix->n && rc == COSO_OK; id++) {
+        double x = (double)rand_f32(&rng);
+        int max_level = coso_max_insert_level(x, pv, pl, (int)Ltop + 1);
+        rc = index_embedding(ix, id, IDX_NONE, ix->lv[Ltop].root_idx, (int)Ltop, max_level, s);
+    }
+    scratch_free(s);
+    free(pv); free(pl);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * flat export / import: node ids ascending with the root (u32::MAX) last; neighbour slots as
+ * internal ids, COSO_SLOT_EMPTY for null pointers.  Slot order is preserved.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint32_t id, idx; } idpair;
+static int cmp_idpair(const void *a, const void *b) {
+    uint32_t x = ((const idpair *)a)->id, y = ((const idpair *)b)->id;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+int coso_index_export_level(const coso_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids, float *nbr_sims) {
+    if (level > ix->p.num_layers) return COSO_ERR_INVALID;
+    const level_t *L = &ix->lv[level];
+    idpair *ord = (idpair *)malloc((size_t)L->n * sizeof(idpair));
+    for (uint32_t i = 0; i < L->n; i++) { ord[i].id = L->node_id[i]; ord[i].idx = i; }
+    qsort(ord, L->n, sizeof(idpair), cmp_idpair);
+    for (uint32_t k = 0; k < L->n; k++) {
+        uint32_t i = ord[k].idx;
+        node_ids[k] = L->node_id[i];
+        for (uint32_t j = 0; j < L->M; j++) {
+            uint32_t nb = L->nbr[(size_t)i * L->M + j];
+            nbr_ids[(size_t)k * L->M + j] = nb == IDX_NONE ? COSO_SLOT_EMPTY : L->node_id[nb];
+            if (nbr_sims) nbr_sims[(size_t)k * L->M + j] = nb == IDX_NONE ? 0.0f : L->nbr_sim[(size_t)i * L->M + j];
+        }
+    }
+    free(ord);
+    return COSO_OK;
+}
+
+static uint32_t find_sorted(const uint32_t *ids, uint32_t n, uint32_t id) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (ids[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && ids[lo] == id) ? lo : IDX_NONE;
+}
+static int resolve_children(coso_index *ix, uint32_t level) {
+    if (level == 0 || level > ix->p.num_layers) return COSO_OK;
+    level_t *L = &ix->lv[level], *D = &ix->lv[level - 1];
+    if (!L->n || !D->n || !L->sorted || !D->sorted) return COSO_OK;
+    for (uint32_t i = 0; i < L->n; i++) {
+        uint32_t c = find_sorted(D->node_id, D->n, L->node_id[i]);
+        if (c == IDX_NONE) return COSO_ERR_INVALID; /* every node exists on all lower levels */
+        L->child[i] = c;
+    }
+    return COSO_OK;
+}
+int coso_index_import_level(coso_index *ix, uint32_t level, uint32_t n_nodes, const uint32_t *node_ids, const uint32_t *nbr_ids) {
+    if (level > ix->p.num_layers || n_nodes == 0) return COSO_ERR_INVALID;
+    level_t *L = &ix->lv[level];
+    level_free(L);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (i && node_ids[i] <= node_ids[i - 1]) return COSO_ERR_INVALID;
+        level_append(L, node_ids[i], (int)ix->p.metric);
+    }
+    L->sorted = 1;
+    if (node_ids[n_nodes - 1] != COSO_ROOT_ID) return COSO_ERR_INVALID;
+    L->root_idx = n_nodes - 1;
+    for (uint32_t i = 0; i < n_nodes; i++)
+        for (uint32_t j = 0; j < L->M; j++) {
+            uint32_t nid = nbr_ids[(size_t)i * L->M + j];
+            if (nid == COSO_SLOT_EMPTY) continue;
+            uint32_t k = find_sorted(L->node_id, L->n, nid);
+            if (k == IDX_NONE) return COSO_ERR_INVALID;
+            L->nbr[(size_t)i * L->M + j] = k;
+        }
+    int rc = resolve_children(ix, level);
+    if (rc == COSO_OK) rc = resolve_children(ix, level + 1);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * exact brute force (ground truth for recall): same formula and arithmetic order as the rerank
+ * ---------------------------------------------------------------------------------------- */
+int coso_bruteforce_topk(const float *raw, uint32_t n, uint32_t dim, const float *queries, uint32_t B, uint32_t k,
+                         uint32_t *out_ids, float *out_scores, int threads) {
+    if (k == 0 || k > n) return COSO_ERR_INVALID;
+    if (threads < 1) threads = 1;
+    float *mags = (float *)malloc((size_t)n * sizeof(float));
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)n; i++) mags[i] = coso_seq_norm_f32(raw + (size_t)i * dim, (int)dim);
+#pragma omp parallel num_threads(threads)
+    {
+        fent *top = (fent *)malloc((size_t)(k + 1) * sizeof(fent));
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            const float *q = queries + (size_t)b * dim;
+            float mq = coso_seq_norm_f32(q, (int)dim);
+            uint32_t cnt = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                float dp = coso_dot_f32(q, raw + (size_t)i * dim, (int)dim);
+                fent e = {dp / (mq * mags[i]), i};
+                if (cnt == k && cmp_fent_desc(&e, &top[k - 1]) >= 0) continue;
+                uint32_t pos = cnt < k ? cnt : k - 1; /* insertion into a sorted (desc) list */
+                while (pos > 0 && cmp_fent_desc(&e, &top[pos - 1]) < 0) { top[pos] = top[pos - 1]; pos--; }
+                top[pos] = e;
+                if (cnt < k) cnt++;
+            }
+            for (uint32_t i = 0; i < k; i++) { out_ids[(size_t)b * k + i] = top[i].id; out_scores[(size_t)b * k + i] = top[i].cs; }
+        }
+        free(top);
+    }
+    free(mags);
+    return COSO_OK;
+}

@@ -1,0 +1,385 @@
+"""ctypes binding of the CPU oracle (oracle/libcosdata_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — see oracle/cosdata_oracle.h.  Importable from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never from cosdata_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcosdata_oracle.so")
+
+METRIC_COSINE, METRIC_EUCLIDEAN, METRIC_HAMMING, METRIC_DOT = 0, 1, 2, 3
+STORAGE_U8, STORAGE_SUBBYTE, STORAGE_F16, STORAGE_F32 = 0, 1, 2, 3
+OK, ERR_STORAGE_MISMATCH, ERR_CALCULATION, ERR_INVALID, ERR_UNIMPLEMENTED = 0, 1, 2, 3, 4
+ROOT_ID, QUERY_ID, SLOT_EMPTY = 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFFFD
+VISITED_REF, VISITED_EXACT = 0, 1
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("dim", C.c_uint32), ("metric", C.c_uint32), ("storage", C.c_uint32), ("resolution", C.c_uint32),
+        ("range_lo", C.c_float), ("range_hi", C.c_float), ("num_layers", C.c_uint32),
+        ("neighbors_count", C.c_uint32), ("level0_neighbors_count", C.c_uint32),
+        ("ef_construction", C.c_uint32), ("ef_search", C.c_uint32), ("shortlist_size", C.c_uint32),
+        ("visited_mode", C.c_uint32), ("seed", C.c_uint64),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("evals", C.c_uint64), ("expansions", C.c_uint64), ("adj_bytes", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    P = C.POINTER
+    vp, f32p, u32p, u8p, u64p = C.c_void_p, P(C.c_float), P(C.c_uint32), P(C.c_uint8), P(C.c_uint64)
+    sig = {
+        "coso_code_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+        "coso_quantize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, f32p]),
+        "coso_dot_u8": (C.c_uint64, [vp, vp, C.c_int]),
+        "coso_dot_u8_scalar": (C.c_uint64, [vp, vp, C.c_int]),
+        "coso_dot_f32": (C.c_float, [vp, vp, C.c_int]),
+        "coso_dot_f32_scalar_order": (C.c_float, [vp, vp, C.c_int]),
+        "coso_dot_f16": (C.c_float, [vp, vp, C.c_int]),
+        "coso_dot_subbyte": (C.c_float, [vp, vp, C.c_int, C.c_int, P(C.c_int)]),
+        "coso_dot_quaternary_scalar": (C.c_float, [vp, vp, C.c_int]),
+        "coso_count_ones": (C.c_uint64, [vp, C.c_int]),
+        "coso_seq_norm_f32": (C.c_float, [vp, C.c_int]),
+        "coso_f32_to_f16": (C.c_uint16, [C.c_float]),
+        "coso_f16_to_f32": (C.c_float, [C.c_uint16]),
+        "coso_distance": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, C.c_float, f32p]),
+        "coso_metric_cmp": (C.c_int, [C.c_int, C.c_float, C.c_float]),
+        "coso_level_probs": (None, [C.c_double, C.c_int, P(C.c_double), u8p]),
+        "coso_max_insert_level": (C.c_int, [C.c_double, P(C.c_double), u8p, C.c_int]),
+        "coso_index_create": (vp, [P(Params)]),
+        "coso_index_destroy": (None, [vp]),
+        "coso_index_set_vectors": (C.c_int, [vp, vp, C.c_uint32]),
+        "coso_index_build": (C.c_int, [vp]),
+        "coso_index_level_count": (C.c_uint32, [vp, C.c_uint32]),
+        "coso_index_export_level": (C.c_int, [vp, C.c_uint32, vp, vp, vp]),
+        "coso_index_import_level": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
+        "coso_index_root_raw": (f32p, [vp]),
+        "coso_index_set_root_raw": (C.c_int, [vp, vp]),
+        "coso_index_codes": (vp, [vp]),
+        "coso_index_mags": (f32p, [vp]),
+        "coso_index_set_ef_search": (None, [vp, C.c_uint32]),
+        "coso_index_set_visited_mode": (None, [vp, C.c_uint32]),
+        "coso_search_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_int]),
+        "coso_ann_search": (C.c_int, [vp, vp, vp, vp, vp]),
+        "coso_bruteforce_topk": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
+        "coso_bm25_idf": (C.c_float, [C.c_uint32, C.c_uint32]),
+        "coso_bm25_tf": (C.c_float, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float]),
+        "coso_bm25_search": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]),
+        "coso_rrf_fuse": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, C.c_float, C.c_uint32, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ------------------------------------------------------------------------------------------------
+# numeric kernels
+# ------------------------------------------------------------------------------------------------
+def code_bytes(storage, resolution, dim):
+    return lib().coso_code_bytes(storage, resolution, dim)
+
+
+def quantize(x, storage, resolution=0, lo=-1.0, hi=1.0):
+    """ScalarQuantization::quantize for one vector -> (code bytes as uint8 array, mag)."""
+    x = _c(x, np.float32)
+    code = np.zeros(code_bytes(storage, resolution, x.size), np.uint8)
+    mag = C.c_float()
+    rc = lib().coso_quantize(_p(x), x.size, storage, resolution, lo, hi, _p(code), C.byref(mag))
+    if rc != OK:
+        raise ValueError(f"coso_quantize status {rc}")
+    return code, np.float32(mag.value)
+
+
+def quantize_batch(X, storage, resolution=0, lo=-1.0, hi=1.0):
+    X = _c(X, np.float32)
+    n, d = X.shape
+    codes = np.zeros((n, code_bytes(storage, resolution, d)), np.uint8)
+    mags = np.zeros(n, np.float32)
+    for i in range(n):
+        codes[i], mags[i] = quantize(X[i], storage, resolution, lo, hi)
+    return codes, mags
+
+
+def dot_u8(a, b, scalar=False):
+    a, b = _c(a, np.uint8), _c(b, np.uint8)
+    f = lib().coso_dot_u8_scalar if scalar else lib().coso_dot_u8
+    return int(f(_p(a), _p(b), a.size))
+
+
+def dot_f32(a, b, scalar_order=False):
+    a, b = _c(a, np.float32), _c(b, np.float32)
+    f = lib().coso_dot_f32_scalar_order if scalar_order else lib().coso_dot_f32
+    return np.float32(f(_p(a), _p(b), a.size))
+
+
+def dot_f16(a_bits, b_bits):
+    a, b = _c(a_bits, np.uint16), _c(b_bits, np.uint16)
+    return np.float32(lib().coso_dot_f16(_p(a), _p(b), a.size))
+
+
+def dot_subbyte(x_planes, y_planes, resolution):
+    """x_planes: uint8 [resolution, plane_bytes] plane-major (plane 0 first, as stored)."""
+    x, y = _c(x_planes, np.uint8), _c(y_planes, np.uint8)
+    st = C.c_int()
+    v = lib().coso_dot_subbyte(_p(x), _p(y), resolution, x.size // max(resolution, 1), C.byref(st))
+    return np.float32(v), st.value
+
+
+def dot_quaternary_scalar(x_planes, y_planes):
+    x, y = _c(x_planes, np.uint8), _c(y_planes, np.uint8)
+    return np.float32(lib().coso_dot_quaternary_scalar(_p(x), _p(y), x.size // 2))
+
+
+def count_ones(buf):
+    b = _c(buf, np.uint8)
+    return int(lib().coso_count_ones(_p(b), b.size))
+
+
+def seq_norm(x):
+    x = _c(x, np.float32)
+    return np.float32(lib().coso_seq_norm_f32(_p(x), x.size))
+
+
+def distance(metric, storage, resolution, dim, x_code, x_mag, y_code, y_mag):
+    """DistanceMetric::calculate -> (status, value)."""
+    x, y = _c(x_code, np.uint8), _c(y_code, np.uint8)
+    out = C.c_float()
+    rc = lib().coso_distance(metric, storage, resolution, dim, _p(x), float(x_mag), _p(y), float(y_mag), C.byref(out))
+    return rc, np.float32(out.value)
+
+
+def metric_cmp(metric, a, b):
+    return lib().coso_metric_cmp(metric, float(a), float(b))
+
+
+def level_probs(x, num_levels):
+    v = (C.c_double * (num_levels + 1))()
+    l = (C.c_uint8 * (num_levels + 1))()
+    lib().coso_level_probs(x, num_levels, v, l)
+    return [(v[i], l[i]) for i in range(num_levels + 1)]
+
+
+def max_insert_level(x, probs):
+    n = len(probs)
+    v = (C.c_double * n)(*[p[0] for p in probs])
+    l = (C.c_uint8 * n)(*[p[1] for p in probs])
+    return lib().coso_max_insert_level(x, v, l, n)
+
+
+# ------------------------------------------------------------------------------------------------
+# HNSW index
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class HNSWParams:
+    dim: int
+    metric: int = METRIC_COSINE
+    storage: int = STORAGE_U8
+    resolution: int = 0
+    range_lo: float = -1.0
+    range_hi: float = 1.0
+    num_layers: int = 9            # config.toml:24
+    neighbors_count: int = 32      # config.toml:20
+    level0_neighbors_count: int = 64
+    ef_construction: int = 128
+    ef_search: int = 256
+    shortlist_size: int = 64       # config.toml:32
+    visited_mode: int = VISITED_REF
+    seed: int = 42
+
+    def to_c(self) -> Params:
+        return Params(self.dim, self.metric, self.storage, self.resolution, self.range_lo, self.range_hi, self.num_layers,
+                      self.neighbors_count, self.level0_neighbors_count, self.ef_construction, self.ef_search,
+                      self.shortlist_size, self.visited_mode, self.seed)
+
+
+class OracleIndex:
+    def __init__(self, params: HNSWParams):
+        self.params = params
+        cp = params.to_c()
+        self._h = lib().coso_index_create(C.byref(cp))
+        if not self._h:
+            raise ValueError("coso_index_create failed (bad params)")
+        self._raw = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().coso_index_destroy(self._h)
+            self._h = None
+
+    def set_vectors(self, raw):
+        self._raw = _c(raw, np.float32)
+        rc = lib().coso_index_set_vectors(self._h, _p(self._raw), self._raw.shape[0])
+        if rc != OK:
+            raise ValueError(f"set_vectors status {rc}")
+        return self
+
+    def build(self):
+        rc = lib().coso_index_build(self._h)
+        if rc != OK:
+            raise ValueError(f"build status {rc}")
+        return self
+
+    @property
+    def n(self):
+        return 0 if self._raw is None else self._raw.shape[0]
+
+    def level_M(self, level):
+        return self.params.level0_neighbors_count if level == 0 else self.params.neighbors_count
+
+    def export_level(self, level, with_sims=False):
+        n = lib().coso_index_level_count(self._h, level)
+        M = self.level_M(level)
+        ids = np.zeros(n, np.uint32)
+        nbr = np.zeros((n, M), np.uint32)
+        sims = np.zeros((n, M), np.float32) if with_sims else None
+        rc = lib().coso_index_export_level(self._h, level, _p(ids), _p(nbr), _p(sims) if with_sims else None)
+        if rc != OK:
+            raise ValueError(f"export status {rc}")
+        return (ids, nbr, sims) if with_sims else (ids, nbr)
+
+    def export_graph(self):
+        return [self.export_level(l) for l in range(self.params.num_layers + 1)]
+
+    def import_level(self, level, node_ids, nbr_ids):
+        ids, nbr = _c(node_ids, np.uint32), _c(nbr_ids, np.uint32)
+        rc = lib().coso_index_import_level(self._h, level, ids.size, _p(ids), _p(nbr))
+        if rc != OK:
+            raise ValueError(f"import status {rc} (level {level})")
+
+    def import_graph(self, levels, root_raw):
+        self.set_root_raw(root_raw)
+        for l, (ids, nbr) in enumerate(levels):
+            self.import_level(l, ids, nbr)
+        return self
+
+    def root_raw(self):
+        p = lib().coso_index_root_raw(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.params.dim,)).copy()
+
+    def set_root_raw(self, root):
+        r = _c(root, np.float32)
+        rc = lib().coso_index_set_root_raw(self._h, _p(r))
+        if rc != OK:
+            raise ValueError(f"set_root_raw status {rc}")
+
+    def codes(self):
+        cb = code_bytes(self.params.storage, self.params.resolution, self.params.dim)
+        p = C.cast(lib().coso_index_codes(self._h), C.POINTER(C.c_uint8))
+        return np.ctypeslib.as_array(p, shape=(self.n + 1, cb)).copy()
+
+    def mags(self):
+        return np.ctypeslib.as_array(lib().coso_index_mags(self._h), shape=(self.n + 1,)).copy()
+
+    def set_ef_search(self, ef):
+        self.params.ef_search = ef
+        lib().coso_index_set_ef_search(self._h, ef)
+
+    def set_visited_mode(self, mode):
+        self.params.visited_mode = mode
+        lib().coso_index_set_visited_mode(self._h, mode)
+
+    def search_batch(self, queries, top_k, threads=1, with_stats=False, raise_on_error=True):
+        q = _c(queries, np.float32)
+        B = q.shape[0]
+        ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+        scores = np.zeros((B, top_k), np.float32)
+        counts = np.zeros(B, np.uint32)
+        status = np.zeros(B, np.int32)
+        stats = (Stats * B)()
+        rc = lib().coso_search_batch(self._h, _p(q), B, top_k, _p(ids), _p(scores), _p(counts), _p(status),
+                                     C.cast(stats, C.c_void_p), threads)
+        if rc != OK and raise_on_error:
+            raise ValueError(f"search status {rc}")
+        out = [ids, scores, counts]
+        if not raise_on_error:
+            out += [rc, status]
+        if with_stats:
+            out.append(np.array([(s.evals, s.expansions, s.adj_bytes) for s in stats], dtype=np.uint64))
+        return tuple(out)
+
+    def ann_search(self, query):
+        """ann_search output before finalisation: (ids, sims, per-level counts top level first)."""
+        q = _c(query, np.float32)
+        cap = (self.params.num_layers + 1) * 100
+        ids = np.zeros(cap, np.uint32)
+        sims = np.zeros(cap, np.float32)
+        lc = np.zeros(self.params.num_layers + 1, np.uint32)
+        n = lib().coso_ann_search(self._h, _p(q), _p(ids), _p(sims), _p(lc))
+        if n < 0:
+            raise ValueError(f"ann_search status {-n}")
+        return ids[:n], sims[:n], lc
+
+
+def bruteforce_topk(raw, queries, k, threads=1):
+    raw, q = _c(raw, np.float32), _c(queries, np.float32)
+    ids = np.zeros((q.shape[0], k), np.uint32)
+    scores = np.zeros((q.shape[0], k), np.float32)
+    rc = lib().coso_bruteforce_topk(_p(raw), raw.shape[0], raw.shape[1], _p(q), q.shape[0], k, _p(ids), _p(scores), threads)
+    if rc != OK:
+        raise ValueError(f"bruteforce status {rc}")
+    return ids, scores
+
+
+# ------------------------------------------------------------------------------------------------
+# BM25 + RRF
+# ------------------------------------------------------------------------------------------------
+def bm25_idf(n_docs, containing):
+    return np.float32(lib().coso_bm25_idf(n_docs, containing))
+
+
+def bm25_tf(count, doc_len, avg_len, k1, b):
+    return np.float32(lib().coso_bm25_tf(count, doc_len, avg_len, k1, b))
+
+
+def bm25_search(term_hashes, offsets, doc_ids, tfs, n_docs, query_terms, top_k):
+    th, off = _c(term_hashes, np.uint32), _c(offsets, np.uint64)
+    di, tf, qt = _c(doc_ids, np.uint32), _c(tfs, np.float32), _c(query_terms, np.uint32)
+    ids = np.zeros(max(top_k, 1), np.uint32)
+    sc = np.zeros(max(top_k, 1), np.float32)
+    m = lib().coso_bm25_search(_p(th), _p(off), th.size, _p(di), _p(tf), n_docs, _p(qt), qt.size, top_k, _p(ids), _p(sc))
+    return ids[:m], sc[:m]
+
+
+def rrf_fuse(dense_ids, sparse_ids, k_rrf, top_k):
+    d, s = _c(dense_ids, np.uint32), _c(sparse_ids, np.uint32)
+    ids = np.zeros(max(top_k, 1), np.uint32)
+    sc = np.zeros(max(top_k, 1), np.float32)
+    m = lib().coso_rrf_fuse(_p(d), d.size, _p(s), s.size, k_rrf, top_k, _p(ids), _p(sc))
+    return ids[:m], sc[:m]
