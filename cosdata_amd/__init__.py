@@ -1,0 +1,4 @@
+"""cosdata_amd — MI355X-native ANN query engine for cosdata's dense/hybrid search path."""
+from ._lib import CosdataError, build  # noqa: F401
+from .index import (DistanceMetric, HNSWHyperParams, HNSWIndex, ScalarQuantization, StorageKind, StorageType,  # noqa: F401
+                    ROOT_ID, QUERY_ID, SLOT_EMPTY, VISITED_REF, VISITED_EXACT)

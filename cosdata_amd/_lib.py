@@ -1,0 +1,129 @@
+"""ctypes loader for libcosdata_hip.so (the C ABI of include/cosdata_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or no gfx950 device is
+visible, calls fail loudly (CosdataError) instead of routing anywhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_PKG, "libcosdata_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+OK, ERR_STORAGE_MISMATCH, ERR_CALCULATION, ERR_INVALID, ERR_UNIMPLEMENTED, ERR_HIP, ERR_NOT_READY, ERR_NO_DEVICE = range(8)
+STATUS_NAMES = {
+    0: "OK", 1: "StorageMismatch", 2: "CalculationError", 3: "Invalid", 4: "Unimplemented", 5: "HipError",
+    6: "NotReady", 7: "NoDevice",
+}
+ABI_VERSION = 1
+
+
+class CosdataError(RuntimeError):
+    """Non-zero cos_status.  `.status` mirrors DistanceError / WaCustomError of the reference:
+    1 = StorageMismatch (QuantizationMismatch), 2 = CalculationError."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[{STATUS_NAMES.get(status, status)}] {message}")
+        self.status = status
+
+
+class CosParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("dim", C.c_uint32), ("metric", C.c_uint32),
+        ("storage", C.c_uint32), ("resolution", C.c_uint32), ("range_lo", C.c_float), ("range_hi", C.c_float),
+        ("num_layers", C.c_uint32), ("neighbors_count", C.c_uint32), ("level0_neighbors_count", C.c_uint32),
+        ("ef_construction", C.c_uint32), ("ef_search", C.c_uint32), ("shortlist_size", C.c_uint32),
+        ("visited_mode", C.c_uint32), ("device", C.c_int32), ("id_base", C.c_uint32), ("reserved", C.c_uint32),
+        ("seed", C.c_uint64),
+    ]
+
+
+class CosSearchStats(C.Structure):
+    _fields_ = [
+        ("evals", C.c_uint64), ("expansions", C.c_uint64), ("adj_bytes", C.c_uint64), ("rerank_rows", C.c_uint64),
+        ("walk_ms", C.c_float), ("finalize_ms", C.c_float), ("prep_ms", C.c_float), ("reserved", C.c_uint32),
+    ]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into cosdata_amd/libcosdata_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_PKG, "..", "include", "cosdata_hip.h"))
+    stale = force or not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if stale:
+        cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+        if not verbose:
+            cmd.append("-s")
+        subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+# every symbol include/cosdata_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "cos_index_create", "cos_index_destroy", "cos_last_error_string", "cos_device_count",
+    "cos_index_upload_vectors", "cos_index_set_root", "cos_index_upload_graph_level", "cos_index_level_count",
+    "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build",
+    "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_ef_search",
+    "cos_index_set_visited_mode", "cos_index_enable_timing", "cos_index_last_stats", "cos_quantize_batch",
+    "cos_code_bytes", "cos_distance_batch", "cos_bruteforce_topk", "cos_bm25_create", "cos_bm25_destroy",
+    "cos_bm25_search_batch", "cos_rrf_fuse_batch", "cos_merge_topk_device",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise CosdataError(ERR_NO_DEVICE, f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                          "(the HIP extension is mandatory; there is no CPU path)")
+    L = C.CDLL(SO_PATH)
+    vp, i32, u32, f32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
+    sig = {
+        "cos_index_create": [C.POINTER(CosParams), C.POINTER(vp)],
+        "cos_index_destroy": [vp],
+        "cos_device_count": [C.POINTER(i32)],
+        "cos_index_upload_vectors": [vp, vp, u32, u32],
+        "cos_index_set_root": [vp, vp],
+        "cos_index_upload_graph_level": [vp, u32, u32, vp, vp],
+        "cos_index_level_count": [vp, u32, C.POINTER(u32)],
+        "cos_index_download_graph_level": [vp, u32, vp, vp],
+        "cos_index_download_codes": [vp, vp, vp],
+        "cos_index_download_root": [vp, vp],
+        "cos_index_build": [vp, u32],
+        "cos_search_batch": [vp, vp, u32, u32, vp, vp, vp, vp],
+        "cos_search_batch_device": [vp, vp, u32, u32, vp, vp, vp, vp, vp],
+        "cos_ann_search_batch": [vp, vp, u32, vp, vp, vp, vp],
+        "cos_index_set_ef_search": [vp, u32],
+        "cos_index_set_visited_mode": [vp, u32],
+        "cos_index_enable_timing": [vp, i32],
+        "cos_index_last_stats": [vp, vp, C.POINTER(CosSearchStats)],
+        "cos_quantize_batch": [u32, u32, u32, f32, f32, vp, u32, vp, vp],
+        "cos_distance_batch": [u32, u32, u32, u32, vp, vp, u32, vp, vp, u32, vp, vp, u32, vp, vp],
+        "cos_bruteforce_topk": [vp, vp, u32, u32, vp, vp],
+        "cos_bm25_create": [i32, vp, vp, u32, vp, vp, u32, C.POINTER(vp)],
+        "cos_bm25_destroy": [vp],
+        "cos_bm25_search_batch": [vp, vp, vp, u32, u32, vp, vp, vp],
+        "cos_rrf_fuse_batch": [vp, vp, u32, vp, vp, u32, u32, f32, u32, vp, vp, vp],
+        "cos_merge_topk_device": [vp, vp, vp, u32, u32, u32, vp, vp, vp, i32, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = args
+    L.cos_last_error_string.restype = C.c_char_p
+    L.cos_last_error_string.argtypes = []
+    L.cos_code_bytes.restype = C.c_size_t
+    L.cos_code_bytes.argtypes = [u32, u32, u32]
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != OK:
+        raise CosdataError(rc, lib().cos_last_error_string().decode("utf-8", "replace"))

@@ -1,0 +1,717 @@
+// engine.hip — host side of libcosdata_hip.so: the opaque index handle, uploads, per-stream
+// workspaces and the C ABI of include/cosdata_hip.h.  No CPU compute path exists here: every
+// numeric result is produced by the gfx950 kernels; without a device the calls fail loudly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cosdata_hip.h"
+#include "engine_types.h"
+
+using namespace cosdev;
+
+namespace cosdev {
+hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
+                                u64 row_stride, float *mags, float *raw_mags, hipStream_t st);
+hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
+hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
+                           const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
+                           u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
+                           hipStream_t st);
+} // namespace cosdev
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int32_t fail(int32_t code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return fail(COS_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *cos_last_error_string(void) { return g_err.c_str(); }
+
+extern "C" int32_t cos_device_count(int32_t *out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *out = 0; return fail(COS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *out = n;
+    return COS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct LevelHost {
+    std::vector<u32> node_ids; // ascending, root last
+    std::vector<u32> nbr_ids;  // [n][M] internal ids / COS_SLOT_EMPTY
+    u32 *d_adj_vec = nullptr, *d_adj_node = nullptr, *d_node_vec = nullptr, *d_child = nullptr;
+    u32 n = 0, M = 0;
+    bool host_valid = false; // node_ids/nbr_ids mirror the device arrays
+};
+
+struct Workspace {
+    u32 capB = 0, cap_topk = 0;
+    uint8_t *q_codes = nullptr;
+    float *q_mags = nullptr, *q_raw_mags = nullptr;
+    u32 *walk_ids = nullptr, *walk_counts = nullptr;
+    float *walk_sims = nullptr;
+    int32_t *walk_status = nullptr;
+    u64 *stats = nullptr;       // [B][4]
+    u64 *rerank_rows = nullptr; // [B]
+    u32 *vis_slab = nullptr;
+    size_t vis_slab_words = 0;
+    // host-API staging (device)
+    float *d_queries = nullptr;
+    u32 *d_out_ids = nullptr, *d_out_counts = nullptr;
+    float *d_out_scores = nullptr;
+    int32_t *d_out_status = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    u32 lastB = 0;
+    bool timed = false;
+};
+
+struct cos_index {
+    cos_params p;
+    int eng = -1;
+    u32 n = 0;
+    bool have_vectors = false, have_root = false, raw_borrowed = false;
+    float *d_raw = nullptr;
+    float *d_raw_mags = nullptr;
+    uint8_t *d_codes = nullptr;
+    float *d_mags = nullptr;
+    u64 row_stride = 0;
+    u32 nchunks = 0, G = 1;
+    std::vector<float> root_raw;
+    std::vector<LevelHost> lv;
+    hipStream_t own_stream = nullptr; // host API stream
+    std::mutex mu;                    // guards workspaces map + timing flag
+    std::map<void *, Workspace *> ws;
+    Workspace *last_ws = nullptr; // most recent batch (cos_index_last_stats with stream == NULL)
+    bool timing = false;
+};
+
+static u32 pow2ceil(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }
+
+static int32_t set_device(const cos_index *ix) {
+    HIP_TRY(hipSetDevice(ix->p.device));
+    return COS_OK;
+}
+
+static bool graph_ready(const cos_index *ix) {
+    if (!ix->have_vectors || !ix->have_root) return false;
+    for (auto &l : ix->lv) if (l.n == 0) return false;
+    return true;
+}
+
+static IndexDev make_index_dev(const cos_index *ix) {
+    IndexDev d;
+    memset(&d, 0, sizeof(d));
+    d.codes = ix->d_codes;
+    d.mags = ix->d_mags;
+    d.raw = ix->d_raw;
+    d.raw_mags = ix->d_raw_mags;
+    d.row_stride = ix->row_stride;
+    d.raw_stride = ix->p.dim;
+    d.n = ix->n;
+    d.dim = ix->p.dim;
+    d.metric = ix->p.metric;
+    d.storage = ix->p.storage;
+    d.num_layers = ix->p.num_layers;
+    d.shortlist = ix->p.shortlist_size;
+    d.visited_mode = ix->p.visited_mode;
+    d.nchunks = ix->nchunks;
+    d.G = ix->G;
+    d.id_base = ix->p.id_base;
+    u32 off = 0;
+    for (u32 l = 0; l <= ix->p.num_layers; l++) {
+        const LevelHost &h = ix->lv[l];
+        d.lv[l].adj_vec = h.d_adj_vec;
+        d.lv[l].adj_node = l == 0 ? h.d_adj_vec : h.d_adj_node;
+        d.lv[l].node_vec = l == 0 ? nullptr : h.d_node_vec;
+        d.lv[l].child = l == 0 ? nullptr : h.d_child;
+        d.lv[l].n = h.n;
+        d.lv[l].M = h.M;
+        d.lv[l].root_idx = h.n ? h.n - 1 : 0;
+        d.lv[l].vis_word_off = off;
+        off += (h.n + 31) / 32;
+    }
+    d.vis_words_per_query = off;
+    return d;
+}
+
+extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
+    if (!p || !out) return fail(COS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (p->struct_size != sizeof(cos_params) || p->abi_version != COS_ABI_VERSION)
+        return fail(COS_ERR_INVALID, "cos_params size/version mismatch (%u/%u, expected %zu/%u)", p->struct_size, p->abi_version,
+                    sizeof(cos_params), COS_ABI_VERSION);
+    if (p->dim == 0) return fail(COS_ERR_INVALID, "dim == 0");
+    auto pow2 = [](u32 v) { return v && !(v & (v - 1)); };
+    if (!pow2(p->neighbors_count) || !pow2(p->level0_neighbors_count) || p->neighbors_count > 256 || p->level0_neighbors_count > 256)
+        return fail(COS_ERR_INVALID, "neighbors_count / level_0_neighbors_count must be powers of two <= 256 (PerformantFixedSet, fixedset.rs)");
+    if (p->num_layers + 1 > (u32)MAX_LEVELS || (p->num_layers + 1) * KEEP_SEARCH > 1024)
+        return fail(COS_ERR_UNIMPLEMENTED, "num_layers > 9 not supported on the device");
+    if (std::min(p->neighbors_count, p->shortlist_size) > 64 || std::min(p->level0_neighbors_count, p->shortlist_size) > 64)
+        return fail(COS_ERR_UNIMPLEMENTED, "more than 64 scanned neighbour slots per node not supported on the device");
+    if (p->ef_search > 512 || p->ef_construction > 512) return fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
+    if (p->metric != COS_METRIC_COSINE && p->metric != COS_METRIC_DOT)
+        return fail(COS_ERR_UNIMPLEMENTED, "device walk implements cosine and dot-product metrics");
+    int eng;
+    u64 row_stride;
+    u32 nchunks = 0, G = 1;
+    switch (p->storage) {
+    case COS_STORAGE_U8:
+        eng = ENG_U8; row_stride = ((u64)p->dim + 15) & ~15ull; nchunks = (u32)(row_stride / 16); G = std::min(64u, pow2ceil(nchunks));
+        if ((nchunks + G - 1) / G > 2) return fail(COS_ERR_UNIMPLEMENTED, "u8 dim > 2048 not supported on the device");
+        break;
+    case COS_STORAGE_SUBBYTE:
+        if (p->resolution != 2) return fail(COS_ERR_UNIMPLEMENTED, "device walk implements SubByte resolution 2 (quaternary)");
+        eng = ENG_Q2; nchunks = (p->dim + 63) / 64; row_stride = (u64)nchunks * 16; G = std::min(64u, pow2ceil(nchunks));
+        if (nchunks > 64) return fail(COS_ERR_UNIMPLEMENTED, "quaternary dim > 4096 not supported on the device");
+        break;
+    case COS_STORAGE_F32:
+        if (p->metric == COS_METRIC_DOT) return fail(COS_ERR_STORAGE_MISMATCH, "DotProductDistance has no FullPrecisionFP arm (dotproduct.rs:20-64)");
+        eng = ENG_F32; row_stride = ((u64)p->dim * 4 + 15) & ~15ull; G = 2;
+        break;
+    default: return fail(COS_ERR_UNIMPLEMENTED, "storage kind %u not supported on the device yet", p->storage);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    if (p->device < 0 || p->device >= ndev) return fail(COS_ERR_INVALID, "device %d out of range (%d visible)", p->device, ndev);
+    cos_index *ix = new cos_index();
+    ix->p = *p;
+    ix->eng = eng;
+    ix->row_stride = row_stride;
+    ix->nchunks = nchunks;
+    ix->G = G;
+    ix->lv.resize(p->num_layers + 1);
+    for (u32 l = 0; l <= p->num_layers; l++) ix->lv[l].M = l == 0 ? p->level0_neighbors_count : p->neighbors_count;
+    if (hipSetDevice(p->device) != hipSuccess || hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ix;
+        return fail(COS_ERR_HIP, "cannot create stream on device %d", p->device);
+    }
+    *out = ix;
+    return COS_OK;
+}
+
+static void free_level(LevelHost &l) {
+    if (l.d_adj_vec) (void)hipFree(l.d_adj_vec);
+    if (l.d_adj_node) (void)hipFree(l.d_adj_node);
+    if (l.d_node_vec) (void)hipFree(l.d_node_vec);
+    if (l.d_child) (void)hipFree(l.d_child);
+    l.d_adj_vec = l.d_adj_node = l.d_node_vec = l.d_child = nullptr;
+    l.n = 0;
+    l.node_ids.clear();
+    l.nbr_ids.clear();
+    l.host_valid = false;
+}
+static void free_ws(Workspace *w) {
+    void *ptrs[] = {w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
+                    w->rerank_rows, w->vis_slab, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : w->ev) if (e) (void)hipEventDestroy(e);
+    delete w;
+}
+
+extern "C" int32_t cos_index_destroy(cos_index *ix) {
+    if (!ix) return COS_OK;
+    (void)hipSetDevice(ix->p.device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : ix->ws) free_ws(kv.second);
+    for (auto &l : ix->lv) free_level(l);
+    if (ix->d_raw && !ix->raw_borrowed) (void)hipFree(ix->d_raw);
+    if (ix->d_raw_mags) (void)hipFree(ix->d_raw_mags);
+    if (ix->d_codes) (void)hipFree(ix->d_codes);
+    if (ix->d_mags) (void)hipFree(ix->d_mags);
+    if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+    delete ix;
+    return COS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// uploads
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uint32_t n, uint32_t flags) {
+    if (!ix || !raw || n == 0) return fail(COS_ERR_INVALID, "null/empty vectors");
+    if (n >= 0xFFFFFFF0u) return fail(COS_ERR_INVALID, "too many vectors");
+    int32_t rc = set_device(ix);
+    if (rc) return rc;
+    if (ix->d_raw && !ix->raw_borrowed) (void)hipFree(ix->d_raw);
+    if (ix->d_raw_mags) (void)hipFree(ix->d_raw_mags);
+    if (ix->d_codes) (void)hipFree(ix->d_codes);
+    if (ix->d_mags) (void)hipFree(ix->d_mags);
+    ix->d_raw = nullptr; ix->d_raw_mags = nullptr; ix->d_codes = nullptr; ix->d_mags = nullptr;
+    ix->have_vectors = false;
+    const u64 dim = ix->p.dim;
+    if (flags & COS_UPLOAD_BORROW_DEVICE) {
+        ix->d_raw = const_cast<float *>(raw);
+        ix->raw_borrowed = true;
+    } else {
+        HIP_TRY(hipMalloc(&ix->d_raw, (size_t)n * dim * 4));
+        HIP_TRY(hipMemcpy(ix->d_raw, raw, (size_t)n * dim * 4, hipMemcpyHostToDevice));
+        ix->raw_borrowed = false;
+    }
+    HIP_TRY(hipMalloc(&ix->d_raw_mags, ((size_t)n + 1) * 4));
+    HIP_TRY(hipMalloc(&ix->d_codes, ((size_t)n + 1) * ix->row_stride));
+    HIP_TRY(hipMalloc(&ix->d_mags, ((size_t)n + 1) * 4));
+    HIP_TRY(hipMemsetAsync(ix->d_codes + (size_t)n * ix->row_stride, 0, ix->row_stride, ix->own_stream));
+    HIP_TRY(launch_quantize_rows(ix->eng, ix->d_raw, dim, n, ix->p.dim, ix->p.range_lo, ix->p.range_hi, ix->d_codes, ix->row_stride,
+                                 ix->d_mags, ix->d_raw_mags, ix->own_stream));
+    HIP_TRY(hipStreamSynchronize(ix->own_stream));
+    ix->n = n;
+    ix->have_vectors = true;
+    ix->have_root = false;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_set_root(cos_index *ix, const float *root_raw) {
+    if (!ix || !root_raw) return fail(COS_ERR_INVALID, "null argument");
+    if (!ix->have_vectors) return fail(COS_ERR_NOT_READY, "upload vectors before the root");
+    int32_t rc = set_device(ix);
+    if (rc) return rc;
+    ix->root_raw.assign(root_raw, root_raw + ix->p.dim);
+    float *d_tmp = nullptr, *d_dummy = nullptr;
+    HIP_TRY(hipMalloc(&d_tmp, (size_t)ix->p.dim * 4));
+    HIP_TRY(hipMalloc(&d_dummy, 4));
+    HIP_TRY(hipMemcpy(d_tmp, root_raw, (size_t)ix->p.dim * 4, hipMemcpyHostToDevice));
+    hipError_t e = launch_quantize_rows(ix->eng, d_tmp, ix->p.dim, 1, ix->p.dim, ix->p.range_lo, ix->p.range_hi,
+                                        ix->d_codes + (size_t)ix->n * ix->row_stride, ix->row_stride, ix->d_mags + ix->n, d_dummy,
+                                        ix->own_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->own_stream);
+    (void)hipFree(d_tmp);
+    (void)hipFree(d_dummy);
+    HIP_TRY(e);
+    ix->have_root = true;
+    return COS_OK;
+}
+
+// id -> vector row (root = row n)
+static inline u32 row_of(const cos_index *ix, u32 id) { return id == COS_ROOT_ID ? ix->n : id; }
+
+static int32_t push_level_to_device(cos_index *ix, u32 level) {
+    LevelHost &L = ix->lv[level];
+    const u32 n = (u32)L.node_ids.size(), M = L.M;
+    std::vector<u32> adj_vec((size_t)n * M), adj_node, node_vec, child;
+    if (level > 0) { adj_node.resize((size_t)n * M); node_vec.resize(n); }
+    for (u32 i = 0; i < n; i++) {
+        if (level > 0) node_vec[i] = row_of(ix, L.node_ids[i]);
+        for (u32 j = 0; j < M; j++) {
+            u32 id = L.nbr_ids[(size_t)i * M + j];
+            if (id == COS_SLOT_EMPTY) {
+                adj_vec[(size_t)i * M + j] = ROW_EMPTY;
+                if (level > 0) adj_node[(size_t)i * M + j] = ROW_EMPTY;
+                continue;
+            }
+            auto it = std::lower_bound(L.node_ids.begin(), L.node_ids.end(), id);
+            if (it == L.node_ids.end() || *it != id) return fail(COS_ERR_INVALID, "level %u: neighbour id %u of node %u is not a node of this level", level, id, L.node_ids[i]);
+            adj_vec[(size_t)i * M + j] = row_of(ix, id);
+            if (level > 0) adj_node[(size_t)i * M + j] = (u32)(it - L.node_ids.begin());
+        }
+    }
+    if (L.d_adj_vec) (void)hipFree(L.d_adj_vec);
+    if (L.d_adj_node) (void)hipFree(L.d_adj_node);
+    if (L.d_node_vec) (void)hipFree(L.d_node_vec);
+    L.d_adj_vec = L.d_adj_node = L.d_node_vec = nullptr;
+    HIP_TRY(hipMalloc(&L.d_adj_vec, adj_vec.size() * 4));
+    HIP_TRY(hipMemcpy(L.d_adj_vec, adj_vec.data(), adj_vec.size() * 4, hipMemcpyHostToDevice));
+    if (level > 0) {
+        HIP_TRY(hipMalloc(&L.d_adj_node, adj_node.size() * 4));
+        HIP_TRY(hipMemcpy(L.d_adj_node, adj_node.data(), adj_node.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&L.d_node_vec, node_vec.size() * 4));
+        HIP_TRY(hipMemcpy(L.d_node_vec, node_vec.data(), node_vec.size() * 4, hipMemcpyHostToDevice));
+    }
+    L.n = n;
+    L.host_valid = true;
+    return COS_OK;
+}
+
+// child links: same id one level down (vector_store.rs:897-903)
+static int32_t resolve_children(cos_index *ix, u32 level) {
+    if (level == 0 || level > ix->p.num_layers) return COS_OK;
+    LevelHost &L = ix->lv[level], &D = ix->lv[level - 1];
+    if (L.node_ids.empty() || D.node_ids.empty()) return COS_OK;
+    std::vector<u32> child(L.node_ids.size());
+    for (size_t i = 0; i < L.node_ids.size(); i++) {
+        auto it = std::lower_bound(D.node_ids.begin(), D.node_ids.end(), L.node_ids[i]);
+        if (it == D.node_ids.end() || *it != L.node_ids[i]) return fail(COS_ERR_INVALID, "node %u of level %u is missing on level %u", L.node_ids[i], level, level - 1);
+        child[i] = (u32)(it - D.node_ids.begin());
+    }
+    if (L.d_child) (void)hipFree(L.d_child);
+    L.d_child = nullptr;
+    HIP_TRY(hipMalloc(&L.d_child, child.size() * 4));
+    HIP_TRY(hipMemcpy(L.d_child, child.data(), child.size() * 4, hipMemcpyHostToDevice));
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_upload_graph_level(cos_index *ix, uint32_t level, uint32_t n_nodes, const uint32_t *node_ids,
+                                                const uint32_t *nbr_ids) {
+    if (!ix || !node_ids || !nbr_ids) return fail(COS_ERR_INVALID, "null argument");
+    if (!ix->have_vectors) return fail(COS_ERR_NOT_READY, "upload vectors before the graph");
+    if (level > ix->p.num_layers || n_nodes == 0) return fail(COS_ERR_INVALID, "bad level / empty level");
+    int32_t rc = set_device(ix);
+    if (rc) return rc;
+    for (u32 i = 0; i < n_nodes; i++) {
+        if (i && node_ids[i] <= node_ids[i - 1]) return fail(COS_ERR_INVALID, "level %u: node_ids must be strictly ascending", level);
+        if (node_ids[i] != COS_ROOT_ID && node_ids[i] >= ix->n) return fail(COS_ERR_INVALID, "level %u: node id %u out of range", level, node_ids[i]);
+    }
+    if (node_ids[n_nodes - 1] != COS_ROOT_ID) return fail(COS_ERR_INVALID, "level %u: the root (0xFFFFFFFF) must be the last node", level);
+    if (level == 0 && n_nodes != ix->n + 1) return fail(COS_ERR_INVALID, "level 0 must hold every vector plus the root (%u nodes, expected %u)", n_nodes, ix->n + 1);
+    LevelHost &L = ix->lv[level];
+    L.node_ids.assign(node_ids, node_ids + n_nodes);
+    L.nbr_ids.assign(nbr_ids, nbr_ids + (size_t)n_nodes * L.M);
+    rc = push_level_to_device(ix, level);
+    if (rc) { free_level(L); return rc; }
+    rc = resolve_children(ix, level);
+    if (rc == COS_OK) rc = resolve_children(ix, level + 1);
+    return rc;
+}
+
+extern "C" int32_t cos_index_level_count(const cos_index *ix, uint32_t level, uint32_t *n_nodes) {
+    if (!ix || !n_nodes || level > ix->p.num_layers) return fail(COS_ERR_INVALID, "bad argument");
+    *n_nodes = ix->lv[level].n;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_download_graph_level(const cos_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids) {
+    if (!ix || level > ix->p.num_layers) return fail(COS_ERR_INVALID, "bad argument");
+    const LevelHost &L = ix->lv[level];
+    if (!L.host_valid) return fail(COS_ERR_NOT_READY, "level %u not resident", level);
+    if (node_ids) memcpy(node_ids, L.node_ids.data(), L.node_ids.size() * 4);
+    if (nbr_ids) memcpy(nbr_ids, L.nbr_ids.data(), L.nbr_ids.size() * 4);
+    return COS_OK;
+}
+
+extern "C" size_t cos_code_bytes(uint32_t storage, uint32_t resolution, uint32_t dim) {
+    switch (storage) {
+    case COS_STORAGE_U8: return dim;
+    case COS_STORAGE_SUBBYTE: return (size_t)resolution * ((dim + 7) / 8);
+    case COS_STORAGE_F16: return (size_t)dim * 2;
+    case COS_STORAGE_F32: return (size_t)dim * 4;
+    default: return 0;
+    }
+}
+
+// device layout -> reference layout for one row
+static void row_to_reference_layout(int eng, u32 dim, const uint8_t *dev_row, uint8_t *ref_row) {
+    if (eng == ENG_U8) memcpy(ref_row, dev_row, dim);
+    else if (eng == ENG_F32) memcpy(ref_row, dev_row, (size_t)dim * 4);
+    else { // Q2: [chunk][plane][8 B] -> plane-major
+        const u32 pb = (dim + 7) / 8;
+        for (u32 p = 0; p < 2; p++)
+            for (u32 b = 0; b < pb; b++) ref_row[(size_t)p * pb + b] = dev_row[(size_t)(b / 8) * 16 + p * 8 + (b % 8)];
+    }
+}
+
+extern "C" int32_t cos_index_download_codes(const cos_index *ix, void *codes, float *mags) {
+    if (!ix || !ix->have_vectors) return fail(COS_ERR_NOT_READY, "no vectors resident");
+    HIP_TRY(hipSetDevice(ix->p.device));
+    const size_t rows = (size_t)ix->n + 1;
+    if (codes) {
+        std::vector<uint8_t> dev(rows * ix->row_stride);
+        HIP_TRY(hipMemcpy(dev.data(), ix->d_codes, dev.size(), hipMemcpyDeviceToHost));
+        const size_t cb = cos_code_bytes(ix->p.storage, ix->p.resolution, ix->p.dim);
+        for (size_t r = 0; r < rows; r++) row_to_reference_layout(ix->eng, ix->p.dim, dev.data() + r * ix->row_stride, (uint8_t *)codes + r * cb);
+    }
+    if (mags) HIP_TRY(hipMemcpy(mags, ix->d_mags, rows * 4, hipMemcpyDeviceToHost));
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_download_root(const cos_index *ix, float *root_raw) {
+    if (!ix || !ix->have_root) return fail(COS_ERR_NOT_READY, "no root");
+    memcpy(root_raw, ix->root_raw.data(), (size_t)ix->p.dim * 4);
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef) {
+    if (!ix || ef > 512) return fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
+    ix->p.ef_search = ef;
+    return COS_OK;
+}
+extern "C" int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode) {
+    if (!ix || mode > 1) return fail(COS_ERR_INVALID, "bad visited mode");
+    ix->p.visited_mode = mode;
+    return COS_OK;
+}
+extern "C" int32_t cos_index_enable_timing(cos_index *ix, int32_t on) {
+    if (!ix) return fail(COS_ERR_INVALID, "null");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->timing = on != 0;
+    return COS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspaces (one per stream; same-stream work is ordered, so reuse is safe)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static hipError_t regrow(T *&p, size_t count) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    return hipMalloc((void **)&p, count * sizeof(T));
+}
+
+static int32_t get_workspace(cos_index *ix, void *stream_key, u32 B, u32 top_k, bool host_api, Workspace **out) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    Workspace *&w = ix->ws[stream_key];
+    if (!w) w = new Workspace();
+    const u32 L1 = ix->p.num_layers + 1;
+    if (B > w->capB) {
+        u32 cap = std::max(B, 64u);
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream_key));
+        HIP_TRY(regrow(w->q_codes, (size_t)cap * ix->row_stride));
+        HIP_TRY(regrow(w->q_mags, cap));
+        HIP_TRY(regrow(w->q_raw_mags, cap));
+        HIP_TRY(regrow(w->walk_ids, (size_t)cap * L1 * KEEP_SEARCH));
+        HIP_TRY(regrow(w->walk_sims, (size_t)cap * L1 * KEEP_SEARCH));
+        HIP_TRY(regrow(w->walk_counts, (size_t)cap * L1));
+        HIP_TRY(regrow(w->walk_status, cap));
+        HIP_TRY(regrow(w->stats, (size_t)cap * 4));
+        HIP_TRY(regrow(w->rerank_rows, cap));
+        HIP_TRY(regrow(w->d_queries, (size_t)cap * ix->p.dim));
+        HIP_TRY(regrow(w->d_out_counts, cap));
+        HIP_TRY(regrow(w->d_out_status, cap));
+        w->capB = cap;
+        w->cap_topk = 0;
+        w->vis_slab_words = 0;
+    }
+    if (host_api && (size_t)top_k * w->capB > (size_t)w->cap_topk * w->capB) {
+        HIP_TRY(regrow(w->d_out_ids, (size_t)w->capB * top_k));
+        HIP_TRY(regrow(w->d_out_scores, (size_t)w->capB * top_k));
+        w->cap_topk = top_k;
+    }
+    if (!w->ev[0]) for (auto &e : w->ev) HIP_TRY(hipEventCreate(&e));
+    *out = w;
+    return COS_OK;
+}
+
+// quantize -> walk -> (finalize) on `st`; all buffers device memory
+static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u32 B, u32 top_k, u32 *d_out_ids, float *d_out_scores,
+                          u32 *d_out_counts, int32_t *d_out_status, bool do_finalize, hipStream_t st) {
+    IndexDev dev = make_index_dev(ix);
+    bool timed;
+    { std::lock_guard<std::mutex> g(ix->mu); timed = ix->timing; }
+    if (dev.visited_mode == COS_VISITED_EXACT) {
+        size_t need = (size_t)B * dev.vis_words_per_query;
+        if (need > w->vis_slab_words) {
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(regrow(w->vis_slab, need));
+            w->vis_slab_words = need;
+        }
+        HIP_TRY(hipMemsetAsync(w->vis_slab, 0, need * 4, st));
+    }
+    if (timed) HIP_TRY(hipEventRecord(w->ev[0], st));
+    HIP_TRY(launch_quantize_rows(ix->eng, d_queries, ix->p.dim, B, ix->p.dim, ix->p.range_lo, ix->p.range_hi, w->q_codes, ix->row_stride,
+                                 w->q_mags, w->q_raw_mags, st));
+    if (timed) HIP_TRY(hipEventRecord(w->ev[1], st));
+    WalkArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.qcodes = w->q_codes;
+    wa.qmags = w->q_mags;
+    wa.vis_slab = w->vis_slab;
+    wa.B = B;
+    wa.ef = ix->p.ef_search;
+    wa.keep = KEEP_SEARCH;
+    wa.out_ids = w->walk_ids;
+    wa.out_sims = w->walk_sims;
+    wa.out_counts = w->walk_counts;
+    wa.out_status = w->walk_status;
+    wa.out_stats = w->stats;
+    HIP_TRY(launch_walk(ix->eng, dev, wa, st));
+    if (timed) HIP_TRY(hipEventRecord(w->ev[2], st));
+    if (do_finalize) {
+        HIP_TRY(launch_finalize(dev, d_queries, ix->p.dim, w->q_raw_mags, w->walk_ids, w->walk_sims, w->walk_counts, w->walk_status, B, top_k,
+                                d_out_ids, d_out_scores, d_out_counts, d_out_status, w->rerank_rows, st));
+    }
+    if (timed) HIP_TRY(hipEventRecord(w->ev[3], st));
+    w->lastB = B;
+    w->timed = timed;
+    { std::lock_guard<std::mutex> g(ix->mu); ix->last_ws = w; }
+    return COS_OK;
+}
+
+static int32_t check_search_args(cos_index *ix, const void *q, u32 B, u32 top_k) {
+    if (!ix || !q) return fail(COS_ERR_INVALID, "null argument");
+    if (!graph_ready(ix)) return fail(COS_ERR_NOT_READY, "index needs vectors, root and every graph level before search");
+    if (top_k == 0 || top_k > 1024) return fail(COS_ERR_INVALID, "top_k must be in [1, 1024]");
+    if (B == 0) return fail(COS_ERR_INVALID, "empty batch");
+    return set_device(ix);
+}
+
+extern "C" int32_t cos_search_batch_device(cos_index *ix, const float *d_queries, uint32_t B, uint32_t top_k, uint32_t *d_out_ids,
+                                           float *d_out_scores, uint32_t *d_out_counts, int32_t *d_out_status, void *stream) {
+    int32_t rc = check_search_args(ix, d_queries, B, top_k);
+    if (rc) return rc;
+    if (!d_out_ids || !d_out_scores || !d_out_counts || !d_out_status) return fail(COS_ERR_INVALID, "null output");
+    Workspace *w;
+    rc = get_workspace(ix, stream, B, top_k, false, &w);
+    if (rc) return rc;
+    return run_search(ix, w, d_queries, B, top_k, d_out_ids, d_out_scores, d_out_counts, d_out_status, true, (hipStream_t)stream);
+}
+
+extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,
+                                    uint32_t *out_counts, int32_t *out_status) {
+    int32_t rc = check_search_args(ix, queries, B, top_k);
+    if (rc) return rc;
+    if (!out_ids || !out_scores || !out_counts) return fail(COS_ERR_INVALID, "null output");
+    // host API: a private stream per calling thread so concurrent callers (rayon workers) do not serialise
+    static thread_local std::map<cos_index *, hipStream_t> tl_streams;
+    hipStream_t st = tl_streams[ix];
+    if (!st) {
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        tl_streams[ix] = st;
+    }
+    Workspace *w;
+    rc = get_workspace(ix, (void *)st, B, top_k, true, &w);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(w->d_queries, queries, (size_t)B * ix->p.dim * 4, hipMemcpyHostToDevice, st));
+    rc = run_search(ix, w, w->d_queries, B, top_k, w->d_out_ids, w->d_out_scores, w->d_out_counts, w->d_out_status, true, st);
+    if (rc) return rc;
+    std::vector<int32_t> status(B);
+    HIP_TRY(hipMemcpyAsync(out_ids, w->d_out_ids, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_scores, w->d_out_scores, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_counts, w->d_out_counts, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status.data(), w->d_out_status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
+    for (u32 b = 0; b < B; b++)
+        if (status[b] != COS_OK) return fail(status[b], "query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", b, status[b]);
+    return COS_OK;
+}
+
+extern "C" int32_t cos_ann_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t *out_ids, float *out_sims,
+                                        uint32_t *out_counts, int32_t *out_status) {
+    int32_t rc = check_search_args(ix, queries, B, 1);
+    if (rc) return rc;
+    hipStream_t st = ix->own_stream;
+    Workspace *w;
+    rc = get_workspace(ix, (void *)st, B, 1, true, &w);
+    if (rc) return rc;
+    const u32 L1 = ix->p.num_layers + 1;
+    HIP_TRY(hipMemcpyAsync(w->d_queries, queries, (size_t)B * ix->p.dim * 4, hipMemcpyHostToDevice, st));
+    rc = run_search(ix, w, w->d_queries, B, 1, nullptr, nullptr, nullptr, nullptr, false, st);
+    if (rc) return rc;
+    std::vector<int32_t> status(B);
+    HIP_TRY(hipMemcpyAsync(out_ids, w->walk_ids, (size_t)B * L1 * KEEP_SEARCH * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_sims, w->walk_sims, (size_t)B * L1 * KEEP_SEARCH * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_counts, w->walk_counts, (size_t)B * L1 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status.data(), w->walk_status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
+    for (u32 b = 0; b < B; b++)
+        if (status[b] != COS_OK) return fail(status[b], "query %u failed with status %d", b, status[b]);
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out) {
+    if (!ix || !out) return fail(COS_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    int32_t rc = set_device(ix);
+    if (rc) return rc;
+    Workspace *w = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        if (stream) {
+            auto it = ix->ws.find(stream);
+            if (it != ix->ws.end()) w = it->second;
+        } else
+            w = ix->last_ws;
+        if (!w) return fail(COS_ERR_NOT_READY, "no batch has run on this stream");
+    }
+    if (w->lastB == 0) return fail(COS_ERR_NOT_READY, "no batch has run on this stream");
+    if (w->timed) {
+        HIP_TRY(hipEventSynchronize(w->ev[3]));
+        HIP_TRY(hipEventElapsedTime(&out->prep_ms, w->ev[0], w->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&out->walk_ms, w->ev[1], w->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&out->finalize_ms, w->ev[2], w->ev[3]));
+    } else {
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    std::vector<u64> st((size_t)w->lastB * 4), rr(w->lastB);
+    HIP_TRY(hipMemcpy(st.data(), w->stats, st.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rr.data(), w->rerank_rows, rr.size() * 8, hipMemcpyDeviceToHost));
+    for (u32 b = 0; b < w->lastB; b++) {
+        out->evals += st[(size_t)b * 4 + 0];
+        out->expansions += st[(size_t)b * 4 + 1];
+        out->adj_bytes += st[(size_t)b * 4 + 2];
+        out->rerank_rows += rr[b];
+    }
+    return COS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// QuantizationMetric::quantize operator
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uint32_t dim, float lo, float hi, const float *x, uint32_t n,
+                                      void *codes, float *mags) {
+    if (!x || !codes || !mags || dim == 0 || n == 0) return fail(COS_ERR_INVALID, "bad argument");
+    int eng;
+    u64 row_stride;
+    if (storage == COS_STORAGE_U8) { eng = ENG_U8; row_stride = ((u64)dim + 15) & ~15ull; }
+    else if (storage == COS_STORAGE_SUBBYTE && resolution == 2) { eng = ENG_Q2; row_stride = (u64)((dim + 63) / 64) * 16; }
+    else if (storage == COS_STORAGE_F32) { eng = ENG_F32; row_stride = ((u64)dim * 4 + 15) & ~15ull; }
+    else return fail(COS_ERR_UNIMPLEMENTED, "storage kind not supported on the device yet");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    float *d_x = nullptr, *d_m = nullptr;
+    uint8_t *d_c = nullptr;
+    HIP_TRY(hipMalloc(&d_x, (size_t)n * dim * 4));
+    HIP_TRY(hipMalloc(&d_m, (size_t)n * 4));
+    HIP_TRY(hipMalloc(&d_c, (size_t)n * row_stride));
+    hipError_t e = hipMemcpy(d_x, x, (size_t)n * dim * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_quantize_rows(eng, d_x, dim, n, dim, lo, hi, d_c, row_stride, d_m, nullptr, 0);
+    std::vector<uint8_t> dev((size_t)n * row_stride);
+    if (e == hipSuccess) e = hipMemcpy(dev.data(), d_c, dev.size(), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(mags, d_m, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)(void)hipFree(d_x); (void)hipFree(d_m); (void)hipFree(d_c);
+    HIP_TRY(e);
+    const size_t cb = cos_code_bytes(storage, resolution, dim);
+    for (size_t r = 0; r < n; r++) row_to_reference_layout(eng, dim, dev.data() + r * row_stride, (uint8_t *)codes + r * cb);
+    return COS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// entry points whose kernels live in other translation units (weak stubs until they are linked in)
+// ------------------------------------------------------------------------------------------------
+#define COS_WEAK_STUB __attribute__((weak))
+extern "C" COS_WEAK_STUB int32_t cos_index_build(cos_index *, uint32_t) { return fail(COS_ERR_UNIMPLEMENTED, "cos_index_build: builder kernels not linked"); }
+extern "C" COS_WEAK_STUB int32_t cos_distance_batch(uint32_t, uint32_t, uint32_t, uint32_t, const void *, const float *, uint32_t, const void *,
+                                                    const float *, uint32_t, const uint32_t *, const uint32_t *, uint32_t, float *, int32_t *) {
+    return fail(COS_ERR_UNIMPLEMENTED, "cos_distance_batch: kernels not linked");
+}
+extern "C" COS_WEAK_STUB int32_t cos_bruteforce_topk(cos_index *, const float *, uint32_t, uint32_t, uint32_t *, float *) {
+    return fail(COS_ERR_UNIMPLEMENTED, "cos_bruteforce_topk: kernels not linked");
+}
+extern "C" COS_WEAK_STUB int32_t cos_bm25_create(int32_t, const uint32_t *, const uint64_t *, uint32_t, const uint32_t *, const float *, uint32_t,
+                                                 cos_bm25 **) {
+    return fail(COS_ERR_UNIMPLEMENTED, "cos_bm25_create: kernels not linked");
+}
+extern "C" COS_WEAK_STUB int32_t cos_bm25_destroy(cos_bm25 *) { return COS_OK; }
+extern "C" COS_WEAK_STUB int32_t cos_bm25_search_batch(cos_bm25 *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t *, float *,
+                                                       uint32_t *) {
+    return fail(COS_ERR_UNIMPLEMENTED, "cos_bm25_search_batch: kernels not linked");
+}
+extern "C" COS_WEAK_STUB int32_t cos_rrf_fuse_batch(const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, uint32_t,
+                                                    uint32_t, float, uint32_t, uint32_t *, float *, uint32_t *) {
+    return fail(COS_ERR_UNIMPLEMENTED, "cos_rrf_fuse_batch: kernels not linked");
+}
+extern "C" COS_WEAK_STUB int32_t cos_merge_topk_device(const uint32_t *, const float *, const uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t *,
+                                                       float *, uint32_t *, int32_t, void *) {
+    return fail(COS_ERR_UNIMPLEMENTED, "cos_merge_topk_device: kernels not linked");
+}

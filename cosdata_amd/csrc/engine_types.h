@@ -1,0 +1,59 @@
+// engine_types.h — POD structs passed by value to the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+#include "device_common.h"
+
+namespace cosdev {
+
+// One HNSW level in HBM (mirrors prob_node.rs:97-109 as flat arrays, slot order preserved).
+struct LevelDev {
+    const u32 *adj_vec;  // [n][M] neighbour's VECTOR ROW (root = row N), ROW_EMPTY = null slot
+    const u32 *adj_node; // [n][M] neighbour's node index within this level (level 0: == adj_vec)
+    const u32 *node_vec; // [n]    node index -> vector row (level 0: nullptr, identity)
+    const u32 *child;    // [n]    node index one level down (level 0: nullptr)
+    u32 n;
+    u32 M;
+    u32 root_idx;
+    u32 vis_word_off; // EXACT mode: offset (in u32 words) of this level's bitset inside a query's slab
+};
+
+struct IndexDev {
+    const uint8_t *codes; // [N+1][row_stride] device code layout, row N = root
+    const float *mags;    // [N+1]
+    const float *raw;     // [N][raw_stride_f] raw f32 (rerank)
+    const float *raw_mags; // [N] sqrt(sequential sum x*x) of raw rows
+    u64 row_stride;       // bytes
+    u64 raw_stride;       // floats
+    u32 n;                // vectors (root row index)
+    u32 dim;
+    u32 metric;
+    u32 storage;
+    u32 num_layers;
+    u32 shortlist;
+    u32 visited_mode;
+    u32 nchunks;   // 16-byte chunks per code row (integer engines)
+    u32 G;         // lanes per row (power of two, integer engines)
+    u32 id_base;
+    u32 vis_words_per_query; // EXACT mode slab size (u32 words)
+    LevelDev lv[MAX_LEVELS];
+};
+
+struct WalkArgs {
+    const uint8_t *qcodes; // query codes in the device layout, [*][row_stride]
+    const float *qmags;
+    const u32 *q_rows;   // optional: query b reads row q_rows[b] of qcodes/qmags (builder: corpus rows)
+    const u32 *self_ids; // optional: id pre-inserted in the visited filter (default COS_QUERY_ID)
+    u32 *vis_slab;       // EXACT mode: [B][vis_words_per_query], zeroed before launch
+    u32 B;
+    u32 ef;
+    u32 keep;            // 100 (search) / 64 (indexing)
+    // outputs: per (query, level) lists, top level first: slot = num_layers - level
+    u32 *out_ids;        // [B][L+1][keep] internal ids (local)
+    float *out_sims;     // [B][L+1][keep]
+    u32 *out_nodes;      // optional [B][L+1][keep] node index within the level (builder)
+    u32 *out_counts;     // [B][L+1]
+    int32_t *out_status; // [B]
+    u64 *out_stats;      // [B][4]: evals, expansions, adj_bytes, reserved
+};
+
+} // namespace cosdev

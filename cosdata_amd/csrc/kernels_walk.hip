@@ -1,0 +1,690 @@
+// kernels_walk.hip — gfx950 kernels of the dense search path:
+//   quantize_rows  : ScalarQuantization::quantize           (quantization/scalar.rs:10-52)
+//   walk           : ann_search / traverse_find_nearest     (vector_store.rs:256-402, 1112-1204)
+//   finalize       : remove_duplicates_and_filter + finalize_ann_results
+//                                                           (models/common.rs:381-412, vector_store.rs:404-445)
+// One wavefront (64 lanes) owns one query: 64 lanes <-> the <=64 neighbour slots of an expansion
+// (level_0_neighbors_count = shortlist_size = 64, config.toml:21,32).  HBM-bound gather work:
+// adjacency rows and code rows are read with coalesced 16-byte-per-lane loads; the candidate pool
+// lives in registers, the visited filter and the popped list in LDS.  No MFMA here by design.
+//
+// Compile with -ffp-contract=off: the reference's arithmetic order (fused only where AVX2 FMA is
+// used, x86_64.rs:418-444) is reproduced with explicit __fmaf_rn / __fmul_rn / __fadd_rn.
+#include <hip/hip_runtime.h>
+#include "engine_types.h"
+
+using namespace cosdev;
+
+#define COS_OK 0
+#define COS_ERR_CALCULATION 2
+#define COS_QUERY_ID 0xFFFFFFFEu
+#define COS_ROOT_ID 0xFFFFFFFFu
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Rust `as` casts and f32::max/min
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t rust_f32_as_u8(float v) {
+    if (!(v == v)) return 0;
+    if (v <= 0.0f) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)(int)v;
+}
+__device__ __forceinline__ u32 rust_f32_as_usize_low2(float v) { // low 2 bits of `v as usize` (saturating, NaN -> 0)
+    if (!(v == v)) return 0;
+    if (v <= 0.0f) return 0;
+    if (v >= 18446744073709551616.0f) return 3u;
+    return (u32)((u64)v & 3ull);
+}
+__device__ __forceinline__ float rust_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+__device__ __forceinline__ float rust_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+
+// sqrt(sequential, non-fused sum of x*x): scalar.rs:31,41,45 / vector_store.rs:414,426.  Executed by ONE lane.
+__device__ __forceinline__ float seq_norm(const float *x, u32 n) {
+    float acc = -0.0f;
+    for (u32 i = 0; i < n; i++) acc = __fadd_rn(acc, __fmul_rn(x[i], x[i]));
+    return sqrtf(acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// quantize_rows: one wave per row.  Writes the DEVICE code layout:
+//   U8  : dim bytes, zero padded to a multiple of 16
+//   Q2  : per 64-dim chunk 16 bytes = [plane0 (MSB as quantize_to_u8_bits stores it) 8 B | plane1 8 B]
+//   F32 : dim floats, zero padded to a multiple of 16 bytes
+// ------------------------------------------------------------------------------------------------
+template <int ENG>
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restrict__ x, u64 x_stride, u32 n, u32 dim, float lo,
+                                                            float hi, uint8_t *__restrict__ codes, u64 row_stride,
+                                                            float *__restrict__ mags, float *__restrict__ raw_mags) {
+    const int lane = threadIdx.x & 63;
+    const u32 row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *xr = x + (u64)row * x_stride;
+    uint8_t *cr = codes + (u64)row * row_stride;
+    float rn = 0.0f;
+    const bool need_seq = (raw_mags != nullptr) || (ENG != ENG_U8);
+    if (need_seq && lane == 0) rn = seq_norm(xr, dim);
+    if (raw_mags && lane == 0) raw_mags[row] = rn;
+    if constexpr (ENG == ENG_U8) {
+        u32 ss = 0;
+        for (u32 i = lane; i < (u32)row_stride; i += 64) {
+            uint8_t q = 0;
+            if (i < dim) {
+                float c = rust_min(rust_max(xr[i], lo), hi);
+                float v = __fmul_rn(__fdiv_rn(__fsub_rn(c, lo), __fsub_rn(hi, lo)), 255.0f);
+                q = rust_f32_as_u8(v);
+            }
+            cr[i] = q;
+            ss += (u32)q * (u32)q;
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) ss += (u32)__shfl_xor((int)ss, m, 64);
+        if (lane == 0) mags[row] = sqrtf((float)ss); // (sum::<u32>() as f32).sqrt()
+    } else if constexpr (ENG == ENG_Q2) {
+        const u32 nch = (u32)(row_stride / 16);
+        for (u32 c = 0; c < nch; c++) {
+            u32 i = c * 64 + lane;
+            u32 lvl = 0;
+            if (i < dim) lvl = rust_f32_as_usize_low2(floorf(__fdiv_rn(__fadd_rn(xr[i], 1.0f), 0.5f))); // step = 2/4
+            u64 p0 = __ballot((lvl >> 1) & 1u); // plane 0 = MSB (common.rs:230-233)
+            u64 p1 = __ballot(lvl & 1u);
+            if (lane == 0) {
+                *(u64 *)(cr + (u64)c * 16) = p0;
+                *(u64 *)(cr + (u64)c * 16 + 8) = p1;
+            }
+        }
+        if (lane == 0) mags[row] = rn; // norm of the ORIGINAL vector (scalar.rs:31-32)
+    } else {
+        float *cf = (float *)cr;
+        for (u32 i = lane; i < (u32)(row_stride / 4); i += 64) cf[i] = i < dim ? xr[i] : 0.0f;
+        if (lane == 0) mags[row] = rn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// integer dot engines: G lanes cooperate on one code row, 16 bytes per lane per chunk
+// ------------------------------------------------------------------------------------------------
+template <int ENG>
+__device__ __forceinline__ u32 chunk_dot(uint4 q, uint4 y, u32 acc);
+
+template <>
+__device__ __forceinline__ u32 chunk_dot<ENG_U8>(uint4 q, uint4 y, u32 acc) { // dot_product_u8 (x86_64.rs:22-66): exact integer
+    acc = __builtin_amdgcn_udot4(q.x, y.x, acc, false);
+    acc = __builtin_amdgcn_udot4(q.y, y.y, acc, false);
+    acc = __builtin_amdgcn_udot4(q.z, y.z, acc, false);
+    acc = __builtin_amdgcn_udot4(q.w, y.w, acc, false);
+    return acc;
+}
+template <>
+__device__ __forceinline__ u32 chunk_dot<ENG_Q2>(uint4 q, uint4 y, u32 acc) { // dot_product_quaternary (dot_product.rs:35-57)
+    // plane 0 is what the reference multiplies as "lsb", plane 1 as "msb"
+    u64 xl = ((u64)q.y << 32) | q.x, xm = ((u64)q.w << 32) | q.z;
+    u64 yl = ((u64)y.y << 32) | y.x, ym = ((u64)y.w << 32) | y.z;
+    u64 mid1 = xl & ym, mid2 = yl & xm;
+    u32 lsbs = (u32)__popcll(xl & yl), carry = (u32)__popcll(mid1 & mid2);
+    u32 msbs = (u32)__popcll(xm & ym), mid = (u32)__popcll(mid1 ^ mid2);
+    return acc + (msbs << 2) + (carry << 2) + (mid << 1) + lsbs;
+}
+
+// reference-order f32 dot (dot_product_f32_simd, x86_64.rs:418-444) by a PAIR of lanes:
+// even lane owns accumulators 0..3, odd lane 4..7; returns the full dot in both lanes.
+__device__ __forceinline__ float f32_pair_dot(const float *__restrict__ row, const float *__restrict__ q_lds, u32 dim, int half) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const u32 chunks = dim >> 3;
+    const float4 *rp = (const float4 *)row + half;
+    const float4 *qp = (const float4 *)q_lds + half;
+    u32 c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+        float4 y[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) y[u] = rp[2 * (c + u)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            float4 qv = qp[2 * (c + u)];
+            a0 = __fmaf_rn(qv.x, y[u].x, a0);
+            a1 = __fmaf_rn(qv.y, y[u].y, a1);
+            a2 = __fmaf_rn(qv.z, y[u].z, a2);
+            a3 = __fmaf_rn(qv.w, y[u].w, a3);
+        }
+    }
+    for (; c < chunks; c++) {
+        float4 yv = rp[2 * c], qv = qp[2 * c];
+        a0 = __fmaf_rn(qv.x, yv.x, a0);
+        a1 = __fmaf_rn(qv.y, yv.y, a1);
+        a2 = __fmaf_rn(qv.z, yv.z, a2);
+        a3 = __fmaf_rn(qv.w, yv.w, a3);
+    }
+    float t = __fadd_rn(__fadd_rn(a0, a1), __fadd_rn(a2, a3)); // (s0+s1)+(s2+s3) | (s4+s5)+(s6+s7)
+    float r = __fadd_rn(t, __shfl_xor(t, 1, 64));               // low half + high half
+    for (u32 i = chunks * 8; i < dim; i++) r = __fadd_rn(r, __fmul_rn(q_lds[i], row[i])); // scalar tail, non-fused
+    return r;
+}
+
+constexpr int PB = 8; // code rows in flight per lane group before the dots are consumed
+
+// ------------------------------------------------------------------------------------------------
+// walk kernel
+// ------------------------------------------------------------------------------------------------
+struct WalkSmem {
+    u32 *vis;     // visited filter words (REF mode)
+    u64 *res;     // popped (key, node) list, ef entries
+    u32 *wl_vec;  // winners of the current expansion: vector rows
+    u32 *wl_node; //                                     node indices
+    float *qf;    // F32 engine: the query vector
+};
+
+template <int ENG, int CH, int R>
+__global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkArgs wa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const u32 qi = blockIdx.x;
+    if (qi >= wa.B) return;
+
+    const u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
+    WalkSmem sm;
+    {
+        unsigned char *p = smem_raw;
+        sm.vis = (u32 *)p;      p += (size_t)Mmax * 8;
+        sm.res = (u64 *)p;      p += (size_t)wa.ef * 8;
+        sm.wl_vec = (u32 *)p;   p += 64 * 4;
+        sm.wl_node = (u32 *)p;  p += 64 * 4;
+        p = (unsigned char *)(((size_t)p + 15) & ~(size_t)15);
+        sm.qf = (float *)p;
+    }
+
+    const u32 qrow = wa.q_rows ? wa.q_rows[qi] : qi;
+    const u32 self_id = wa.self_ids ? wa.self_ids[qi] : COS_QUERY_ID;
+    const uint8_t *qcode = wa.qcodes + (u64)qrow * ix.row_stride;
+    const float qmag = wa.qmags[qrow];
+    const u32 N = ix.n;
+    const u32 L = ix.num_layers;
+    const u32 metric = ix.metric;
+    const bool exact = ix.visited_mode != 0;
+    u32 *vis_slab = exact ? wa.vis_slab + (u64)qi * ix.vis_words_per_query : nullptr;
+
+    // ---- engine set-up -------------------------------------------------------------------------
+    const int G = (ENG == ENG_F32) ? 2 : (int)ix.G;
+    const int lig = lane & (G - 1);  // lane in group
+    const int grp = lane / G;        // group index
+    const int RP = 64 / G;           // rows per pass
+    uint4 qreg[CH];
+    if constexpr (ENG != ENG_F32) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            u32 chunk = (u32)lig + (u32)c * (u32)G;
+            qreg[c] = chunk < ix.nchunks ? *(const uint4 *)(qcode + (u64)chunk * 16) : make_uint4(0, 0, 0, 0);
+        }
+    } else {
+        const float *qg = (const float *)qcode;
+        for (u32 i = lane; i < (u32)(ix.row_stride / 4); i += 64) sm.qf[i] = qg[i];
+        __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+        for (int c = 0; c < CH; c++) qreg[c] = make_uint4(0, 0, 0, 0);
+    }
+
+    u64 n_evals = 0, n_exp = 0, adj_bytes = 0;
+    int32_t status = COS_OK;
+    u32 entry = ix.lv[L].root_idx;
+
+    // distance of ONE row computed by group 0 (entry node); result valid in every lane
+    auto single_distance = [&](u32 row, float &sim_out) -> bool {
+        float dotf;
+        if constexpr (ENG != ENG_F32) {
+            u32 acc = 0;
+            if (grp == 0) {
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    u32 chunk = (u32)lig + (u32)c * (u32)G;
+                    if (chunk < ix.nchunks) acc = chunk_dot<ENG>(qreg[c], *(const uint4 *)(ix.codes + (u64)row * ix.row_stride + (u64)chunk * 16), acc);
+                }
+            }
+            for (int m = G >> 1; m > 0; m >>= 1) acc += (u32)__shfl_xor((int)acc, m, 64);
+            acc = readlane_u32(acc, 0);
+            dotf = (float)acc; // integer dot `as f32` (RNE)
+        } else {
+            float d = f32_pair_dot((const float *)(ix.codes + (u64)row * ix.row_stride), sm.qf, ix.dim, lane & 1);
+            dotf = __uint_as_float(readlane_u32(__float_as_uint(d), 0));
+        }
+        if (metric == 0u) { // cosine_similarity_from_dot_product (cosine.rs:223-235)
+            float den = __fmul_rn(qmag, ix.mags[row]);
+            if (den == 0.0f) return false;
+            sim_out = __fdiv_rn(dotf, den);
+        } else {
+            sim_out = dotf; // DotProductDistance (dotproduct.rs:14-64)
+        }
+        return true;
+    };
+
+    for (int level = (int)L; level >= 0; level--) {
+        const LevelDev lv = ix.lv[level];
+        const u32 M = lv.M;
+        const u32 slots = M < ix.shortlist ? M : ix.shortlist;
+        const u32 bitmask = 64u * M - 1u;
+        u32 *vis = exact ? (vis_slab + lv.vis_word_off) : sm.vis;
+        const u32 out_slot = L - (u32)level;
+
+        // fresh visited filter, pre-seeded with the query / new-node id (vector_store.rs:266-271, :807)
+        if (!exact) {
+            for (u32 w = lane; w < 2 * M; w += 64) sm.vis[w] = 0;
+            if (lane == 0) {
+                u32 b = self_id & bitmask;
+                sm.vis[b >> 5] |= 1u << (b & 31);
+            }
+        }
+
+        Pool<R> pool;
+        pool.clear();
+        u32 npool = 0, npop = 0;
+
+        // start node (vector_store.rs:1144-1148)
+        {
+            const u32 erow = lv.node_vec ? lv.node_vec[entry] : entry;
+            float s0;
+            n_evals++;
+            if (!single_distance(erow, s0)) { status = COS_ERR_CALCULATION; break; }
+            const u32 eid = erow == N ? COS_ROOT_ID : erow;
+            if (lane == 0) {
+                if (!exact) { u32 b = eid & bitmask; sm.vis[b >> 5] |= 1u << (b & 31); }
+                else atomicOr(&vis[entry >> 5], 1u << (entry & 31));
+            }
+            pool.insert_at(pack_key(metric_key(metric, s0), entry), 0, lane);
+            npool = 1;
+        }
+
+        bool failed = false;
+        while (npool > 0) {
+            const u64 cur = pool.head();
+            pool.pop_head(lane);
+            npool--;
+            if (npop >= wa.ef) break; // the popped element is discarded (vector_store.rs:1151-1153)
+            if (lane == 0) sm.res[npop] = cur;
+            npop++;
+            n_exp++;
+            adj_bytes += (u64)M * 4;
+            const u32 node = (u32)cur;
+            const int limit = (int)wa.ef - (int)npop; // future pops still allowed
+
+            // neighbour slots in slot order, one per lane (vector_store.rs:1161-1171)
+            u32 nb_vec = ROW_EMPTY, nb_node = ROW_EMPTY;
+            if ((u32)lane < slots) {
+                nb_vec = lv.adj_vec[(u64)node * M + lane];
+                nb_node = lv.adj_node[(u64)node * M + lane];
+            }
+            const bool valid = nb_vec != ROW_EMPTY;
+            bool win;
+            if (!exact) {
+                // PerformantFixedSet: bucket=(id>>6)&(M-1), bit=id&63  <=> linear bit id & (64M-1)
+                const u32 id = nb_vec == N ? COS_ROOT_ID : nb_vec;
+                const u32 bit = id & bitmask;
+                const u32 word = bit >> 5, msk = 1u << (bit & 31);
+                const bool pre = valid && (sm.vis[word] & msk);
+                const bool cand = valid && !pre;
+                u32 old = 0;
+                if (cand) old = atomicOr(&sm.vis[word], msk);
+                const bool lost = cand && (old & msk);
+                win = cand && !lost;
+                u64 lostmask = __ballot(lost);
+                // two slots of this expansion alias the same residue: the LOWER slot wins (sequential scan order)
+                while (lostmask) {
+                    const int l = __ffsll((long long)lostmask) - 1;
+                    const u32 b = readlane_u32(bit, l);
+                    const u64 g = __ballot(cand && bit == b);
+                    const int w = __ffsll((long long)g) - 1;
+                    if (cand && bit == b) win = (lane == w);
+                    lostmask &= ~g;
+                }
+            } else {
+                bool pre = false;
+                if (valid) pre = (vis[nb_node >> 5] >> (nb_node & 31)) & 1u;
+                win = valid && !pre;
+                if (win) atomicOr(&vis[nb_node >> 5], 1u << (nb_node & 31));
+            }
+
+            // compact winners (slot order) into LDS
+            const u64 wmask = __ballot(win);
+            const int W = __popcll(wmask);
+            if (win) {
+                const int rank = __popcll(wmask & ((1ull << lane) - 1ull));
+                sm.wl_vec[rank] = nb_vec;
+                sm.wl_node[rank] = nb_node;
+            }
+            n_evals += (u64)W;
+
+            // evaluate winners: RP rows per pass, PB passes in flight
+            for (int base = 0; base < W; base += RP * PB) {
+                u32 prow[PB];
+                float pmag[PB];
+                uint4 buf[PB][CH];
+                float fdot[PB];
+#pragma unroll
+                for (int p = 0; p < PB; p++) {
+                    const int my = base + p * RP + grp;
+                    const bool v = my < W;
+                    prow[p] = v ? sm.wl_vec[my] : 0u;
+                    pmag[p] = 1.0f;
+                    if (v) pmag[p] = ix.mags[prow[p]];
+                    if constexpr (ENG != ENG_F32) {
+#pragma unroll
+                        for (int c = 0; c < CH; c++) {
+                            u32 chunk = (u32)lig + (u32)c * (u32)G;
+                            buf[p][c] = make_uint4(0, 0, 0, 0);
+                            if (v && chunk < ix.nchunks) buf[p][c] = *(const uint4 *)(ix.codes + (u64)prow[p] * ix.row_stride + (u64)chunk * 16);
+                        }
+                    }
+                }
+                if constexpr (ENG == ENG_F32) {
+                    // every lane pair must run the (uniform-trip-count) dot; invalid pairs read row 0 and are ignored
+#pragma unroll
+                    for (int p = 0; p < PB; p++) {
+                        if (base + p * RP < W)
+                            fdot[p] = f32_pair_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 1);
+                        else
+                            fdot[p] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < PB; p++) {
+                    if (base + p * RP >= W) break; // wave-uniform
+                    float dotf;
+                    if constexpr (ENG != ENG_F32) {
+                        u32 acc = 0;
+#pragma unroll
+                        for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
+                        for (int m = G >> 1; m > 0; m >>= 1) acc += (u32)__shfl_xor((int)acc, m, 64);
+                        dotf = (float)acc;
+                    } else {
+                        dotf = fdot[p];
+                    }
+                    float sim;
+                    bool bad = false;
+                    if (metric == 0u) {
+                        const float den = __fmul_rn(qmag, pmag[p]);
+                        const int my = base + p * RP + grp;
+                        bad = (my < W) && (den == 0.0f);
+                        sim = __fdiv_rn(dotf, den);
+                    } else {
+                        sim = dotf;
+                    }
+                    if (__any(bad)) { failed = true; break; }
+                    const u32 key = metric_key(metric, sim);
+                    // insert this pass's rows in winner order
+                    for (int g = 0; g < RP; g++) {
+                        const int my = base + p * RP + g;
+                        if (my >= W) break;
+                        const u32 k = readlane_u32(key, g * G);
+                        const u64 kk = pack_key(k, sm.wl_node[my]);
+                        const int pos = pool.rank_of(kk);
+                        if (pos < limit) {
+                            pool.insert_at(kk, pos, lane);
+                            if (npool < (u32)(64 * R)) npool++;
+                        }
+                    }
+                }
+                if (failed) break;
+            }
+            if (failed) break;
+        }
+        if (failed) { status = COS_ERR_CALCULATION; break; }
+
+        // keep the best `keep`, sorted descending (vector_store.rs:1194-1201)
+        u64 rk[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const u32 e = (u32)lane * R + r;
+            rk[r] = e < npop ? sm.res[e] : 0ull;
+        }
+        bitonic_sort_desc<R>(rk, lane);
+        u32 cnt = npop < wa.keep ? npop : wa.keep;
+        // npop == 0 only if ef == 0: fall back to the entry node's own distance (vector_store.rs:329-380)
+        if (npop == 0) {
+            const u32 erow = lv.node_vec ? lv.node_vec[entry] : entry;
+            float s0;
+            if (!single_distance(erow, s0)) { status = COS_ERR_CALCULATION; break; }
+            rk[0] = lane == 0 ? pack_key(metric_key(metric, s0), entry) : 0ull;
+            cnt = 1;
+        }
+        const u64 obase = ((u64)qi * (L + 1) + out_slot) * wa.keep;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const u32 e = (u32)lane * R + r;
+            if (e < cnt) {
+                const u32 nd = (u32)rk[r];
+                const u32 vrow = lv.node_vec ? lv.node_vec[nd] : nd;
+                wa.out_ids[obase + e] = vrow == N ? COS_ROOT_ID : vrow;
+                wa.out_sims[obase + e] = metric_key_inv(metric, (u32)(rk[r] >> 32));
+                if (wa.out_nodes) wa.out_nodes[obase + e] = nd;
+            }
+        }
+        if (lane == 0) wa.out_counts[(u64)qi * (L + 1) + out_slot] = cnt;
+        // descend through the best hit's child link (vector_store.rs:382-385)
+        if (level > 0) {
+            const u32 best = (u32)readlane_u64(rk[0], 0);
+            entry = lv.child[best];
+        }
+    }
+
+    if (lane == 0) {
+        wa.out_status[qi] = status;
+        if (wa.out_stats) {
+            wa.out_stats[(u64)qi * 4 + 0] = n_evals;
+            wa.out_stats[(u64)qi * 4 + 1] = n_exp;
+            wa.out_stats[(u64)qi * 4 + 2] = adj_bytes;
+            wa.out_stats[(u64)qi * 4 + 3] = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: one wave per query.
+//   remove_duplicates_and_filter: first-seen dedup, drop root, sort desc by quantized score, keep 5k
+//   finalize_ann_results: cs = dot_f32(q, raw) / (|q| * |raw|) in the reference order, sort desc, top k
+// ------------------------------------------------------------------------------------------------
+struct FinalizeArgs {
+    const float *queries; // raw f32 [B][q_stride]
+    u64 q_stride;
+    const float *q_raw_mags; // [B] sqrt(seq sum q*q)
+    const u32 *walk_ids;     // [B][L+1][100]
+    const float *walk_sims;
+    const u32 *walk_counts;  // [B][L+1]
+    const int32_t *walk_status;
+    u32 B, top_k;
+    u32 *out_ids;     // [B][top_k] (id_base + local id)
+    float *out_scores;
+    u32 *out_counts;
+    int32_t *out_status;
+    u64 *out_rerank_rows; // [B]
+};
+
+template <int FR>
+__global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const FinalizeArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const u32 qi = blockIdx.x;
+    if (qi >= fa.B) return;
+    const u32 L = ix.num_layers;
+    const u32 metric = ix.metric;
+    float *qf = (float *)smem_raw;                                   // dim floats (padded to 16 B)
+    u32 *cand = (u32 *)(smem_raw + (((size_t)ix.dim * 4 + 15) & ~(size_t)15)); // 64*FR candidate ids
+
+    const int32_t wst = fa.walk_status[qi];
+    if (wst != COS_OK) {
+        if (lane == 0) { fa.out_status[qi] = wst; fa.out_counts[qi] = 0; if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = 0; }
+        return;
+    }
+    const float *q = fa.queries + (u64)qi * fa.q_stride;
+    for (u32 i = lane; i < ix.dim; i += 64) qf[i] = q[i];
+
+    // gather the concatenated per-level lists (top level first) as (key, id) pairs
+    u64 k[FR];
+#pragma unroll
+    for (int r = 0; r < FR; r++) k[r] = 0ull;
+    {
+        u32 off = 0;
+        for (u32 s = 0; s <= L; s++) {
+            const u32 c = fa.walk_counts[(u64)qi * (L + 1) + s];
+            const u64 b = ((u64)qi * (L + 1) + s) * KEEP_SEARCH;
+            // element index off + j  lives in lane (off+j)/FR, register (off+j)%FR
+#pragma unroll
+            for (int r = 0; r < FR; r++) {
+                const u32 e = (u32)lane * FR + r;
+                if (e >= off && e < off + c) {
+                    const u32 j = e - off;
+                    const u32 id = fa.walk_ids[b + j];
+                    const float sv = fa.walk_sims[b + j];
+                    k[r] = id == COS_ROOT_ID ? 0ull : pack_key(metric_key(metric, sv), id); // root filtered (common.rs:397)
+                }
+            }
+            off += c;
+        }
+    }
+    bitonic_sort_desc<FR>(k, lane);
+    // duplicates of a node carry identical (score, id) keys and are adjacent after the sort: keep the first
+    const u64 prev_last = shfl_up1_u64(k[FR - 1]);
+    u32 keepbits = 0;
+#pragma unroll
+    for (int r = 0; r < FR; r++) {
+        const u64 prev = (r == 0) ? (lane == 0 ? ~0ull : prev_last) : k[r > 0 ? r - 1 : 0];
+        if (k[r] != 0ull && k[r] != prev) keepbits |= 1u << r;
+    }
+    // exclusive prefix of kept counts across lanes
+    const u32 mine = (u32)__popc(keepbits);
+    u32 incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = (u32)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    u32 pos = incl - mine;
+    const u32 total = readlane_u32(incl, 63);
+    const u32 want = 5u * fa.top_k; // truncate(5*k) (common.rs:409)
+    const u32 ncand = total < want ? total : want;
+#pragma unroll
+    for (int r = 0; r < FR; r++) {
+        if (keepbits & (1u << r)) {
+            if (pos < ncand) cand[pos] = (u32)k[r];
+            pos++;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    // exact rerank on raw f32 (vector_store.rs:404-445); 32 candidates per pass (one lane pair each)
+    const float mag_query = fa.q_raw_mags[qi];
+    u64 rk[FR];
+#pragma unroll
+    for (int r = 0; r < FR; r++) rk[r] = 0ull;
+    const int pair = lane >> 1;
+    for (u32 base = 0; base < ncand; base += 32) {
+        const u32 my = base + (u32)pair;
+        const u32 id = my < ncand ? cand[my] : 0u;
+        const float dp = f32_pair_dot(ix.raw + (u64)id * ix.raw_stride, qf, ix.dim, lane & 1);
+        const float cs = __fdiv_rn(dp, __fmul_rn(mag_query, ix.raw_mags[id]));
+        const u64 key = pack_key(simkey(cs), id); // results.sort_unstable_by(total_cmp) desc; larger id first on ties
+        // scatter into the blocked register layout: element my -> lane my/FR, reg my%FR
+        for (u32 j = 0; j < 32 && base + j < ncand; j++) {
+            const u64 kv = readlane_u64(key, (int)(2 * j));
+            const u32 e = base + j;
+            if ((u32)lane == e / FR) {
+#pragma unroll
+                for (int r = 0; r < FR; r++)
+                    if ((e % FR) == (u32)r) rk[r] = kv;
+            }
+        }
+    }
+    bitonic_sort_desc<FR>(rk, lane);
+    const u32 nout = ncand < fa.top_k ? ncand : fa.top_k;
+#pragma unroll
+    for (int r = 0; r < FR; r++) {
+        const u32 e = (u32)lane * FR + r;
+        if (e < nout) {
+            fa.out_ids[(u64)qi * fa.top_k + e] = (u32)rk[r] + ix.id_base;
+            fa.out_scores[(u64)qi * fa.top_k + e] = simkey_inv((u32)(rk[r] >> 32));
+        }
+    }
+    if (lane == 0) {
+        fa.out_counts[qi] = nout;
+        fa.out_status[qi] = COS_OK;
+        if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = ncand;
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (called from engine.hip)
+// ------------------------------------------------------------------------------------------------
+namespace cosdev {
+
+hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
+                                u64 row_stride, float *mags, float *raw_mags, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    dim3 block(256), grid((n + 3) / 4);
+    switch (eng) {
+    case ENG_U8: hipLaunchKernelGGL(quantize_rows_kernel<ENG_U8>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
+    case ENG_Q2: hipLaunchKernelGGL(quantize_rows_kernel<ENG_Q2>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
+    case ENG_F32: hipLaunchKernelGGL(quantize_rows_kernel<ENG_F32>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
+    u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
+    size_t b = (size_t)Mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2;
+    b = (b + 15) & ~(size_t)15;
+    if (eng == ENG_F32) b += (size_t)ix.row_stride;
+    return b + 16;
+}
+
+template <int ENG, int CH>
+static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
+    const size_t smem = walk_smem_bytes(ix, wa.ef, ENG);
+    dim3 grid(wa.B), block(64);
+    if (wa.ef <= 64) hipLaunchKernelGGL((walk_kernel<ENG, CH, 1>), grid, block, smem, st, ix, wa);
+    else if (wa.ef <= 256) hipLaunchKernelGGL((walk_kernel<ENG, CH, 4>), grid, block, smem, st, ix, wa);
+    else if (wa.ef <= 512) hipLaunchKernelGGL((walk_kernel<ENG, CH, 8>), grid, block, smem, st, ix, wa);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
+    if (wa.B == 0) return hipSuccess;
+    const u32 ch = eng == ENG_F32 ? 1 : (ix.nchunks + ix.G - 1) / ix.G;
+    switch (eng) {
+    case ENG_U8:
+        if (ch == 1) return launch_walk_r<ENG_U8, 1>(ix, wa, st);
+        if (ch == 2) return launch_walk_r<ENG_U8, 2>(ix, wa, st);
+        return hipErrorInvalidValue;
+    case ENG_Q2:
+        if (ch == 1) return launch_walk_r<ENG_Q2, 1>(ix, wa, st);
+        return hipErrorInvalidValue;
+    case ENG_F32: return launch_walk_r<ENG_F32, 1>(ix, wa, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
+                           const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
+                           u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
+                           hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    FinalizeArgs fa{queries, q_stride, q_raw_mags, walk_ids, walk_sims, walk_counts, walk_status, B, top_k,
+                    out_ids, out_scores, out_counts, out_status, out_rerank_rows};
+    const u32 total = (ix.num_layers + 1) * KEEP_SEARCH;
+    dim3 grid(B), block(64);
+    if (total <= 64 * 4) {
+        size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 4 * 4;
+        hipLaunchKernelGGL(finalize_kernel<4>, grid, block, smem, st, ix, fa);
+    } else if (total <= 64 * 16) {
+        size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 16 * 4;
+        hipLaunchKernelGGL(finalize_kernel<16>, grid, block, smem, st, ix, fa);
+    } else if (total <= 64 * 32) {
+        size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 32 * 4;
+        hipLaunchKernelGGL(finalize_kernel<32>, grid, block, smem, st, ix, fa);
+    } else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+} // namespace cosdev

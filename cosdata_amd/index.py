@@ -1,0 +1,264 @@
+"""Host-side mirror of the reference's operator interface for the dense search path.
+
+Names, argument meaning and error behaviour follow cosdata's Rust API (paths relative to the
+reference root) so the parity tests read like the reference's own:
+
+    HNSWHyperParams            src/indexes/hnsw/types.rs:10-17
+    DistanceMetric             src/models/types.rs:462-468
+    StorageType                src/quantization/mod.rs:20-25
+    HNSWIndex.search_internal  src/indexes/hnsw/mod.rs:390-440
+    HNSWIndex.batch_search     src/indexes/mod.rs:260-272
+    ScalarQuantization.quantize   src/quantization/scalar.rs:10-52
+
+Everything numeric happens in libcosdata_hip.so (hand-written gfx950 kernels) through the C ABI
+of include/cosdata_hip.h.  There is no CPU fallback here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import CosdataError, CosParams, CosSearchStats, check
+
+ROOT_ID, QUERY_ID, SLOT_EMPTY = 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFFFD
+VISITED_REF, VISITED_EXACT = 0, 1
+
+
+class DistanceMetric(enum.IntEnum):
+    Cosine = 0
+    Euclidean = 1
+    Hamming = 2
+    DotProduct = 3
+
+
+class StorageKind(enum.IntEnum):
+    UnsignedByte = 0
+    SubByte = 1
+    HalfPrecisionFP = 2
+    FullPrecisionFP = 3
+
+
+@dataclass(frozen=True)
+class StorageType:
+    """quantization::StorageType; SubByte carries its resolution (bits)."""
+    kind: StorageKind
+    resolution: int = 0
+
+    @staticmethod
+    def UnsignedByte():
+        return StorageType(StorageKind.UnsignedByte)
+
+    @staticmethod
+    def SubByte(resolution: int):
+        return StorageType(StorageKind.SubByte, resolution)
+
+    @staticmethod
+    def FullPrecisionFP():
+        return StorageType(StorageKind.FullPrecisionFP)
+
+    @staticmethod
+    def HalfPrecisionFP():
+        return StorageType(StorageKind.HalfPrecisionFP)
+
+
+@dataclass
+class HNSWHyperParams:
+    """indexes/hnsw/types.rs:10-17 with config.toml:20-24 defaults."""
+    num_layers: int = 9
+    ef_construction: int = 128
+    ef_search: int = 256
+    level_0_neighbors_count: int = 64
+    neighbors_count: int = 32
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class ScalarQuantization:
+    """QuantizationMetric::Scalar — quantize() runs the device kernel and returns codes in the
+    reference's Storage layout."""
+
+    @staticmethod
+    def quantize(vectors, storage_type: StorageType, values_range: Tuple[float, float]):
+        x = _c(np.atleast_2d(vectors), np.float32)
+        n, d = x.shape
+        cb = _lib.lib().cos_code_bytes(int(storage_type.kind), storage_type.resolution, d)
+        codes = np.zeros((n, cb), np.uint8)
+        mags = np.zeros(n, np.float32)
+        check(_lib.lib().cos_quantize_batch(int(storage_type.kind), storage_type.resolution, d, values_range[0], values_range[1],
+                                            _p(x), n, _p(codes), _p(mags)))
+        return codes, mags
+
+
+class HNSWIndex:
+    """Device-resident snapshot of one HNSW index (one shard)."""
+
+    def __init__(self, dim: int, hnsw_params: Optional[HNSWHyperParams] = None,
+                 distance_metric: DistanceMetric = DistanceMetric.Cosine,
+                 storage_type: StorageType = StorageType.UnsignedByte(),
+                 values_range: Tuple[float, float] = (-1.0, 1.0), shortlist_size: int = 64,
+                 visited_mode: int = VISITED_REF, device: int = 0, id_base: int = 0, seed: int = 42):
+        self.dim = dim
+        self.hnsw_params = hnsw_params or HNSWHyperParams()
+        self.distance_metric = distance_metric
+        self.storage_type = storage_type
+        self.values_range = values_range
+        hp = self.hnsw_params
+        self._params = CosParams(C.sizeof(CosParams), _lib.ABI_VERSION, dim, int(distance_metric), int(storage_type.kind),
+                                 storage_type.resolution, values_range[0], values_range[1], hp.num_layers, hp.neighbors_count,
+                                 hp.level_0_neighbors_count, hp.ef_construction, hp.ef_search, shortlist_size, visited_mode,
+                                 device, id_base, 0, seed)
+        self._h = C.c_void_p()
+        check(_lib.lib().cos_index_create(C.byref(self._params), C.byref(self._h)))
+        self.n = 0
+        self._keepalive = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().cos_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- uploads ----------------------------------------------------------------------------
+    def upload_vectors(self, raw):
+        raw = _c(raw, np.float32)
+        assert raw.ndim == 2 and raw.shape[1] == self.dim
+        check(_lib.lib().cos_index_upload_vectors(self._h, _p(raw), raw.shape[0], 0))
+        self.n = raw.shape[0]
+        return self
+
+    def upload_vectors_device(self, dev_ptr: int, n: int, keepalive=None):
+        """raw f32 [n][dim] already in HBM (e.g. a torch tensor's data_ptr()); borrowed, not copied."""
+        check(_lib.lib().cos_index_upload_vectors(self._h, C.c_void_p(dev_ptr), n, 1))
+        self.n = n
+        self._keepalive = keepalive
+        return self
+
+    def set_root(self, root_raw):
+        r = _c(root_raw, np.float32)
+        check(_lib.lib().cos_index_set_root(self._h, _p(r)))
+        return self
+
+    def level_M(self, level: int) -> int:
+        return self.hnsw_params.level_0_neighbors_count if level == 0 else self.hnsw_params.neighbors_count
+
+    def upload_graph_level(self, level: int, node_ids, nbr_ids):
+        ids, nbr = _c(node_ids, np.uint32), _c(nbr_ids, np.uint32)
+        assert nbr.shape == (ids.size, self.level_M(level))
+        check(_lib.lib().cos_index_upload_graph_level(self._h, level, ids.size, _p(ids), _p(nbr)))
+        return self
+
+    def upload_graph(self, levels: Sequence[Tuple[np.ndarray, np.ndarray]], root_raw):
+        self.set_root(root_raw)
+        for l, (ids, nbr) in enumerate(levels):
+            self.upload_graph_level(l, ids, nbr)
+        return self
+
+    def level_count(self, level: int) -> int:
+        n = C.c_uint32()
+        check(_lib.lib().cos_index_level_count(self._h, level, C.byref(n)))
+        return n.value
+
+    def download_graph(self):
+        out = []
+        for l in range(self.hnsw_params.num_layers + 1):
+            n = self.level_count(l)
+            ids = np.zeros(n, np.uint32)
+            nbr = np.zeros((n, self.level_M(l)), np.uint32)
+            check(_lib.lib().cos_index_download_graph_level(self._h, l, _p(ids), _p(nbr)))
+            out.append((ids, nbr))
+        return out
+
+    def download_root(self):
+        r = np.zeros(self.dim, np.float32)
+        check(_lib.lib().cos_index_download_root(self._h, _p(r)))
+        return r
+
+    def download_codes(self):
+        cb = _lib.lib().cos_code_bytes(int(self.storage_type.kind), self.storage_type.resolution, self.dim)
+        codes = np.zeros((self.n + 1, cb), np.uint8)
+        mags = np.zeros(self.n + 1, np.float32)
+        check(_lib.lib().cos_index_download_codes(self._h, _p(codes), _p(mags)))
+        return codes, mags
+
+    def build(self, batch_size: int = 0):
+        """vector_store::index_embeddings on the device."""
+        check(_lib.lib().cos_index_build(self._h, batch_size))
+        return self
+
+    # ---- search -----------------------------------------------------------------------------
+    def set_ef_search(self, ef: int):
+        check(_lib.lib().cos_index_set_ef_search(self._h, ef))
+        self.hnsw_params.ef_search = ef
+
+    def set_visited_mode(self, mode: int):
+        check(_lib.lib().cos_index_set_visited_mode(self._h, mode))
+
+    def batch_search(self, queries, top_k: int, return_status: bool = False):
+        """IndexOps::batch_search: [B][dim] raw f32 -> (ids [B][k], scores [B][k], counts [B]).
+        Raises CosdataError (status 2 = CalculationError) if any query fails, like the
+        reference's collect::<Result<_>>; return_status=True returns per-query statuses instead."""
+        q = _c(np.atleast_2d(queries), np.float32)
+        B = q.shape[0]
+        ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+        scores = np.zeros((B, top_k), np.float32)
+        counts = np.zeros(B, np.uint32)
+        status = np.zeros(B, np.int32)
+        rc = _lib.lib().cos_search_batch(self._h, _p(q), B, top_k, _p(ids), _p(scores), _p(counts), _p(status))
+        if return_status:
+            return ids, scores, counts, rc, status
+        check(rc)
+        return ids, scores, counts
+
+    def search_internal(self, query, top_k: int):
+        """HNSWIndex::search_internal for one query -> list of (internal_id, score)."""
+        ids, scores, counts = self.batch_search(np.asarray(query, np.float32)[None, :], top_k)
+        return [(int(ids[0, i]), float(scores[0, i])) for i in range(int(counts[0]))]
+
+    def batch_search_device(self, q_ptr: int, B: int, top_k: int, out_ids_ptr: int, out_scores_ptr: int, out_counts_ptr: int,
+                            out_status_ptr: int, stream: int = 0):
+        """Device-pointer variant (inputs resident in HBM, enqueued on `stream`, no sync)."""
+        check(_lib.lib().cos_search_batch_device(self._h, C.c_void_p(q_ptr), B, top_k, C.c_void_p(out_ids_ptr),
+                                                 C.c_void_p(out_scores_ptr), C.c_void_p(out_counts_ptr),
+                                                 C.c_void_p(out_status_ptr), C.c_void_p(stream)))
+
+    def ann_search_batch(self, queries):
+        """ann_search's per-level lists before finalisation: ids/sims [B][L+1][100], counts [B][L+1]."""
+        q = _c(np.atleast_2d(queries), np.float32)
+        B, L1 = q.shape[0], self.hnsw_params.num_layers + 1
+        ids = np.zeros((B, L1, 100), np.uint32)
+        sims = np.zeros((B, L1, 100), np.float32)
+        counts = np.zeros((B, L1), np.uint32)
+        status = np.zeros(B, np.int32)
+        check(_lib.lib().cos_ann_search_batch(self._h, _p(q), B, _p(ids), _p(sims), _p(counts), _p(status)))
+        return ids, sims, counts
+
+    def enable_timing(self, on: bool = True):
+        check(_lib.lib().cos_index_enable_timing(self._h, 1 if on else 0))
+
+    def last_stats(self, stream: int = 0) -> CosSearchStats:
+        st = CosSearchStats()
+        check(_lib.lib().cos_index_last_stats(self._h, C.c_void_p(stream), C.byref(st)))
+        return st
+
+    def bruteforce_topk(self, queries, k: int):
+        q = _c(np.atleast_2d(queries), np.float32)
+        ids = np.zeros((q.shape[0], k), np.uint32)
+        scores = np.zeros((q.shape[0], k), np.float32)
+        check(_lib.lib().cos_bruteforce_topk(self._h, _p(q), q.shape[0], k, _p(ids), _p(scores)))
+        return ids, scores

@@ -1,0 +1,197 @@
+/*
+ * cosdata_hip.h — C ABI of the MI355X-native ANN query engine for cosdata's dense/hybrid
+ * search path (libcosdata_hip.so, hand-written HIP kernels for gfx950).
+ *
+ * The reference (cosdata/cosdata @ 2025-09-19) has no FFI/plugin seam; this header introduces
+ * it at the L3<->L2 line of SURVEY.md §1.  Every entry point names the reference interface it
+ * stands behind (paths relative to the reference root).  INTEGRATION.md shows the Rust
+ * `extern "C"` block and the call sites a maintainer would redirect.
+ *
+ * Conventions
+ *   - plain pointers and sizes, POD structs with an explicit struct_size; no C++/torch types;
+ *   - every function returns a cos_status (0 = ok) and never unwinds or aborts across the ABI;
+ *     cos_last_error_string() gives a per-thread message for the last non-zero status;
+ *   - host buffers are borrowed for the duration of the call only; the library owns all device
+ *     memory behind the opaque handle (exception: COS_UPLOAD_BORROW_DEVICE);
+ *   - search entry points are thread-safe on a shared handle (the reference calls search from
+ *     rayon workers, indexes/mod.rs:268-271); uploads/builds are exclusive;
+ *   - internal ids follow the reference: vectors 0..n-1 (collection.rs:451-468, sequential),
+ *     root = 0xFFFFFFFF (vector_store.rs:47), query = 0xFFFFFFFE (indexes/hnsw/mod.rs:398).
+ */
+#ifndef COSDATA_HIP_H
+#define COSDATA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COS_ABI_VERSION 1u
+
+/* models/types.rs:462-468 DistanceMetric */
+typedef enum { COS_METRIC_COSINE = 0, COS_METRIC_EUCLIDEAN = 1, COS_METRIC_HAMMING = 2, COS_METRIC_DOT = 3 } cos_metric;
+/* quantization/mod.rs:20-25 StorageType; SubByte carries its resolution separately */
+typedef enum { COS_STORAGE_U8 = 0, COS_STORAGE_SUBBYTE = 1, COS_STORAGE_F16 = 2, COS_STORAGE_F32 = 3 } cos_storage;
+
+typedef enum {
+    COS_OK = 0,
+    COS_ERR_STORAGE_MISMATCH = 1, /* DistanceError::StorageMismatch  -> WaCustomError::QuantizationMismatch */
+    COS_ERR_CALCULATION = 2,      /* DistanceError::CalculationError (zero norm; cosine.rs:228-232)          */
+    COS_ERR_INVALID = 3,          /* bad params / sizes / ordering of an upload                              */
+    COS_ERR_UNIMPLEMENTED = 4,    /* arms the reference leaves `unimplemented!()` or not yet on the GPU      */
+    COS_ERR_HIP = 5,              /* HIP runtime error (message has the hipError string)                     */
+    COS_ERR_NOT_READY = 6,        /* search before vectors + graph are resident                              */
+    COS_ERR_NO_DEVICE = 7         /* no usable gfx950 device: the product path never falls back to the CPU   */
+} cos_status;
+
+#define COS_ROOT_ID 0xFFFFFFFFu
+#define COS_QUERY_ID 0xFFFFFFFEu
+#define COS_SLOT_EMPTY 0xFFFFFFFDu /* a null neighbour pointer (prob_node.rs:97) in flat graph uploads */
+
+/* visited-set semantics of the walk */
+#define COS_VISITED_REF 0u   /* PerformantFixedSet replica (models/fixedset.rs): 64*M-bit lossy filter -> ID parity */
+#define COS_VISITED_EXACT 1u /* exact visited set (recall mode; not ID-identical to the reference) */
+
+/* upload flags */
+#define COS_UPLOAD_DEFAULT 0u
+#define COS_UPLOAD_BORROW_DEVICE 1u /* raw f32 pointer is device memory the caller keeps alive; no copy */
+
+/* HNSWHyperParams (indexes/hnsw/types.rs:10-17) + the index fields search needs
+ * (indexes/hnsw/mod.rs:59-78) + config.search.shortlist_size (config.toml:32). */
+typedef struct {
+    uint32_t struct_size; /* = sizeof(cos_params) */
+    uint32_t abi_version; /* = COS_ABI_VERSION */
+    uint32_t dim;
+    uint32_t metric;     /* cos_metric */
+    uint32_t storage;    /* cos_storage */
+    uint32_t resolution; /* SubByte bits (1..3) */
+    float range_lo, range_hi; /* values_range */
+    uint32_t num_layers;             /* levels 0..num_layers */
+    uint32_t neighbors_count;        /* M  (power of two, <= 256) */
+    uint32_t level0_neighbors_count; /* M0 (power of two, <= 256) */
+    uint32_t ef_construction;
+    uint32_t ef_search;
+    uint32_t shortlist_size;
+    uint32_t visited_mode; /* COS_VISITED_* */
+    int32_t device;        /* HIP device ordinal */
+    uint32_t id_base;      /* shard support: global id of local vector 0; output ids = id_base + local id */
+    uint32_t reserved;
+    uint64_t seed;         /* GPU builder: level draws + root vector */
+} cos_params;
+
+typedef struct cos_index cos_index; /* opaque: one immutable device-resident index snapshot (one shard) */
+
+/* Per-batch counters written by the kernels; the roofline's ALGORITHMIC bytes come from these. */
+typedef struct {
+    uint64_t evals;        /* distance evaluations (walk) */
+    uint64_t expansions;   /* popped + expanded nodes */
+    uint64_t adj_bytes;    /* sum over expansions of M_level * 4 */
+    uint64_t rerank_rows;  /* raw f32 rows gathered by the exact rerank */
+    float walk_ms;         /* HIP-event time of the walk kernel of the last call on this stream (0 if timing off) */
+    float finalize_ms;
+    float prep_ms;
+    uint32_t reserved;
+} cos_search_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+/* api_service.rs:26 init_hnsw_index_for_collection -> HNSWIndex::new (indexes/hnsw/mod.rs:81). */
+int32_t cos_index_create(const cos_params *params, cos_index **out);
+int32_t cos_index_destroy(cos_index *ix);
+const char *cos_last_error_string(void);
+int32_t cos_device_count(int32_t *out);
+
+/* ---- data upload (host side of the snapshot; the Rust host walks its graph once) ------------ */
+/* Collection::index_embeddings' raw f32 values (collection.rs:368, get_raw_emb_by_internal_id) for
+ * internal ids [0,n).  The library quantizes them on the device with the index's StorageType
+ * (ScalarQuantization::quantize, quantization/scalar.rs:10-52) and keeps raw for the exact rerank. */
+int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uint32_t n, uint32_t flags);
+/* create_root_node's random vector (vector_store.rs:30-36), id u32::MAX. */
+int32_t cos_index_set_root(cos_index *ix, const float *root_raw);
+/* One HNSW level as flat arrays exported from ProbNode (prob_node.rs:97-109):
+ * node_ids[n_nodes] ascending with COS_ROOT_ID last; nbr_ids[n_nodes][M_level] in SLOT ORDER,
+ * COS_SLOT_EMPTY for null slots.  Level 0 must hold every vector.  Child links are implied
+ * (same id one level down, vector_store.rs:897-903). */
+int32_t cos_index_upload_graph_level(cos_index *ix, uint32_t level, uint32_t n_nodes, const uint32_t *node_ids,
+                                     const uint32_t *nbr_ids);
+int32_t cos_index_level_count(const cos_index *ix, uint32_t level, uint32_t *n_nodes);
+int32_t cos_index_download_graph_level(const cos_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids);
+/* quantized codes in the REFERENCE layout (SubByte plane-major) + mags, rows [0,n] (row n = root) */
+int32_t cos_index_download_codes(const cos_index *ix, void *codes, float *mags);
+int32_t cos_index_download_root(const cos_index *ix, float *root_raw);
+
+/* vector_store::index_embeddings (vector_store.rs:714) on the device: builds every level for the
+ * uploaded vectors with the reference's edge semantics, batch-synchronously. */
+int32_t cos_index_build(cos_index *ix, uint32_t batch_size);
+
+/* ---- search --------------------------------------------------------------------------------- */
+/* IndexOps::batch_search -> HNSWIndex::search_internal (indexes/mod.rs:260, indexes/hnsw/mod.rs:390):
+ * quantize query -> ann_search (every level, ef_search) -> finalize_ann_results (exact f32 rerank).
+ * queries [B][dim] raw f32; outputs [B][top_k] (internal id + id_base, cosine score), out_counts[B].
+ * Like the reference's collect::<Result<_>>, any failing query fails the call (first error
+ * returned); out_status[B] (optional) has the per-query cos_status. */
+int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                         float *out_scores, uint32_t *out_counts, int32_t *out_status);
+/* Same, all pointers DEVICE memory, enqueued on `stream` (hipStream_t) without synchronising.
+ * Statuses land in d_out_status[B] (required).  One in-flight batch per stream; concurrent host
+ * threads use distinct streams. */
+int32_t cos_search_batch_device(cos_index *ix, const float *d_queries, uint32_t B, uint32_t top_k, uint32_t *d_out_ids,
+                                float *d_out_scores, uint32_t *d_out_counts, int32_t *d_out_status, void *stream);
+/* ann_search's raw per-level output (vector_store.rs:256): ids/sims [B][(num_layers+1)][100],
+ * counts [B][num_layers+1], top level first.  Host buffers. */
+int32_t cos_ann_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t *out_ids, float *out_sims,
+                             uint32_t *out_counts, int32_t *out_status);
+int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef_search);
+int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode);
+/* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
+int32_t cos_index_enable_timing(cos_index *ix, int32_t on);
+int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out);
+
+/* ---- operators (L1 of SURVEY.md §1) --------------------------------------------------------- */
+/* QuantizationMetric::quantize (models/types.rs:504) for n vectors; codes in the REFERENCE layout
+ * (u8: dim bytes; SubByte: resolution planes x ceil(dim/8) bytes plane-major, plane 0 = MSB;
+ * f16: dim x 2; f32: dim x 4), mags[n].  Host buffers. */
+int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uint32_t dim, float range_lo, float range_hi,
+                           const float *x, uint32_t n, void *codes, float *mags);
+size_t cos_code_bytes(uint32_t storage, uint32_t resolution, uint32_t dim);
+/* DistanceMetric::calculate (models/types.rs:469) for explicit (x_i, y_j) pairs of stored vectors
+ * in the reference layout: out[p] = metric(x[pair_x[p]], y[pair_y[p]]); status[p] per pair. */
+int32_t cos_distance_batch(uint32_t metric, uint32_t storage, uint32_t resolution, uint32_t dim, const void *x_codes,
+                           const float *x_mags, uint32_t nx, const void *y_codes, const float *y_mags, uint32_t ny,
+                           const uint32_t *pair_x, const uint32_t *pair_y, uint32_t n_pairs, float *out,
+                           int32_t *status);
+/* exact brute-force cosine top-k on the resident raw vectors (ground truth for recall@k):
+ * MFMA f32 GEMM for candidate generation + reference-order re-score of the survivors. */
+int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t *out_ids,
+                            float *out_scores);
+
+/* ---- hybrid (config c5) --------------------------------------------------------------------- */
+typedef struct cos_bm25 cos_bm25;
+/* TFIDFIndexRoot postings as CSR (models/tf_idf_index.rs, versioned_vec.rs:208-224): term hashes
+ * ascending, offsets[T+1], (doc_id, stored tf) doc-id ascending within a term. */
+int32_t cos_bm25_create(int32_t device, const uint32_t *term_hashes, const uint64_t *offsets, uint32_t n_terms,
+                        const uint32_t *doc_ids, const float *tfs, uint32_t documents_count, cos_bm25 **out);
+int32_t cos_bm25_destroy(cos_bm25 *b);
+/* SparseAnnQueryBasic::search_bm25 (models/sparse_ann_query.rs:149) for B queries given as
+ * pre-hashed terms (CSR q_offsets[B+1] into q_terms); outputs [B][top_k]. */
+int32_t cos_bm25_search_batch(cos_bm25 *b, const uint32_t *q_terms, const uint32_t *q_offsets, uint32_t B,
+                              uint32_t top_k, uint32_t *out_ids, float *out_scores, uint32_t *out_counts);
+/* RRF fusion of hybrid_search (api/vectordb/search/repo.rs:311-340) for B queries. */
+int32_t cos_rrf_fuse_batch(const uint32_t *dense_ids, const uint32_t *dense_counts, uint32_t dense_stride,
+                           const uint32_t *sparse_ids, const uint32_t *sparse_counts, uint32_t sparse_stride, uint32_t B,
+                           float fusion_constant_k, uint32_t top_k, uint32_t *out_ids, float *out_scores,
+                           uint32_t *out_counts);
+
+/* ---- multi-GPU helper ----------------------------------------------------------------------- */
+/* S-way merge of per-shard top-k lists gathered by the caller's RCCL all-gather
+ * (SURVEY.md §8e): in [S][B][k] -> out [B][k], total_cmp desc, larger id first on ties.
+ * All pointers device memory; enqueued on stream. */
+int32_t cos_merge_topk_device(const uint32_t *d_ids, const float *d_scores, const uint32_t *d_counts, uint32_t S,
+                              uint32_t B, uint32_t k, uint32_t *d_out_ids, float *d_out_scores,
+                              uint32_t *d_out_counts, int32_t device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSDATA_HIP_H */

@@ -1,0 +1,88 @@
+"""GPU parity: the HIP path (through the C ABI) must match the oracle bit-exactly on identical inputs."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+STORAGES = [
+    ("u8", O.STORAGE_U8, 0),
+    ("q2", O.STORAGE_SUBBYTE, 2),
+    ("f32", O.STORAGE_F32, 0),
+]
+
+
+@pytest.mark.parametrize("name,storage,res", STORAGES)
+@pytest.mark.parametrize("dim", [96, 100, 768])
+def test_quantize_matches_oracle(name, storage, res, dim):
+    import cosdata_amd as ca
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1.3, 1.3, (37, dim)).astype(np.float32)
+    x[0, :4] = [1.0, -1.0, np.nan, 5e30]  # wrap / saturate / NaN / huge quirks (SURVEY App. C 1,4)
+    x[1, :] = 0.0
+    codes, mags = ca.ScalarQuantization.quantize(x, ca.StorageType(ca.StorageKind(storage), res), (-1.0, 1.0))
+    ocodes, omags = O.quantize_batch(x, storage, res, -1.0, 1.0)
+    assert np.array_equal(codes, ocodes)
+    assert np.array_equal(mags.view(np.uint32), omags.view(np.uint32))
+
+
+def _assert_same_search(oix, dix, Q, top_k):
+    ids, sc, cnt = dix.batch_search(Q, top_k)
+    oids, osc, ocnt = oix.search_batch(Q, top_k, threads=4)[:3]
+    assert np.array_equal(cnt, ocnt)
+    for b in range(Q.shape[0]):
+        c = int(cnt[b])
+        assert np.array_equal(ids[b, :c], oids[b, :c]), f"query {b}: ids differ\n{ids[b,:c]}\n{oids[b,:c]}"
+        assert np.array_equal(sc[b, :c].view(np.uint32), osc[b, :c].view(np.uint32)), f"query {b}: scores differ"
+
+
+def _assert_same_walk(oix, dix, Q):
+    ids, sims, counts = dix.ann_search_batch(Q)
+    for b in range(Q.shape[0]):
+        oi, osim, olc = oix.ann_search(Q[b])
+        assert np.array_equal(counts[b], olc), f"query {b}: level counts {counts[b]} vs {olc}"
+        off = 0
+        for s, c in enumerate(olc):
+            c = int(c)
+            assert np.array_equal(ids[b, s, :c], oi[off:off + c]), f"query {b} slot {s}: walk ids differ"
+            assert np.array_equal(sims[b, s, :c].view(np.uint32), osim[off:off + c].view(np.uint32)), f"query {b} slot {s}: sims differ"
+            off += c
+
+
+@pytest.mark.parametrize("name,storage,res", STORAGES)
+@pytest.mark.parametrize("n,dim,ef", [(2000, 96, 64), (3000, 100, 32), (6000, 768, 256)])
+def test_search_matches_oracle(name, storage, res, n, dim, ef):
+    X = H.uniform_corpus(n, dim, seed=7)
+    oix = H.oracle_index(X, storage, res, num_layers=5, ef_construction=64, ef_search=ef)
+    dix = H.device_index_from_oracle(oix, X)
+    Q = np.concatenate([H.queries_from(X, 24, seed=3), H.uniform_corpus(8, dim, seed=99)])
+    _assert_same_walk(oix, dix, Q)
+    _assert_same_search(oix, dix, Q, 10)
+    _assert_same_search(oix, dix, Q, 5)
+
+
+def test_search_clustered_default_params():
+    X = H.clustered_corpus(20000, 128, seed=5)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, ef_construction=64)
+    dix = H.device_index_from_oracle(oix, X)
+    Q = H.queries_from(X, 64, seed=11)
+    _assert_same_walk(oix, dix, Q)
+    _assert_same_search(oix, dix, Q, 10)
+
+
+def test_zero_norm_query_is_calculation_error():
+    import cosdata_amd as ca
+    X = H.uniform_corpus(500, 96, seed=2)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=3, ef_construction=32, ef_search=32)
+    dix = H.device_index_from_oracle(oix, X)
+    Q = H.queries_from(X, 4)
+    Q[2, :] = -1.0  # quantizes to all-zero bytes -> |q| = 0 -> DistanceError::CalculationError (cosine.rs:228-232)
+    with pytest.raises(ca.CosdataError) as ei:
+        dix.batch_search(Q, 5)
+    assert ei.value.status == 2
+    ids, sc, cnt, rc, status = dix.batch_search(Q, 5, return_status=True)
+    o = oix.search_batch(Q, 5, raise_on_error=False)
+    assert rc == 2 and o[3] == 2
+    assert np.array_equal(status, o[4])
