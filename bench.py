@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""bench.py — QPS of the dense HNSW search path on MI355X (driver contract: see the task prompt).
+
+A "step" is one pass of the hot path over one query batch: cos_search_batch_device() =
+quantize -> HNSW walk (every level, ef_search) -> dedup/top-5k -> exact f32 rerank -> top-k,
+with the index and the queries resident in HBM.  Like the reference's own RPS harness
+(tests/rps-test.py: 32 client threads x batches of 200) several batches are kept in flight on
+separate HIP streams (`--inflight`); the single-stream rate is reported alongside.
+
+Default workload = BASELINE.json configs[1]: 1M x 768 dense cosine HNSW, query batch 256, one GPU
+(`--workload c4shard` = one 12.5M x 1024 shard of configs[3]).  N > 1: one process per GPU, every
+rank owns an independent shard (ID-range partition, weak scaling), queries are replicated, and each
+step ends with the RCCL all-gather of the per-shard top-k + the S-way merge kernel.
+
+Synthetic data (no network): a seeded Gaussian-mixture corpus, L2-normalised, generated on the
+device; queries are fresh draws from the same mixture.  recall@10 is measured against exact
+brute-force cosine on the same corpus, outside the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import cosdata_amd as ca  # noqa: E402
+
+METRIC = "QPS at recall@10≥0.95, 1024-dim dense cosine, 1/2/4/8 MI355X"
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (n per GPU, dim, description)
+    "c2": (1_000_000, 768, "BASELINE configs[1]: 1M x 768 dense cosine HNSW, query-batch 256, u8 auto-quantized storage"),
+    "c4shard": (12_500_000, 1024, "one 12.5M x 1024 shard of BASELINE configs[3] (100M x 1024 over 8 GPUs)"),
+    "smoke": (50_000, 768, "reduced-size plumbing run (NOT a benchmark number)"),
+}
+
+
+def mixture(n, d, seed, device, centers, sigma=0.8):
+    """Gaussian mixture around shared unit-norm centres, L2-normalised (cf. tests/test-dataset.py:414-430)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty(n, d, device=device, dtype=torch.float32)
+    step = 1 << 18
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        a = torch.randint(0, centers.shape[0], (m,), generator=g, device=device)
+        x = centers[a] + (sigma / d ** 0.5) * torch.randn(m, d, generator=g, device=device)
+        out[s:s + m] = x / x.norm(dim=1, keepdim=True)
+    return out
+
+
+def bruteforce_top10(X, Q, k=10):
+    """exact cosine top-k (ground truth for recall; independent of the engine under test)."""
+    ids = []
+    for s in range(0, Q.shape[0], 256):
+        sims = Q[s:s + 256] @ X.T
+        ids.append(sims.topk(k, dim=1).indices)
+    return torch.cat(ids)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--n", type=int, default=0, help="override vectors per GPU (marks the run as non-standard)")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--inflight", type=int, default=16, help="query batches kept in flight (HIP streams)")
+    ap.add_argument("--ef", type=int, default=256, help="ef_search (config.toml default 256)")
+    ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--build-batch", type=int, default=4096)
+    ap.add_argument("--recall-queries", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    n, d, desc = WORKLOADS[args.workload]
+    if args.n:
+        n = args.n
+    B, k, ef = args.batch, args.top_k, args.ef
+    t_setup = time.time()
+
+    # ---- synthetic shard + queries (resident in HBM) -------------------------------------------
+    gc = torch.Generator(device=dev)
+    gc.manual_seed(4242)
+    n_centers = max(64, (n * world) // 1000)
+    centers = torch.randn(n_centers, d, generator=gc, device=dev)
+    centers /= centers.norm(dim=1, keepdim=True)
+    X = mixture(n, d, 42 + 1000 * rank, dev, centers)            # this rank's shard: global ids [rank*n, (rank+1)*n)
+    n_qsets = max(args.inflight, 4)
+    Q = mixture(B * n_qsets, d, 43, dev, centers)                 # identical on every rank
+    torch.cuda.synchronize()
+
+    # ---- index: reference defaults (config.toml:20-24,32), "auto" quantization = u8 + range (-1,1) ---
+    hp = ca.HNSWHyperParams(num_layers=9, ef_construction=128, ef_search=ef, level_0_neighbors_count=64, neighbors_count=32)
+    ix = ca.HNSWIndex(d, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), (-1.0, 1.0), shortlist_size=64,
+                      device=local_rank, id_base=rank * n, seed=42 + rank)
+    ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
+    t0 = time.time()
+    ix.build(args.build_batch)
+    build_s = time.time() - t0
+
+    # ---- buffers + streams ------------------------------------------------------------------------
+    S = args.inflight
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    o_ids = torch.zeros(S, B, k, dtype=torch.int32, device=dev)
+    o_sc = torch.zeros(S, B, k, dtype=torch.float32, device=dev)
+    o_cnt = torch.zeros(S, B, dtype=torch.int32, device=dev)
+    o_st = torch.zeros(S, B, dtype=torch.int32, device=dev)
+    if world > 1:
+        g_ids = torch.zeros(S, world, B, k, dtype=torch.int32, device=dev)
+        g_sc = torch.zeros(S, world, B, k, dtype=torch.float32, device=dev)
+        g_cnt = torch.zeros(S, world, B, dtype=torch.int32, device=dev)
+        m_ids = torch.zeros(S, B, k, dtype=torch.int32, device=dev)
+        m_sc = torch.zeros(S, B, k, dtype=torch.float32, device=dev)
+        m_cnt = torch.zeros(S, B, dtype=torch.int32, device=dev)
+    lib = ca._lib.lib()
+
+    def step(i):
+        s = i % S
+        st = streams[s]
+        q = Q[(i % n_qsets) * B:(i % n_qsets + 1) * B]
+        ix.batch_search_device(q.data_ptr(), B, k, o_ids[s].data_ptr(), o_sc[s].data_ptr(), o_cnt[s].data_ptr(), o_st[s].data_ptr(),
+                               st.cuda_stream)
+        if world > 1:  # per-shard top-k -> RCCL all-gather over xGMI -> S-way merge
+            import torch.distributed as dist
+            with torch.cuda.stream(st):
+                dist.all_gather_into_tensor(g_ids[s], o_ids[s])
+                dist.all_gather_into_tensor(g_sc[s], o_sc[s])
+                dist.all_gather_into_tensor(g_cnt[s], o_cnt[s])
+            ca._lib.check(lib.cos_merge_topk_device(g_ids[s].data_ptr(), g_sc[s].data_ptr(), g_cnt[s].data_ptr(), world, B, k,
+                                                    m_ids[s].data_ptr(), m_sc[s].data_ptr(), m_cnt[s].data_ptr(), local_rank,
+                                                    st.cuda_stream))
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # ---- recall@10 vs exact brute force (outside the timed region) ---------------------------------
+    nrq = min(args.recall_queries, B * n_qsets)
+    gt_local = bruteforce_top10(X, Q[:nrq], k)
+    ann = torch.zeros(nrq, k, dtype=torch.int64, device=dev)
+    for s0 in range(0, nrq, B):
+        m = min(B, nrq - s0)
+        ix.batch_search_device(Q[s0:s0 + m].data_ptr(), m, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(),
+                               o_st[0].data_ptr(), streams[0].cuda_stream)
+        streams[0].synchronize()
+        ann[s0:s0 + m] = o_ids[0][:m].to(torch.int64) & 0xFFFFFFFF
+    if world > 1:
+        import torch.distributed as dist
+        # global ground truth / global ANN answer = merge of the per-shard lists by exact cosine
+        def merge(local_ids_global, Xl):
+            sims = torch.gather(Q[:nrq] @ Xl.T, 1, (local_ids_global - rank * n))
+            all_ids = [torch.zeros_like(local_ids_global) for _ in range(world)]
+            all_s = [torch.zeros_like(sims) for _ in range(world)]
+            dist.all_gather(all_ids, local_ids_global.contiguous())
+            dist.all_gather(all_s, sims.contiguous())
+            ci, cs = torch.cat(all_ids, 1), torch.cat(all_s, 1)
+            top = cs.topk(k, dim=1).indices
+            return torch.gather(ci, 1, top)
+        gt = merge(gt_local + rank * n, X)
+        ann_g = merge(ann, X)
+    else:
+        gt, ann_g = gt_local, ann
+    hits = (ann_g.unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().sum(dim=1)
+    recall = float(hits.mean().item() / k)
+    status_bad = int((o_st != 0).sum().item())
+
+    # ---- warmup + timed region ----------------------------------------------------------------------
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    ix.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    qps = args.steps * B / elapsed
+
+    # per-launch walk-kernel figures: HIP events recorded by the library on the launch stream
+    row_bytes = d + 4  # u8 code row + f32 norm per distance evaluation
+    per = []
+    for s in range(min(S, args.steps)):
+        stt = ix.last_stats(streams[s].cuda_stream)
+        per.append((stt.walk_ms, stt.evals * row_bytes + stt.adj_bytes, stt.evals, stt.expansions, stt.finalize_ms, stt.prep_ms))
+    ix.enable_timing(False)
+    avg_ms = float(np.mean([p[0] for p in per]))
+    avg_bytes = float(np.mean([p[1] for p in per]))
+    # launches overlap on the chip: in-flight concurrency = sum of launch durations / wall time
+    overlap = max(1.0, min(float(S), avg_ms * 1e-3 * args.steps / elapsed))
+    achieved = avg_bytes * args.steps / elapsed / 1e9  # aggregate algorithmic GB/s of the walk kernel
+
+    # single-stream (one batch at a time) rate
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for i in range(8):
+        ix.batch_search_device(Q[:B].data_ptr(), B, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(), o_st[0].data_ptr(),
+                               streams[0].cuda_stream)
+    streams[0].synchronize()
+    serial_qps = 8 * B / (time.perf_counter() - t1)
+
+    # ---- CPU baseline: the oracle (C restatement of the Rust path) on this box's host cores ----------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        cores = os.cpu_count() or 1
+        Xh = X.cpu().numpy()
+        op = O.HNSWParams(dim=d, storage=O.STORAGE_U8, num_layers=9, ef_construction=128, ef_search=ef, seed=42)
+        oix = O.OracleIndex(op).set_vectors(Xh)
+        oix.import_graph(ix.download_graph(), ix.download_root())
+        Qh = Q.cpu().numpy()
+        t2 = time.perf_counter()
+        probe = oix.search_batch(Qh[:max(64, cores)], k, threads=cores)
+        rate = max(64, cores) / (time.perf_counter() - t2)
+        nq = int(min(Qh.shape[0], max(256, rate * args.cpu_seconds)))
+        t2 = time.perf_counter()
+        oids, osc, ocnt = oix.search_batch(Qh[:nq], k, threads=cores)[:3]
+        cpu_s = time.perf_counter() - t2
+        cpu = {"value": nq / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
+               "sample": f"{nq} queries of the same workload ({cpu_s:.1f} s wall), C/AVX2 restatement of the Rust path "
+                         f"(oracle/), one OpenMP thread per core like batch_search's rayon fan-out"}
+        # free parity check on the same sample: GPU ids/scores vs oracle
+        gi = np.zeros((nq, k), np.uint32)
+        gs = np.zeros((nq, k), np.float32)
+        for s0 in range(0, nq, B):
+            m = min(B, nq - s0)
+            ix.batch_search_device(Q[s0:s0 + m].data_ptr(), m, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(),
+                                   o_st[0].data_ptr(), streams[0].cuda_stream)
+            streams[0].synchronize()
+            gi[s0:s0 + m] = o_ids[0][:m].cpu().numpy().view(np.uint32)
+            gs[s0:s0 + m] = o_sc[0][:m].cpu().numpy()
+        parity = {"queries": nq, "id_mismatch_queries": int((gi != oids).any(axis=1).sum()),
+                  "score_bit_mismatches": int((gs.view(np.uint32) != osc.view(np.uint32)).sum())}
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": args.workload + ": " + desc, "standard_size": not bool(args.n), "vectors_per_gpu": n, "dim": d,
+                       "query_batch": B, "batches_in_flight": S, "top_k": k, "ef_search": ef, "M": 32, "M0": 64, "num_layers": 9,
+                       "storage": "u8 (auto quantization, range (-1,1))", "visited": "reference PerformantFixedSet (ID parity mode)",
+                       "parallelism": f"id-range shards x{world}" + (" + RCCL all-gather top-k merge" if world > 1 else ""),
+                       "corpus": f"Gaussian mixture, {n_centers} centres, sigma 0.8/sqrt(d), L2-normalised, seed 42"},
+            "recall_at_10": recall, "recall_queries": nrq, "failed_queries": status_bad,
+            "single_stream_qps": serial_qps, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel": "walk_kernel<ENG_U8,1,4>",
+                         "per_launch": {"algorithmic_bytes": avg_bytes, "avg_ms": avg_ms, "in_flight": overlap,
+                                        "evals": float(np.mean([p[2] for p in per])), "expansions": float(np.mean([p[3] for p in per])),
+                                        "finalize_ms": float(np.mean([p[4] for p in per])), "prep_ms": float(np.mean([p[5] for p in per]))},
+                         "note": "achieved = algorithmic bytes per launch x launches / timed wall time = bytes/avg_ms x in_flight "
+                                 "(launches of different streams overlap on the chip)"},
+            "cpu_baseline": cpu, "parity_vs_oracle": parity,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,314 @@
+// builder.hip — vector_store::index_embeddings (vector_store.rs:714-1109) for a device-resident index.
+//
+// Batch-synchronous construction: the ids of a batch run the reference's per-level walk
+// (traverse_find_nearest with ef_construction, keep 64, visited pre-seeded with the new id) on the
+// GPU against the graph snapshot that precedes the batch — one wavefront per new vector, the same
+// walk kernel the search path uses — then their edges are connected in id order with the
+// reference's exact edge semantics (create_node_edges / ProbNode::add_neighbor: replace-lowest slot,
+// bidirectional accept-or-rollback, evictee drops its back edge, stale lowest cache).  The link step
+// is graph bookkeeping on the host mirror; the rows it dirtied are scattered back to HBM before the
+// next batch.  oracle/cosdata_oracle_hnsw.c:coso_index_build_batched is the CPU statement of the same
+// schedule; tests assert the two graphs are identical.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "engine_internal.h"
+
+using namespace cosdev;
+
+namespace {
+
+constexpr u32 NONE = 0xFFFFFFFFu;
+
+__global__ void scatter_rows_kernel(u32 *__restrict__ dst, const u32 *__restrict__ rows, const u32 *__restrict__ packed, u32 n_rows, u32 M) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (u64)n_rows * M) return;
+    const u32 r = (u32)(i / M), j = (u32)(i % M);
+    dst[(u64)rows[r] * M + j] = packed[i];
+}
+
+inline uint64_t splitmix64(uint64_t &st) {
+    uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline float rand_f32(uint64_t &st) { return (float)(splitmix64(st) >> 40) * (1.0f / 16777216.0f); }
+
+inline int32_t total_key(float v) {
+    int32_t b;
+    memcpy(&b, &v, 4);
+    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+    return b;
+}
+// MetricResult::cmp (models/types.rs:401-411)
+inline int metric_cmp(u32 metric, float a, float b) {
+    int32_t ka = total_key(a), kb = total_key(b);
+    int c = (ka > kb) - (ka < kb);
+    return (metric == COS_METRIC_EUCLIDEAN || metric == COS_METRIC_HAMMING) ? -c : c;
+}
+inline float metric_min(u32 metric) { return metric == COS_METRIC_COSINE ? -1.0f : -INFINITY; }
+inline float metric_max(u32 metric) { return metric == COS_METRIC_COSINE ? 2.0f : INFINITY; }
+
+struct LevelBuild {
+    u32 n = 0, M = 0;
+    std::vector<u32> node_ids, node_vec, child;
+    std::vector<u32> nbr;   // [n][M] node index / NONE
+    std::vector<float> sim; // [n][M]
+    std::vector<uint8_t> low_idx;
+    std::vector<float> low_sim;
+    std::vector<u32> stamp; // dirty marker per node (batch number + 1)
+    std::vector<u32> dirty;
+    u32 cursor = 0;         // first node of this level not yet inserted
+};
+
+inline void mark_dirty(LevelBuild &L, u32 node, u32 batch_no) {
+    if (L.stamp[node] != batch_no) { L.stamp[node] = batch_no; L.dirty.push_back(node); }
+}
+
+// ProbNode::add_neighbor (prob_node.rs:210-283) on the host mirror. Returns slot or -1.
+int add_neighbor(LevelBuild &L, u32 metric, u32 self, u32 nbr, float dist, u32 batch_no) {
+    const u32 M = L.M;
+    const u32 lowest_idx = L.low_idx[self];
+    const float lowest_sim = L.low_sim[self];
+    if (metric_cmp(metric, dist, lowest_sim) <= 0) return -1;
+    u32 *nb = &L.nbr[(size_t)self * M];
+    float *ns = &L.sim[(size_t)self * M];
+    const bool ok = nb[lowest_idx] == NONE || metric_cmp(metric, dist, ns[lowest_idx]) > 0;
+    u32 old = NONE;
+    if (ok) { old = nb[lowest_idx]; nb[lowest_idx] = nbr; ns[lowest_idx] = dist; mark_dirty(L, self, batch_no); }
+    u32 nl = 0;
+    float nsim = metric_max(metric);
+    for (u32 j = 0; j < M; j++) {
+        if (nb[j] == NONE) { nsim = metric_min(metric); nl = j; break; }
+        if (metric_cmp(metric, ns[j], nsim) < 0) { nsim = ns[j]; nl = j; }
+    }
+    L.low_idx[self] = (uint8_t)nl;
+    L.low_sim[self] = nsim;
+    if (!ok) return -1;
+    if (old != NONE) { // the evictee drops its back edge; its lowest cache is NOT refreshed (prob_node.rs:285-306)
+        u32 *ob = &L.nbr[(size_t)old * M];
+        for (u32 j = 0; j < M; j++)
+            if (ob[j] == self) { ob[j] = NONE; mark_dirty(L, old, batch_no); break; }
+    }
+    return (int)lowest_idx;
+}
+
+// create_node_edges (vector_store.rs:976-1074)
+void create_node_edges(LevelBuild &L, u32 metric, u32 node, const u32 *z_nodes, const float *z_sims, u32 zn, u32 batch_no) {
+    u32 succ = 0;
+    for (u32 i = 0; i < zn; i++) {
+        if (succ >= L.M) break;
+        const int r = add_neighbor(L, metric, node, z_nodes[i], z_sims[i], batch_no);
+        if (r >= 0) {
+            const int r2 = add_neighbor(L, metric, z_nodes[i], node, z_sims[i], batch_no);
+            if (r2 >= 0) succ++;
+            else if (L.nbr[(size_t)node * L.M + (u32)r] == z_nodes[i]) { // remove_neighbor_by_index_and_id
+                L.nbr[(size_t)node * L.M + (u32)r] = NONE;
+                mark_dirty(L, node, batch_no);
+            }
+        }
+    }
+}
+
+template <typename T>
+hipError_t dmalloc(T *&p, size_t count) { return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)); }
+
+} // namespace
+
+namespace cosdev {
+hipError_t launch_scatter_rows(u32 *dst, const u32 *rows, const u32 *packed, u32 n_rows, u32 M, hipStream_t st) {
+    if (n_rows == 0) return hipSuccess;
+    const u64 total = (u64)n_rows * M;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((u32)((total + 255) / 256)), dim3(256), 0, st, dst, rows, packed, n_rows, M);
+    return hipGetLastError();
+}
+} // namespace cosdev
+
+extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
+    if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before building");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    const u32 n = ix->n, Ltop = ix->p.num_layers, metric = ix->p.metric;
+    const u32 Bmax = batch_size ? batch_size : 4096u;
+    hipStream_t st = ix->own_stream;
+
+    // ---- root + level draws (same RNG stream as the oracle builder) ----------------------------
+    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
+    std::vector<float> root(ix->p.dim);
+    for (u32 i = 0; i < ix->p.dim; i++) root[i] = ix->p.range_lo + rand_f32(rng) * (ix->p.range_hi - ix->p.range_lo); // vector_store.rs:30-36
+    rc = cos_index_set_root(ix, root.data());
+    if (rc) return rc;
+    std::vector<double> pv(Ltop + 1);
+    for (u32 k = 0; k <= Ltop; k++) { // generate_level_probs(4.0, L): 1 - 4^-n, n = L..0 (common.rs:421-429)
+        const int nn = (int)(Ltop - k);
+        double r = 1.0, a = 4.0;
+        for (int b = nn;;) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; }
+        pv[k] = 1.0 - 1.0 / r;
+    }
+    std::vector<uint8_t> max_level(n);
+    for (u32 id = 0; id < n; id++) {
+        const double x = (double)rand_f32(rng);
+        u32 k = 0;
+        while (k < Ltop && !(x >= pv[k])) k++; // get_max_insert_level (common.rs:373-379)
+        max_level[id] = (uint8_t)(Ltop - k);
+    }
+
+    // ---- level skeletons -----------------------------------------------------------------------
+    std::vector<LevelBuild> lb(Ltop + 1);
+    for (u32 l = 0; l <= Ltop; l++) {
+        LevelBuild &L = lb[l];
+        L.M = ix->lv[l].M;
+        for (u32 id = 0; id < n; id++)
+            if (max_level[id] >= l) L.node_ids.push_back(id);
+        L.node_ids.push_back(COS_ROOT_ID);
+        L.n = (u32)L.node_ids.size();
+        L.node_vec.resize(L.n);
+        for (u32 i = 0; i < L.n; i++) L.node_vec[i] = L.node_ids[i] == COS_ROOT_ID ? n : L.node_ids[i];
+        L.nbr.assign((size_t)L.n * L.M, NONE);
+        L.sim.assign((size_t)L.n * L.M, 0.0f);
+        L.low_idx.assign(L.n, 0);                    // prob_node.rs:140
+        L.low_sim.assign(L.n, metric_min(metric));
+        L.stamp.assign(L.n, 0);
+        if (l > 0) {
+            L.child.resize(L.n);
+            const std::vector<u32> &D = lb[l - 1].node_ids;
+            for (u32 i = 0; i < L.n; i++) L.child[i] = (u32)(std::lower_bound(D.begin(), D.end(), L.node_ids[i]) - D.begin());
+        }
+    }
+    // device arrays at full size, every slot empty
+    for (u32 l = 0; l <= Ltop; l++) {
+        LevelHost &H = ix->lv[l];
+        LevelBuild &L = lb[l];
+        if (H.d_adj_vec) (void)hipFree(H.d_adj_vec);
+        if (H.d_adj_node) (void)hipFree(H.d_adj_node);
+        if (H.d_node_vec) (void)hipFree(H.d_node_vec);
+        if (H.d_child) (void)hipFree(H.d_child);
+        H.d_adj_vec = H.d_adj_node = H.d_node_vec = H.d_child = nullptr;
+        H.host_valid = false;
+        HIP_TRY(dmalloc(H.d_adj_vec, (size_t)L.n * L.M));
+        HIP_TRY(hipMemsetAsync(H.d_adj_vec, 0xFF, (size_t)L.n * L.M * 4, st));
+        if (l > 0) {
+            HIP_TRY(dmalloc(H.d_adj_node, (size_t)L.n * L.M));
+            HIP_TRY(hipMemsetAsync(H.d_adj_node, 0xFF, (size_t)L.n * L.M * 4, st));
+            HIP_TRY(dmalloc(H.d_node_vec, L.n));
+            HIP_TRY(hipMemcpyAsync(H.d_node_vec, L.node_vec.data(), (size_t)L.n * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(dmalloc(H.d_child, L.n));
+            HIP_TRY(hipMemcpyAsync(H.d_child, L.child.data(), (size_t)L.n * 4, hipMemcpyHostToDevice, st));
+        }
+        H.n = L.n;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // ---- batch workspace -----------------------------------------------------------------------
+    const u32 L1 = Ltop + 1, KEEP = (u32)KEEP_INDEX;
+    u32 *d_rows = nullptr, *d_out_ids = nullptr, *d_out_nodes = nullptr, *d_out_counts = nullptr, *d_drows = nullptr, *d_pack = nullptr;
+    float *d_out_sims = nullptr;
+    int32_t *d_status = nullptr;
+    u32 *d_vis = nullptr;
+    size_t pack_cap = 0, drows_cap = 0;
+    HIP_TRY(dmalloc(d_rows, Bmax));
+    HIP_TRY(dmalloc(d_out_ids, (size_t)Bmax * L1 * KEEP));
+    HIP_TRY(dmalloc(d_out_nodes, (size_t)Bmax * L1 * KEEP));
+    HIP_TRY(dmalloc(d_out_sims, (size_t)Bmax * L1 * KEEP));
+    HIP_TRY(dmalloc(d_out_counts, (size_t)Bmax * L1));
+    HIP_TRY(dmalloc(d_status, Bmax));
+    std::vector<u32> h_rows(Bmax), h_nodes((size_t)Bmax * L1 * KEEP), h_counts((size_t)Bmax * L1), h_drows, h_pack;
+    std::vector<float> h_sims((size_t)Bmax * L1 * KEEP);
+    std::vector<int32_t> h_status(Bmax);
+    auto cleanup = [&]() {
+        void *ptrs[] = {d_rows, d_out_ids, d_out_nodes, d_out_sims, d_out_counts, d_status, d_drows, d_pack, d_vis};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+    };
+
+    IndexDev dev = cos_make_index_dev(ix);
+    if (dev.visited_mode == COS_VISITED_EXACT) {
+        hipError_t e = dmalloc(d_vis, (size_t)Bmax * dev.vis_words_per_query);
+        if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
+    }
+
+    u32 inserted = 0, batch_no = 0;
+    while (inserted < n) {
+        batch_no++;
+        const u32 bs = std::min({Bmax, std::max(1u, inserted / 4u), n - inserted});
+        for (u32 b = 0; b < bs; b++) h_rows[b] = inserted + b;
+        hipError_t e = hipMemcpyAsync(d_rows, h_rows.data(), (size_t)bs * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && d_vis) e = hipMemsetAsync(d_vis, 0, (size_t)bs * dev.vis_words_per_query * 4, st);
+        WalkArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.qcodes = ix->d_codes;
+        wa.qmags = ix->d_mags;
+        wa.q_rows = d_rows;
+        wa.self_ids = d_rows; // the new node's id is pre-inserted in the visited filter (vector_store.rs:807)
+        wa.vis_slab = d_vis;
+        wa.B = bs;
+        wa.ef = ix->p.ef_construction;
+        wa.keep = KEEP;
+        wa.out_ids = d_out_ids;
+        wa.out_sims = d_out_sims;
+        wa.out_nodes = d_out_nodes;
+        wa.out_counts = d_out_counts;
+        wa.out_status = d_status;
+        if (e == hipSuccess) e = launch_walk(ix->eng, dev, wa, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_nodes.data(), d_out_nodes, (size_t)bs * L1 * KEEP * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_sims.data(), d_out_sims, (size_t)bs * L1 * KEEP * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_counts.data(), d_out_counts, (size_t)bs * L1 * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status, (size_t)bs * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
+        for (u32 b = 0; b < bs; b++)
+            if (h_status[b] != COS_OK) {
+                cleanup();
+                return cos_fail(h_status[b], "vector %u cannot be indexed (zero norm -> DistanceError::CalculationError)", inserted + b);
+            }
+
+        // connect edges level by level, new nodes in id order (create_node_edges, vector_store.rs:923-936)
+        for (u32 l = 0; l <= Ltop; l++) {
+            LevelBuild &L = lb[l];
+            L.dirty.clear();
+            for (u32 b = 0; b < bs; b++) {
+                const u32 id = inserted + b;
+                if (max_level[id] < l) continue;
+                const u32 me = L.cursor++;
+                const u32 slot = Ltop - l;
+                const size_t base = ((size_t)b * L1 + slot) * KEEP;
+                create_node_edges(L, metric, me, &h_nodes[base], &h_sims[base], h_counts[(size_t)b * L1 + slot], batch_no);
+            }
+            // scatter the dirtied adjacency rows back to HBM
+            const u32 nd = (u32)L.dirty.size();
+            if (nd == 0) continue;
+            const size_t need = (size_t)nd * L.M;
+            if (need > pack_cap) { if (d_pack) (void)hipFree(d_pack); d_pack = nullptr; pack_cap = need * 2; e = dmalloc(d_pack, pack_cap); if (e != hipSuccess) { cleanup(); HIP_TRY(e); } }
+            if (nd > drows_cap) { if (d_drows) (void)hipFree(d_drows); d_drows = nullptr; drows_cap = (size_t)nd * 2; e = dmalloc(d_drows, drows_cap); if (e != hipSuccess) { cleanup(); HIP_TRY(e); } }
+            h_pack.resize(need);
+            e = hipMemcpyAsync(d_drows, L.dirty.data(), (size_t)nd * 4, hipMemcpyHostToDevice, st);
+            for (int pass = 0; pass < (l == 0 ? 1 : 2) && e == hipSuccess; pass++) {
+                // pass 0: neighbour VECTOR ROWS (adj_vec); pass 1 (levels >= 1): neighbour NODE indices (adj_node)
+                for (u32 i = 0; i < nd; i++)
+                    for (u32 j = 0; j < L.M; j++) {
+                        const u32 nb = L.nbr[(size_t)L.dirty[i] * L.M + j];
+                        h_pack[(size_t)i * L.M + j] = nb == NONE ? ROW_EMPTY : (pass == 0 ? L.node_vec[nb] : nb);
+                    }
+                e = hipMemcpyAsync(d_pack, h_pack.data(), need * 4, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = launch_scatter_rows(pass == 0 ? ix->lv[l].d_adj_vec : ix->lv[l].d_adj_node, d_drows, d_pack, nd, L.M, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st); // h_pack is reused by the next pass
+            }
+            if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
+        }
+        inserted += bs;
+    }
+    cleanup();
+
+    // ---- host copy of the graph in the id format (cos_index_download_graph_level) ---------------
+    for (u32 l = 0; l <= Ltop; l++) {
+        LevelHost &H = ix->lv[l];
+        LevelBuild &L = lb[l];
+        H.node_ids = L.node_ids;
+        H.nbr_ids.resize((size_t)L.n * L.M);
+        for (size_t i = 0; i < (size_t)L.n * L.M; i++) H.nbr_ids[i] = L.nbr[i] == NONE ? COS_SLOT_EMPTY : L.node_ids[L.nbr[i]];
+        H.host_valid = true;
+    }
+    return COS_OK;
+}

@@ -12,26 +12,15 @@
 #include <string>
 #include <vector>
 
-#include "../../include/cosdata_hip.h"
-#include "engine_types.h"
+#include "engine_internal.h"
 
 using namespace cosdev;
-
-namespace cosdev {
-hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
-                                u64 row_stride, float *mags, float *raw_mags, hipStream_t st);
-hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
-hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
-                           const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
-                           u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
-                           hipStream_t st);
-} // namespace cosdev
 
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int32_t fail(int32_t code, const char *fmt, ...) {
+int32_t cos_fail(int32_t code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -40,77 +29,20 @@ static int32_t fail(int32_t code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t _e = (expr);                                                                        \
-        if (_e != hipSuccess) return fail(COS_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
 
 extern "C" const char *cos_last_error_string(void) { return g_err.c_str(); }
 
 extern "C" int32_t cos_device_count(int32_t *out) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) { *out = 0; return fail(COS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { *out = 0; return cos_fail(COS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     *out = n;
     return COS_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// handle
-// ------------------------------------------------------------------------------------------------
-struct LevelHost {
-    std::vector<u32> node_ids; // ascending, root last
-    std::vector<u32> nbr_ids;  // [n][M] internal ids / COS_SLOT_EMPTY
-    u32 *d_adj_vec = nullptr, *d_adj_node = nullptr, *d_node_vec = nullptr, *d_child = nullptr;
-    u32 n = 0, M = 0;
-    bool host_valid = false; // node_ids/nbr_ids mirror the device arrays
-};
-
-struct Workspace {
-    u32 capB = 0, cap_topk = 0;
-    uint8_t *q_codes = nullptr;
-    float *q_mags = nullptr, *q_raw_mags = nullptr;
-    u32 *walk_ids = nullptr, *walk_counts = nullptr;
-    float *walk_sims = nullptr;
-    int32_t *walk_status = nullptr;
-    u64 *stats = nullptr;       // [B][4]
-    u64 *rerank_rows = nullptr; // [B]
-    u32 *vis_slab = nullptr;
-    size_t vis_slab_words = 0;
-    // host-API staging (device)
-    float *d_queries = nullptr;
-    u32 *d_out_ids = nullptr, *d_out_counts = nullptr;
-    float *d_out_scores = nullptr;
-    int32_t *d_out_status = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    u32 lastB = 0;
-    bool timed = false;
-};
-
-struct cos_index {
-    cos_params p;
-    int eng = -1;
-    u32 n = 0;
-    bool have_vectors = false, have_root = false, raw_borrowed = false;
-    float *d_raw = nullptr;
-    float *d_raw_mags = nullptr;
-    uint8_t *d_codes = nullptr;
-    float *d_mags = nullptr;
-    u64 row_stride = 0;
-    u32 nchunks = 0, G = 1;
-    std::vector<float> root_raw;
-    std::vector<LevelHost> lv;
-    hipStream_t own_stream = nullptr; // host API stream
-    std::mutex mu;                    // guards workspaces map + timing flag
-    std::map<void *, Workspace *> ws;
-    Workspace *last_ws = nullptr; // most recent batch (cos_index_last_stats with stream == NULL)
-    bool timing = false;
-};
-
 static u32 pow2ceil(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }
 
-static int32_t set_device(const cos_index *ix) {
+int32_t cos_set_device(const cos_index *ix) {
     HIP_TRY(hipSetDevice(ix->p.device));
     return COS_OK;
 }
@@ -121,7 +53,7 @@ static bool graph_ready(const cos_index *ix) {
     return true;
 }
 
-static IndexDev make_index_dev(const cos_index *ix) {
+IndexDev cos_make_index_dev(const cos_index *ix) {
     IndexDev d;
     memset(&d, 0, sizeof(d));
     d.codes = ix->d_codes;
@@ -158,44 +90,44 @@ static IndexDev make_index_dev(const cos_index *ix) {
 }
 
 extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
-    if (!p || !out) return fail(COS_ERR_INVALID, "null argument");
+    if (!p || !out) return cos_fail(COS_ERR_INVALID, "null argument");
     *out = nullptr;
     if (p->struct_size != sizeof(cos_params) || p->abi_version != COS_ABI_VERSION)
-        return fail(COS_ERR_INVALID, "cos_params size/version mismatch (%u/%u, expected %zu/%u)", p->struct_size, p->abi_version,
+        return cos_fail(COS_ERR_INVALID, "cos_params size/version mismatch (%u/%u, expected %zu/%u)", p->struct_size, p->abi_version,
                     sizeof(cos_params), COS_ABI_VERSION);
-    if (p->dim == 0) return fail(COS_ERR_INVALID, "dim == 0");
+    if (p->dim == 0) return cos_fail(COS_ERR_INVALID, "dim == 0");
     auto pow2 = [](u32 v) { return v && !(v & (v - 1)); };
     if (!pow2(p->neighbors_count) || !pow2(p->level0_neighbors_count) || p->neighbors_count > 256 || p->level0_neighbors_count > 256)
-        return fail(COS_ERR_INVALID, "neighbors_count / level_0_neighbors_count must be powers of two <= 256 (PerformantFixedSet, fixedset.rs)");
+        return cos_fail(COS_ERR_INVALID, "neighbors_count / level_0_neighbors_count must be powers of two <= 256 (PerformantFixedSet, fixedset.rs)");
     if (p->num_layers + 1 > (u32)MAX_LEVELS || (p->num_layers + 1) * KEEP_SEARCH > 1024)
-        return fail(COS_ERR_UNIMPLEMENTED, "num_layers > 9 not supported on the device");
+        return cos_fail(COS_ERR_UNIMPLEMENTED, "num_layers > 9 not supported on the device");
     if (std::min(p->neighbors_count, p->shortlist_size) > 64 || std::min(p->level0_neighbors_count, p->shortlist_size) > 64)
-        return fail(COS_ERR_UNIMPLEMENTED, "more than 64 scanned neighbour slots per node not supported on the device");
-    if (p->ef_search > 512 || p->ef_construction > 512) return fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
+        return cos_fail(COS_ERR_UNIMPLEMENTED, "more than 64 scanned neighbour slots per node not supported on the device");
+    if (p->ef_search > 512 || p->ef_construction > 512) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
     if (p->metric != COS_METRIC_COSINE && p->metric != COS_METRIC_DOT)
-        return fail(COS_ERR_UNIMPLEMENTED, "device walk implements cosine and dot-product metrics");
+        return cos_fail(COS_ERR_UNIMPLEMENTED, "device walk implements cosine and dot-product metrics");
     int eng;
     u64 row_stride;
     u32 nchunks = 0, G = 1;
     switch (p->storage) {
     case COS_STORAGE_U8:
         eng = ENG_U8; row_stride = ((u64)p->dim + 15) & ~15ull; nchunks = (u32)(row_stride / 16); G = std::min(64u, pow2ceil(nchunks));
-        if ((nchunks + G - 1) / G > 2) return fail(COS_ERR_UNIMPLEMENTED, "u8 dim > 2048 not supported on the device");
+        if ((nchunks + G - 1) / G > 2) return cos_fail(COS_ERR_UNIMPLEMENTED, "u8 dim > 2048 not supported on the device");
         break;
     case COS_STORAGE_SUBBYTE:
-        if (p->resolution != 2) return fail(COS_ERR_UNIMPLEMENTED, "device walk implements SubByte resolution 2 (quaternary)");
+        if (p->resolution != 2) return cos_fail(COS_ERR_UNIMPLEMENTED, "device walk implements SubByte resolution 2 (quaternary)");
         eng = ENG_Q2; nchunks = (p->dim + 63) / 64; row_stride = (u64)nchunks * 16; G = std::min(64u, pow2ceil(nchunks));
-        if (nchunks > 64) return fail(COS_ERR_UNIMPLEMENTED, "quaternary dim > 4096 not supported on the device");
+        if (nchunks > 64) return cos_fail(COS_ERR_UNIMPLEMENTED, "quaternary dim > 4096 not supported on the device");
         break;
     case COS_STORAGE_F32:
-        if (p->metric == COS_METRIC_DOT) return fail(COS_ERR_STORAGE_MISMATCH, "DotProductDistance has no FullPrecisionFP arm (dotproduct.rs:20-64)");
+        if (p->metric == COS_METRIC_DOT) return cos_fail(COS_ERR_STORAGE_MISMATCH, "DotProductDistance has no FullPrecisionFP arm (dotproduct.rs:20-64)");
         eng = ENG_F32; row_stride = ((u64)p->dim * 4 + 15) & ~15ull; G = 2;
         break;
-    default: return fail(COS_ERR_UNIMPLEMENTED, "storage kind %u not supported on the device yet", p->storage);
+    default: return cos_fail(COS_ERR_UNIMPLEMENTED, "storage kind %u not supported on the device yet", p->storage);
     }
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
-    if (p->device < 0 || p->device >= ndev) return fail(COS_ERR_INVALID, "device %d out of range (%d visible)", p->device, ndev);
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    if (p->device < 0 || p->device >= ndev) return cos_fail(COS_ERR_INVALID, "device %d out of range (%d visible)", p->device, ndev);
     cos_index *ix = new cos_index();
     ix->p = *p;
     ix->eng = eng;
@@ -206,7 +138,7 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
     for (u32 l = 0; l <= p->num_layers; l++) ix->lv[l].M = l == 0 ? p->level0_neighbors_count : p->neighbors_count;
     if (hipSetDevice(p->device) != hipSuccess || hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ix;
-        return fail(COS_ERR_HIP, "cannot create stream on device %d", p->device);
+        return cos_fail(COS_ERR_HIP, "cannot create stream on device %d", p->device);
     }
     *out = ix;
     return COS_OK;
@@ -250,9 +182,9 @@ extern "C" int32_t cos_index_destroy(cos_index *ix) {
 // uploads
 // ------------------------------------------------------------------------------------------------
 extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uint32_t n, uint32_t flags) {
-    if (!ix || !raw || n == 0) return fail(COS_ERR_INVALID, "null/empty vectors");
-    if (n >= 0xFFFFFFF0u) return fail(COS_ERR_INVALID, "too many vectors");
-    int32_t rc = set_device(ix);
+    if (!ix || !raw || n == 0) return cos_fail(COS_ERR_INVALID, "null/empty vectors");
+    if (n >= 0xFFFFFFF0u) return cos_fail(COS_ERR_INVALID, "too many vectors");
+    int32_t rc = cos_set_device(ix);
     if (rc) return rc;
     if (ix->d_raw && !ix->raw_borrowed) (void)hipFree(ix->d_raw);
     if (ix->d_raw_mags) (void)hipFree(ix->d_raw_mags);
@@ -283,9 +215,9 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
 }
 
 extern "C" int32_t cos_index_set_root(cos_index *ix, const float *root_raw) {
-    if (!ix || !root_raw) return fail(COS_ERR_INVALID, "null argument");
-    if (!ix->have_vectors) return fail(COS_ERR_NOT_READY, "upload vectors before the root");
-    int32_t rc = set_device(ix);
+    if (!ix || !root_raw) return cos_fail(COS_ERR_INVALID, "null argument");
+    if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before the root");
+    int32_t rc = cos_set_device(ix);
     if (rc) return rc;
     ix->root_raw.assign(root_raw, root_raw + ix->p.dim);
     float *d_tmp = nullptr, *d_dummy = nullptr;
@@ -321,7 +253,7 @@ static int32_t push_level_to_device(cos_index *ix, u32 level) {
                 continue;
             }
             auto it = std::lower_bound(L.node_ids.begin(), L.node_ids.end(), id);
-            if (it == L.node_ids.end() || *it != id) return fail(COS_ERR_INVALID, "level %u: neighbour id %u of node %u is not a node of this level", level, id, L.node_ids[i]);
+            if (it == L.node_ids.end() || *it != id) return cos_fail(COS_ERR_INVALID, "level %u: neighbour id %u of node %u is not a node of this level", level, id, L.node_ids[i]);
             adj_vec[(size_t)i * M + j] = row_of(ix, id);
             if (level > 0) adj_node[(size_t)i * M + j] = (u32)(it - L.node_ids.begin());
         }
@@ -351,7 +283,7 @@ static int32_t resolve_children(cos_index *ix, u32 level) {
     std::vector<u32> child(L.node_ids.size());
     for (size_t i = 0; i < L.node_ids.size(); i++) {
         auto it = std::lower_bound(D.node_ids.begin(), D.node_ids.end(), L.node_ids[i]);
-        if (it == D.node_ids.end() || *it != L.node_ids[i]) return fail(COS_ERR_INVALID, "node %u of level %u is missing on level %u", L.node_ids[i], level, level - 1);
+        if (it == D.node_ids.end() || *it != L.node_ids[i]) return cos_fail(COS_ERR_INVALID, "node %u of level %u is missing on level %u", L.node_ids[i], level, level - 1);
         child[i] = (u32)(it - D.node_ids.begin());
     }
     if (L.d_child) (void)hipFree(L.d_child);
@@ -363,17 +295,17 @@ static int32_t resolve_children(cos_index *ix, u32 level) {
 
 extern "C" int32_t cos_index_upload_graph_level(cos_index *ix, uint32_t level, uint32_t n_nodes, const uint32_t *node_ids,
                                                 const uint32_t *nbr_ids) {
-    if (!ix || !node_ids || !nbr_ids) return fail(COS_ERR_INVALID, "null argument");
-    if (!ix->have_vectors) return fail(COS_ERR_NOT_READY, "upload vectors before the graph");
-    if (level > ix->p.num_layers || n_nodes == 0) return fail(COS_ERR_INVALID, "bad level / empty level");
-    int32_t rc = set_device(ix);
+    if (!ix || !node_ids || !nbr_ids) return cos_fail(COS_ERR_INVALID, "null argument");
+    if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before the graph");
+    if (level > ix->p.num_layers || n_nodes == 0) return cos_fail(COS_ERR_INVALID, "bad level / empty level");
+    int32_t rc = cos_set_device(ix);
     if (rc) return rc;
     for (u32 i = 0; i < n_nodes; i++) {
-        if (i && node_ids[i] <= node_ids[i - 1]) return fail(COS_ERR_INVALID, "level %u: node_ids must be strictly ascending", level);
-        if (node_ids[i] != COS_ROOT_ID && node_ids[i] >= ix->n) return fail(COS_ERR_INVALID, "level %u: node id %u out of range", level, node_ids[i]);
+        if (i && node_ids[i] <= node_ids[i - 1]) return cos_fail(COS_ERR_INVALID, "level %u: node_ids must be strictly ascending", level);
+        if (node_ids[i] != COS_ROOT_ID && node_ids[i] >= ix->n) return cos_fail(COS_ERR_INVALID, "level %u: node id %u out of range", level, node_ids[i]);
     }
-    if (node_ids[n_nodes - 1] != COS_ROOT_ID) return fail(COS_ERR_INVALID, "level %u: the root (0xFFFFFFFF) must be the last node", level);
-    if (level == 0 && n_nodes != ix->n + 1) return fail(COS_ERR_INVALID, "level 0 must hold every vector plus the root (%u nodes, expected %u)", n_nodes, ix->n + 1);
+    if (node_ids[n_nodes - 1] != COS_ROOT_ID) return cos_fail(COS_ERR_INVALID, "level %u: the root (0xFFFFFFFF) must be the last node", level);
+    if (level == 0 && n_nodes != ix->n + 1) return cos_fail(COS_ERR_INVALID, "level 0 must hold every vector plus the root (%u nodes, expected %u)", n_nodes, ix->n + 1);
     LevelHost &L = ix->lv[level];
     L.node_ids.assign(node_ids, node_ids + n_nodes);
     L.nbr_ids.assign(nbr_ids, nbr_ids + (size_t)n_nodes * L.M);
@@ -385,15 +317,15 @@ extern "C" int32_t cos_index_upload_graph_level(cos_index *ix, uint32_t level, u
 }
 
 extern "C" int32_t cos_index_level_count(const cos_index *ix, uint32_t level, uint32_t *n_nodes) {
-    if (!ix || !n_nodes || level > ix->p.num_layers) return fail(COS_ERR_INVALID, "bad argument");
+    if (!ix || !n_nodes || level > ix->p.num_layers) return cos_fail(COS_ERR_INVALID, "bad argument");
     *n_nodes = ix->lv[level].n;
     return COS_OK;
 }
 
 extern "C" int32_t cos_index_download_graph_level(const cos_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids) {
-    if (!ix || level > ix->p.num_layers) return fail(COS_ERR_INVALID, "bad argument");
+    if (!ix || level > ix->p.num_layers) return cos_fail(COS_ERR_INVALID, "bad argument");
     const LevelHost &L = ix->lv[level];
-    if (!L.host_valid) return fail(COS_ERR_NOT_READY, "level %u not resident", level);
+    if (!L.host_valid) return cos_fail(COS_ERR_NOT_READY, "level %u not resident", level);
     if (node_ids) memcpy(node_ids, L.node_ids.data(), L.node_ids.size() * 4);
     if (nbr_ids) memcpy(nbr_ids, L.nbr_ids.data(), L.nbr_ids.size() * 4);
     return COS_OK;
@@ -421,7 +353,7 @@ static void row_to_reference_layout(int eng, u32 dim, const uint8_t *dev_row, ui
 }
 
 extern "C" int32_t cos_index_download_codes(const cos_index *ix, void *codes, float *mags) {
-    if (!ix || !ix->have_vectors) return fail(COS_ERR_NOT_READY, "no vectors resident");
+    if (!ix || !ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "no vectors resident");
     HIP_TRY(hipSetDevice(ix->p.device));
     const size_t rows = (size_t)ix->n + 1;
     if (codes) {
@@ -435,23 +367,23 @@ extern "C" int32_t cos_index_download_codes(const cos_index *ix, void *codes, fl
 }
 
 extern "C" int32_t cos_index_download_root(const cos_index *ix, float *root_raw) {
-    if (!ix || !ix->have_root) return fail(COS_ERR_NOT_READY, "no root");
+    if (!ix || !ix->have_root) return cos_fail(COS_ERR_NOT_READY, "no root");
     memcpy(root_raw, ix->root_raw.data(), (size_t)ix->p.dim * 4);
     return COS_OK;
 }
 
 extern "C" int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef) {
-    if (!ix || ef > 512) return fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
+    if (!ix || ef > 512) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
     ix->p.ef_search = ef;
     return COS_OK;
 }
 extern "C" int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode) {
-    if (!ix || mode > 1) return fail(COS_ERR_INVALID, "bad visited mode");
+    if (!ix || mode > 1) return cos_fail(COS_ERR_INVALID, "bad visited mode");
     ix->p.visited_mode = mode;
     return COS_OK;
 }
 extern "C" int32_t cos_index_enable_timing(cos_index *ix, int32_t on) {
-    if (!ix) return fail(COS_ERR_INVALID, "null");
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->timing = on != 0;
     return COS_OK;
@@ -504,7 +436,7 @@ static int32_t get_workspace(cos_index *ix, void *stream_key, u32 B, u32 top_k, 
 // quantize -> walk -> (finalize) on `st`; all buffers device memory
 static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u32 B, u32 top_k, u32 *d_out_ids, float *d_out_scores,
                           u32 *d_out_counts, int32_t *d_out_status, bool do_finalize, hipStream_t st) {
-    IndexDev dev = make_index_dev(ix);
+    IndexDev dev = cos_make_index_dev(ix);
     bool timed;
     { std::lock_guard<std::mutex> g(ix->mu); timed = ix->timing; }
     if (dev.visited_mode == COS_VISITED_EXACT) {
@@ -547,18 +479,18 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
 }
 
 static int32_t check_search_args(cos_index *ix, const void *q, u32 B, u32 top_k) {
-    if (!ix || !q) return fail(COS_ERR_INVALID, "null argument");
-    if (!graph_ready(ix)) return fail(COS_ERR_NOT_READY, "index needs vectors, root and every graph level before search");
-    if (top_k == 0 || top_k > 1024) return fail(COS_ERR_INVALID, "top_k must be in [1, 1024]");
-    if (B == 0) return fail(COS_ERR_INVALID, "empty batch");
-    return set_device(ix);
+    if (!ix || !q) return cos_fail(COS_ERR_INVALID, "null argument");
+    if (!graph_ready(ix)) return cos_fail(COS_ERR_NOT_READY, "index needs vectors, root and every graph level before search");
+    if (top_k == 0 || top_k > 1024) return cos_fail(COS_ERR_INVALID, "top_k must be in [1, 1024]");
+    if (B == 0) return cos_fail(COS_ERR_INVALID, "empty batch");
+    return cos_set_device(ix);
 }
 
 extern "C" int32_t cos_search_batch_device(cos_index *ix, const float *d_queries, uint32_t B, uint32_t top_k, uint32_t *d_out_ids,
                                            float *d_out_scores, uint32_t *d_out_counts, int32_t *d_out_status, void *stream) {
     int32_t rc = check_search_args(ix, d_queries, B, top_k);
     if (rc) return rc;
-    if (!d_out_ids || !d_out_scores || !d_out_counts || !d_out_status) return fail(COS_ERR_INVALID, "null output");
+    if (!d_out_ids || !d_out_scores || !d_out_counts || !d_out_status) return cos_fail(COS_ERR_INVALID, "null output");
     Workspace *w;
     rc = get_workspace(ix, stream, B, top_k, false, &w);
     if (rc) return rc;
@@ -569,7 +501,7 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
                                     uint32_t *out_counts, int32_t *out_status) {
     int32_t rc = check_search_args(ix, queries, B, top_k);
     if (rc) return rc;
-    if (!out_ids || !out_scores || !out_counts) return fail(COS_ERR_INVALID, "null output");
+    if (!out_ids || !out_scores || !out_counts) return cos_fail(COS_ERR_INVALID, "null output");
     // host API: a private stream per calling thread so concurrent callers (rayon workers) do not serialise
     static thread_local std::map<cos_index *, hipStream_t> tl_streams;
     hipStream_t st = tl_streams[ix];
@@ -591,7 +523,7 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
     HIP_TRY(hipStreamSynchronize(st));
     if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
     for (u32 b = 0; b < B; b++)
-        if (status[b] != COS_OK) return fail(status[b], "query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", b, status[b]);
+        if (status[b] != COS_OK) return cos_fail(status[b], "query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", b, status[b]);
     return COS_OK;
 }
 
@@ -615,14 +547,14 @@ extern "C" int32_t cos_ann_search_batch(cos_index *ix, const float *queries, uin
     HIP_TRY(hipStreamSynchronize(st));
     if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
     for (u32 b = 0; b < B; b++)
-        if (status[b] != COS_OK) return fail(status[b], "query %u failed with status %d", b, status[b]);
+        if (status[b] != COS_OK) return cos_fail(status[b], "query %u failed with status %d", b, status[b]);
     return COS_OK;
 }
 
 extern "C" int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out) {
-    if (!ix || !out) return fail(COS_ERR_INVALID, "null argument");
+    if (!ix || !out) return cos_fail(COS_ERR_INVALID, "null argument");
     memset(out, 0, sizeof(*out));
-    int32_t rc = set_device(ix);
+    int32_t rc = cos_set_device(ix);
     if (rc) return rc;
     Workspace *w = nullptr;
     {
@@ -632,9 +564,9 @@ extern "C" int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_
             if (it != ix->ws.end()) w = it->second;
         } else
             w = ix->last_ws;
-        if (!w) return fail(COS_ERR_NOT_READY, "no batch has run on this stream");
+        if (!w) return cos_fail(COS_ERR_NOT_READY, "no batch has run on this stream");
     }
-    if (w->lastB == 0) return fail(COS_ERR_NOT_READY, "no batch has run on this stream");
+    if (w->lastB == 0) return cos_fail(COS_ERR_NOT_READY, "no batch has run on this stream");
     if (w->timed) {
         HIP_TRY(hipEventSynchronize(w->ev[3]));
         HIP_TRY(hipEventElapsedTime(&out->prep_ms, w->ev[0], w->ev[1]));
@@ -660,15 +592,15 @@ extern "C" int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_
 // ------------------------------------------------------------------------------------------------
 extern "C" int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uint32_t dim, float lo, float hi, const float *x, uint32_t n,
                                       void *codes, float *mags) {
-    if (!x || !codes || !mags || dim == 0 || n == 0) return fail(COS_ERR_INVALID, "bad argument");
+    if (!x || !codes || !mags || dim == 0 || n == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
     int eng;
     u64 row_stride;
     if (storage == COS_STORAGE_U8) { eng = ENG_U8; row_stride = ((u64)dim + 15) & ~15ull; }
     else if (storage == COS_STORAGE_SUBBYTE && resolution == 2) { eng = ENG_Q2; row_stride = (u64)((dim + 63) / 64) * 16; }
     else if (storage == COS_STORAGE_F32) { eng = ENG_F32; row_stride = ((u64)dim * 4 + 15) & ~15ull; }
-    else return fail(COS_ERR_UNIMPLEMENTED, "storage kind not supported on the device yet");
+    else return cos_fail(COS_ERR_UNIMPLEMENTED, "storage kind not supported on the device yet");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
     float *d_x = nullptr, *d_m = nullptr;
     uint8_t *d_c = nullptr;
     HIP_TRY(hipMalloc(&d_x, (size_t)n * dim * 4));
@@ -690,28 +622,28 @@ extern "C" int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uin
 // entry points whose kernels live in other translation units (weak stubs until they are linked in)
 // ------------------------------------------------------------------------------------------------
 #define COS_WEAK_STUB __attribute__((weak))
-extern "C" COS_WEAK_STUB int32_t cos_index_build(cos_index *, uint32_t) { return fail(COS_ERR_UNIMPLEMENTED, "cos_index_build: builder kernels not linked"); }
+extern "C" COS_WEAK_STUB int32_t cos_index_build(cos_index *, uint32_t) { return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_index_build: builder kernels not linked"); }
 extern "C" COS_WEAK_STUB int32_t cos_distance_batch(uint32_t, uint32_t, uint32_t, uint32_t, const void *, const float *, uint32_t, const void *,
                                                     const float *, uint32_t, const uint32_t *, const uint32_t *, uint32_t, float *, int32_t *) {
-    return fail(COS_ERR_UNIMPLEMENTED, "cos_distance_batch: kernels not linked");
+    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_distance_batch: kernels not linked");
 }
 extern "C" COS_WEAK_STUB int32_t cos_bruteforce_topk(cos_index *, const float *, uint32_t, uint32_t, uint32_t *, float *) {
-    return fail(COS_ERR_UNIMPLEMENTED, "cos_bruteforce_topk: kernels not linked");
+    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_bruteforce_topk: kernels not linked");
 }
 extern "C" COS_WEAK_STUB int32_t cos_bm25_create(int32_t, const uint32_t *, const uint64_t *, uint32_t, const uint32_t *, const float *, uint32_t,
                                                  cos_bm25 **) {
-    return fail(COS_ERR_UNIMPLEMENTED, "cos_bm25_create: kernels not linked");
+    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_bm25_create: kernels not linked");
 }
 extern "C" COS_WEAK_STUB int32_t cos_bm25_destroy(cos_bm25 *) { return COS_OK; }
 extern "C" COS_WEAK_STUB int32_t cos_bm25_search_batch(cos_bm25 *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t *, float *,
                                                        uint32_t *) {
-    return fail(COS_ERR_UNIMPLEMENTED, "cos_bm25_search_batch: kernels not linked");
+    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_bm25_search_batch: kernels not linked");
 }
 extern "C" COS_WEAK_STUB int32_t cos_rrf_fuse_batch(const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, uint32_t,
                                                     uint32_t, float, uint32_t, uint32_t *, float *, uint32_t *) {
-    return fail(COS_ERR_UNIMPLEMENTED, "cos_rrf_fuse_batch: kernels not linked");
+    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_rrf_fuse_batch: kernels not linked");
 }
 extern "C" COS_WEAK_STUB int32_t cos_merge_topk_device(const uint32_t *, const float *, const uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t *,
                                                        float *, uint32_t *, int32_t, void *) {
-    return fail(COS_ERR_UNIMPLEMENTED, "cos_merge_topk_device: kernels not linked");
+    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_merge_topk_device: kernels not linked");
 }

@@ -1,0 +1,88 @@
+// engine_internal.h — host-side structures shared by engine.hip and builder.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cosdata_hip.h"
+#include "engine_types.h"
+
+namespace cosdev {
+hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
+                                u64 row_stride, float *mags, float *raw_mags, hipStream_t st);
+hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
+hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
+                           const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
+                           u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
+                           hipStream_t st);
+hipError_t launch_scatter_rows(u32 *dst, const u32 *rows, const u32 *packed, u32 n_rows, u32 M, hipStream_t st);
+} // namespace cosdev
+
+using cosdev::u32;
+using cosdev::u64;
+
+int32_t cos_fail(int32_t code, const char *fmt, ...);
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return cos_fail(COS_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct LevelHost {
+    std::vector<u32> node_ids; // ascending, root last
+    std::vector<u32> nbr_ids;  // [n][M] internal ids / COS_SLOT_EMPTY
+    u32 *d_adj_vec = nullptr, *d_adj_node = nullptr, *d_node_vec = nullptr, *d_child = nullptr;
+    u32 n = 0, M = 0;
+    bool host_valid = false; // node_ids/nbr_ids mirror the device arrays
+};
+
+struct Workspace {
+    u32 capB = 0, cap_topk = 0;
+    uint8_t *q_codes = nullptr;
+    float *q_mags = nullptr, *q_raw_mags = nullptr;
+    u32 *walk_ids = nullptr, *walk_counts = nullptr;
+    float *walk_sims = nullptr;
+    int32_t *walk_status = nullptr;
+    u64 *stats = nullptr;       // [B][4]
+    u64 *rerank_rows = nullptr; // [B]
+    u32 *vis_slab = nullptr;
+    size_t vis_slab_words = 0;
+    // host-API staging (device)
+    float *d_queries = nullptr;
+    u32 *d_out_ids = nullptr, *d_out_counts = nullptr;
+    float *d_out_scores = nullptr;
+    int32_t *d_out_status = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    u32 lastB = 0;
+    bool timed = false;
+};
+
+struct cos_index {
+    cos_params p;
+    int eng = -1;
+    u32 n = 0;
+    bool have_vectors = false, have_root = false, raw_borrowed = false;
+    float *d_raw = nullptr;
+    float *d_raw_mags = nullptr;
+    uint8_t *d_codes = nullptr;
+    float *d_mags = nullptr;
+    u64 row_stride = 0;
+    u32 nchunks = 0, G = 1;
+    std::vector<float> root_raw;
+    std::vector<LevelHost> lv;
+    hipStream_t own_stream = nullptr; // host API stream
+    std::mutex mu;                    // guards workspaces map + timing flag
+    std::map<void *, Workspace *> ws;
+    Workspace *last_ws = nullptr; // most recent batch (cos_index_last_stats with stream == NULL)
+    bool timing = false;
+};
+
+
+cosdev::IndexDev cos_make_index_dev(const cos_index *ix);
+int32_t cos_set_device(const cos_index *ix);

@@ -119,6 +119,8 @@ int coso_index_set_vectors(coso_index *ix, const float *raw, uint32_t n);
 /* Deterministic single-threaded builder with reference edge semantics (App. A.4).
  * Inserts ids [0, n) in order.  Creates the root first (random vector in values_range). */
 int coso_index_build(coso_index *ix);
+/* Batch-synchronous schedule (CPU statement of the device builder, cosdata_amd/csrc/builder.hip). */
+int coso_index_build_batched(coso_index *ix, uint32_t batch_size);
 /* Flat export/import (the same arrays include/cosdata_hip.h uploads). */
 uint32_t coso_index_level_count(const coso_index *ix, uint32_t level);
 int coso_index_export_level(const coso_index *ix, uint32_t level, uint32_t *node_ids /*[n_l]*/,

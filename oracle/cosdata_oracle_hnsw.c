@@ -540,6 +540,86 @@ int coso_index_build(coso_index *ix) {
     return rc;
 }
 
+/* Batch-synchronous variant of the builder — the CPU statement of cosdata_amd/csrc/builder.hip:
+ * every id of a batch walks the graph snapshot that precedes the batch (all levels, ef_construction,
+ * keep 64, visited pre-seeded with its id); then nodes are created and edges connected level by
+ * level in id order with the same create_node_edges/add_neighbor semantics.  Batch sizes follow
+ * min(Bmax, max(1, inserted/4)).  With Bmax = 1 this is NOT coso_index_build (there the lower
+ * levels are linked before the upper level's walk result is used) but differs only in schedule. */
+int coso_index_build_batched(coso_index *ix, uint32_t batch_size) {
+    if (!ix || !ix->codes) return COSO_ERR_INVALID;
+    const uint32_t Ltop = ix->p.num_layers, L1 = Ltop + 1;
+    const uint32_t Bmax = batch_size ? batch_size : 4096u;
+    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
+    for (uint32_t l = 0; l <= Ltop; l++) level_free(&ix->lv[l]);
+    for (uint32_t i = 0; i < ix->p.dim; i++) ix->root_raw[i] = ix->p.range_lo + rand_f32(&rng) * (ix->p.range_hi - ix->p.range_lo);
+    int rc = coso_index_set_root_raw(ix, ix->root_raw);
+    if (rc != COSO_OK) return rc;
+    for (uint32_t l = 0; l <= Ltop; l++) {
+        uint32_t r = level_append(&ix->lv[l], COSO_ROOT_ID, (int)ix->p.metric);
+        ix->lv[l].root_idx = r;
+        if (l > 0) ix->lv[l].child[r] = ix->lv[l - 1].root_idx;
+    }
+    double *pv = (double *)malloc(L1 * sizeof(double));
+    uint8_t *pl = (uint8_t *)malloc(L1);
+    coso_level_probs(4.0, (int)Ltop, pv, pl);
+    uint8_t *max_level = (uint8_t *)malloc(ix->n ? ix->n : 1);
+    for (uint32_t id = 0; id < ix->n; id++) max_level[id] = (uint8_t)coso_max_insert_level((double)rand_f32(&rng), pv, pl, (int)L1);
+    scratch_t *s = scratch_new(ix);
+    zent *z = (zent *)malloc((size_t)Bmax * L1 * KEEP_INDEX * sizeof(zent));
+    uint32_t *zn = (uint32_t *)malloc((size_t)Bmax * L1 * 4);
+    uint32_t *me = (uint32_t *)malloc((size_t)Bmax * L1 * 4);
+    uint32_t inserted = 0;
+    while (inserted < ix->n && rc == COSO_OK) {
+        uint32_t bs = inserted / 4u;
+        if (bs < 1) bs = 1;
+        if (bs > Bmax) bs = Bmax;
+        if (bs > ix->n - inserted) bs = ix->n - inserted;
+        /* 1. walks on the snapshot */
+        for (uint32_t b = 0; b < bs && rc == COSO_OK; b++) {
+            const uint32_t id = inserted + b, row = id;
+            const uint8_t *code = ix->codes + (size_t)row * ix->cb;
+            uint32_t entry = ix->lv[Ltop].root_idx;
+            for (int level = (int)Ltop; level >= 0; level--) {
+                zent *zz = z + ((size_t)b * L1 + (uint32_t)level) * KEEP_INDEX;
+                int cnt = walk_level(ix, (uint32_t)level, entry, code, ix->mags[row], id, ix->p.ef_construction, KEEP_INDEX, s, NULL);
+                if (cnt < 0) { rc = -cnt; break; }
+                if (cnt == 0) {
+                    float d;
+                    rc = node_distance(ix, code, ix->mags[row], row_of(ix, ix->lv[level].node_id[entry]), &d);
+                    if (rc != COSO_OK) break;
+                    zz[0].idx = entry; zz[0].sim = d; cnt = 1;
+                } else
+                    for (int i = 0; i < cnt; i++) { zz[i].idx = s->res[i].idx; zz[i].sim = s->res[i].sim; }
+                zn[(size_t)b * L1 + (uint32_t)level] = (uint32_t)cnt;
+                if (level > 0) entry = ix->lv[level].child[zz[0].idx];
+            }
+        }
+        if (rc != COSO_OK) break;
+        /* 2. create the nodes of the batch (child links top-down) */
+        for (uint32_t b = 0; b < bs; b++) {
+            const uint32_t id = inserted + b;
+            uint32_t parent = IDX_NONE;
+            for (int level = (int)max_level[id]; level >= 0; level--) {
+                uint32_t m = level_append(&ix->lv[level], id, (int)ix->p.metric);
+                me[(size_t)b * L1 + (uint32_t)level] = m;
+                if (parent != IDX_NONE) ix->lv[level + 1].child[parent] = m;
+                parent = m;
+            }
+        }
+        /* 3. connect edges level by level, new nodes in id order */
+        for (uint32_t l = 0; l <= Ltop; l++)
+            for (uint32_t b = 0; b < bs; b++) {
+                if (max_level[inserted + b] < l) continue;
+                create_node_edges(ix, l, me[(size_t)b * L1 + l], z + ((size_t)b * L1 + l) * KEEP_INDEX, (int)zn[(size_t)b * L1 + l]);
+            }
+        inserted += bs;
+    }
+    free(z); free(zn); free(me); free(max_level); free(pv); free(pl);
+    scratch_free(s);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------
  * flat export / import: node ids ascending with the root (u32::MAX) last; neighbour slots as
  * internal ids, COSO_SLOT_EMPTY for null pointers.  Slot order is preserved.
@@ -598,11 +678,14 @@ int coso_index_import_level(coso_index *ix, uint32_t level, uint32_t n_nodes, co
     L->sorted = 1;
     if (node_ids[n_nodes - 1] != COSO_ROOT_ID) return COSO_ERR_INVALID;
     L->root_idx = n_nodes - 1;
+    int dense = 1; /* level 0 holds ids 0..n-2 then the root: id -> index without searching */
+    for (uint32_t i = 0; i + 1 < n_nodes; i++)
+        if (node_ids[i] != i) { dense = 0; break; }
     for (uint32_t i = 0; i < n_nodes; i++)
         for (uint32_t j = 0; j < L->M; j++) {
             uint32_t nid = nbr_ids[(size_t)i * L->M + j];
             if (nid == COSO_SLOT_EMPTY) continue;
-            uint32_t k = find_sorted(L->node_id, L->n, nid);
+            uint32_t k = dense ? (nid == COSO_ROOT_ID ? n_nodes - 1 : (nid < n_nodes - 1 ? nid : IDX_NONE)) : find_sorted(L->node_id, L->n, nid);
             if (k == IDX_NONE) return COSO_ERR_INVALID;
             L->nbr[(size_t)i * L->M + j] = k;
         }

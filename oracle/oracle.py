@@ -76,6 +76,7 @@ def lib():
         "coso_index_destroy": (None, [vp]),
         "coso_index_set_vectors": (C.c_int, [vp, vp, C.c_uint32]),
         "coso_index_build": (C.c_int, [vp]),
+        "coso_index_build_batched": (C.c_int, [vp, C.c_uint32]),
         "coso_index_level_count": (C.c_uint32, [vp, C.c_uint32]),
         "coso_index_export_level": (C.c_int, [vp, C.c_uint32, vp, vp, vp]),
         "coso_index_import_level": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
@@ -254,6 +255,12 @@ class OracleIndex:
         rc = lib().coso_index_build(self._h)
         if rc != OK:
             raise ValueError(f"build status {rc}")
+        return self
+
+    def build_batched(self, batch_size=0):
+        rc = lib().coso_index_build_batched(self._h, batch_size)
+        if rc != OK:
+            raise ValueError(f"build_batched status {rc}")
         return self
 
     @property

@@ -1,0 +1,40 @@
+"""Device builder (cos_index_build) vs the oracle's batch-synchronous builder: identical graphs."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_index(X, storage, res, **kw):
+    import cosdata_amd as ca
+    hp = ca.HNSWHyperParams(num_layers=kw.get("num_layers", 9), ef_construction=kw.get("ef_construction", 128),
+                            ef_search=kw.get("ef_search", 256))
+    dix = ca.HNSWIndex(X.shape[1], hp, ca.DistanceMetric.Cosine, ca.StorageType(ca.StorageKind(storage), res), seed=kw.get("seed", 42))
+    dix.upload_vectors(X)
+    return dix
+
+
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2), (O.STORAGE_F32, 0)])
+@pytest.mark.parametrize("n,dim,bs", [(1500, 96, 64), (4000, 128, 512)])
+def test_device_build_equals_oracle_batched(storage, res, n, dim, bs):
+    X = H.clustered_corpus(n, dim, n_centers=16, seed=9)
+    kw = dict(num_layers=5, ef_construction=64, ef_search=64, seed=77)
+    dix = _device_index(X, storage, res, **kw).build(bs)
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, storage=storage, resolution=res, **kw)).set_vectors(X).build_batched(bs)
+    assert np.array_equal(dix.download_root(), oix.root_raw())
+    dg, og = dix.download_graph(), oix.export_graph()
+    for l, ((di, dn), (oi, on)) in enumerate(zip(dg, og)):
+        assert np.array_equal(di, oi), f"level {l}: node sets differ"
+        assert np.array_equal(dn, on), f"level {l}: adjacency differs in {np.count_nonzero((dn != on).any(axis=1))} rows"
+    # and the freshly built device graph answers exactly like the oracle on it
+    Q = H.queries_from(X, 32, seed=5)
+    ids, sc, cnt = dix.batch_search(Q, 10)
+    oids, osc, ocnt = oix.search_batch(Q, 10, threads=4)[:3]
+    assert np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    gt, _ = O.bruteforce_topk(X, Q, 10, threads=4)
+    recall = np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(len(Q))])
+    if storage != O.STORAGE_SUBBYTE:  # the reference's 2-bit quantizer ignores values_range: normalised data collapses to ~1 bit
+        assert recall >= 0.8, recall
