@@ -5,7 +5,10 @@ A "step" is one pass of the hot path over one query batch: cos_search_batch_devi
 quantize -> HNSW walk (every level, ef_search) -> dedup/top-5k -> exact f32 rerank -> top-k,
 with the index and the queries resident in HBM.  Like the reference's own RPS harness
 (tests/rps-test.py: 32 client threads x batches of 200) several batches are kept in flight on
-separate HIP streams (`--inflight`); the single-stream rate is reported alongside.
+the device: `--coalesce` client batches of 256 are fused into one launch (server-side dynamic
+batching: the walk kernel gives every query one wavefront, so a 256-CU chip needs thousands of
+queries per launch) and `--inflight` launches overlap on separate HIP streams.  The rate of one
+un-coalesced 256-query batch at a time is reported alongside (`single_batch_qps`).
 
 Default workload = BASELINE.json configs[1]: 1M x 768 dense cosine HNSW, query batch 256, one GPU
 (`--workload c4shard` = one 12.5M x 1024 shard of configs[3]).  N > 1: one process per GPU, every
@@ -69,12 +72,13 @@ def bruteforce_top10(X, Q, k=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override vectors per GPU (marks the run as non-standard)")
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--inflight", type=int, default=16, help="query batches kept in flight (HIP streams)")
+    ap.add_argument("--coalesce", type=int, default=16, help="client batches fused per launch (dynamic batching)")
+    ap.add_argument("--inflight", type=int, default=3, help="launches kept in flight (HIP streams)")
     ap.add_argument("--ef", type=int, default=256, help="ef_search (config.toml default 256)")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--build-batch", type=int, default=4096)
@@ -96,7 +100,11 @@ def main():
     n, d, desc = WORKLOADS[args.workload]
     if args.n:
         n = args.n
-    B, k, ef = args.batch, args.top_k, args.ef
+    Bc, k, ef = args.batch, args.top_k, args.ef   # Bc = client batch (a "step"); B = queries per launch
+    C = max(1, args.coalesce)
+    B = Bc * C
+    n_launch = (args.steps + C - 1) // C
+    n_warm = (args.warmup + C - 1) // C
     t_setup = time.time()
 
     # ---- synthetic shard + queries (resident in HBM) -------------------------------------------
@@ -106,7 +114,7 @@ def main():
     centers = torch.randn(n_centers, d, generator=gc, device=dev)
     centers /= centers.norm(dim=1, keepdim=True)
     X = mixture(n, d, 42 + 1000 * rank, dev, centers)            # this rank's shard: global ids [rank*n, (rank+1)*n)
-    n_qsets = max(args.inflight, 4)
+    n_qsets = max(args.inflight, 2)
     Q = mixture(B * n_qsets, d, 43, dev, centers)                 # identical on every rank
     torch.cuda.synchronize()
 
@@ -189,12 +197,12 @@ def main():
     status_bad = int((o_st != 0).sum().item())
 
     # ---- warmup + timed region ----------------------------------------------------------------------
-    for i in range(args.warmup):
+    for i in range(n_warm):
         step(i)
     sync_all()
     ix.enable_timing(True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(n_launch):   # n_launch launches = n_launch * C client batches ("steps")
         step(i)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -203,29 +211,30 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    qps = args.steps * B / elapsed
+    steps_done = n_launch * C
+    qps = steps_done * Bc / elapsed
 
     # per-launch walk-kernel figures: HIP events recorded by the library on the launch stream
     row_bytes = d + 4  # u8 code row + f32 norm per distance evaluation
     per = []
-    for s in range(min(S, args.steps)):
+    for s in range(min(S, n_launch)):
         stt = ix.last_stats(streams[s].cuda_stream)
         per.append((stt.walk_ms, stt.evals * row_bytes + stt.adj_bytes, stt.evals, stt.expansions, stt.finalize_ms, stt.prep_ms))
     ix.enable_timing(False)
     avg_ms = float(np.mean([p[0] for p in per]))
     avg_bytes = float(np.mean([p[1] for p in per]))
     # launches overlap on the chip: in-flight concurrency = sum of launch durations / wall time
-    overlap = max(1.0, min(float(S), avg_ms * 1e-3 * args.steps / elapsed))
-    achieved = avg_bytes * args.steps / elapsed / 1e9  # aggregate algorithmic GB/s of the walk kernel
+    overlap = max(1.0, min(float(S), avg_ms * 1e-3 * n_launch / elapsed))
+    achieved = avg_bytes * n_launch / elapsed / 1e9  # aggregate algorithmic GB/s of the walk kernel
 
     # single-stream (one batch at a time) rate
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     for i in range(8):
-        ix.batch_search_device(Q[:B].data_ptr(), B, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(), o_st[0].data_ptr(),
+        ix.batch_search_device(Q[:Bc].data_ptr(), Bc, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(), o_st[0].data_ptr(),
                                streams[0].cuda_stream)
     streams[0].synchronize()
-    serial_qps = 8 * B / (time.perf_counter() - t1)
+    serial_qps = 8 * Bc / (time.perf_counter() - t1)
 
     # ---- CPU baseline: the oracle (C restatement of the Rust path) on this box's host cores ----------
     cpu = None
@@ -263,23 +272,23 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": METRIC, "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": METRIC, "value": qps, "unit": "queries/s", "n_gpus": world, "steps": steps_done, "warmup": n_warm * C,
+            "ms_per_step": elapsed / steps_done * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload + ": " + desc, "standard_size": not bool(args.n), "vectors_per_gpu": n, "dim": d,
-                       "query_batch": B, "batches_in_flight": S, "top_k": k, "ef_search": ef, "M": 32, "M0": 64, "num_layers": 9,
+                       "query_batch": Bc, "batches_per_launch": C, "launches_in_flight": S, "top_k": k, "ef_search": ef, "M": 32, "M0": 64, "num_layers": 9,
                        "storage": "u8 (auto quantization, range (-1,1))", "visited": "reference PerformantFixedSet (ID parity mode)",
                        "parallelism": f"id-range shards x{world}" + (" + RCCL all-gather top-k merge" if world > 1 else ""),
                        "corpus": f"Gaussian mixture, {n_centers} centres, sigma 0.8/sqrt(d), L2-normalised, seed 42"},
             "recall_at_10": recall, "recall_queries": nrq, "failed_queries": status_bad,
-            "single_stream_qps": serial_qps, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
+            "single_batch_qps": serial_qps, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None, "kernel": "walk_kernel<ENG_U8,1,4>",
                          "per_launch": {"algorithmic_bytes": avg_bytes, "avg_ms": avg_ms, "in_flight": overlap,
                                         "evals": float(np.mean([p[2] for p in per])), "expansions": float(np.mean([p[3] for p in per])),
                                         "finalize_ms": float(np.mean([p[4] for p in per])), "prep_ms": float(np.mean([p[5] for p in per]))},
-                         "note": "achieved = algorithmic bytes per launch x launches / timed wall time = bytes/avg_ms x in_flight "
-                                 "(launches of different streams overlap on the chip)"},
+                         "note": "one walk launch = query_batch x batches_per_launch queries; achieved = algorithmic bytes per launch x "
+                                 "launches / timed wall time = bytes/avg_ms x in_flight (launches on different streams overlap)"},
             "cpu_baseline": cpu, "parity_vs_oracle": parity,
         }
         print(json.dumps(out))

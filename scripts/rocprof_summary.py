@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd .db (kernel trace, optional PMC) for the kernels of this repo."""
+import sqlite3
+import sys
+
+
+def short(name):
+    for key in ("walk_kernel", "finalize_kernel", "quantize_rows_kernel", "scatter_rows_kernel", "merge_topk_kernel", "flat_", "bm25_"):
+        if key in name:
+            i = name.index(key)
+            j = name.find("(", i)
+            return name[i:j if j > 0 else None]
+    return name[:60]
+
+
+def main(path):
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    print(f"# {path}")
+    print("## kernel trace: name | grid (workgroups) | calls | avg_us | min_us | max_us | total_ms")
+    rows = cur.execute("select name, grid_x/workgroup_x, count(*), avg(duration), min(duration), max(duration), sum(duration) "
+                       "from kernels group by name, grid_x/workgroup_x order by sum(duration) desc limit 14").fetchall()
+    for name, grid, calls, avg, mn, mx, tot in rows:
+        print(f"{short(name):45s} | {grid:8d} | {calls:6d} | {avg/1e3:10.1f} | {mn/1e3:10.1f} | {mx/1e3:10.1f} | {tot/1e6:10.2f}")
+    try:
+        pm = cur.execute("select kernel_name, grid_size/workgroup_size, counter_name, count(*), avg(value), sum(value) from counters_collection "
+                         "group by kernel_name, grid_size/workgroup_size, counter_name order by sum(value) desc limit 12").fetchall()
+    except sqlite3.Error:
+        pm = []
+    if pm:
+        print("## PMC: kernel | grid | counter | dispatches | avg per dispatch | total")
+        for name, grid, cn, calls, avg, tot in pm:
+            print(f"{short(name):45s} | {grid:8d} | {cn} | {calls} | {avg:.1f} | {tot:.1f}")
+
+
+if __name__ == "__main__":
+    for p in sys.argv[1:]:
+        main(p)
