@@ -1,0 +1,314 @@
+// kernels_hybrid.hip — BM25 scoring over CSR postings and reciprocal-rank fusion (config c5).
+//   SparseAnnQueryBasic::search_bm25   models/sparse_ann_query.rs:149-233
+//   get_idf                            models/sparse_ann_query.rs:298-302 (ln_1p on the HOST libm, like the reference)
+//   RRF fusion of hybrid_search        api/vectordb/search/repo.rs:311-340
+//
+// BM25 is HBM-bound streaming work: every posting (8 B: doc id + stored tf) of every query term is read
+// once, coalesced.  The reference's document-at-a-time heap merge is restated as a tiled term-at-a-time
+// accumulation that produces bit-identical f32 sums: the doc-id space is cut into tiles of TILE ids; inside
+// a tile the query's terms are applied in ASCENDING TERM-HASH order (the documented order, oracle/…bm25.c)
+// with a workgroup barrier between terms, so each document's score is p0, then +p1, then +p2 … exactly like
+// the sequential merge.  Postings of one term are distinct documents, so lanes never collide inside a term.
+// The 512 result buckets (doc_id % 512, strictly-greater score wins, first seen = smallest id on ties) are
+// an order-independent max over the key (score, ~doc_id): one 64-bit LDS/global atomic max.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "engine_internal.h"
+
+using namespace cosdev;
+
+namespace {
+
+constexpr u32 BUCKETS = 512;  // sparse_ann_query.rs:154
+constexpr u32 TILE = 8192;    // doc ids per LDS accumulator tile (32 KB of f32 + 1 KB of touched bits)
+constexpr u32 MAX_QTERMS = 64;
+
+struct QueryTerms { // per query, terms ascending by hash, only those that have a posting list
+    u64 begin[MAX_QTERMS];
+    u64 end[MAX_QTERMS];
+    float idf[MAX_QTERMS];
+    u32 n;
+};
+
+__device__ __forceinline__ u64 lower_bound_doc(const u32 *__restrict__ docs, u64 lo, u64 hi, u32 key) {
+    while (lo < hi) {
+        u64 mid = lo + (hi - lo) / 2;
+        if (docs[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// grid = (B, splits): block (q, s) owns the tiles s, s+splits, s+2*splits, ...
+__global__ __launch_bounds__(256) void bm25_score_kernel(const u32 *__restrict__ docs, const float *__restrict__ tfs,
+                                                         const QueryTerms *__restrict__ qts, u32 n_docs, u64 *__restrict__ buckets /*[B][512]*/) {
+    __shared__ float acc[TILE];
+    __shared__ u32 touched[TILE / 32];
+    __shared__ u64 lb[BUCKETS];
+    const u32 q = blockIdx.x;
+    const QueryTerms *qt = &qts[q];
+    const u32 nt = qt->n;
+    if (nt == 0) return;
+    for (u32 i = threadIdx.x; i < BUCKETS; i += blockDim.x) lb[i] = 0ull;
+    const u32 n_tiles = (n_docs + TILE - 1) / TILE;
+    for (u32 tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
+        const u32 d0 = tile * TILE, d1 = d0 + TILE; // [d0, d1)
+        for (u32 i = threadIdx.x; i < TILE / 32; i += blockDim.x) touched[i] = 0;
+        __syncthreads();
+        for (u32 t = 0; t < nt; t++) {
+            const u64 b = lower_bound_doc(docs, qt->begin[t], qt->end[t], d0);
+            const u64 e = lower_bound_doc(docs, b, qt->end[t], d1 < d0 ? 0xFFFFFFFFu : d1);
+            const float idf = qt->idf[t];
+            for (u64 i = b + threadIdx.x; i < e; i += blockDim.x) {
+                const u32 slot = docs[i] - d0;
+                const float p = __fmul_rn(tfs[i], idf); // tf * head.idf
+                const u32 w = slot >> 5, m = 1u << (slot & 31);
+                const bool seen = touched[w] & m;        // bits of earlier terms only (barrier below)
+                acc[slot] = seen ? __fadd_rn(acc[slot], p) : p;
+                if (!seen) atomicOr(&touched[w], m);
+            }
+            __syncthreads();
+        }
+        for (u32 slot = threadIdx.x; slot < TILE; slot += blockDim.x) {
+            if (touched[slot >> 5] & (1u << (slot & 31))) {
+                const u32 doc = d0 + slot;
+                const u64 key = pack_key(simkey(acc[slot]), ~doc); // larger score, then smaller doc id
+                atomicMax((unsigned long long *)&lb[doc % BUCKETS], (unsigned long long)key);
+            }
+        }
+        __syncthreads();
+    }
+    for (u32 i = threadIdx.x; i < BUCKETS; i += blockDim.x)
+        if (lb[i]) atomicMax((unsigned long long *)&buckets[(u64)q * BUCKETS + i], (unsigned long long)lb[i]);
+}
+
+// one wave per query: 512 buckets -> sort by (score desc, larger id first) -> top k
+__global__ __launch_bounds__(64) void bm25_topk_kernel(const u64 *__restrict__ buckets, u32 B, u32 top_k, u32 *__restrict__ out_ids,
+                                                       float *__restrict__ out_scores, u32 *__restrict__ out_counts) {
+    const int lane = threadIdx.x;
+    const u32 q = blockIdx.x;
+    if (q >= B) return;
+    u64 k[8];
+    u32 cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const u64 v = buckets[(u64)q * BUCKETS + (u32)lane * 8 + r];
+        k[r] = v ? pack_key((u32)(v >> 32), ~(u32)v) : 0ull; // back to (score, doc id)
+        cnt += v != 0ull;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) cnt += (u32)__shfl_xor((int)cnt, m, 64);
+    bitonic_sort_desc<8>(k, lane);
+    const u32 n = cnt < top_k ? cnt : top_k;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const u32 e = (u32)lane * 8 + r;
+        if (e < n) {
+            out_ids[(u64)q * top_k + e] = (u32)k[r];
+            out_scores[(u64)q * top_k + e] = simkey_inv((u32)(k[r] >> 32));
+        }
+    }
+    if (lane == 0) out_counts[q] = n;
+}
+
+// RRF: one wave per query.  score(id) = [last dense occurrence: 1/(rank+k+eps)] then += each sparse occurrence.
+template <int R>
+__global__ __launch_bounds__(64) void rrf_kernel(const u32 *__restrict__ dense_ids, const u32 *__restrict__ dense_counts, u32 dense_stride,
+                                                 const u32 *__restrict__ sparse_ids, const u32 *__restrict__ sparse_counts, u32 sparse_stride, u32 B,
+                                                 float kc, u32 top_k, u32 *__restrict__ out_ids, float *__restrict__ out_scores,
+                                                 u32 *__restrict__ out_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *ids = (u32 *)smem_raw; // [nd + ns]
+    const int lane = threadIdx.x;
+    const u32 q = blockIdx.x;
+    if (q >= B) return;
+    const u32 nd = dense_counts[q], ns = sparse_counts[q], n = nd + ns;
+    for (u32 i = lane; i < n; i += 64) ids[i] = i < nd ? dense_ids[(u64)q * dense_stride + i] : sparse_ids[(u64)q * sparse_stride + (i - nd)];
+    __builtin_amdgcn_wave_barrier();
+    u64 key[R];
+    u32 cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const u32 e = (u32)lane * R + r;
+        key[r] = 0ull;
+        if (e < n) {
+            const u32 id = ids[e];
+            bool first = true;
+            for (u32 j = 0; j < e; j++) first &= ids[j] != id;
+            if (first) { // the first occurrence owns the id
+                float score = 0.0f;
+                for (u32 j = 0; j < nd; j++)
+                    if (ids[j] == id) score = __fdiv_rn(1.0f, __fadd_rn(__fadd_rn((float)j, kc), 1.1920929e-07f)); // insert() overwrites
+                for (u32 j = nd; j < n; j++)
+                    if (ids[j] == id) score = __fadd_rn(score, __fdiv_rn(1.0f, __fadd_rn(__fadd_rn((float)(j - nd), kc), 1.1920929e-07f)));
+                key[r] = pack_key(simkey(score), id);
+                cnt++;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) cnt += (u32)__shfl_xor((int)cnt, m, 64);
+    bitonic_sort_desc<R>(key, lane);
+    const u32 nout = cnt < top_k ? cnt : top_k;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const u32 e = (u32)lane * R + r;
+        if (e < nout) {
+            out_ids[(u64)q * top_k + e] = (u32)key[r];
+            out_scores[(u64)q * top_k + e] = simkey_inv((u32)(key[r] >> 32));
+        }
+    }
+    if (lane == 0) out_counts[q] = nout;
+}
+
+} // namespace
+
+struct cos_bm25 {
+    int32_t device = 0;
+    u32 n_terms = 0, documents_count = 0, max_doc = 0;
+    std::vector<u32> term_hashes;
+    std::vector<u64> offsets;
+    u32 *d_docs = nullptr;
+    float *d_tfs = nullptr;
+};
+
+extern "C" int32_t cos_bm25_create(int32_t device, const uint32_t *term_hashes, const uint64_t *offsets, uint32_t n_terms, const uint32_t *doc_ids,
+                                   const float *tfs, uint32_t documents_count, cos_bm25 **out) {
+    if (!term_hashes || !offsets || !doc_ids || !tfs || !out || n_terms == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    for (u32 t = 1; t < n_terms; t++)
+        if (term_hashes[t] <= term_hashes[t - 1]) return cos_fail(COS_ERR_INVALID, "term hashes must be strictly ascending");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    HIP_TRY(hipSetDevice(device));
+    cos_bm25 *b = new cos_bm25();
+    b->device = device;
+    b->n_terms = n_terms;
+    b->documents_count = documents_count;
+    b->term_hashes.assign(term_hashes, term_hashes + n_terms);
+    b->offsets.assign(offsets, offsets + n_terms + 1);
+    const u64 nnz = offsets[n_terms];
+    for (u32 t = 0; t < n_terms; t++)
+        if (offsets[t + 1] > offsets[t]) b->max_doc = std::max(b->max_doc, doc_ids[offsets[t + 1] - 1]); // lists are doc-id ascending
+    hipError_t e = hipMalloc(&b->d_docs, std::max<u64>(nnz, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&b->d_tfs, std::max<u64>(nnz, 1) * 4);
+    if (e == hipSuccess) e = hipMemcpy(b->d_docs, doc_ids, nnz * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_tfs, tfs, nnz * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cos_bm25_destroy(b); HIP_TRY(e); }
+    *out = b;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_bm25_destroy(cos_bm25 *b) {
+    if (!b) return COS_OK;
+    (void)hipSetDevice(b->device);
+    if (b->d_docs) (void)hipFree(b->d_docs);
+    if (b->d_tfs) (void)hipFree(b->d_tfs);
+    delete b;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_bm25_search_batch(cos_bm25 *b, const uint32_t *q_terms, const uint32_t *q_offsets, uint32_t B, uint32_t top_k,
+                                         uint32_t *out_ids, float *out_scores, uint32_t *out_counts) {
+    if (!b || !q_terms || !q_offsets || !out_ids || !out_scores || !out_counts || B == 0 || top_k == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(b->device));
+    // host: sort each query's terms by hash, look the posting lists up, idf via libm log1pf (sparse_ann_query.rs:298-302)
+    std::vector<QueryTerms> qts(B);
+    for (u32 q = 0; q < B; q++) {
+        std::vector<u32> t(q_terms + q_offsets[q], q_terms + q_offsets[q + 1]);
+        std::sort(t.begin(), t.end());
+        QueryTerms &qt = qts[q];
+        qt.n = 0;
+        for (u32 h : t) {
+            auto it = std::lower_bound(b->term_hashes.begin(), b->term_hashes.end(), h);
+            if (it == b->term_hashes.end() || *it != h) continue; // no node / no term: skipped (:165-167)
+            if (qt.n == MAX_QTERMS) return cos_fail(COS_ERR_UNIMPLEMENTED, "more than %u matching terms in query %u", MAX_QTERMS, q);
+            const size_t ti = (size_t)(it - b->term_hashes.begin());
+            const u32 len = (u32)(b->offsets[ti + 1] - b->offsets[ti]);
+            qt.begin[qt.n] = b->offsets[ti];
+            qt.end[qt.n] = b->offsets[ti + 1];
+            qt.idf[qt.n] = log1pf(((float)(u32)(b->documents_count - len) + 0.5f) / ((float)len + 0.5f));
+            qt.n++;
+        }
+    }
+    QueryTerms *d_qt = nullptr;
+    u64 *d_buckets = nullptr;
+    u32 *d_ids = nullptr, *d_cnt = nullptr;
+    float *d_sc = nullptr;
+    hipError_t e = hipMalloc(&d_qt, (size_t)B * sizeof(QueryTerms));
+    if (e == hipSuccess) e = hipMalloc(&d_buckets, (size_t)B * BUCKETS * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_ids, (size_t)B * top_k * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_sc, (size_t)B * top_k * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_qt, qts.data(), (size_t)B * sizeof(QueryTerms), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_buckets, 0, (size_t)B * BUCKETS * 8);
+    if (e == hipSuccess) {
+        const u32 max_doc = b->max_doc; // doc ids are internal ids; the largest one bounds the tile count
+        const u32 span = max_doc + 1;
+        const u32 n_tiles = (span + TILE - 1) / TILE;
+        const u32 splits = std::max(1u, std::min(n_tiles, std::max(1u, 2048u / B)));
+        hipLaunchKernelGGL(bm25_score_kernel, dim3(B, splits), dim3(256), 0, 0, b->d_docs, b->d_tfs, d_qt, span, d_buckets);
+        e = hipGetLastError();
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bm25_topk_kernel, dim3(B), dim3(64), 0, 0, d_buckets, B, top_k, d_ids, d_sc, d_cnt);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_ids, d_ids, (size_t)B * top_k * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_scores, d_sc, (size_t)B * top_k * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_counts, d_cnt, (size_t)B * 4, hipMemcpyDeviceToHost);
+    void *ptrs[] = {d_qt, d_buckets, d_ids, d_sc, d_cnt};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    HIP_TRY(e);
+    return COS_OK;
+}
+
+extern "C" int32_t cos_rrf_fuse_batch(const uint32_t *dense_ids, const uint32_t *dense_counts, uint32_t dense_stride, const uint32_t *sparse_ids,
+                                      const uint32_t *sparse_counts, uint32_t sparse_stride, uint32_t B, float fusion_constant_k, uint32_t top_k,
+                                      uint32_t *out_ids, float *out_scores, uint32_t *out_counts) {
+    if (!dense_ids || !dense_counts || !sparse_ids || !sparse_counts || !out_ids || !out_scores || !out_counts || B == 0 || top_k == 0)
+        return cos_fail(COS_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    u32 maxn = 0;
+    for (u32 q = 0; q < B; q++) {
+        if (dense_counts[q] > dense_stride || sparse_counts[q] > sparse_stride) return cos_fail(COS_ERR_INVALID, "count exceeds stride (query %u)", q);
+        maxn = std::max(maxn, dense_counts[q] + sparse_counts[q]);
+    }
+    if (maxn > 1024) return cos_fail(COS_ERR_UNIMPLEMENTED, "RRF lists longer than 1024 entries");
+    u32 *d_d = nullptr, *d_dc = nullptr, *d_s = nullptr, *d_sc = nullptr, *d_oi = nullptr, *d_oc = nullptr;
+    float *d_os = nullptr;
+    hipError_t e = hipMalloc(&d_d, (size_t)B * dense_stride * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_s, (size_t)B * sparse_stride * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_dc, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_sc, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_oi, (size_t)B * top_k * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_os, (size_t)B * top_k * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_oc, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_d, dense_ids, (size_t)B * dense_stride * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_s, sparse_ids, (size_t)B * sparse_stride * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_dc, dense_counts, (size_t)B * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_sc, sparse_counts, (size_t)B * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const size_t smem = (size_t)std::max(maxn, 1u) * 4;
+#define LAUNCH(R) hipLaunchKernelGGL(rrf_kernel<R>, dim3(B), dim3(64), smem, 0, d_d, d_dc, dense_stride, d_s, d_sc, sparse_stride, B, fusion_constant_k, top_k, d_oi, d_os, d_oc)
+        if (maxn <= 64) LAUNCH(1);
+        else if (maxn <= 128) LAUNCH(2);
+        else if (maxn <= 256) LAUNCH(4);
+        else if (maxn <= 512) LAUNCH(8);
+        else LAUNCH(16);
+#undef LAUNCH
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_ids, d_oi, (size_t)B * top_k * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_scores, d_os, (size_t)B * top_k * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_counts, d_oc, (size_t)B * 4, hipMemcpyDeviceToHost);
+    void *ptrs[] = {d_d, d_s, d_dc, d_sc, d_oi, d_os, d_oc};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    HIP_TRY(e);
+    return COS_OK;
+}

@@ -2,6 +2,7 @@
 //  and the src/distance operator on explicit pairs (cos_distance_batch).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <vector>
 
 #include "engine_internal.h"
@@ -67,5 +68,157 @@ extern "C" int32_t cos_merge_topk_device(const uint32_t *d_ids, const float *d_s
     else return cos_fail(COS_ERR_UNIMPLEMENTED, "S*k > 1024 not supported by the merge kernel");
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
+    return COS_OK;
+}
+
+// ================================================================================================
+// cos_distance_batch — DistanceMetric::calculate (models/types.rs:469) on explicit pairs
+// ================================================================================================
+#include "dot_engines.h"
+
+namespace {
+
+struct DistArgs {
+    const uint8_t *x_codes, *y_codes; // device layout
+    const float *x_mags, *y_mags;
+    const u32 *pair_x, *pair_y;
+    u64 row_stride;
+    u32 n_pairs, dim, metric, nchunks;
+    float *out;
+    int32_t *status;
+};
+
+// one wave per pair
+template <int ENG>
+__global__ __launch_bounds__(64) void distance_pairs_kernel(const DistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const u32 p = blockIdx.x;
+    if (p >= a.n_pairs) return;
+    const uint8_t *xr = a.x_codes + (u64)a.pair_x[p] * a.row_stride;
+    const uint8_t *yr = a.y_codes + (u64)a.pair_y[p] * a.row_stride;
+    const float xm = a.x_mags[a.pair_x[p]], ym = a.y_mags[a.pair_y[p]];
+    float val = 0.0f;
+    int32_t st = COS_OK;
+    if (a.metric == COS_METRIC_COSINE || a.metric == COS_METRIC_DOT) {
+        float dotf;
+        if constexpr (ENG == ENG_F32) {
+            float *qf = (float *)smem_raw;
+            for (u32 i = lane; i < (u32)(a.row_stride / 4); i += 64) qf[i] = ((const float *)xr)[i];
+            dotf = f32_pair_dot((const float *)yr, qf, a.dim, lane & 1);
+            if (a.metric == COS_METRIC_DOT) st = COS_ERR_STORAGE_MISMATCH; // dotproduct.rs: no FullPrecisionFP arm
+        } else {
+            u32 acc = 0;
+            for (u32 c = lane; c < a.nchunks; c += 64) acc = chunk_dot<ENG>(*(const uint4 *)(xr + (u64)c * 16), *(const uint4 *)(yr + (u64)c * 16), acc);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) acc += (u32)__shfl_xor((int)acc, m, 64);
+            dotf = (float)acc;
+        }
+        if (a.metric == COS_METRIC_COSINE) { // cosine.rs:223-235
+            const float den = __fmul_rn(xm, ym);
+            if (den == 0.0f) st = COS_ERR_CALCULATION;
+            else val = __fdiv_rn(dotf, den);
+        } else
+            val = dotf;
+    } else if (a.metric == COS_METRIC_HAMMING) { // hamming.rs:60-98 (integer counts < 2^24: exact in f32 in any order)
+        if constexpr (ENG == ENG_F32) st = COS_ERR_STORAGE_MISMATCH;
+        else {
+            u32 acc = 0;
+            for (u32 c = lane; c < a.nchunks; c += 64) {
+                const uint4 x = *(const uint4 *)(xr + (u64)c * 16), y = *(const uint4 *)(yr + (u64)c * 16);
+                acc += __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) acc += (u32)__shfl_xor((int)acc, m, 64);
+            val = (float)acc;
+        }
+    } else if (a.metric == COS_METRIC_EUCLIDEAN) { // euclidean.rs:42-53: sequential f32 sum of (diff*diff) as i16 (wrapping)
+        if constexpr (ENG == ENG_U8) {
+            float acc = -0.0f;
+            if (lane == 0)
+                for (u32 i = 0; i < a.dim; i++) {
+                    const int16_t diff = (int16_t)((int16_t)xr[i] - (int16_t)yr[i]);
+                    const int16_t sq = (int16_t)(diff * diff);
+                    acc = __fadd_rn(acc, (float)sq);
+                }
+            val = sqrtf(__uint_as_float(readlane_u32(__float_as_uint(acc), 0)));
+        } else if constexpr (ENG == ENG_Q2)
+            st = COS_ERR_UNIMPLEMENTED; // euclidean.rs:34-37 unimplemented!()
+        else
+            st = COS_ERR_STORAGE_MISMATCH;
+    }
+    if (lane == 0) { a.out[p] = st == COS_OK ? val : 0.0f; a.status[p] = st; }
+}
+
+// reference layout -> device layout (host side)
+void rows_to_device_layout(int eng, u32 dim, const uint8_t *ref, size_t cb, u32 n, u64 row_stride, std::vector<uint8_t> &dev) {
+    dev.assign((size_t)n * row_stride, 0);
+    for (u32 r = 0; r < n; r++) {
+        const uint8_t *s = ref + (size_t)r * cb;
+        uint8_t *d = dev.data() + (size_t)r * row_stride;
+        if (eng == ENG_U8) memcpy(d, s, dim);
+        else if (eng == ENG_F32) memcpy(d, s, (size_t)dim * 4);
+        else {
+            const u32 pb = (dim + 7) / 8;
+            for (u32 p = 0; p < 2; p++)
+                for (u32 b = 0; b < pb; b++) d[(size_t)(b / 8) * 16 + p * 8 + (b % 8)] = s[(size_t)p * pb + b];
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int32_t cos_distance_batch(uint32_t metric, uint32_t storage, uint32_t resolution, uint32_t dim, const void *x_codes,
+                                      const float *x_mags, uint32_t nx, const void *y_codes, const float *y_mags, uint32_t ny,
+                                      const uint32_t *pair_x, const uint32_t *pair_y, uint32_t n_pairs, float *out, int32_t *status) {
+    if (!x_codes || !y_codes || !x_mags || !y_mags || !pair_x || !pair_y || !out || !status || dim == 0 || n_pairs == 0)
+        return cos_fail(COS_ERR_INVALID, "bad argument");
+    if (metric > COS_METRIC_DOT) return cos_fail(COS_ERR_INVALID, "unknown metric");
+    int eng;
+    u64 row_stride;
+    u32 nchunks = 0;
+    if (storage == COS_STORAGE_U8) { eng = ENG_U8; row_stride = ((u64)dim + 15) & ~15ull; nchunks = (u32)(row_stride / 16); }
+    else if (storage == COS_STORAGE_SUBBYTE && resolution == 2) { eng = ENG_Q2; nchunks = (dim + 63) / 64; row_stride = (u64)nchunks * 16; }
+    else if (storage == COS_STORAGE_F32) { eng = ENG_F32; row_stride = ((u64)dim * 4 + 15) & ~15ull; }
+    else return cos_fail(COS_ERR_UNIMPLEMENTED, "storage kind not supported on the device yet");
+    for (u32 p = 0; p < n_pairs; p++)
+        if (pair_x[p] >= nx || pair_y[p] >= ny) return cos_fail(COS_ERR_INVALID, "pair %u out of range", p);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    const size_t cb = cos_code_bytes(storage, resolution, dim);
+    std::vector<uint8_t> hx, hy;
+    rows_to_device_layout(eng, dim, (const uint8_t *)x_codes, cb, nx, row_stride, hx);
+    rows_to_device_layout(eng, dim, (const uint8_t *)y_codes, cb, ny, row_stride, hy);
+    uint8_t *dx = nullptr, *dy = nullptr;
+    float *dxm = nullptr, *dym = nullptr, *dout = nullptr;
+    u32 *dpx = nullptr, *dpy = nullptr;
+    int32_t *dst = nullptr;
+    hipError_t e = hipMalloc(&dx, hx.size());
+    if (e == hipSuccess) e = hipMalloc(&dy, hy.size());
+    if (e == hipSuccess) e = hipMalloc(&dxm, (size_t)nx * 4);
+    if (e == hipSuccess) e = hipMalloc(&dym, (size_t)ny * 4);
+    if (e == hipSuccess) e = hipMalloc(&dpx, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMalloc(&dpy, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMalloc(&dst, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMemcpy(dx, hx.data(), hx.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy, hy.data(), hy.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dxm, x_mags, (size_t)nx * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dym, y_mags, (size_t)ny * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dpx, pair_x, (size_t)n_pairs * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dpy, pair_y, (size_t)n_pairs * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        DistArgs a{dx, dy, dxm, dym, dpx, dpy, row_stride, n_pairs, dim, metric, nchunks, dout, dst};
+        dim3 grid(n_pairs), block(64);
+        if (eng == ENG_U8) hipLaunchKernelGGL(distance_pairs_kernel<ENG_U8>, grid, block, 0, 0, a);
+        else if (eng == ENG_Q2) hipLaunchKernelGGL(distance_pairs_kernel<ENG_Q2>, grid, block, 0, 0, a);
+        else hipLaunchKernelGGL(distance_pairs_kernel<ENG_F32>, grid, block, (size_t)row_stride, 0, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n_pairs * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(status, dst, (size_t)n_pairs * 4, hipMemcpyDeviceToHost);
+    void *ptrs[] = {dx, dy, dxm, dym, dpx, dpy, dout, dst};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    HIP_TRY(e);
     return COS_OK;
 }

@@ -12,6 +12,7 @@
 // used, x86_64.rs:418-444) is reproduced with explicit __fmaf_rn / __fmul_rn / __fadd_rn.
 #include <hip/hip_runtime.h>
 #include "engine_types.h"
+#include "dot_engines.h"
 
 using namespace cosdev;
 
@@ -21,31 +22,6 @@ using namespace cosdev;
 #define COS_ROOT_ID 0xFFFFFFFFu
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------
-// Rust `as` casts and f32::max/min
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint8_t rust_f32_as_u8(float v) {
-    if (!(v == v)) return 0;
-    if (v <= 0.0f) return 0;
-    if (v >= 255.0f) return 255;
-    return (uint8_t)(int)v;
-}
-__device__ __forceinline__ u32 rust_f32_as_usize_low2(float v) { // low 2 bits of `v as usize` (saturating, NaN -> 0)
-    if (!(v == v)) return 0;
-    if (v <= 0.0f) return 0;
-    if (v >= 18446744073709551616.0f) return 3u;
-    return (u32)((u64)v & 3ull);
-}
-__device__ __forceinline__ float rust_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
-__device__ __forceinline__ float rust_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
-
-// sqrt(sequential, non-fused sum of x*x): scalar.rs:31,41,45 / vector_store.rs:414,426.  Executed by ONE lane.
-__device__ __forceinline__ float seq_norm(const float *x, u32 n) {
-    float acc = -0.0f;
-    for (u32 i = 0; i < n; i++) acc = __fadd_rn(acc, __fmul_rn(x[i], x[i]));
-    return sqrtf(acc);
-}
 
 // ------------------------------------------------------------------------------------------------
 // quantize_rows: one wave per row.  Writes the DEVICE code layout:
@@ -100,65 +76,6 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
         for (u32 i = lane; i < (u32)(row_stride / 4); i += 64) cf[i] = i < dim ? xr[i] : 0.0f;
         if (lane == 0) mags[row] = rn;
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// integer dot engines: G lanes cooperate on one code row, 16 bytes per lane per chunk
-// ------------------------------------------------------------------------------------------------
-template <int ENG>
-__device__ __forceinline__ u32 chunk_dot(uint4 q, uint4 y, u32 acc);
-
-template <>
-__device__ __forceinline__ u32 chunk_dot<ENG_U8>(uint4 q, uint4 y, u32 acc) { // dot_product_u8 (x86_64.rs:22-66): exact integer
-    acc = __builtin_amdgcn_udot4(q.x, y.x, acc, false);
-    acc = __builtin_amdgcn_udot4(q.y, y.y, acc, false);
-    acc = __builtin_amdgcn_udot4(q.z, y.z, acc, false);
-    acc = __builtin_amdgcn_udot4(q.w, y.w, acc, false);
-    return acc;
-}
-template <>
-__device__ __forceinline__ u32 chunk_dot<ENG_Q2>(uint4 q, uint4 y, u32 acc) { // dot_product_quaternary (dot_product.rs:35-57)
-    // plane 0 is what the reference multiplies as "lsb", plane 1 as "msb"
-    u64 xl = ((u64)q.y << 32) | q.x, xm = ((u64)q.w << 32) | q.z;
-    u64 yl = ((u64)y.y << 32) | y.x, ym = ((u64)y.w << 32) | y.z;
-    u64 mid1 = xl & ym, mid2 = yl & xm;
-    u32 lsbs = (u32)__popcll(xl & yl), carry = (u32)__popcll(mid1 & mid2);
-    u32 msbs = (u32)__popcll(xm & ym), mid = (u32)__popcll(mid1 ^ mid2);
-    return acc + (msbs << 2) + (carry << 2) + (mid << 1) + lsbs;
-}
-
-// reference-order f32 dot (dot_product_f32_simd, x86_64.rs:418-444) by a PAIR of lanes:
-// even lane owns accumulators 0..3, odd lane 4..7; returns the full dot in both lanes.
-__device__ __forceinline__ float f32_pair_dot(const float *__restrict__ row, const float *__restrict__ q_lds, u32 dim, int half) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const u32 chunks = dim >> 3;
-    const float4 *rp = (const float4 *)row + half;
-    const float4 *qp = (const float4 *)q_lds + half;
-    u32 c = 0;
-    for (; c + 8 <= chunks; c += 8) {
-        float4 y[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) y[u] = rp[2 * (c + u)];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            float4 qv = qp[2 * (c + u)];
-            a0 = __fmaf_rn(qv.x, y[u].x, a0);
-            a1 = __fmaf_rn(qv.y, y[u].y, a1);
-            a2 = __fmaf_rn(qv.z, y[u].z, a2);
-            a3 = __fmaf_rn(qv.w, y[u].w, a3);
-        }
-    }
-    for (; c < chunks; c++) {
-        float4 yv = rp[2 * c], qv = qp[2 * c];
-        a0 = __fmaf_rn(qv.x, yv.x, a0);
-        a1 = __fmaf_rn(qv.y, yv.y, a1);
-        a2 = __fmaf_rn(qv.z, yv.z, a2);
-        a3 = __fmaf_rn(qv.w, yv.w, a3);
-    }
-    float t = __fadd_rn(__fadd_rn(a0, a1), __fadd_rn(a2, a3)); // (s0+s1)+(s2+s3) | (s4+s5)+(s6+s7)
-    float r = __fadd_rn(t, __shfl_xor(t, 1, 64));               // low half + high half
-    for (u32 i = chunks * 8; i < dim; i++) r = __fadd_rn(r, __fmul_rn(q_lds[i], row[i])); // scalar tail, non-fused
-    return r;
 }
 
 constexpr int PB = 8; // code rows in flight per lane group before the dots are consumed

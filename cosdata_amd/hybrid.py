@@ -1,0 +1,73 @@
+"""Host-side mirror of the reference's operators around the dense walk:
+
+    distance_batch      DistanceMetric::calculate            src/models/types.rs:469
+    BM25Index           TFIDFIndex / search_bm25             src/indexes/tf_idf/mod.rs:243, src/models/sparse_ann_query.rs:149
+    rrf_fuse_batch      RRF fusion of hybrid_search          src/api/vectordb/search/repo.rs:311-340
+
+All numeric work runs in libcosdata_hip.so (gfx950 kernels); no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .index import DistanceMetric, StorageType, _c, _p
+
+
+def distance_batch(metric: DistanceMetric, storage_type: StorageType, dim: int, x_codes, x_mags, y_codes, y_mags, pair_x, pair_y):
+    """out[p] = metric(x[pair_x[p]], y[pair_y[p]]) on stored vectors in the reference Storage layout.
+    Returns (values f32[n_pairs], status i32[n_pairs]); status 2 = CalculationError (zero norm), 1 = StorageMismatch."""
+    xc, yc = _c(x_codes, np.uint8), _c(y_codes, np.uint8)
+    xm, ym = _c(x_mags, np.float32), _c(y_mags, np.float32)
+    px, py = _c(pair_x, np.uint32), _c(pair_y, np.uint32)
+    out = np.zeros(px.size, np.float32)
+    status = np.zeros(px.size, np.int32)
+    check(_lib.lib().cos_distance_batch(int(metric), int(storage_type.kind), storage_type.resolution, dim, _p(xc), _p(xm), xc.shape[0],
+                                        _p(yc), _p(ym), yc.shape[0], _p(px), _p(py), px.size, _p(out), _p(status)))
+    return out, status
+
+
+class BM25Index:
+    """Device-resident CSR postings of a TFIDFIndexRoot: term hashes ascending, offsets[T+1], (doc id, stored tf)."""
+
+    def __init__(self, term_hashes, offsets, doc_ids, tfs, documents_count: int, device: int = 0):
+        th, off = _c(term_hashes, np.uint32), _c(offsets, np.uint64)
+        di, tf = _c(doc_ids, np.uint32), _c(tfs, np.float32)
+        self._h = C.c_void_p()
+        check(_lib.lib().cos_bm25_create(device, _p(th), _p(off), th.size, _p(di), _p(tf), documents_count, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().cos_bm25_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_batch(self, q_terms, q_offsets, top_k: int):
+        """search_bm25 for B queries given as pre-hashed terms (CSR). -> ids [B][k], scores [B][k], counts [B]."""
+        qt, qo = _c(q_terms, np.uint32), _c(q_offsets, np.uint32)
+        B = qo.size - 1
+        ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+        sc = np.zeros((B, top_k), np.float32)
+        cnt = np.zeros(B, np.uint32)
+        check(_lib.lib().cos_bm25_search_batch(self._h, _p(qt), _p(qo), B, top_k, _p(ids), _p(sc), _p(cnt)))
+        return ids, sc, cnt
+
+
+def rrf_fuse_batch(dense_ids, dense_counts, sparse_ids, sparse_counts, fusion_constant_k: float, top_k: int):
+    d, s = _c(dense_ids, np.uint32), _c(sparse_ids, np.uint32)
+    dc, sc_ = _c(dense_counts, np.uint32), _c(sparse_counts, np.uint32)
+    B = d.shape[0]
+    ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+    sc = np.zeros((B, top_k), np.float32)
+    cnt = np.zeros(B, np.uint32)
+    check(_lib.lib().cos_rrf_fuse_batch(_p(d), _p(dc), d.shape[1], _p(s), _p(sc_), s.shape[1], B, fusion_constant_k, top_k,
+                                        _p(ids), _p(sc), _p(cnt)))
+    return ids, sc, cnt

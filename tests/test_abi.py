@@ -1,0 +1,72 @@
+"""The C-ABI library loads, exports every symbol include/cosdata_hip.h declares, and keeps its error
+contract without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "cosdata_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cos_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cosdata_amd import _lib
+    L = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(_lib.ABI_SYMBOLS) == declared  # the ctypes table tracks the header
+
+
+def test_params_struct_layout_matches_header(tmp_path):
+    from cosdata_amd._lib import CosParams, CosSearchStats
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cosdata_hip.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu\\n", sizeof(cos_params), offsetof(cos_params, seed), '
+                   'offsetof(cos_params, device), sizeof(cos_search_stats));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sz, off_seed, off_dev, sz_stats = map(int, subprocess.check_output([str(exe)]).split())
+    assert C.sizeof(CosParams) == sz == 80
+    assert CosParams.seed.offset == off_seed and CosParams.device.offset == off_dev
+    assert C.sizeof(CosSearchStats) == sz_stats
+
+
+def test_cxx_host_links_and_error_contract(tmp_path):
+    exe = tmp_path / "abi_smoke"
+    so_dir = os.path.join(ROOT, "cosdata_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx", "abi_smoke.cpp"),
+                           "-L", so_dir, "-lcosdata_hip", f"-Wl,-rpath,{so_dir}", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("OK")
+
+
+def test_no_cpu_fallback_without_device(gpu_available):
+    import numpy as np
+    import cosdata_amd as ca
+    if gpu_available:
+        pytest.skip("a GPU is present: the no-device contract is checked on CPU-only boxes")
+    with pytest.raises(ca.CosdataError) as ei:
+        ca.HNSWIndex(64)
+    assert ei.value.status == 7  # NoDevice
+    with pytest.raises(ca.CosdataError):
+        ca.ScalarQuantization.quantize(np.zeros((2, 64), np.float32), ca.StorageType.UnsignedByte(), (-1.0, 1.0))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "cosdata_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                code = "\n".join(l for l in src.splitlines() if not l.strip().startswith(("//", "#", "*", "/*")))
+                assert "import oracle" not in code and "from oracle" not in code and "libcosdata_oracle" not in code, f
