@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import cosdata_amd as ca  # noqa: E402
+from cosdata_amd.sharding import allgather_topk, merge_topk_device  # noqa: E402
 
 METRIC = "QPS at recall@10≥0.95, 1024-dim dense cosine, 1/2/4/8 MI355X"
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -150,14 +151,9 @@ def main():
         ix.batch_search_device(q.data_ptr(), B, k, o_ids[s].data_ptr(), o_sc[s].data_ptr(), o_cnt[s].data_ptr(), o_st[s].data_ptr(),
                                st.cuda_stream)
         if world > 1:  # per-shard top-k -> RCCL all-gather over xGMI -> S-way merge
-            import torch.distributed as dist
             with torch.cuda.stream(st):
-                dist.all_gather_into_tensor(g_ids[s], o_ids[s])
-                dist.all_gather_into_tensor(g_sc[s], o_sc[s])
-                dist.all_gather_into_tensor(g_cnt[s], o_cnt[s])
-            ca._lib.check(lib.cos_merge_topk_device(g_ids[s].data_ptr(), g_sc[s].data_ptr(), g_cnt[s].data_ptr(), world, B, k,
-                                                    m_ids[s].data_ptr(), m_sc[s].data_ptr(), m_cnt[s].data_ptr(), local_rank,
-                                                    st.cuda_stream))
+                allgather_topk(o_ids[s], o_sc[s], o_cnt[s], g_ids[s], g_sc[s], g_cnt[s])
+            merge_topk_device(g_ids[s], g_sc[s], g_cnt[s], m_ids[s], m_sc[s], m_cnt[s], local_rank, st.cuda_stream)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -219,7 +215,7 @@ def main():
     per = []
     for s in range(min(S, n_launch)):
         stt = ix.last_stats(streams[s].cuda_stream)
-        per.append((stt.walk_ms, stt.evals * row_bytes + stt.adj_bytes, stt.evals, stt.expansions, stt.finalize_ms, stt.prep_ms))
+        per.append((stt.walk_ms, stt.evals * row_bytes + stt.adj_bytes, stt.evals, stt.expansions, stt.finalize_ms, stt.prep_ms, stt.reserved))
     ix.enable_timing(False)
     avg_ms = float(np.mean([p[0] for p in per]))
     avg_bytes = float(np.mean([p[1] for p in per]))
@@ -286,7 +282,8 @@ def main():
                          "traffic": None, "kernel": "walk_kernel<ENG_U8,1,4>",
                          "per_launch": {"algorithmic_bytes": avg_bytes, "avg_ms": avg_ms, "in_flight": overlap,
                                         "evals": float(np.mean([p[2] for p in per])), "expansions": float(np.mean([p[3] for p in per])),
-                                        "finalize_ms": float(np.mean([p[4] for p in per])), "prep_ms": float(np.mean([p[5] for p in per]))},
+                                        "finalize_ms": float(np.mean([p[4] for p in per])), "prep_ms": float(np.mean([p[5] for p in per])),
+                                        "adjacency_rounds": float(np.mean([p[6] for p in per]))},
                          "note": "one walk launch = query_batch x batches_per_launch queries; achieved = algorithmic bytes per launch x "
                                  "launches / timed wall time = bytes/avg_ms x in_flight (launches on different streams overlap)"},
             "cpu_baseline": cpu, "parity_vs_oracle": parity,

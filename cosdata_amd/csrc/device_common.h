@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace cosdev {
 
@@ -53,12 +54,52 @@ __device__ __forceinline__ u64 shfl_down1_u64(u64 v) { // lane l <- lane l+1 (la
     hi = (u32)__shfl_down((int)hi, 1, WAVE);
     return ((u64)hi << 32) | lo;
 }
+// ---- DPP (data-parallel primitives): cross-lane moves inside the VALU, no LDS round trip -------------
+// dpp_ctrl encodings (gfx9): quad_perm = 0x00-0xFF, row_shr:n = 0x110+n, wave_shl:1 = 0x130, wave_shr:1 = 0x138,
+// row_mirror = 0x140, row_half_mirror = 0x141.
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_mov(u32 fill, u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64 dpp_wave_shr1_u64(u64 v, u64 fill) { // lane l <- lane l-1, lane 0 <- fill
+    u32 lo = dpp_mov<0x138>((u32)fill, (u32)v), hi = dpp_mov<0x138>((u32)(fill >> 32), (u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 dpp_wave_shl1_u64(u64 v, u64 fill) { // lane l <- lane l+1, lane 63 <- fill
+    u32 lo = dpp_mov<0x130>((u32)fill, (u32)v), hi = dpp_mov<0x130>((u32)(fill >> 32), (u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+// sum over aligned groups of G lanes (G power of two, 2..64); every lane of a group (G <= 32) or of the
+// wave (G = 64) ends with the group total.  Integer adds: order-independent, exact.
+__device__ __forceinline__ u32 group_reduce_add_u32(u32 v, int G) {
+    if (G >= 2) v += dpp_mov<0xB1>(0u, v);     // quad_perm [1,0,3,2]: xor 1
+    if (G >= 4) v += dpp_mov<0x4E>(0u, v);     // quad_perm [2,3,0,1]: xor 2
+    if (G >= 8) v += dpp_mov<0x141>(0u, v);    // row_half_mirror: the other quad of the 8-lane half
+    if (G >= 16) v += dpp_mov<0x140>(0u, v);   // row_mirror: the other half of the 16-lane row
+    if (G == 32) v += (u32)__shfl_xor((int)v, 16, WAVE);
+    if (G == 64) {
+        const u32 t = (u32)__builtin_amdgcn_readlane((int)v, 0) + (u32)__builtin_amdgcn_readlane((int)v, 16) +
+                      (u32)__builtin_amdgcn_readlane((int)v, 32) + (u32)__builtin_amdgcn_readlane((int)v, 48);
+        v = t;
+    }
+    return v;
+}
+
 __device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
     u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, lane);
     u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), lane);
     return ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ u32 readlane_u32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // Bitonic sort (descending) of 64*R u64 keys held R per lane, blocked layout e = lane*R + r.
 // Empty entries are 0 and sink to the end.  Fully unrolled: every register index is static.
@@ -110,9 +151,11 @@ struct Pool {
         for (int r = 0; r < R; r++) e[r] = 0;
     }
     __device__ __forceinline__ u64 head() const { return readlane_u64(e[0], 0); }
+    // entry at sorted position I (wave-uniform result); static register index
+    template <int I>
+    __device__ __forceinline__ u64 peek() const { return readlane_u64(e[I % R], I / R); }
     __device__ __forceinline__ void pop_head(int lane) {
-        u64 nxt = shfl_down1_u64(e[0]);
-        if (lane == WAVE - 1) nxt = 0;
+        const u64 nxt = dpp_wave_shl1_u64(e[0], 0ull); // lane l <- lane l+1's first entry; lane 63 <- empty
 #pragma unroll
         for (int r = 0; r + 1 < R; r++) e[r] = e[r + 1];
         e[R - 1] = nxt;
@@ -127,7 +170,7 @@ struct Pool {
     // insert wave-uniform key k at position p (entries >= p shift up by one, the last one drops)
     __device__ __forceinline__ void insert_at(u64 k, int p, int lane) {
         const int lp = p / R, rp = p % R;
-        u64 prev_last = shfl_up1_u64(e[R - 1]);
+        const u64 prev_last = dpp_wave_shr1_u64(e[R - 1], 0ull); // lane l <- lane l-1's last entry
 #pragma unroll
         for (int r = R - 1; r >= 0; r--) {
             u64 src = (r == 0) ? prev_last : e[r > 0 ? r - 1 : 0];

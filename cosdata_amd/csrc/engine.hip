@@ -582,6 +582,7 @@ extern "C" int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_
         out->evals += st[(size_t)b * 4 + 0];
         out->expansions += st[(size_t)b * 4 + 1];
         out->adj_bytes += st[(size_t)b * 4 + 2];
+        out->reserved += (uint32_t)st[(size_t)b * 4 + 3]; // walk rounds (lookahead windows issued)
         out->rerank_rows += rr[b];
     }
     return COS_OK;

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
     }
 }
 
-constexpr int PB = 8; // code rows in flight per lane group before the dots are consumed
+constexpr int PB = 4; // code rows in flight per lane group before the dots are consumed
+constexpr int LA = 4; // lookahead window: adjacency rows prefetched per round
+constexpr int PB64 = 4; // G = 64 path: code rows in flight per wave
 
 // ------------------------------------------------------------------------------------------------
 // walk kernel
@@ -88,10 +90,13 @@ struct WalkSmem {
     u64 *res;     // popped (key, node) list, ef entries
     u32 *wl_vec;  // winners of the current expansion: vector rows
     u32 *wl_node; //                                     node indices
+    u32 *win_vec; // lookahead window: prefetched adjacency rows [LA][64]
+    u32 *win_node;
+    u64 *win_key; // [LA]
     float *qf;    // F32 engine: the query vector
 };
 
-template <int ENG, int CH, int R>
+template <int ENG, int CH, int R, bool G64>
 __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkArgs wa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x;
@@ -106,6 +111,9 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
         sm.res = (u64 *)p;      p += (size_t)wa.ef * 8;
         sm.wl_vec = (u32 *)p;   p += 64 * 4;
         sm.wl_node = (u32 *)p;  p += 64 * 4;
+        sm.win_vec = (u32 *)p;  p += LA * 64 * 4;
+        sm.win_node = (u32 *)p; p += LA * 64 * 4;
+        sm.win_key = (u64 *)p;  p += LA * 8;
         p = (unsigned char *)(((size_t)p + 15) & ~(size_t)15);
         sm.qf = (float *)p;
     }
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
         for (int c = 0; c < CH; c++) qreg[c] = make_uint4(0, 0, 0, 0);
     }
 
-    u64 n_evals = 0, n_exp = 0, adj_bytes = 0;
+    u64 n_evals = 0, n_exp = 0, adj_bytes = 0, n_rounds = 0;
     int32_t status = COS_OK;
     u32 entry = ix.lv[L].root_idx;
 
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                     if (chunk < ix.nchunks) acc = chunk_dot<ENG>(qreg[c], *(const uint4 *)(ix.codes + (u64)row * ix.row_stride + (u64)chunk * 16), acc);
                 }
             }
-            for (int m = G >> 1; m > 0; m >>= 1) acc += (u32)__shfl_xor((int)acc, m, 64);
+            acc = group_reduce_add_u32(acc, G);
             acc = readlane_u32(acc, 0);
             dotf = (float)acc; // integer dot `as f32` (RNE)
         } else {
@@ -210,135 +218,214 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
         }
 
         bool failed = false;
-        while (npool > 0) {
-            const u64 cur = pool.head();
-            pool.pop_head(lane);
-            npool--;
-            if (npop >= wa.ef) break; // the popped element is discarded (vector_store.rs:1151-1153)
-            if (lane == 0) sm.res[npop] = cur;
-            npop++;
-            n_exp++;
-            adj_bytes += (u64)M * 4;
-            const u32 node = (u32)cur;
-            const int limit = (int)wa.ef - (int)npop; // future pops still allowed
-
-            // neighbour slots in slot order, one per lane (vector_store.rs:1161-1171)
-            u32 nb_vec = ROW_EMPTY, nb_node = ROW_EMPTY;
-            if ((u32)lane < slots) {
-                nb_vec = lv.adj_vec[(u64)node * M + lane];
-                nb_node = lv.adj_node[(u64)node * M + lane];
-            }
-            const bool valid = nb_vec != ROW_EMPTY;
-            bool win;
-            if (!exact) {
-                // PerformantFixedSet: bucket=(id>>6)&(M-1), bit=id&63  <=> linear bit id & (64M-1)
-                const u32 id = nb_vec == N ? COS_ROOT_ID : nb_vec;
-                const u32 bit = id & bitmask;
-                const u32 word = bit >> 5, msk = 1u << (bit & 31);
-                const bool pre = valid && (sm.vis[word] & msk);
-                const bool cand = valid && !pre;
-                u32 old = 0;
-                if (cand) old = atomicOr(&sm.vis[word], msk);
-                const bool lost = cand && (old & msk);
-                win = cand && !lost;
-                u64 lostmask = __ballot(lost);
-                // two slots of this expansion alias the same residue: the LOWER slot wins (sequential scan order)
-                while (lostmask) {
-                    const int l = __ffsll((long long)lostmask) - 1;
-                    const u32 b = readlane_u32(bit, l);
-                    const u64 g = __ballot(cand && bit == b);
-                    const int w = __ffsll((long long)g) - 1;
-                    if (cand && bit == b) win = (lane == w);
-                    lostmask &= ~g;
+        // Lookahead window: the adjacency rows of the next LA pool entries are fetched together (independent
+        // loads, one latency); entry i+1 of the window is consumed only while it is still provably the next pop,
+        // i.e. while no candidate has been inserted ahead of it.  Most pops of a walk discover nothing new
+        // (3-4 evaluations per pop on average), so this collapses chains of dependent HBM round trips.
+        while (npool > 0 && npop < wa.ef) {
+            n_rounds++;
+            u32 kwin = npool < (u32)LA ? npool : (u32)LA;
+            if (kwin > wa.ef - npop) kwin = wa.ef - npop;
+            // the window lives in LDS so the consume loop below is a runtime loop (small code, no extra VGPRs)
+            static_for<0, LA>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const u64 wk = pool.template peek<i>();
+                u32 v = ROW_EMPTY, nn = ROW_EMPTY;
+                if ((u32)i < kwin && (u32)lane < slots) {
+                    const u32 nd = (u32)wk;
+                    v = lv.adj_vec[(u64)nd * M + lane];
+                    nn = level == 0 ? v : lv.adj_node[(u64)nd * M + lane];
                 }
-            } else {
-                bool pre = false;
-                if (valid) pre = (vis[nb_node >> 5] >> (nb_node & 31)) & 1u;
-                win = valid && !pre;
-                if (win) atomicOr(&vis[nb_node >> 5], 1u << (nb_node & 31));
-            }
+                sm.win_vec[i * 64 + lane] = v;
+                sm.win_node[i * 64 + lane] = nn;
+                if (lane == 0) sm.win_key[i] = wk;
+            });
+            for (u32 wi = 0; wi < kwin; wi++) {
+                const u64 cur = sm.win_key[wi];
+                pool.pop_head(lane);
+                npool--;
+                if (lane == 0) sm.res[npop] = cur;
+                npop++;
+                n_exp++;
+                adj_bytes += (u64)M * 4;
+                const int limit = (int)wa.ef - (int)npop; // future pops still allowed
+                const int ahead = (int)kwin - 1 - (int)wi; // window entries still waiting at pool positions 0..ahead-1
+                bool window_ok = true;
 
-            // compact winners (slot order) into LDS
-            const u64 wmask = __ballot(win);
-            const int W = __popcll(wmask);
-            if (win) {
-                const int rank = __popcll(wmask & ((1ull << lane) - 1ull));
-                sm.wl_vec[rank] = nb_vec;
-                sm.wl_node[rank] = nb_node;
-            }
-            n_evals += (u64)W;
+                // neighbour slots in slot order, one per lane (vector_store.rs:1161-1171)
+                const u32 nb_vec = sm.win_vec[wi * 64 + lane], nb_node = sm.win_node[wi * 64 + lane];
+                const bool valid = nb_vec != ROW_EMPTY;
+                bool win;
+                if (!exact) {
+                    // PerformantFixedSet: bucket=(id>>6)&(M-1), bit=id&63  <=> linear bit id & (64M-1)
+                    const u32 id = nb_vec == N ? COS_ROOT_ID : nb_vec;
+                    const u32 bit = id & bitmask;
+                    const u32 word = bit >> 5, msk = 1u << (bit & 31);
+                    const bool pre = valid && (sm.vis[word] & msk);
+                    const bool cand = valid && !pre;
+                    if (!__any(cand)) continue; // nothing new: the next window entry is certainly the next pop
+                    u32 old = 0;
+                    if (cand) old = atomicOr(&sm.vis[word], msk);
+                    const bool lost = cand && (old & msk);
+                    win = cand && !lost;
+                    u64 lostmask = __ballot(lost);
+                    // two slots of this expansion alias the same residue: the LOWER slot wins (sequential scan order)
+                    while (lostmask) {
+                        const int l = __ffsll((long long)lostmask) - 1;
+                        const u32 b = readlane_u32(bit, l);
+                        const u64 g = __ballot(cand && bit == b);
+                        const int w = __ffsll((long long)g) - 1;
+                        if (cand && bit == b) win = (lane == w);
+                        lostmask &= ~g;
+                    }
+                } else {
+                    bool pre = false;
+                    if (valid) pre = (__hip_atomic_load(&vis[nb_node >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (nb_node & 31)) & 1u;
+                    win = valid && !pre;
+                    if (!__any(win)) continue;
+                    if (win) atomicOr(&vis[nb_node >> 5], 1u << (nb_node & 31));
+                }
 
-            // evaluate winners: RP rows per pass, PB passes in flight
-            for (int base = 0; base < W; base += RP * PB) {
-                u32 prow[PB];
-                float pmag[PB];
-                uint4 buf[PB][CH];
-                float fdot[PB];
+                const u64 wmask = __ballot(win);
+                const int W = __popcll(wmask);
+                if constexpr (G64 && ENG != ENG_F32) {
+                    // One code row per wave pass (64 lanes x 16 B cover the row): the winner's row index is
+                    // wave-uniform, so it is taken straight from the owning lane with v_readlane, the row base
+                    // lives in SGPRs and nothing goes through LDS.  PB64 rows are in flight before the dots.
+                    n_evals += (u64)W;
+                    u64 m = wmask;
+                    while (m && !failed) {
+                        uint4 buf[PB64][CH];
+                        int wl[PB64];
+                        float mg[PB64];
+                        int cnt = 0;
 #pragma unroll
-                for (int p = 0; p < PB; p++) {
-                    const int my = base + p * RP + grp;
-                    const bool v = my < W;
-                    prow[p] = v ? sm.wl_vec[my] : 0u;
-                    pmag[p] = 1.0f;
-                    if (v) pmag[p] = ix.mags[prow[p]];
-                    if constexpr (ENG != ENG_F32) {
+                        for (int p = 0; p < PB64; p++) {
+                            wl[p] = 0;
+                            mg[p] = 1.0f;
+                            if (m) {
+                                const int l = __ffsll((long long)m) - 1;
+                                m &= m - 1;
+                                wl[p] = l;
+                                const u32 row = readlane_u32(nb_vec, l);
+                                const uint8_t *rp = ix.codes + (u64)row * ix.row_stride;
+                                mg[p] = ix.mags[row];
 #pragma unroll
-                        for (int c = 0; c < CH; c++) {
-                            u32 chunk = (u32)lig + (u32)c * (u32)G;
-                            buf[p][c] = make_uint4(0, 0, 0, 0);
-                            if (v && chunk < ix.nchunks) buf[p][c] = *(const uint4 *)(ix.codes + (u64)prow[p] * ix.row_stride + (u64)chunk * 16);
+                                for (int c = 0; c < CH; c++) {
+                                    const u32 chunk = (u32)lane + (u32)c * 64u;
+                                    buf[p][c] = make_uint4(0, 0, 0, 0);
+                                    if (chunk < ix.nchunks) buf[p][c] = *(const uint4 *)(rp + (u64)chunk * 16);
+                                }
+                                cnt++;
+                            }
+                        }
+#pragma unroll
+                        for (int p = 0; p < PB64; p++) {
+                            if (p >= cnt) break;
+                            u32 acc = 0;
+#pragma unroll
+                            for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
+                            acc = group_reduce_add_u32(acc, 64);
+                            const float dotf = (float)acc;
+                            float sim = dotf;
+                            if (metric == 0u) {
+                                const float den = __fmul_rn(qmag, mg[p]);
+                                if (den == 0.0f) { failed = true; break; }
+                                sim = __fdiv_rn(dotf, den);
+                            }
+                            const u64 kk = pack_key(metric_key(metric, sim), readlane_u32(nb_node, wl[p]));
+                            const int pos = pool.rank_of(kk);
+                            if (pos < limit) {
+                                pool.insert_at(kk, pos, lane);
+                                if (npool < (u32)(64 * R)) npool++;
+                                if (pos < ahead) window_ok = false;
+                            }
                         }
                     }
+                    if (failed || !window_ok) break;
+                    continue;
                 }
-                if constexpr (ENG == ENG_F32) {
-                    // every lane pair must run the (uniform-trip-count) dot; invalid pairs read row 0 and are ignored
+                // compact winners (slot order) into LDS
+                if (win) {
+                    const int rank = __popcll(wmask & ((1ull << lane) - 1ull));
+                    sm.wl_vec[rank] = nb_vec;
+                    sm.wl_node[rank] = nb_node;
+                }
+                n_evals += (u64)W;
+
+                // evaluate winners: RP rows per pass, PB passes in flight
+                for (int base = 0; base < W; base += RP * PB) {
+                    u32 prow[PB];
+                    float pmag[PB];
+                    uint4 buf[PB][CH];
+                    float fdot[PB];
 #pragma unroll
                     for (int p = 0; p < PB; p++) {
-                        if (base + p * RP < W)
-                            fdot[p] = f32_pair_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 1);
-                        else
-                            fdot[p] = 0.0f;
-                    }
-                }
-#pragma unroll
-                for (int p = 0; p < PB; p++) {
-                    if (base + p * RP >= W) break; // wave-uniform
-                    float dotf;
-                    if constexpr (ENG != ENG_F32) {
-                        u32 acc = 0;
-#pragma unroll
-                        for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
-                        for (int m = G >> 1; m > 0; m >>= 1) acc += (u32)__shfl_xor((int)acc, m, 64);
-                        dotf = (float)acc;
-                    } else {
-                        dotf = fdot[p];
-                    }
-                    float sim;
-                    bool bad = false;
-                    if (metric == 0u) {
-                        const float den = __fmul_rn(qmag, pmag[p]);
+                        if (base + p * RP >= W) break; // wave-uniform
                         const int my = base + p * RP + grp;
-                        bad = (my < W) && (den == 0.0f);
-                        sim = __fdiv_rn(dotf, den);
-                    } else {
-                        sim = dotf;
-                    }
-                    if (__any(bad)) { failed = true; break; }
-                    const u32 key = metric_key(metric, sim);
-                    // insert this pass's rows in winner order
-                    for (int g = 0; g < RP; g++) {
-                        const int my = base + p * RP + g;
-                        if (my >= W) break;
-                        const u32 k = readlane_u32(key, g * G);
-                        const u64 kk = pack_key(k, sm.wl_node[my]);
-                        const int pos = pool.rank_of(kk);
-                        if (pos < limit) {
-                            pool.insert_at(kk, pos, lane);
-                            if (npool < (u32)(64 * R)) npool++;
+                        const bool v = my < W;
+                        prow[p] = v ? sm.wl_vec[my] : 0u;
+                        pmag[p] = 1.0f;
+                        if (v) pmag[p] = ix.mags[prow[p]];
+                        if constexpr (ENG != ENG_F32) {
+#pragma unroll
+                            for (int c = 0; c < CH; c++) {
+                                u32 chunk = (u32)lig + (u32)c * (u32)G;
+                                buf[p][c] = make_uint4(0, 0, 0, 0);
+                                if (v && chunk < ix.nchunks) buf[p][c] = *(const uint4 *)(ix.codes + (u64)prow[p] * ix.row_stride + (u64)chunk * 16);
+                            }
                         }
                     }
+                    if constexpr (ENG == ENG_F32) {
+                        // every lane pair must run the (uniform-trip-count) dot; invalid pairs read row 0 and are ignored
+#pragma unroll
+                        for (int p = 0; p < PB; p++) {
+                            if (base + p * RP >= W) break;
+                            fdot[p] = f32_pair_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 1);
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < PB; p++) {
+                        if (base + p * RP >= W) break; // wave-uniform
+                        float dotf;
+                        if constexpr (ENG != ENG_F32) {
+                            u32 acc = 0;
+#pragma unroll
+                            for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
+                            acc = group_reduce_add_u32(acc, G);
+                            dotf = (float)acc;
+                        } else {
+                            dotf = fdot[p];
+                        }
+                        float sim;
+                        bool bad = false;
+                        if (metric == 0u) {
+                            const float den = __fmul_rn(qmag, pmag[p]);
+                            const int my = base + p * RP + grp;
+                            bad = (my < W) && (den == 0.0f);
+                            sim = __fdiv_rn(dotf, den);
+                        } else {
+                            sim = dotf;
+                        }
+                        if (__any(bad)) { failed = true; break; }
+                        const u32 key = metric_key(metric, sim);
+                        // insert this pass's rows in winner order
+                        for (int g = 0; g < RP; g++) {
+                            const int my = base + p * RP + g;
+                            if (my >= W) break;
+                            const u32 k = readlane_u32(key, g * G);
+                            const u64 kk = pack_key(k, sm.wl_node[my]);
+                            const int pos = pool.rank_of(kk);
+                            if (pos < limit) {
+                                pool.insert_at(kk, pos, lane);
+                                if (npool < (u32)(64 * R)) npool++;
+                                if (pos < ahead) window_ok = false; // landed ahead of a prefetched entry: the window is stale
+                            }
+                        }
+                    }
+                    if (failed) break;
                 }
-                if (failed) break;
+                if (failed || !window_ok) break;
             }
             if (failed) break;
         }
@@ -387,7 +474,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
             wa.out_stats[(u64)qi * 4 + 0] = n_evals;
             wa.out_stats[(u64)qi * 4 + 1] = n_exp;
             wa.out_stats[(u64)qi * 4 + 2] = adj_bytes;
-            wa.out_stats[(u64)qi * 4 + 3] = 0;
+            wa.out_stats[(u64)qi * 4 + 3] = n_rounds;
         }
     }
 }
@@ -548,19 +635,19 @@ hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u3
 
 size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
-    size_t b = (size_t)Mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2;
+    size_t b = (size_t)Mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2 + (size_t)LA * 64 * 4 * 2 + (size_t)LA * 8;
     b = (b + 15) & ~(size_t)15;
     if (eng == ENG_F32) b += (size_t)ix.row_stride;
     return b + 16;
 }
 
-template <int ENG, int CH>
+template <int ENG, int CH, bool G64>
 static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     const size_t smem = walk_smem_bytes(ix, wa.ef, ENG);
     dim3 grid(wa.B), block(64);
-    if (wa.ef <= 64) hipLaunchKernelGGL((walk_kernel<ENG, CH, 1>), grid, block, smem, st, ix, wa);
-    else if (wa.ef <= 256) hipLaunchKernelGGL((walk_kernel<ENG, CH, 4>), grid, block, smem, st, ix, wa);
-    else if (wa.ef <= 512) hipLaunchKernelGGL((walk_kernel<ENG, CH, 8>), grid, block, smem, st, ix, wa);
+    if (wa.ef <= 64) hipLaunchKernelGGL((walk_kernel<ENG, CH, 1, G64>), grid, block, smem, st, ix, wa);
+    else if (wa.ef <= 256) hipLaunchKernelGGL((walk_kernel<ENG, CH, 4, G64>), grid, block, smem, st, ix, wa);
+    else if (wa.ef <= 512) hipLaunchKernelGGL((walk_kernel<ENG, CH, 8, G64>), grid, block, smem, st, ix, wa);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -570,13 +657,13 @@ hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStrea
     const u32 ch = eng == ENG_F32 ? 1 : (ix.nchunks + ix.G - 1) / ix.G;
     switch (eng) {
     case ENG_U8:
-        if (ch == 1) return launch_walk_r<ENG_U8, 1>(ix, wa, st);
-        if (ch == 2) return launch_walk_r<ENG_U8, 2>(ix, wa, st);
+        if (ch == 1) return ix.G == 64 ? launch_walk_r<ENG_U8, 1, true>(ix, wa, st) : launch_walk_r<ENG_U8, 1, false>(ix, wa, st);
+        if (ch == 2) return launch_walk_r<ENG_U8, 2, true>(ix, wa, st);
         return hipErrorInvalidValue;
     case ENG_Q2:
-        if (ch == 1) return launch_walk_r<ENG_Q2, 1>(ix, wa, st);
+        if (ch == 1) return ix.G == 64 ? launch_walk_r<ENG_Q2, 1, true>(ix, wa, st) : launch_walk_r<ENG_Q2, 1, false>(ix, wa, st);
         return hipErrorInvalidValue;
-    case ENG_F32: return launch_walk_r<ENG_F32, 1>(ix, wa, st);
+    case ENG_F32: return launch_walk_r<ENG_F32, 1, false>(ix, wa, st);
     default: return hipErrorInvalidValue;
     }
 }

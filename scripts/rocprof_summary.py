@@ -24,7 +24,8 @@ def main(path):
         print(f"{short(name):45s} | {grid:8d} | {calls:6d} | {avg/1e3:10.1f} | {mn/1e3:10.1f} | {mx/1e3:10.1f} | {tot/1e6:10.2f}")
     try:
         pm = cur.execute("select kernel_name, grid_size/workgroup_size, counter_name, count(*), avg(value), sum(value) from counters_collection "
-                         "group by kernel_name, grid_size/workgroup_size, counter_name order by sum(value) desc limit 12").fetchall()
+                         "where kernel_name like '%cosdev%' or kernel_name like '%anonymous namespace%' "
+                         "group by kernel_name, grid_size/workgroup_size, counter_name having count(*) > 0 order by kernel_name, grid_size/workgroup_size, counter_name").fetchall()
     except sqlite3.Error:
         pm = []
     if pm:

@@ -52,7 +52,8 @@ def _assert_same_walk(oix, dix, Q):
 
 
 @pytest.mark.parametrize("name,storage,res", STORAGES)
-@pytest.mark.parametrize("n,dim,ef", [(2000, 96, 64), (3000, 100, 32), (6000, 768, 256)])
+@pytest.mark.parametrize("n,dim,ef", [(2000, 96, 64), (3000, 100, 32), (6000, 768, 256), (1000, 48, 32), (1500, 400, 40), (800, 16, 16),
+                                      (1200, 1536, 64)])
 def test_search_matches_oracle(name, storage, res, n, dim, ef):
     X = H.uniform_corpus(n, dim, seed=7)
     oix = H.oracle_index(X, storage, res, num_layers=5, ef_construction=64, ef_search=ef)
