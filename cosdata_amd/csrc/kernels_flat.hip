@@ -1,0 +1,211 @@
+// kernels_flat.hip — exhaustive (flat) cosine scan of the resident raw vectors: the one genuine dense
+// contraction of the path, S = Q[B x d] . X^T[d x N], on the f32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered fmaf chain, 157 TF peak on gfx950).
+// Used for recall ground truth and as the exhaustive per-shard mode.  Pipeline per N-chunk:
+//   flat_gemm_f32      128x128 tile per workgroup (4 waves, 2x2 MFMA tiles of 32x32 per wave), LDS-staged K panels,
+//                      epilogue divides by |q|*|x| and writes cosine scores [B][chunk]
+//   flat_select        one wave per query keeps a running top-64 (sorted register pool, threshold filter)
+//   flat_rescore       exact reference-order re-score (dot_product_f32_simd order) of the 64 survivors -> top-k
+// MFMA accumulation order differs from the reference's 8-lane tree in the last ulp, so the GEMM only
+// GENERATES candidates (64 >= 2k with margin); the returned ids/scores come from the reference-order kernel
+// and are bit-identical to the oracle's brute force.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "dot_engines.h"
+#include "engine_internal.h"
+
+using namespace cosdev;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BK + 1; // +1 float pad: conflict-free ds_read_b32 column reads
+constexpr int SEL = 64;                                  // survivors per query
+
+__global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q, u64 q_stride, const float *__restrict__ qmags, u32 B,
+                                                     const float *__restrict__ X, u64 x_stride, const float *__restrict__ xmags, u32 n0,
+                                                     u32 n_chunk, u32 dim, float *__restrict__ scores /*[B][n_chunk_padded]*/, u64 s_stride) {
+    __shared__ float As[BM * LDT];
+    __shared__ float Bs[BN * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); remap so that each XCD
+    // walks a contiguous strip of candidate tiles and re-uses the query panel in its own L2.
+    const u32 tiles_n = gridDim.x, tiles_m = gridDim.y;
+    u32 wg = blockIdx.y * tiles_n + blockIdx.x;
+    const u32 total = tiles_n * tiles_m;
+    {
+        const u32 q = total / 8, r = total % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; // bijective for any total
+    }
+    const u32 tn = wg % tiles_n, tm = wg / tiles_n;
+    const u32 row0 = tm * BM, col0 = tn * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int lr = tid >> 1, lc = (tid & 1) * 8; // staging: thread -> (row, 8 consecutive k)
+    for (u32 k0 = 0; k0 < dim; k0 += BK) {
+        {
+            const u32 qr = row0 + lr;
+            const float *src = Q + (u64)qr * q_stride + k0 + lc;
+#pragma unroll
+            for (int e = 0; e < 8; e++) As[lr * LDT + lc + e] = (qr < B && k0 + lc + e < dim) ? src[e] : 0.0f;
+            const u32 xr = col0 + lr;
+            const float *srx = X + (u64)(n0 + xr) * x_stride + k0 + lc;
+#pragma unroll
+            for (int e = 0; e < 8; e++) Bs[lr * LDT + lc + e] = (xr < n_chunk && k0 + lc + e < dim) ? srx[e] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int kq = kk + (lane >> 5);
+            const float a0 = As[(wr * 64 + (lane & 31)) * LDT + kq], a1 = As[(wr * 64 + 32 + (lane & 31)) * LDT + kq];
+            const float b0 = Bs[(wc * 64 + (lane & 31)) * LDT + kq], b1 = Bs[(wc * 64 + 32 + (lane & 31)) * LDT + kq];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const u32 col = col0 + wc * 64 + j * 32 + (lane & 31);
+            const float xm = col < n_chunk ? xmags[n0 + col] : 1.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32 row = row0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < B && col < n_chunk) scores[(u64)row * s_stride + col] = acc[i][j][r] / (qmags[row] * xm);
+            }
+        }
+}
+
+// one wave per query: fold a chunk of scores into the running top-SEL pool (keys = (simkey(score), global id))
+__global__ __launch_bounds__(64) void flat_select(const float *__restrict__ scores, u64 s_stride, u32 B, u32 n0, u32 n_chunk, u64 *__restrict__ pool_mem /*[B][64]*/) {
+    const int lane = threadIdx.x;
+    const u32 q = blockIdx.x;
+    if (q >= B) return;
+    Pool<1> pool;
+    pool.e[0] = pool_mem[(u64)q * SEL + lane];
+    u64 thr = readlane_u64(pool.e[0], SEL - 1); // current SEL-th best (0 while not full)
+    const float *sr = scores + (u64)q * s_stride;
+    for (u32 c = 0; c < n_chunk; c += 64) {
+        const u32 col = c + lane;
+        u64 key = 0ull;
+        if (col < n_chunk) key = pack_key(simkey(sr[col]), n0 + col);
+        u64 m = __ballot(key > thr);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const u64 kk = readlane_u64(key, l);
+            if (kk > thr) {
+                pool.insert_at(kk, pool.rank_of(kk), lane);
+                thr = readlane_u64(pool.e[0], SEL - 1);
+            }
+        }
+    }
+    pool_mem[(u64)q * SEL + lane] = pool.e[0];
+}
+
+// exact re-score of the survivors in the reference order, sort, top-k
+__global__ __launch_bounds__(64) void flat_rescore(const float *__restrict__ Q, u64 q_stride, const float *__restrict__ qmags, u32 B,
+                                                   const float *__restrict__ X, u64 x_stride, const float *__restrict__ xmags, u32 dim,
+                                                   const u64 *__restrict__ pool_mem, u32 k, u32 id_base, u32 *__restrict__ out_ids,
+                                                   float *__restrict__ out_scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *qf = (float *)smem_raw;
+    const int lane = threadIdx.x;
+    const u32 q = blockIdx.x;
+    if (q >= B) return;
+    for (u32 i = lane; i < dim; i += 64) qf[i] = Q[(u64)q * q_stride + i];
+    const u64 mine = pool_mem[(u64)q * SEL + lane];
+    const float mq = qmags[q];
+    u64 res[1] = {0ull};
+    for (int base = 0; base < SEL; base += 32) { // 32 survivors per pass, one lane pair each
+        const int src = base + (lane >> 1);
+        const u32 sid = (u32)__shfl((int)(u32)mine, src, 64);
+        const bool valid = __shfl((int)(u32)(mine >> 32), src, 64) != 0;
+        const u32 row = valid ? sid : 0u;
+        const float dp = f32_pair_dot(X + (u64)row * x_stride, qf, dim, lane & 1);
+        const float cs = dp / (mq * xmags[row]); // dp / (mag_query * mag_raw), vector_store.rs:427
+        const u64 key = valid ? pack_key(simkey(cs), sid) : 0ull;
+        // survivor base + j was computed by lanes 2j and 2j+1 -> hand it to lane base + j
+        const int from = (2 * (lane - base)) & 63;
+        const u32 klo = (u32)__shfl((int)(u32)key, from, 64), khi = (u32)__shfl((int)(u32)(key >> 32), from, 64);
+        if (lane >= base && lane < base + 32) res[0] = ((u64)khi << 32) | klo;
+    }
+    bitonic_sort_desc<1>(res, lane);
+    if ((u32)lane < k) {
+        const bool ok = res[0] != 0ull;
+        out_ids[(u64)q * k + lane] = ok ? (u32)res[0] + id_base : 0xFFFFFFFFu;
+        out_scores[(u64)q * k + lane] = ok ? simkey_inv((u32)(res[0] >> 32)) : 0.0f;
+    }
+}
+
+} // namespace
+
+extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t *out_ids, float *out_scores) {
+    if (!ix || !queries || !out_ids || !out_scores || B == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors first");
+    if (k == 0 || k > 32 || k > ix->n) return cos_fail(COS_ERR_INVALID, "k must be in [1, min(32, n)]");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    const u32 dim = ix->p.dim, n = ix->n;
+    // candidates per pass: the [B][chunk] score buffer stays <= 1 GiB
+    u32 chunk = (u32)std::min<u64>(1u << 18, ((1ull << 30) / B / 4) / BN * BN);
+    chunk = std::min(n, std::max<u32>(chunk, BN));
+    const u64 s_stride = ((u64)chunk + 63) & ~63ull;
+    float *d_q = nullptr, *d_qm = nullptr, *d_scores = nullptr, *d_os = nullptr, *d_dummy = nullptr;
+    u64 *d_pool = nullptr;
+    u32 *d_oi = nullptr;
+    uint8_t *d_codes = nullptr;
+    hipStream_t st = ix->own_stream;
+    hipError_t e = hipMalloc(&d_q, (size_t)B * dim * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_qm, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_dummy, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_codes, (size_t)B * (((size_t)dim * 4 + 15) & ~(size_t)15));
+    if (e == hipSuccess) e = hipMalloc(&d_scores, (size_t)B * s_stride * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_pool, (size_t)B * SEL * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_oi, (size_t)B * k * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_os, (size_t)B * k * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
+    // |q| in the reference's sequential order (vector_store.rs:414): reuse the F32 quantize kernel's raw_mags output
+    if (e == hipSuccess) e = launch_quantize_rows(ENG_F32, d_q, dim, B, dim, 0.f, 0.f, d_codes, ((u64)dim * 4 + 15) & ~15ull, d_dummy, d_qm, st);
+    for (u32 n0 = 0; n0 < n && e == hipSuccess; n0 += chunk) {
+        const u32 nc = std::min(chunk, n - n0);
+        dim3 grid((nc + BN - 1) / BN, (B + BM - 1) / BM);
+        hipLaunchKernelGGL(flat_gemm_f32, grid, dim3(256), 0, st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim, ix->d_raw_mags, n0, nc, dim, d_scores, s_stride);
+        e = hipGetLastError();
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(flat_select, dim3(B), dim3(64), 0, st, d_scores, s_stride, B, n0, nc, d_pool);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(flat_rescore, dim3(B), dim3(64), (((size_t)dim * 4 + 15) & ~(size_t)15), st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim,
+                           ix->d_raw_mags, dim, d_pool, k, ix->p.id_base, d_oi, d_os);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_oi, (size_t)B * k * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_os, (size_t)B * k * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    void *ptrs[] = {d_q, d_qm, d_dummy, d_codes, d_scores, d_pool, d_oi, d_os};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    HIP_TRY(e);
+    return COS_OK;
+}

@@ -1,0 +1,41 @@
+"""MFMA flat scan (cos_bruteforce_topk): the ids/scores must equal the oracle's exact brute force bit-for-bit
+(the GEMM only generates candidates; the reference-order kernel produces the answer)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,dim,B,k", [(3000, 96, 37, 10), (20000, 768, 130, 10), (5001, 100, 5, 32), (700, 20, 300, 1)])
+def test_bruteforce_matches_oracle(n, dim, B, k):
+    import cosdata_amd as ca
+    X = H.clustered_corpus(n, dim, n_centers=20, seed=3)
+    Q = H.queries_from(X, B, noise=0.05, seed=8)
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType.UnsignedByte())
+    ix.upload_vectors(X)
+    ids, sc = ix.bruteforce_topk(Q, k)
+    oids, osc = O.bruteforce_topk(X, Q, k, threads=4)
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+
+
+def test_bruteforce_transpose_detecting():
+    """asymmetric inputs: a swapped MFMA C/D mapping or operand transpose cannot pass (cdna guide G9)."""
+    import cosdata_amd as ca
+    n, dim = 512, 64
+    X = np.zeros((n, dim), np.float32)
+    for i in range(n):
+        X[i, i % dim] = 1.0
+        X[i, (i * 7 + 3) % dim] += 0.25 + (i // dim) * 0.01
+    Q = np.zeros((200, dim), np.float32)
+    for b in range(200):
+        Q[b, (b * 5) % dim] = 1.0
+        Q[b, (b * 11 + 1) % dim] = 0.1 + 0.001 * b
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3))
+    ix.upload_vectors(X)
+    ids, sc = ix.bruteforce_topk(Q, 8)
+    oids, osc = O.bruteforce_topk(X, Q, 8, threads=2)
+    assert np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
