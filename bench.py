@@ -88,12 +88,18 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    # COS_FORCE_DIST=1 exercises the N>1 code path (process group, all-gather, merge kernel) with a single rank
+    force_dist = os.environ.get("COS_FORCE_DIST", "0") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or force_dist
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
@@ -135,7 +141,7 @@ def main():
     o_sc = torch.zeros(S, B, k, dtype=torch.float32, device=dev)
     o_cnt = torch.zeros(S, B, dtype=torch.int32, device=dev)
     o_st = torch.zeros(S, B, dtype=torch.int32, device=dev)
-    if world > 1:
+    if dist_on:
         g_ids = torch.zeros(S, world, B, k, dtype=torch.int32, device=dev)
         g_sc = torch.zeros(S, world, B, k, dtype=torch.float32, device=dev)
         g_cnt = torch.zeros(S, world, B, dtype=torch.int32, device=dev)
@@ -150,14 +156,14 @@ def main():
         q = Q[(i % n_qsets) * B:(i % n_qsets + 1) * B]
         ix.batch_search_device(q.data_ptr(), B, k, o_ids[s].data_ptr(), o_sc[s].data_ptr(), o_cnt[s].data_ptr(), o_st[s].data_ptr(),
                                st.cuda_stream)
-        if world > 1:  # per-shard top-k -> RCCL all-gather over xGMI -> S-way merge
+        if dist_on:  # per-shard top-k -> RCCL all-gather over xGMI -> S-way merge
             with torch.cuda.stream(st):
                 allgather_topk(o_ids[s], o_sc[s], o_cnt[s], g_ids[s], g_sc[s], g_cnt[s])
             merge_topk_device(g_ids[s], g_sc[s], g_cnt[s], m_ids[s], m_sc[s], m_cnt[s], local_rank, st.cuda_stream)
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize(dev)
@@ -184,7 +190,7 @@ def main():
                                o_st[0].data_ptr(), streams[0].cuda_stream)
         streams[0].synchronize()
         ann[s0:s0 + m] = o_ids[0][:m].to(torch.int64) & 0xFFFFFFFF
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         # global ground truth / global ANN answer = merge of the per-shard lists by exact cosine
         def merge(local_ids_global, Xl):
@@ -214,7 +220,7 @@ def main():
         step(i)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -301,7 +307,7 @@ def main():
             "flat_scan_ground_truth": flat, "cpu_baseline": cpu, "parity_vs_oracle": parity,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -48,6 +48,10 @@ class CosSearchStats(C.Structure):
     ]
 
 
+class CosFlatStats(C.Structure):
+    _fields_ = [("gemm_ms", C.c_float), ("gemm_launches", C.c_uint32), ("int8_ops", C.c_double), ("code_bytes", C.c_double)]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into cosdata_amd/libcosdata_hip.so (in-tree)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
@@ -70,7 +74,7 @@ ABI_SYMBOLS = [
     "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build",
     "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_ef_search",
     "cos_index_set_visited_mode", "cos_index_enable_timing", "cos_index_last_stats", "cos_quantize_batch",
-    "cos_code_bytes", "cos_distance_batch", "cos_bruteforce_topk", "cos_bm25_create", "cos_bm25_destroy",
+    "cos_code_bytes", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
     "cos_bm25_search_batch", "cos_rrf_fuse_batch", "cos_merge_topk_device",
 ]
 
@@ -106,6 +110,7 @@ def lib():
         "cos_quantize_batch": [u32, u32, u32, f32, f32, vp, u32, vp, vp],
         "cos_distance_batch": [u32, u32, u32, u32, vp, vp, u32, vp, vp, u32, vp, vp, u32, vp, vp],
         "cos_bruteforce_topk": [vp, vp, u32, u32, vp, vp],
+        "cos_flat_search_batch": [vp, vp, u32, u32, vp, vp, vp, C.POINTER(CosFlatStats)],
         "cos_bm25_create": [i32, vp, vp, u32, vp, vp, u32, C.POINTER(vp)],
         "cos_bm25_destroy": [vp],
         "cos_bm25_search_batch": [vp, vp, vp, u32, u32, vp, vp, vp],

@@ -156,6 +156,164 @@ __global__ __launch_bounds__(64) void flat_rescore(const float *__restrict__ Q, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exhaustive scan over the QUANTIZED codes as an exact-integer i8 MFMA GEMM (config c3 / per-shard flat mode).
+//   u8 codes   : a' = a - 128 (flip the top bit) makes them signed; sum(a*b) = S' + 128*sum(a) + 128*sum(b) - 16384*K
+//                with S' = sum(a'*b') from v_mfma_i32_32x32x32_i8 — every term an exact integer
+//   quaternary : the two bit planes are expanded to the digit (plane0 bit + 2 * plane1 bit), i.e. exactly the
+//                value dot_product_quaternary multiplies (dot_product.rs:35-57), 4 digits per u32 via
+//                (nibble * 0x00204081) & 0x01010101
+// A/B fragments are read K-contiguous (16 B per lane, k-block = lane >> 5) for both operands, so the result is
+// the plain sum over k whatever the hardware's internal k order is; C/D layout as in flat_gemm_f32.
+// Workgroup = 8 waves, tile 256 queries x 128 candidates, K step 64; rows padded to 80 B in LDS (conflict-free
+// ds_read_b128).  Integer dots are converted with RNE and divided by |q|*|v| like cosine.rs:223-235.
+// ------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+constexpr int CM = 256, CN = 128, CK = 64, CLD = 80;
+
+__device__ __forceinline__ u32 spread4(u32 nib) { return (nib * 0x00204081u) & 0x01010101u; }
+
+// 16 digits (dims k0..k0+15 of a 64-dim chunk) -> 16 i8 values
+template <int ENG>
+__device__ __forceinline__ uint4 stage16(const uint8_t *__restrict__ row, u32 k0 /*multiple of 16*/, bool valid) {
+    uint4 o = make_uint4(0, 0, 0, 0);
+    if constexpr (ENG == ENG_U8) {
+        if (valid) o = *(const uint4 *)(row + k0);
+        o.x ^= 0x80808080u; o.y ^= 0x80808080u; o.z ^= 0x80808080u; o.w ^= 0x80808080u; // padding (0) becomes -128 too: see epilogue
+    } else {
+        if (valid) {
+            const u32 chunk = k0 >> 6, sh = k0 & 63; // 16 B per 64 dims: [plane0 8 B | plane1 8 B]
+            const u64 p0 = *(const u64 *)(row + (u64)chunk * 16), p1 = *(const u64 *)(row + (u64)chunk * 16 + 8);
+            const u32 b0 = (u32)(p0 >> sh) & 0xFFFFu, b1 = (u32)(p1 >> sh) & 0xFFFFu;
+            o.x = spread4(b0 & 15u) + 2u * spread4(b1 & 15u);
+            o.y = spread4((b0 >> 4) & 15u) + 2u * spread4((b1 >> 4) & 15u);
+            o.z = spread4((b0 >> 8) & 15u) + 2u * spread4((b1 >> 8) & 15u);
+            o.w = spread4((b0 >> 12) & 15u) + 2u * spread4((b1 >> 12) & 15u);
+        }
+    }
+    return o;
+}
+
+template <int ENG>
+__global__ __launch_bounds__(512) void flat_codes_gemm_i8(const uint8_t *__restrict__ qcodes, const float *__restrict__ qmags,
+                                                          const u32 *__restrict__ qsums, u32 B, const uint8_t *__restrict__ codes,
+                                                          const float *__restrict__ mags, const u32 *__restrict__ csums, u64 row_stride,
+                                                          u32 n0, u32 n_chunk, u32 kdims /*padded to 64*/, u32 metric,
+                                                          float *__restrict__ scores, u64 s_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[CM * CLD];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[CN * CLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1; // 4 x 2 waves, 64 x 64 outputs each
+    const u32 row0 = blockIdx.y * CM, col0 = blockIdx.x * CN;
+    i32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
+    const u32 code_k = ENG == ENG_U8 ? (u32)row_stride : (u32)(row_stride / 16) * 64; // dims covered by stored bytes
+    for (u32 k0 = 0; k0 < kdims; k0 += CK) {
+        { // A: 256 rows x 64 B = 1024 x 16 B pieces, 2 per thread;  B: 128 rows x 64 B = 512 pieces, 1 per thread
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int piece = tid * 2 + h, r = piece >> 2, kq = (piece & 3) * 16;
+                const u32 qr = row0 + r;
+                *(uint4 *)(As + r * CLD + kq) = stage16<ENG>(qcodes + (u64)qr * row_stride, k0 + kq, qr < B && k0 + kq < code_k);
+            }
+            const int r = tid >> 2, kq = (tid & 3) * 16;
+            const u32 xr = col0 + r;
+            *(uint4 *)(Bs + r * CLD + kq) = stage16<ENG>(codes + (u64)(n0 + xr) * row_stride, k0 + kq, xr < n_chunk && k0 + kq < code_k);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < CK; ks += 32) {
+            const int ko = ks + (lane >> 5) * 16;
+            const i32x4 a0 = *(const i32x4 *)(As + (wr * 64 + (lane & 31)) * CLD + ko), a1 = *(const i32x4 *)(As + (wr * 64 + 32 + (lane & 31)) * CLD + ko);
+            const i32x4 b0 = *(const i32x4 *)(Bs + (wc * 64 + (lane & 31)) * CLD + ko), b1 = *(const i32x4 *)(Bs + (wc * 64 + 32 + (lane & 31)) * CLD + ko);
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const u32 col = col0 + wc * 64 + j * 32 + (lane & 31);
+            const bool cv = col < n_chunk;
+            const float xm = cv ? mags[n0 + col] : 1.0f;
+            const int cs = (ENG == ENG_U8 && cv) ? (int)csums[n0 + col] : 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32 row = row0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < B && cv) {
+                    int dot = acc[i][j][r];
+                    if constexpr (ENG == ENG_U8) dot += 128 * (int)qsums[row] + 128 * cs - 16384 * (int)kdims;
+                    const float dotf = (float)(u32)dot; // exact integer -> f32 RNE, like `as f32` on the u64 dot
+                    float sc = dotf;
+                    if (metric == 0u) sc = __fdiv_rn(dotf, __fmul_rn(qmags[row], xm)); // zero norms are screened on the host side
+                    scores[(u64)row * s_stride + col] = sc;
+                }
+            }
+        }
+}
+
+__global__ void code_sums_kernel(const uint8_t *__restrict__ codes, u64 row_stride, u32 n, u32 *__restrict__ sums) {
+    const int lane = threadIdx.x & 63;
+    const u32 row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    u32 s = 0;
+    for (u32 i = lane * 4; i < (u32)row_stride; i += 256) {
+        const u32 w = *(const u32 *)(codes + (u64)row * row_stride + i);
+        s += (w & 255u) + ((w >> 8) & 255u) + ((w >> 16) & 255u) + (w >> 24);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) s += (u32)__shfl_xor((int)s, m, 64);
+    if (lane == 0) sums[row] = s;
+}
+
+// exact rerank of the best `ncand` survivors (pool is sorted desc by quantized score, larger id first) -> top k
+__global__ __launch_bounds__(64) void flat_rerank_top5k(const float *__restrict__ Q, u64 q_stride, const float *__restrict__ qraw_mags, u32 B,
+                                                        const float *__restrict__ X, u64 x_stride, const float *__restrict__ xmags, u32 dim,
+                                                        const u64 *__restrict__ pool_mem, u32 ncand_max, u32 k, u32 id_base,
+                                                        u32 *__restrict__ out_ids, float *__restrict__ out_scores, u32 *__restrict__ out_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *qf = (float *)smem_raw;
+    const int lane = threadIdx.x;
+    const u32 q = blockIdx.x;
+    if (q >= B) return;
+    for (u32 i = lane; i < dim; i += 64) qf[i] = Q[(u64)q * q_stride + i];
+    const u64 mine = pool_mem[(u64)q * SEL + lane];
+    const u32 have = (u32)__popcll(__ballot(mine != 0ull));
+    const u32 ncand = have < ncand_max ? have : ncand_max;
+    const float mq = qraw_mags[q];
+    u64 res[1] = {0ull};
+    for (int base = 0; base < SEL; base += 32) {
+        if ((u32)base >= ncand) break;
+        const int src = base + (lane >> 1);
+        const u32 sid = (u32)__shfl((int)(u32)mine, src, 64);
+        const bool valid = (u32)src < ncand;
+        const u32 row = valid ? sid : 0u;
+        const float dp = f32_pair_dot(X + (u64)row * x_stride, qf, dim, lane & 1);
+        const float cs = dp / (mq * xmags[row]);
+        const u64 key = valid ? pack_key(simkey(cs), sid) : 0ull;
+        const int from = (2 * (lane - base)) & 63;
+        const u32 klo = (u32)__shfl((int)(u32)key, from, 64), khi = (u32)__shfl((int)(u32)(key >> 32), from, 64);
+        if (lane >= base && lane < base + 32) res[0] = ((u64)khi << 32) | klo;
+    }
+    bitonic_sort_desc<1>(res, lane);
+    const u32 nout = ncand < k ? ncand : k;
+    if ((u32)lane < nout) {
+        out_ids[(u64)q * k + lane] = (u32)res[0] + id_base;
+        out_scores[(u64)q * k + lane] = simkey_inv((u32)(res[0] >> 32));
+    }
+    if (lane == 0) out_counts[q] = nout;
+}
+
 } // namespace
 
 extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t *out_ids, float *out_scores) {
@@ -207,5 +365,107 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     void *ptrs[] = {d_q, d_qm, d_dummy, d_codes, d_scores, d_pool, d_oi, d_os};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     HIP_TRY(e);
+    return COS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cos_flat_search_batch: exhaustive search over the index's quantized codes (i8 MFMA) + exact rerank of the best 5k
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,
+                                         uint32_t *out_counts, cos_flat_stats *stats) {
+    if (!ix || !queries || !out_ids || !out_scores || !out_counts || B == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors first");
+    if (top_k == 0 || 5 * top_k > (u32)SEL) return cos_fail(COS_ERR_UNIMPLEMENTED, "flat search keeps 64 survivors: top_k must be in [1, 12]");
+    if (ix->eng != ENG_U8 && ix->eng != ENG_Q2) return cos_fail(COS_ERR_UNIMPLEMENTED, "flat search over codes implements u8 and quaternary storage");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    const u32 dim = ix->p.dim, n = ix->n;
+    const u32 kdims = ix->eng == ENG_U8 ? (u32)((ix->row_stride + 63) / 64 * 64) : (u32)(ix->row_stride / 16) * 64;
+    u32 chunk = (u32)std::min<u64>(1u << 20, ((1ull << 31) / B / 4) / CN * CN);
+    chunk = std::min(n, std::max<u32>(chunk, CN));
+    const u64 s_stride = ((u64)chunk + 63) & ~63ull;
+    hipStream_t st = ix->own_stream;
+    float *d_q = nullptr, *d_qm = nullptr, *d_qrm = nullptr, *d_scores = nullptr, *d_os = nullptr;
+    uint8_t *d_qc = nullptr;
+    u32 *d_qs = nullptr, *d_cs = nullptr, *d_oi = nullptr, *d_oc = nullptr;
+    u64 *d_pool = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipError_t e = hipMalloc(&d_q, (size_t)B * dim * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_qm, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_qrm, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_qc, (size_t)B * ix->row_stride);
+    if (e == hipSuccess) e = hipMalloc(&d_qs, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_cs, ((size_t)n + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_scores, (size_t)B * s_stride * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_pool, (size_t)B * SEL * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_oi, (size_t)B * top_k * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_os, (size_t)B * top_k * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_oc, (size_t)B * 4);
+    if (e == hipSuccess) e = hipEventCreate(&ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ev1);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
+    if (e == hipSuccess) e = launch_quantize_rows(ix->eng, d_q, dim, B, dim, ix->p.range_lo, ix->p.range_hi, d_qc, ix->row_stride, d_qm, d_qrm, st);
+    if (e == hipSuccess && ix->eng == ENG_U8) {
+        hipLaunchKernelGGL(code_sums_kernel, dim3((B + 3) / 4), dim3(256), 0, st, d_qc, ix->row_stride, B, d_qs);
+        hipLaunchKernelGGL(code_sums_kernel, dim3((n + 3) / 4), dim3(256), 0, st, ix->d_codes, ix->row_stride, n, d_cs);
+        e = hipGetLastError();
+    }
+    // zero-norm screening (cosine): the reference aborts a search on the first zero denominator it meets; an
+    // exhaustive scan meets every vector, so any zero |q| or zero |v| is a CalculationError for the call.
+    std::vector<float> hq(B), hm;
+    if (e == hipSuccess) e = hipMemcpyAsync(hq.data(), d_qm, (size_t)B * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && ix->p.metric == COS_METRIC_COSINE) { hm.resize(n); e = hipMemcpyAsync(hm.data(), ix->d_mags, (size_t)n * 4, hipMemcpyDeviceToHost, st); }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    bool zero = false;
+    if (e == hipSuccess && ix->p.metric == COS_METRIC_COSINE) {
+        for (float v : hq) zero |= (v == 0.0f);
+        for (float v : hm) zero |= (v == 0.0f);
+    }
+    float gemm_ms = 0.f;
+    u32 launches = 0;
+    if (e == hipSuccess && !zero) {
+        for (u32 n0 = 0; n0 < n && e == hipSuccess; n0 += chunk) {
+            const u32 nc = std::min(chunk, n - n0);
+            dim3 grid((nc + CN - 1) / CN, (B + CM - 1) / CM);
+            e = hipEventRecord(ev0, st);
+            if (ix->eng == ENG_U8)
+                hipLaunchKernelGGL(flat_codes_gemm_i8<ENG_U8>, grid, dim3(512), 0, st, d_qc, d_qm, d_qs, B, ix->d_codes, ix->d_mags, d_cs, ix->row_stride, n0, nc, kdims, ix->p.metric, d_scores, s_stride);
+            else
+                hipLaunchKernelGGL(flat_codes_gemm_i8<ENG_Q2>, grid, dim3(512), 0, st, d_qc, d_qm, d_qs, B, ix->d_codes, ix->d_mags, d_cs, ix->row_stride, n0, nc, kdims, ix->p.metric, d_scores, s_stride);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(ev1, st);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(flat_select, dim3(B), dim3(64), 0, st, d_scores, s_stride, B, n0, nc, d_pool);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipEventSynchronize(ev1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+            gemm_ms += ms;
+            launches++;
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(flat_rerank_top5k, dim3(B), dim3(64), (((size_t)dim * 4 + 15) & ~(size_t)15), st, d_q, (u64)dim, d_qrm, B, ix->d_raw, (u64)dim,
+                               ix->d_raw_mags, dim, d_pool, 5 * top_k, top_k, ix->p.id_base, d_oi, d_os, d_oc);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_oi, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_os, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_oc, (size_t)B * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (stats) {
+        stats->gemm_ms = gemm_ms;
+        stats->gemm_launches = launches;
+        stats->int8_ops = 2.0 * (double)B * (double)n * (double)kdims;
+        stats->code_bytes = (double)n * (double)ix->row_stride * (double)((B + CM - 1) / CM);
+    }
+    void *ptrs[] = {d_q, d_qm, d_qrm, d_qc, d_qs, d_cs, d_scores, d_pool, d_oi, d_os, d_oc};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    HIP_TRY(e);
+    if (zero) return cos_fail(COS_ERR_CALCULATION, "zero-norm query or stored vector: DistanceError::CalculationError (cosine.rs:228-232)");
     return COS_OK;
 }

@@ -23,7 +23,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import CosdataError, CosParams, CosSearchStats, check
+from ._lib import CosdataError, CosFlatStats, CosParams, CosSearchStats, check
 
 ROOT_ID, QUERY_ID, SLOT_EMPTY = 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFFFD
 VISITED_REF, VISITED_EXACT = 0, 1
@@ -255,6 +255,17 @@ class HNSWIndex:
         st = CosSearchStats()
         check(_lib.lib().cos_index_last_stats(self._h, C.c_void_p(stream), C.byref(st)))
         return st
+
+    def flat_search(self, queries, top_k: int, with_stats: bool = False):
+        """Exhaustive search over the quantized codes (i8 MFMA GEMM) + exact rerank of the best 5k."""
+        q = _c(np.atleast_2d(queries), np.float32)
+        B = q.shape[0]
+        ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+        scores = np.zeros((B, top_k), np.float32)
+        counts = np.zeros(B, np.uint32)
+        st = CosFlatStats()
+        check(_lib.lib().cos_flat_search_batch(self._h, _p(q), B, top_k, _p(ids), _p(scores), _p(counts), C.byref(st)))
+        return (ids, scores, counts, st) if with_stats else (ids, scores, counts)
 
     def bruteforce_topk(self, queries, k: int):
         q = _c(np.atleast_2d(queries), np.float32)

@@ -166,6 +166,20 @@ int32_t cos_distance_batch(uint32_t metric, uint32_t storage, uint32_t resolutio
 int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t *out_ids,
                             float *out_scores);
 
+/* Exhaustive search over the index's QUANTIZED codes (u8 / quaternary) as an exact-integer i8 MFMA GEMM,
+ * then the reference's finalisation on the full candidate set: sort by quantized score (desc, larger id
+ * first), keep 5k, exact f32 rerank (vector_store.rs:404-445), top-k (k <= 12).  The result is what
+ * ann_search + finalize_ann_results would return if the walk visited every node: config c3's flat scan and
+ * the exhaustive per-shard mode.  Host buffers. */
+typedef struct {
+    float gemm_ms;          /* summed HIP-event time of the i8 MFMA GEMM launches */
+    uint32_t gemm_launches;
+    double int8_ops;        /* 2 * B * n * padded_dim */
+    double code_bytes;      /* bytes of codes streamed from HBM (n * row bytes * query-tile rows) */
+} cos_flat_stats;
+int32_t cos_flat_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                              float *out_scores, uint32_t *out_counts, cos_flat_stats *stats /* optional */);
+
 /* ---- hybrid (config c5) --------------------------------------------------------------------- */
 typedef struct cos_bm25 cos_bm25;
 /* TFIDFIndexRoot postings as CSR (models/tf_idf_index.rs, versioned_vec.rs:208-224): term hashes

@@ -152,6 +152,9 @@ int coso_search_batch(const coso_index *ix, const float *queries, uint32_t B, ui
  * out_ids/out_sims: [ (num_layers+1) * 100 ]; returns count or negative status. */
 int coso_ann_search(const coso_index *ix, const float *query, uint32_t *out_ids, float *out_sims,
                     uint32_t *level_counts /*[num_layers+1], top level first*/);
+/* exhaustive search over the quantized codes + exact rerank of the best 5k (device "flat" mode) */
+int coso_flat_search_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                           float *out_scores, uint32_t *out_counts, int threads);
 /* exact brute-force cosine top-k on raw f32 (reference-order dot, same formula as the rerank) */
 int coso_bruteforce_topk(const float *raw, uint32_t n, uint32_t dim, const float *queries, uint32_t B,
                          uint32_t k, uint32_t *out_ids, float *out_scores, int threads);

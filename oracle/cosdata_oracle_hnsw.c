@@ -695,6 +695,60 @@ int coso_index_import_level(coso_index *ix, uint32_t level, uint32_t n_nodes, co
 }
 
 /* ------------------------------------------------------------------------------------------
+ * exhaustive search over the QUANTIZED codes ("flat" mode of the device engine): every stored vector is
+ * scored with the index metric exactly like one traverse_find_nearest evaluation, the list is sorted like
+ * remove_duplicates_and_filter (desc, larger id first), cut to 5k and handed to finalize_ann_results' exact
+ * f32 rerank.  It is what the walk would return if it visited every node.
+ * ---------------------------------------------------------------------------------------- */
+int coso_flat_search_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                           float *out_scores, uint32_t *out_counts, int threads) {
+    if (!ix || !ix->raw || top_k == 0) return COSO_ERR_INVALID;
+    if (threads < 1) threads = 1;
+    int first_err = COSO_OK;
+    const int d = (int)ix->p.dim;
+#pragma omp parallel num_threads(threads)
+    {
+        hent *all = (hent *)malloc((size_t)(ix->n ? ix->n : 1) * sizeof(hent));
+        fent *f = (fent *)malloc((size_t)(5 * top_k + 1) * sizeof(fent));
+        uint8_t *qcode = (uint8_t *)malloc(ix->cb);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            const float *q = queries + (size_t)b * d;
+            float qmag;
+            int rc = coso_quantize(q, d, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo, ix->p.range_hi, qcode, &qmag);
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < ix->n && rc == COSO_OK; i++) {
+                float sv;
+                rc = node_distance(ix, qcode, qmag, i, &sv);
+                if (rc != COSO_OK) break;
+                hent e = {order_key((int)ix->p.metric, sv), i, i, sv};
+                all[m++] = e;
+            }
+            out_counts[b] = 0;
+            if (rc != COSO_OK) {
+#pragma omp critical
+                if (first_err == COSO_OK) first_err = rc;
+                continue;
+            }
+            qsort(all, m, sizeof(hent), cmp_hent_desc);
+            if (m > 5 * top_k) m = 5 * top_k;
+            float mag_query = coso_seq_norm_f32(q, d);
+            for (uint32_t i = 0; i < m; i++) {
+                const float *rv = ix->raw + (size_t)all[i].id * d;
+                fent t = {coso_dot_f32(q, rv, d) / (mag_query * coso_seq_norm_f32(rv, d)), all[i].id};
+                f[i] = t;
+            }
+            qsort(f, m, sizeof(fent), cmp_fent_desc);
+            if (m > top_k) m = top_k;
+            for (uint32_t i = 0; i < m; i++) { out_ids[(size_t)b * top_k + i] = f[i].id; out_scores[(size_t)b * top_k + i] = f[i].cs; }
+            out_counts[b] = m;
+        }
+        free(all); free(f); free(qcode);
+    }
+    return first_err;
+}
+
+/* ------------------------------------------------------------------------------------------
  * exact brute force (ground truth for recall): same formula and arithmetic order as the rerank
  * ---------------------------------------------------------------------------------------- */
 int coso_bruteforce_topk(const float *raw, uint32_t n, uint32_t dim, const float *queries, uint32_t B, uint32_t k,

@@ -88,6 +88,7 @@ def lib():
         "coso_index_set_visited_mode": (None, [vp, C.c_uint32]),
         "coso_search_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_int]),
         "coso_ann_search": (C.c_int, [vp, vp, vp, vp, vp]),
+        "coso_flat_search_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_int]),
         "coso_bruteforce_topk": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
         "coso_bm25_idf": (C.c_float, [C.c_uint32, C.c_uint32]),
         "coso_bm25_tf": (C.c_float, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float]),
@@ -340,6 +341,17 @@ class OracleIndex:
         if with_stats:
             out.append(np.array([(s.evals, s.expansions, s.adj_bytes) for s in stats], dtype=np.uint64))
         return tuple(out)
+
+    def flat_search_batch(self, queries, top_k, threads=1):
+        q = _c(queries, np.float32)
+        B = q.shape[0]
+        ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+        scores = np.zeros((B, top_k), np.float32)
+        counts = np.zeros(B, np.uint32)
+        rc = lib().coso_flat_search_batch(self._h, _p(q), B, top_k, _p(ids), _p(scores), _p(counts), threads)
+        if rc != OK:
+            raise ValueError(f"flat search status {rc}")
+        return ids, scores, counts
 
     def ann_search(self, query):
         """ann_search output before finalisation: (ids, sims, per-level counts top level first)."""

@@ -39,3 +39,32 @@ def test_bruteforce_transpose_detecting():
     ids, sc = ix.bruteforce_topk(Q, 8)
     oids, osc = O.bruteforce_topk(X, Q, 8, threads=2)
     assert np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+
+
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2)])
+@pytest.mark.parametrize("n,dim,B,k", [(4000, 96, 70, 10), (9000, 768, 300, 10), (3001, 100, 5, 12), (2500, 1000, 33, 3)])
+def test_flat_code_scan_matches_oracle(storage, res, n, dim, B, k):
+    """i8-MFMA exhaustive scan over the quantized codes + exact rerank == the oracle's flat search, bit for bit."""
+    import cosdata_amd as ca
+    X = H.uniform_corpus(n, dim, seed=13) * 0.9
+    Q = np.concatenate([H.queries_from(X, B - 2, noise=0.05, seed=8), H.uniform_corpus(2, dim, seed=77)])
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType(ca.StorageKind(storage), res))
+    ix.upload_vectors(X)
+    ids, sc, cnt, st = ix.flat_search(Q, k, with_stats=True)
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, storage=storage, resolution=res, num_layers=3)).set_vectors(X)
+    oids, osc, ocnt = oix.flat_search_batch(Q, k, threads=4)
+    assert np.array_equal(cnt, ocnt)
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    assert st.gemm_launches >= 1 and st.gemm_ms > 0
+
+
+def test_flat_code_scan_zero_norm_is_calculation_error():
+    import cosdata_amd as ca
+    X = H.uniform_corpus(500, 64, seed=1)
+    X[17] = -1.0  # all-zero u8 code -> zero norm
+    ix = ca.HNSWIndex(64, ca.HNSWHyperParams(num_layers=3))
+    ix.upload_vectors(X)
+    with pytest.raises(ca.CosdataError) as ei:
+        ix.flat_search(X[:4], 5)
+    assert ei.value.status == 2

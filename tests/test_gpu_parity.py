@@ -87,3 +87,19 @@ def test_zero_norm_query_is_calculation_error():
     o = oix.search_batch(Q, 5, raise_on_error=False)
     assert rc == 2 and o[3] == 2
     assert np.array_equal(status, o[4])
+
+
+@pytest.mark.parametrize("name,storage,res", STORAGES[:2])
+def test_exact_visited_mode_matches_oracle(name, storage, res):
+    """COS_VISITED_EXACT (recall mode): exact per-query visited bitset instead of the lossy PerformantFixedSet."""
+    X = H.clustered_corpus(5000, 96, n_centers=16, seed=21)
+    oix = H.oracle_index(X, storage, res, num_layers=4, ef_construction=48, ef_search=48)
+    dix = H.device_index_from_oracle(oix, X)
+    Q = H.queries_from(X, 40, seed=2)
+    ref_ids = dix.batch_search(Q, 10)[0]
+    oix.set_visited_mode(O.VISITED_EXACT)
+    dix.set_visited_mode(1)
+    _assert_same_walk(oix, dix, Q)
+    _assert_same_search(oix, dix, Q, 10)
+    exact_ids = dix.batch_search(Q, 10)[0]
+    assert exact_ids.shape == ref_ids.shape
