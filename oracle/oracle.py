@@ -241,9 +241,12 @@ class OracleIndex:
         self._raw = None
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().coso_index_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().coso_index_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def set_vectors(self, raw):
         self._raw = _c(raw, np.float32)

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Config c3 (BASELINE.json configs[2]): 10M x 768 quaternary-quantized distance on one MI355X.
+(i) exhaustive scan of the 2-bit codes (i8 MFMA GEMM, cos_flat_search_batch) and (ii) HNSW walk with
+quaternary distance + f32 rerank on a 1M subset; recall@10 vs exact f32 brute force for both.
+Prints one JSON line.  Not the driver's bench (that is bench.py / c2)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import cosdata_amd as ca
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=10_000_000)
+ap.add_argument("--dim", type=int, default=768)
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--walk-n", type=int, default=1_000_000)
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(7)
+n, d, B = a.n, a.dim, a.batch
+nc = max(64, n // 1000)
+centers = torch.rand(nc, d, generator=g, device=dev) * 1.6 - 0.8
+def draw(m, seed):
+    gg = torch.Generator(device=dev); gg.manual_seed(seed)
+    out = torch.empty(m, d, device=dev)
+    for s in range(0, m, 1 << 18):
+        k = min(1 << 18, m - s)
+        idx = torch.randint(0, nc, (k,), generator=gg, device=dev)
+        out[s:s + k] = (centers[idx] + 0.2 * torch.randn(k, d, generator=gg, device=dev)).clamp_(-0.999, 0.999)
+    return out
+X = draw(n, 42)
+Q = draw(B, 43)
+torch.cuda.synchronize()
+st_q2 = ca.StorageType.SubByte(2)
+ix = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, st_q2, (-1.0, 1.0))
+t = time.time(); ix.upload_vectors_device(X.data_ptr(), n, keepalive=X); t_up = time.time() - t
+Qh = Q.cpu().numpy()
+gt, _ = ix.bruteforce_topk(Qh, 10)
+best = None
+for _ in range(a.reps):
+    t = time.time()
+    ids, sc, cnt, st = ix.flat_search(Qh, 10, with_stats=True)
+    wall = time.time() - t
+    if best is None or st.gemm_ms < best[0]:
+        best = (st.gemm_ms, wall, st)
+gemm_ms, wall, st = best
+rec_flat = float(np.mean([len(set(ids[i].tolist()) & set(gt[i].tolist())) / 10 for i in range(B)]))
+out = {"config": f"c3: {n} x {d} quaternary (SubByte 2), flat scan of the codes, query batch {B}",
+       "flat": {"gemm_ms": gemm_ms, "gemm_launches": st.gemm_launches, "int8_tops": st.int8_ops / gemm_ms / 1e9,
+                "int8_peak_tops_dense": 5000.0, "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall,
+                "qps_end_to_end": B / wall, "recall_at_10_vs_f32_bruteforce": rec_flat, "upload_quantize_s": t_up}}
+del ix
+# (ii) HNSW walk with quaternary distance on a 1M subset
+m = min(a.walk_n, n)
+Xs = X[:m].contiguous()
+ix2 = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, st_q2, (-1.0, 1.0))
+ix2.upload_vectors_device(Xs.data_ptr(), m, keepalive=Xs)
+t = time.time(); ix2.build(4096); t_build = time.time() - t
+gt2, _ = ix2.bruteforce_topk(Qh, 10)
+Bq = 8192
+Qb = draw(Bq, 44)
+o_i = torch.zeros(Bq, 10, dtype=torch.int32, device=dev); o_s = torch.zeros(Bq, 10, device=dev)
+o_c = torch.zeros(Bq, dtype=torch.int32, device=dev); o_t = torch.zeros(Bq, dtype=torch.int32, device=dev)
+s0 = torch.cuda.Stream()
+for _ in range(2):
+    ix2.batch_search_device(Qb.data_ptr(), Bq, 10, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), o_t.data_ptr(), s0.cuda_stream)
+torch.cuda.synchronize()
+ix2.enable_timing(True)
+t = time.time()
+for _ in range(8):
+    ix2.batch_search_device(Qb.data_ptr(), Bq, 10, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), o_t.data_ptr(), s0.cuda_stream)
+torch.cuda.synchronize()
+el = time.time() - t
+stt = ix2.last_stats(s0.cuda_stream)
+ids2 = ix2.batch_search(Qh, 10)[0]
+rec_walk = float(np.mean([len(set(ids2[i].tolist()) & set(gt2[i].tolist())) / 10 for i in range(B)]))
+row_b = 2 * ((d + 63) // 64) * 8 + 4
+out["hnsw_walk_quaternary_1M"] = {"n": m, "build_s": t_build, "qps": 8 * Bq / el, "walk_ms_per_8192": stt.walk_ms,
+                                  "algorithmic_GBps": (stt.evals * row_b + stt.adj_bytes) / stt.walk_ms / 1e6,
+                                  "evals_per_query": stt.evals / Bq, "recall_at_10_vs_f32_bruteforce": rec_walk}
+print(json.dumps(out))
