@@ -80,10 +80,14 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--coalesce", type=int, default=32, help="client batches fused per launch (dynamic batching)")
     ap.add_argument("--inflight", type=int, default=2, help="launches kept in flight (HIP streams)")
-    ap.add_argument("--ef", type=int, default=256, help="ef_search (config.toml default 256)")
+    ap.add_argument("--ef", default="auto", help="ef_search: an integer, or 'auto' = smallest of 32,48,64,96,128,192,256 whose "
+                    "measured recall@10 is >= --recall-target (the metric is QPS AT recall@10 >= 0.95); config.toml default is 256")
+    ap.add_argument("--recall-target", type=float, default=0.95)
     ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--quantization", default="auto", choices=["auto", "range11"], help="auto = sampled values_range; range11 = (-1,1)")
+    ap.add_argument("--ef-sweep", default="256", help="comma list of extra ef_search values to time after the main run (256 = config.toml default)")
     ap.add_argument("--build-batch", type=int, default=4096)
-    ap.add_argument("--recall-queries", type=int, default=1024)
+    ap.add_argument("--recall-queries", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -107,7 +111,8 @@ def main():
     n, d, desc = WORKLOADS[args.workload]
     if args.n:
         n = args.n
-    Bc, k, ef = args.batch, args.top_k, args.ef   # Bc = client batch (a "step"); B = queries per launch
+    Bc, k = args.batch, args.top_k                # Bc = client batch (a "step"); B = queries per launch
+    ef = 256 if args.ef == "auto" else int(args.ef)
     C = max(1, args.coalesce)
     B = Bc * C
     n_launch = (args.steps + C - 1) // C
@@ -125,9 +130,17 @@ def main():
     Q = mixture(B * n_qsets, d, 43, dev, centers)                 # identical on every rank
     torch.cuda.synchronize()
 
-    # ---- index: reference defaults (config.toml:20-24,32), "auto" quantization = u8 + range (-1,1) ---
+    # ---- index: reference defaults (config.toml:20-24,32); "auto" quantization = u8 + values_range sampled from the
+    # first sample_threshold embeddings (indexes/hnsw/mod.rs:202-351; tests/rps-test.py:73 uses the same mode) ---
+    sample_threshold = 1000
+    values_range = ca.sample_values_range(X[:sample_threshold].cpu().numpy(), 1.0) if args.quantization == "auto" else (-1.0, 1.0)
+    if dist_on and world > 1:  # every shard must quantize with the same range: take rank 0's sample
+        import torch.distributed as dist
+        vr = torch.tensor(values_range, device=dev, dtype=torch.float64)
+        dist.broadcast(vr, 0)
+        values_range = (float(vr[0].item()), float(vr[1].item()))
     hp = ca.HNSWHyperParams(num_layers=9, ef_construction=128, ef_search=ef, level_0_neighbors_count=64, neighbors_count=32)
-    ix = ca.HNSWIndex(d, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), (-1.0, 1.0), shortlist_size=64,
+    ix = ca.HNSWIndex(d, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), values_range, shortlist_size=64,
                       device=local_rank, id_base=rank * n, seed=42 + rank)
     ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
     t0 = time.time()
@@ -184,30 +197,45 @@ def main():
             "agreement_with_torch_topk": gt_agree,
             "note": "cos_bruteforce_topk incl. H2D/D2H, selection and exact re-score; kernel-level MFMA rate: profiles/"}
     ann = torch.zeros(nrq, k, dtype=torch.int64, device=dev)
-    for s0 in range(0, nrq, B):
-        m = min(B, nrq - s0)
-        ix.batch_search_device(Q[s0:s0 + m].data_ptr(), m, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(),
-                               o_st[0].data_ptr(), streams[0].cuda_stream)
-        streams[0].synchronize()
-        ann[s0:s0 + m] = o_ids[0][:m].to(torch.int64) & 0xFFFFFFFF
-    if dist_on:
+
+    def merge_global(local_ids_global):
+        """global answer = merge of the per-shard lists by exact cosine (recall bookkeeping only)"""
         import torch.distributed as dist
-        # global ground truth / global ANN answer = merge of the per-shard lists by exact cosine
-        def merge(local_ids_global, Xl):
-            sims = torch.gather(Q[:nrq] @ Xl.T, 1, (local_ids_global - rank * n))
-            all_ids = [torch.zeros_like(local_ids_global) for _ in range(world)]
-            all_s = [torch.zeros_like(sims) for _ in range(world)]
-            dist.all_gather(all_ids, local_ids_global.contiguous())
-            dist.all_gather(all_s, sims.contiguous())
-            ci, cs = torch.cat(all_ids, 1), torch.cat(all_s, 1)
-            top = cs.topk(k, dim=1).indices
-            return torch.gather(ci, 1, top)
-        gt = merge(gt_local + rank * n, X)
-        ann_g = merge(ann, X)
-    else:
-        gt, ann_g = gt_local, ann
-    hits = (ann_g.unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().sum(dim=1)
-    recall = float(hits.mean().item() / k)
+        sims = torch.gather(Q[:nrq] @ X.T, 1, (local_ids_global - rank * n).clamp_(0, n - 1))
+        all_ids = [torch.zeros_like(local_ids_global) for _ in range(world)]
+        all_s = [torch.zeros_like(sims) for _ in range(world)]
+        dist.all_gather(all_ids, local_ids_global.contiguous())
+        dist.all_gather(all_s, sims.contiguous())
+        ci, cs = torch.cat(all_ids, 1), torch.cat(all_s, 1)
+        return torch.gather(ci, 1, cs.topk(k, dim=1).indices)
+
+    gt = merge_global(gt_local + rank * n) if dist_on else gt_local
+
+    def measure_recall(ef_value):
+        ix.set_ef_search(ef_value)
+        for s0 in range(0, nrq, B):
+            m = min(B, nrq - s0)
+            ix.batch_search_device(Q[s0:s0 + m].data_ptr(), m, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(),
+                                   o_st[0].data_ptr(), streams[0].cuda_stream)
+            streams[0].synchronize()
+            ann[s0:s0 + m] = o_ids[0][:m].to(torch.int64) & 0xFFFFFFFF
+        ann_g = merge_global(ann) if dist_on else ann
+        hits = (ann_g.unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().sum(dim=1)
+        r = hits.mean() / k
+        if dist_on:
+            import torch.distributed as dist
+            dist.broadcast(r, 0)  # every rank must take the same decision
+        return float(r.item())
+
+    ef_table = []
+    if args.ef == "auto":
+        for cand in (32, 48, 64, 96, 128, 192, 256):
+            r = measure_recall(cand)
+            ef_table.append({"ef_search": cand, "recall_at_10": r})
+            ef = cand
+            if r >= args.recall_target:
+                break
+    recall = measure_recall(ef)
     status_bad = int((o_st != 0).sum().item())
 
     # ---- warmup + timed region ----------------------------------------------------------------------
@@ -250,6 +278,20 @@ def main():
     streams[0].synchronize()
     serial_qps = 8 * Bc / (time.perf_counter() - t1)
 
+    # ---- optional ef_search sweep (same index, same launch shape): QPS and recall per ef ----------------------
+    sweep = []
+    for ef2 in [int(v) for v in args.ef_sweep.split(",") if v]:
+        rec2 = measure_recall(ef2)
+        for i in range(n_warm):
+            step(i)
+        sync_all()
+        t2 = time.perf_counter()
+        for i in range(n_launch):
+            step(i)
+        sync_all()
+        sweep.append({"ef_search": ef2, "qps": n_launch * C * Bc / (time.perf_counter() - t2), "recall_at_10": rec2})
+    ix.set_ef_search(ef)
+
     # ---- CPU baseline: the oracle (C restatement of the Rust path) on this box's host cores ----------
     cpu = None
     parity = None
@@ -257,7 +299,8 @@ def main():
         from oracle import oracle as O
         cores = os.cpu_count() or 1
         Xh = X.cpu().numpy()
-        op = O.HNSWParams(dim=d, storage=O.STORAGE_U8, num_layers=9, ef_construction=128, ef_search=ef, seed=42)
+        op = O.HNSWParams(dim=d, storage=O.STORAGE_U8, num_layers=9, ef_construction=128, ef_search=ef, seed=42,
+                          range_lo=values_range[0], range_hi=values_range[1])
         oix = O.OracleIndex(op).set_vectors(Xh)
         oix.import_graph(ix.download_graph(), ix.download_root())
         Qh = Q.cpu().numpy()
@@ -290,14 +333,14 @@ def main():
             "ms_per_step": elapsed / steps_done * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload + ": " + desc, "standard_size": not bool(args.n), "vectors_per_gpu": n, "dim": d,
-                       "query_batch": Bc, "batches_per_launch": C, "launches_in_flight": S, "top_k": k, "ef_search": ef, "M": 32, "M0": 64, "num_layers": 9,
-                       "storage": "u8 (auto quantization, range (-1,1))", "visited": "reference PerformantFixedSet (ID parity mode)",
+                       "query_batch": Bc, "batches_per_launch": C, "launches_in_flight": S, "top_k": k, "ef_search": ef, "ef_policy": ("smallest ef with recall@10 >= %.2f" % args.recall_target) if args.ef == "auto" else "fixed", "M": 32, "M0": 64, "num_layers": 9,
+                       "storage": f"u8 (quantization {args.quantization}, values_range {values_range})", "visited": "reference PerformantFixedSet (ID parity mode)",
                        "parallelism": f"id-range shards x{world}" + (" + RCCL all-gather top-k merge" if world > 1 else ""),
                        "corpus": f"Gaussian mixture, {n_centers} centres, sigma 0.8/sqrt(d), L2-normalised, seed 42"},
             "recall_at_10": recall, "recall_queries": nrq, "failed_queries": status_bad,
-            "single_batch_qps": serial_qps, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
+            "single_batch_qps": serial_qps, "ef_selection": ef_table, "ef_sweep": sweep, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "walk_kernel<ENG_U8,1,4>",
+                         "traffic": None, "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64>" % (1 if ef <= 64 else (4 if ef <= 256 else 8)),
                          "per_launch": {"algorithmic_bytes": avg_bytes, "avg_ms": avg_ms, "in_flight": overlap,
                                         "evals": float(np.mean([p[2] for p in per])), "expansions": float(np.mean([p[3] for p in per])),
                                         "finalize_ms": float(np.mean([p[4] for p in per])), "prep_ms": float(np.mean([p[5] for p in per])),

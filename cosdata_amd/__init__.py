@@ -1,5 +1,6 @@
 """cosdata_amd — MI355X-native ANN query engine for cosdata's dense/hybrid search path."""
 from ._lib import CosdataError, build  # noqa: F401
+from .index import sample_values_range  # noqa: F401
 from .index import (DistanceMetric, HNSWHyperParams, HNSWIndex, ScalarQuantization, StorageKind, StorageType,  # noqa: F401
                     ROOT_ID, QUERY_ID, SLOT_EMPTY, VISITED_REF, VISITED_EXACT)
 from .hybrid import BM25Index, distance_batch, rrf_fuse_batch  # noqa: F401,E402

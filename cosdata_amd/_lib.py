@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build",
     "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_ef_search",
     "cos_index_set_visited_mode", "cos_index_enable_timing", "cos_index_last_stats", "cos_quantize_batch",
-    "cos_code_bytes", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
+    "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
     "cos_bm25_search_batch", "cos_rrf_fuse_batch", "cos_merge_topk_device",
 ]
 
@@ -108,6 +108,7 @@ def lib():
         "cos_index_enable_timing": [vp, i32],
         "cos_index_last_stats": [vp, vp, C.POINTER(CosSearchStats)],
         "cos_quantize_batch": [u32, u32, u32, f32, f32, vp, u32, vp, vp],
+        "cos_sample_values_range": [vp, u32, u32, f32, C.POINTER(f32), C.POINTER(f32)],
         "cos_distance_batch": [u32, u32, u32, u32, vp, vp, u32, vp, vp, u32, vp, vp, u32, vp, vp],
         "cos_bruteforce_topk": [vp, vp, u32, u32, vp, vp],
         "cos_flat_search_batch": [vp, vp, u32, u32, vp, vp, vp, C.POINTER(CosFlatStats)],

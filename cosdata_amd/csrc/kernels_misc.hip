@@ -222,3 +222,61 @@ extern "C" int32_t cos_distance_batch(uint32_t metric, uint32_t storage, uint32_
     HIP_TRY(e);
     return COS_OK;
 }
+
+// ================================================================================================
+// cos_sample_values_range — "auto" quantization range sampling (indexes/hnsw/mod.rs:202-351)
+// ================================================================================================
+namespace {
+__global__ void sample_counts_kernel(const float *__restrict__ x, u64 total, unsigned long long *__restrict__ counts /*[14]*/) {
+    // thresholds of sample_embedding: value > t for t in {.025,.05,.1,.2,.3,.4,.5} and value < -t
+    const float T[7] = {0.025f, 0.05f, 0.1f, 0.2f, 0.3f, 0.4f, 0.5f};
+    u32 c[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) c[i] = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const float v = x[i];
+#pragma unroll
+        for (int t = 0; t < 7; t++) { c[t] += v > T[t]; c[7 + t] += v < -T[t]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        u32 s = c[i];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) s += (u32)__shfl_xor((int)s, m, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counts[i], (unsigned long long)s);
+    }
+}
+} // namespace
+
+extern "C" int32_t cos_sample_values_range(const float *x, uint32_t n, uint32_t dim, float clamp_margin_percent, float *range_lo, float *range_hi) {
+    if (!x || !range_lo || !range_hi || n == 0 || dim == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    const u64 total = (u64)n * dim;
+    float *d_x = nullptr;
+    unsigned long long *d_c = nullptr, h_c[14];
+    hipError_t e = hipMalloc(&d_x, total * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_c, 14 * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, total * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_c, 0, 14 * 8);
+    if (e == hipSuccess) {
+        const u32 blocks = (u32)std::min<u64>(2048, (total + 255) / 256);
+        hipLaunchKernelGGL(sample_counts_kernel, dim3(blocks), dim3(256), 0, 0, d_x, total, d_c);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_c, d_c, 14 * 8, hipMemcpyDeviceToHost);
+    if (d_x) (void)hipFree(d_x);
+    if (d_c) (void)hipFree(d_c);
+    HIP_TRY(e);
+    // finalize_sampling: first threshold whose tail holds <= clamp_margin_percent of all values, else +-1.0
+    const float values_count = (float)total; // (dimension * embeddings.len()) as f32
+    const float T[7] = {0.025f, 0.05f, 0.1f, 0.2f, 0.3f, 0.4f, 0.5f};
+    float hi = 1.0f, lo = -1.0f;
+    for (int t = 0; t < 7; t++)
+        if (((float)h_c[t] / values_count) * 100.0f <= clamp_margin_percent) { hi = T[t]; break; }
+    for (int t = 0; t < 7; t++)
+        if (((float)h_c[7 + t] / values_count) * 100.0f <= clamp_margin_percent) { lo = -T[t]; break; }
+    *range_lo = lo;
+    *range_hi = hi;
+    return COS_OK;
+}

@@ -100,6 +100,14 @@ class ScalarQuantization:
         return codes, mags
 
 
+def sample_values_range(sample, clamp_margin_percent: float = 1.0):
+    """"auto" quantization (indexes/hnsw/mod.rs:202-351): values_range from the first sample_threshold embeddings."""
+    x = _c(np.atleast_2d(sample), np.float32)
+    lo, hi = C.c_float(), C.c_float()
+    check(_lib.lib().cos_sample_values_range(_p(x), x.shape[0], x.shape[1], clamp_margin_percent, C.byref(lo), C.byref(hi)))
+    return (lo.value, hi.value)
+
+
 class HNSWIndex:
     """Device-resident snapshot of one HNSW index (one shard)."""
 

@@ -155,6 +155,11 @@ int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out)
 int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uint32_t dim, float range_lo, float range_hi,
                            const float *x, uint32_t n, void *codes, float *mags);
 size_t cos_code_bytes(uint32_t storage, uint32_t resolution, uint32_t dim);
+/* "auto" quantization: HNSWIndex::sample_embedding + finalize_sampling (indexes/hnsw/mod.rs:202-351) over the
+ * first sample_threshold embeddings: the range is the first of +-{.025,.05,.1,.2,.3,.4,.5} whose tail holds at
+ * most clamp_margin_percent (config.toml:38, default 1.0) of all sampled values, else +-1.0.  Host buffer. */
+int32_t cos_sample_values_range(const float *x, uint32_t n, uint32_t dim, float clamp_margin_percent, float *range_lo,
+                                float *range_hi);
 /* DistanceMetric::calculate (models/types.rs:469) for explicit (x_i, y_j) pairs of stored vectors
  * in the reference layout: out[p] = metric(x[pair_x[p]], y[pair_y[p]]); status[p] per pair. */
 int32_t cos_distance_batch(uint32_t metric, uint32_t storage, uint32_t resolution, uint32_t dim, const void *x_codes,

@@ -87,6 +87,9 @@ int coso_metric_cmp(int metric, float a, float b);
 void coso_level_probs(double x, int num_levels, double *values, uint8_t *levels); /* num_levels+1 entries */
 int coso_max_insert_level(double x, const double *values, const uint8_t *levels, int n);
 
+/* "auto" quantization range sampling (indexes/hnsw/mod.rs:202-351) */
+void coso_sample_values_range(const float *x, uint64_t total, float clamp_margin_percent, float *lo, float *hi);
+
 /* PerformantFixedSet, exposed for unit tests */
 typedef struct { uint64_t *buckets; uint32_t len; } coso_fixedset;
 void coso_fixedset_insert(coso_fixedset *s, uint32_t v);

@@ -400,3 +400,21 @@ int coso_fixedset_is_member(const coso_fixedset *s, uint32_t v) {
     uint32_t mask = s->len - 1;
     return (s->buckets[(v >> 6) & mask] >> (v & 0x3f)) & 1ull;
 }
+
+/* indexes/hnsw/mod.rs:202-351 — sample_embedding counters + finalize_sampling thresholds */
+void coso_sample_values_range(const float *x, uint64_t total, float clamp_margin_percent, float *lo, float *hi) {
+    static const float T[7] = {0.025f, 0.05f, 0.1f, 0.2f, 0.3f, 0.4f, 0.5f};
+    uint64_t above[7] = {0}, below[7] = {0};
+    for (uint64_t i = 0; i < total; i++)
+        for (int t = 0; t < 7; t++) {
+            if (x[i] > T[t]) above[t]++;
+            if (x[i] < -T[t]) below[t]++;
+        }
+    const float values_count = (float)total;
+    *hi = 1.0f;
+    *lo = -1.0f;
+    for (int t = 0; t < 7; t++)
+        if (((float)above[t] / values_count) * 100.0f <= clamp_margin_percent) { *hi = T[t]; break; }
+    for (int t = 0; t < 7; t++)
+        if (((float)below[t] / values_count) * 100.0f <= clamp_margin_percent) { *lo = -T[t]; break; }
+}

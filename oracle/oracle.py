@@ -72,6 +72,7 @@ def lib():
         "coso_metric_cmp": (C.c_int, [C.c_int, C.c_float, C.c_float]),
         "coso_level_probs": (None, [C.c_double, C.c_int, P(C.c_double), u8p]),
         "coso_max_insert_level": (C.c_int, [C.c_double, P(C.c_double), u8p, C.c_int]),
+        "coso_sample_values_range": (None, [vp, C.c_uint64, C.c_float, f32p, f32p]),
         "coso_index_create": (vp, [P(Params)]),
         "coso_index_destroy": (None, [vp]),
         "coso_index_set_vectors": (C.c_int, [vp, vp, C.c_uint32]),
@@ -189,6 +190,13 @@ def distance(metric, storage, resolution, dim, x_code, x_mag, y_code, y_mag):
 
 def metric_cmp(metric, a, b):
     return lib().coso_metric_cmp(metric, float(a), float(b))
+
+
+def sample_values_range(sample, clamp_margin_percent=1.0):
+    x = _c(sample, np.float32)
+    lo, hi = C.c_float(), C.c_float()
+    lib().coso_sample_values_range(_p(x), x.size, clamp_margin_percent, C.byref(lo), C.byref(hi))
+    return (lo.value, hi.value)
 
 
 def level_probs(x, num_levels):

@@ -103,3 +103,12 @@ def test_exact_visited_mode_matches_oracle(name, storage, res):
     _assert_same_search(oix, dix, Q, 10)
     exact_ids = dix.batch_search(Q, 10)[0]
     assert exact_ids.shape == ref_ids.shape
+
+
+def test_auto_quantization_sampler_matches_oracle():
+    import cosdata_amd as ca
+    r = np.random.default_rng(4)
+    for scale, n, d in [(0.036, 1000, 768), (0.2, 100, 96), (1.0, 64, 100), (0.01, 7, 33)]:
+        x = (r.standard_normal((n, d)) * scale).astype(np.float32)
+        assert ca.sample_values_range(x, 1.0) == O.sample_values_range(x, 1.0)
+        assert ca.sample_values_range(x, 5.0) == O.sample_values_range(x, 5.0)

@@ -321,3 +321,21 @@ def test_bm25_formulae_buckets_and_rrf():
     exp = {5: r(0), 6: r(1), 7: np.float32(r(2) + r(0)), 8: r(1)}
     order = sorted(exp.items(), key=lambda kv: (kv[1], kv[0]), reverse=True)[:3]
     assert fi.tolist() == [k for k, _ in order] and fs.tolist() == [float(v) for _, v in order]
+
+
+def test_auto_quantization_sampler_thresholds():
+    # indexes/hnsw/mod.rs:202-351: first threshold whose tail holds <= clamp_margin_percent of the sampled values
+    r = np.random.default_rng(9)
+    x = r.standard_normal((400, 96)).astype(np.float32) * 0.06
+    lo, hi = O.sample_values_range(x, 1.0)
+    T = [0.025, 0.05, 0.1, 0.2, 0.3, 0.4, 0.5]
+    tot = np.float32(x.size)
+    exp_hi = next((t for t in T if np.float32(np.float32((x > np.float32(t)).sum()) / tot) * np.float32(100) <= np.float32(1.0)), 1.0)
+    exp_lo = next((-t for t in T if np.float32(np.float32((x < -np.float32(t)).sum()) / tot) * np.float32(100) <= np.float32(1.0)), -1.0)
+    assert (lo, hi) == (np.float32(exp_lo), np.float32(exp_hi)) and hi in (np.float32(0.1), np.float32(0.2))
+    assert O.sample_values_range(r.uniform(-1, 1, (100, 768)).astype(np.float32)) == (-1.0, 1.0)   # tests/test.py data
+    assert O.sample_values_range(np.zeros((10, 8), np.float32)) == (np.float32(-0.025), np.float32(0.025))
+    xs = np.zeros((1, 200), np.float32); xs[0, :2] = 0.7                                               # exactly 1 % above 0.5
+    assert O.sample_values_range(xs, 1.0)[1] == np.float32(0.025)
+    xs[0, 2] = 0.7                                                                                      # 1.5 % above every threshold
+    assert O.sample_values_range(xs, 1.0)[1] == 1.0
