@@ -599,9 +599,11 @@ extern "C" int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uin
     if (storage == COS_STORAGE_U8) { eng = ENG_U8; row_stride = ((u64)dim + 15) & ~15ull; }
     else if (storage == COS_STORAGE_SUBBYTE && resolution == 2) { eng = ENG_Q2; row_stride = (u64)((dim + 63) / 64) * 16; }
     else if (storage == COS_STORAGE_F32) { eng = ENG_F32; row_stride = ((u64)dim * 4 + 15) & ~15ull; }
-    else return cos_fail(COS_ERR_UNIMPLEMENTED, "storage kind not supported on the device yet");
+    else if (storage == COS_STORAGE_F16 || (storage == COS_STORAGE_SUBBYTE && resolution >= 1 && resolution <= 8)) { eng = -1; row_stride = 0; }
+    else return cos_fail(COS_ERR_INVALID, "unknown storage kind / resolution");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    if (eng < 0) return quantize_ref_layout(storage, resolution, dim, x, n, codes, mags);
     float *d_x = nullptr, *d_m = nullptr;
     uint8_t *d_c = nullptr;
     HIP_TRY(hipMalloc(&d_x, (size_t)n * dim * 4));

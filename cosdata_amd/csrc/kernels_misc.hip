@@ -180,11 +180,13 @@ extern "C" int32_t cos_distance_batch(uint32_t metric, uint32_t storage, uint32_
     if (storage == COS_STORAGE_U8) { eng = ENG_U8; row_stride = ((u64)dim + 15) & ~15ull; nchunks = (u32)(row_stride / 16); }
     else if (storage == COS_STORAGE_SUBBYTE && resolution == 2) { eng = ENG_Q2; nchunks = (dim + 63) / 64; row_stride = (u64)nchunks * 16; }
     else if (storage == COS_STORAGE_F32) { eng = ENG_F32; row_stride = ((u64)dim * 4 + 15) & ~15ull; }
-    else return cos_fail(COS_ERR_UNIMPLEMENTED, "storage kind not supported on the device yet");
+    else if (storage == COS_STORAGE_F16 || storage == COS_STORAGE_SUBBYTE) { eng = -1; row_stride = 0; }
+    else return cos_fail(COS_ERR_INVALID, "unknown storage kind");
     for (u32 p = 0; p < n_pairs; p++)
         if (pair_x[p] >= nx || pair_y[p] >= ny) return cos_fail(COS_ERR_INVALID, "pair %u out of range", p);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
+    if (eng < 0) return distance_ref_layout(metric, storage, resolution, dim, x_codes, x_mags, nx, y_codes, y_mags, ny, pair_x, pair_y, n_pairs, out, status);
     const size_t cb = cos_code_bytes(storage, resolution, dim);
     std::vector<uint8_t> hx, hy;
     rows_to_device_layout(eng, dim, (const uint8_t *)x_codes, cb, nx, row_stride, hx);
@@ -280,3 +282,184 @@ extern "C" int32_t cos_sample_values_range(const float *x, uint32_t n, uint32_t 
     *range_hi = hi;
     return COS_OK;
 }
+
+// ================================================================================================
+// Remaining Storage kinds of the operators (reference layouts, no device re-layout): HalfPrecisionFP and
+// SubByte with any resolution 1..3 — quantize (scalar.rs:29-42, common.rs:226-275) and
+// DistanceMetric::calculate for all four metrics with the reference's error arms.
+// ================================================================================================
+#include <hip/hip_fp16.h>
+
+namespace {
+
+// one wave per row; writes the REFERENCE layout directly
+__global__ __launch_bounds__(256) void quantize_ref_kernel(const float *__restrict__ x, u32 n, u32 dim, u32 storage, u32 res,
+                                                           uint8_t *__restrict__ codes, u64 cb, float *__restrict__ mags) {
+    const int lane = threadIdx.x & 63;
+    const u32 row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *xr = x + (u64)row * dim;
+    uint8_t *cr = codes + (u64)row * cb;
+    if (lane == 0) mags[row] = seq_norm(xr, dim); // norm of the ORIGINAL vector for both kinds
+    if (storage == COS_STORAGE_F16) {
+        __half *h = (__half *)cr;
+        for (u32 i = lane; i < dim; i += 64) h[i] = __float2half_rn(xr[i]); // half::f16::from_f32 (RNE)
+        return;
+    }
+    const u32 pb = (dim + 7) / 8;
+    const float step = 2.0f / (float)(1u << res);
+    for (u32 c = 0; c * 64 < dim; c++) {
+        const u32 i = c * 64 + lane;
+        u32 lvl = 0;
+        if (i < dim) {
+            const float f = floorf(__fdiv_rn(__fadd_rn(xr[i], 1.0f), step));
+            // `as usize` saturates (NaN -> 0); only the low `res` bits reach the planes
+            if (f == f && f > 0.0f) lvl = f >= 18446744073709551616.0f ? 0xFFFFFFFFu : (u32)((u64)f & 0xFFull);
+        }
+        for (u32 p = 0; p < res; p++) {
+            const u64 m = __ballot((lvl >> (res - 1 - p)) & 1u); // plane 0 = MSB
+            if (lane < 8 && c * 8 + lane < pb) cr[(u64)p * pb + c * 8 + lane] = (uint8_t)(m >> (8 * lane));
+        }
+    }
+}
+
+struct DistRefArgs {
+    const uint8_t *x_codes, *y_codes;
+    const float *x_mags, *y_mags;
+    const u32 *pair_x, *pair_y;
+    u64 cb;
+    u32 n_pairs, dim, metric, storage, res;
+    float *out;
+    int32_t *status;
+};
+
+// one wave per pair, reference layouts
+__global__ __launch_bounds__(64) void distance_ref_kernel(const DistRefArgs a) {
+    const int lane = threadIdx.x;
+    const u32 p = blockIdx.x;
+    if (p >= a.n_pairs) return;
+    const uint8_t *xr = a.x_codes + (u64)a.pair_x[p] * a.cb, *yr = a.y_codes + (u64)a.pair_y[p] * a.cb;
+    const float xm = a.x_mags[a.pair_x[p]], ym = a.y_mags[a.pair_y[p]];
+    float val = 0.0f;
+    int32_t st = COS_OK;
+    const bool want_dot = a.metric == COS_METRIC_COSINE || a.metric == COS_METRIC_DOT;
+    if (a.storage == COS_STORAGE_F16) {
+        const __half *xh = (const __half *)xr, *yh = (const __half *)yr;
+        if (a.metric == COS_METRIC_HAMMING) { // hamming.rs:100-115: popcount of the bit patterns, exact in any order
+            u32 acc = 0;
+            for (u32 i = lane; i < a.dim; i += 64) acc += __popc((u32)(__half_as_ushort(xh[i]) ^ __half_as_ushort(yh[i])));
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) acc += (u32)__shfl_xor((int)acc, m, 64);
+            val = (float)acc;
+        } else { // sequential f32 chains (dot_product.rs:13-19, euclidean.rs:55-66): one lane
+            float acc = -0.0f;
+            if (lane == 0) {
+                if (want_dot)
+                    for (u32 i = 0; i < a.dim; i++) acc = __fadd_rn(acc, __fmul_rn(__half2float(xh[i]), __half2float(yh[i])));
+                else
+                    for (u32 i = 0; i < a.dim; i++) {
+                        const float d = __fsub_rn(__half2float(xh[i]), __half2float(yh[i]));
+                        acc = __fadd_rn(acc, __fmul_rn(d, d));
+                    }
+            }
+            acc = __uint_as_float(readlane_u32(__float_as_uint(acc), 0));
+            if (a.metric == COS_METRIC_EUCLIDEAN) val = sqrtf(acc);
+            else if (a.metric == COS_METRIC_DOT) val = acc;
+            else {
+                const float den = __fmul_rn(xm, ym);
+                if (den == 0.0f) st = COS_ERR_CALCULATION; else val = __fdiv_rn(acc, den);
+            }
+        }
+    } else { // SubByte, plane-major; plane index as multiplied by the reference: x_vec[0] = least significant
+        const u32 pb = (a.dim + 7) / 8, res = a.res;
+        if (a.metric == COS_METRIC_EUCLIDEAN) st = COS_ERR_UNIMPLEMENTED; // euclidean.rs:34-37
+        else if (a.metric == COS_METRIC_HAMMING) { // hamming.rs:73-98: only (8/res)*res low bits of every byte take part
+            if (res == 0 || res > 8) val = INFINITY;
+            else {
+                const u32 mask = (1u << ((8 / res) * res)) - 1u;
+                u32 acc = 0;
+                for (u32 i = lane; i < res * pb; i += 64) acc += __popc((u32)(xr[i] ^ yr[i]) & mask);
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) acc += (u32)__shfl_xor((int)acc, m, 64);
+                val = (float)acc;
+            }
+        } else if (res < 1 || res > 3) st = COS_ERR_CALCULATION; // cosine.rs:151-153
+        else {
+            // sum over dims of x*y with x = sum_a 2^a x_a: sum_{a,b} 2^(a+b) popcount(plane_a(x) & plane_b(y))
+            // (res 2: identical to msbs*4 + carry*4 + mid*2 + lsbs of dot_product_quaternary; res 3: the octal LUT)
+            u32 acc = 0;
+            for (u32 i = lane; i < pb; i += 64)
+                for (u32 pa = 0; pa < res; pa++)
+                    for (u32 pbb = 0; pbb < res; pbb++) acc += (u32)__popc((u32)(xr[(u64)pa * pb + i] & yr[(u64)pbb * pb + i])) << (pa + pbb);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) acc += (u32)__shfl_xor((int)acc, m, 64);
+            const float dotf = (float)acc;
+            if (a.metric == COS_METRIC_DOT) val = dotf;
+            else {
+                const float den = __fmul_rn(xm, ym);
+                if (den == 0.0f) st = COS_ERR_CALCULATION; else val = __fdiv_rn(dotf, den);
+            }
+        }
+    }
+    if (lane == 0) { a.out[p] = st == COS_OK ? val : 0.0f; a.status[p] = st; }
+}
+
+} // namespace
+
+namespace cosdev {
+// reference-layout operators for the kinds that have no device index layout
+int32_t quantize_ref_layout(uint32_t storage, uint32_t res, uint32_t dim, const float *x, uint32_t n, void *codes, float *mags) {
+    const size_t cb = cos_code_bytes(storage, res, dim);
+    float *d_x = nullptr, *d_m = nullptr;
+    uint8_t *d_c = nullptr;
+    hipError_t e = hipMalloc(&d_x, (size_t)n * dim * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_m, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_c, (size_t)n * cb);
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, (size_t)n * dim * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_c, 0, (size_t)n * cb);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(quantize_ref_kernel, dim3((n + 3) / 4), dim3(256), 0, 0, d_x, n, dim, storage, res, d_c, (u64)cb, d_m);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(codes, d_c, (size_t)n * cb, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(mags, d_m, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_x); (void)hipFree(d_m); (void)hipFree(d_c);
+    HIP_TRY(e);
+    return COS_OK;
+}
+
+int32_t distance_ref_layout(uint32_t metric, uint32_t storage, uint32_t res, uint32_t dim, const void *x_codes, const float *x_mags, uint32_t nx,
+                            const void *y_codes, const float *y_mags, uint32_t ny, const uint32_t *pair_x, const uint32_t *pair_y, uint32_t n_pairs,
+                            float *out, int32_t *status) {
+    const size_t cb = cos_code_bytes(storage, res, dim);
+    uint8_t *dx = nullptr, *dy = nullptr;
+    float *dxm = nullptr, *dym = nullptr, *dout = nullptr;
+    u32 *dpx = nullptr, *dpy = nullptr;
+    int32_t *dst = nullptr;
+    hipError_t e = hipMalloc(&dx, std::max<size_t>((size_t)nx * cb, 16));
+    if (e == hipSuccess) e = hipMalloc(&dy, std::max<size_t>((size_t)ny * cb, 16));
+    if (e == hipSuccess) e = hipMalloc(&dxm, (size_t)nx * 4);
+    if (e == hipSuccess) e = hipMalloc(&dym, (size_t)ny * 4);
+    if (e == hipSuccess) e = hipMalloc(&dpx, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMalloc(&dpy, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMalloc(&dst, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMemcpy(dx, x_codes, (size_t)nx * cb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy, y_codes, (size_t)ny * cb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dxm, x_mags, (size_t)nx * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dym, y_mags, (size_t)ny * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dpx, pair_x, (size_t)n_pairs * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dpy, pair_y, (size_t)n_pairs * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        DistRefArgs a{dx, dy, dxm, dym, dpx, dpy, (u64)cb, n_pairs, dim, metric, storage, res, dout, dst};
+        hipLaunchKernelGGL(distance_ref_kernel, dim3(n_pairs), dim3(64), 0, 0, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n_pairs * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(status, dst, (size_t)n_pairs * 4, hipMemcpyDeviceToHost);
+    void *ptrs[] = {dx, dy, dxm, dym, dpx, dpy, dout, dst};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    HIP_TRY(e);
+    return COS_OK;
+}
+} // namespace cosdev

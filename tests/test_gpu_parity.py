@@ -112,3 +112,34 @@ def test_auto_quantization_sampler_matches_oracle():
         x = (r.standard_normal((n, d)) * scale).astype(np.float32)
         assert ca.sample_values_range(x, 1.0) == O.sample_values_range(x, 1.0)
         assert ca.sample_values_range(x, 5.0) == O.sample_values_range(x, 5.0)
+
+
+ALL_STORAGES = [("u8", O.STORAGE_U8, 0), ("bin", O.STORAGE_SUBBYTE, 1), ("q2", O.STORAGE_SUBBYTE, 2), ("oct", O.STORAGE_SUBBYTE, 3),
+                ("f16", O.STORAGE_F16, 0), ("f32", O.STORAGE_F32, 0)]
+
+
+@pytest.mark.parametrize("name,storage,res", ALL_STORAGES)
+@pytest.mark.parametrize("dim", [100, 768])
+def test_operators_every_storage_and_metric(name, storage, res, dim):
+    """QuantizationMetric::quantize + DistanceMetric::calculate for every Storage kind x metric, incl. the error arms
+    (StorageMismatch / CalculationError / unimplemented!) — values bit-exact vs the oracle."""
+    import cosdata_amd as ca
+    r = np.random.default_rng(17)
+    x = r.uniform(-1.2, 1.2, (40, dim)).astype(np.float32)
+    x[3] = 0.0
+    x[4] = -1.0
+    stype = ca.StorageType(ca.StorageKind(storage), res)
+    codes, mags = ca.ScalarQuantization.quantize(x, stype, (-1.0, 1.0))
+    ocodes, omags = O.quantize_batch(x, storage, res, -1.0, 1.0)
+    assert np.array_equal(codes, ocodes)
+    assert np.array_equal(mags.view(np.uint32), omags.view(np.uint32))
+    px = r.integers(0, 40, 96).astype(np.uint32)
+    py = r.integers(0, 40, 96).astype(np.uint32)
+    px[:2], py[:2] = [3, 4], [5, 6]
+    for metric in (O.METRIC_COSINE, O.METRIC_EUCLIDEAN, O.METRIC_HAMMING, O.METRIC_DOT):
+        vals, status = ca.distance_batch(ca.DistanceMetric(metric), stype, dim, codes, mags, codes, mags, px, py)
+        for p in range(px.size):
+            rc, v = O.distance(metric, storage, res, dim, ocodes[px[p]], omags[px[p]], ocodes[py[p]], omags[py[p]])
+            assert status[p] == rc, (name, metric, p, status[p], rc)
+            if rc == 0:
+                assert np.float32(vals[p]).tobytes() == np.float32(v).tobytes() or (np.isnan(vals[p]) and np.isnan(v)), (name, metric, p, vals[p], v)
