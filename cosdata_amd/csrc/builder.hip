@@ -10,8 +10,12 @@
 // next batch.  oracle/cosdata_oracle_hnsw.c:coso_index_build_batched is the CPU statement of the same
 // schedule; tests assert the two graphs are identical.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "engine_internal.h"
 
@@ -54,62 +58,83 @@ inline float metric_max(u32 metric) { return metric == COS_METRIC_COSINE ? 2.0f 
 struct LevelBuild {
     u32 n = 0, M = 0;
     std::vector<u32> node_ids, node_vec, child;
-    std::vector<u32> nbr;   // [n][M] node index / NONE
-    std::vector<float> sim; // [n][M]
+    std::vector<u32> nbr;       // [n][M] node index / NONE
+    std::vector<int32_t> key;   // [n][M] MetricResult order key of the slot's similarity; EMPTY_KEY for a null slot
     std::vector<uint8_t> low_idx;
-    std::vector<float> low_sim;
-    std::vector<u32> stamp; // dirty marker per node (batch number + 1)
+    std::vector<int32_t> low_key; // cached (lowest_index, lowest_sim) of prob_node.rs:108, as an order key
+    std::vector<u32> stamp;     // dirty marker per node (batch number)
     std::vector<u32> dirty;
-    u32 cursor = 0;         // first node of this level not yet inserted
+    u32 cursor = 0;             // first node of this level not yet inserted
 };
+constexpr int32_t EMPTY_KEY = INT32_MIN; // below every real key: the first-minimum scan finds the first empty slot
+
+inline int32_t order_key(u32 metric, float v) {
+    const int32_t k = total_key(v);
+    return (metric == COS_METRIC_EUCLIDEAN || metric == COS_METRIC_HAMMING) ? ~k : k;
+}
 
 inline void mark_dirty(LevelBuild &L, u32 node, u32 batch_no) {
     if (L.stamp[node] != batch_no) { L.stamp[node] = batch_no; L.dirty.push_back(node); }
 }
 
-// ProbNode::add_neighbor (prob_node.rs:210-283) on the host mirror. Returns slot or -1.
-int add_neighbor(LevelBuild &L, u32 metric, u32 self, u32 nbr, float dist, u32 batch_no) {
+// ProbNode::add_neighbor (prob_node.rs:210-283) on the host mirror; similarities are compared through their
+// MetricResult order keys (types.rs:401-411).  Returns the slot or -1.
+inline int add_neighbor(LevelBuild &L, int32_t kmin, int32_t kmax, u32 self, u32 nbr, int32_t dist, u32 batch_no) {
     const u32 M = L.M;
     const u32 lowest_idx = L.low_idx[self];
-    const float lowest_sim = L.low_sim[self];
-    if (metric_cmp(metric, dist, lowest_sim) <= 0) return -1;
+    if (dist <= L.low_key[self]) return -1;
     u32 *nb = &L.nbr[(size_t)self * M];
-    float *ns = &L.sim[(size_t)self * M];
-    const bool ok = nb[lowest_idx] == NONE || metric_cmp(metric, dist, ns[lowest_idx]) > 0;
+    int32_t *nk = &L.key[(size_t)self * M];
+    const bool ok = nb[lowest_idx] == NONE || dist > nk[lowest_idx];
     u32 old = NONE;
-    if (ok) { old = nb[lowest_idx]; nb[lowest_idx] = nbr; ns[lowest_idx] = dist; mark_dirty(L, self, batch_no); }
-    u32 nl = 0;
-    float nsim = metric_max(metric);
-    for (u32 j = 0; j < M; j++) {
-        if (nb[j] == NONE) { nsim = metric_min(metric); nl = j; break; }
-        if (metric_cmp(metric, ns[j], nsim) < 0) { nsim = ns[j]; nl = j; }
-    }
-    L.low_idx[self] = (uint8_t)nl;
-    L.low_sim[self] = nsim;
+    if (ok) { old = nb[lowest_idx]; nb[lowest_idx] = nbr; nk[lowest_idx] = dist; mark_dirty(L, self, batch_no); }
+    // new lowest: the first empty slot if any (lowest_sim = MetricResult::min), else the first strictly-smallest similarity
+    // (the scan starts from MetricResult::max — 2.0 for cosine — exactly like prob_node.rs:245-259: slots whose
+    // similarity is not below it can never become the lowest; quantized "cosines" above 2 do occur)
+    int32_t mn = kmax;
+    u32 mi = 0;
+    for (u32 j = 0; j < M; j++)
+        if (nk[j] < mn) { mn = nk[j]; mi = j; }
+    L.low_idx[self] = (uint8_t)mi;
+    L.low_key[self] = mn == EMPTY_KEY ? kmin : mn;
     if (!ok) return -1;
     if (old != NONE) { // the evictee drops its back edge; its lowest cache is NOT refreshed (prob_node.rs:285-306)
         u32 *ob = &L.nbr[(size_t)old * M];
         for (u32 j = 0; j < M; j++)
-            if (ob[j] == self) { ob[j] = NONE; mark_dirty(L, old, batch_no); break; }
+            if (ob[j] == self) { ob[j] = NONE; L.key[(size_t)old * M + j] = EMPTY_KEY; mark_dirty(L, old, batch_no); break; }
     }
     return (int)lowest_idx;
 }
 
 // create_node_edges (vector_store.rs:976-1074)
-void create_node_edges(LevelBuild &L, u32 metric, u32 node, const u32 *z_nodes, const float *z_sims, u32 zn, u32 batch_no) {
+inline void create_node_edges(LevelBuild &L, u32 metric, int32_t kmin, int32_t kmax, u32 node, const u32 *z_nodes, const float *z_sims, u32 zn, u32 batch_no) {
     u32 succ = 0;
     for (u32 i = 0; i < zn; i++) {
         if (succ >= L.M) break;
-        const int r = add_neighbor(L, metric, node, z_nodes[i], z_sims[i], batch_no);
+        const int32_t dk = order_key(metric, z_sims[i]);
+        const int r = add_neighbor(L, kmin, kmax, node, z_nodes[i], dk, batch_no);
         if (r >= 0) {
-            const int r2 = add_neighbor(L, metric, z_nodes[i], node, z_sims[i], batch_no);
+            const int r2 = add_neighbor(L, kmin, kmax, z_nodes[i], node, dk, batch_no);
             if (r2 >= 0) succ++;
             else if (L.nbr[(size_t)node * L.M + (u32)r] == z_nodes[i]) { // remove_neighbor_by_index_and_id
                 L.nbr[(size_t)node * L.M + (u32)r] = NONE;
+                L.key[(size_t)node * L.M + (u32)r] = EMPTY_KEY;
                 mark_dirty(L, node, batch_no);
             }
         }
     }
+}
+
+// scatter dirtied rows: packed holds neighbour NODE indices; the vector-row array is derived on the device
+__global__ void scatter_rows2_kernel(u32 *__restrict__ adj_vec, u32 *__restrict__ adj_node, const u32 *__restrict__ node_vec,
+                                     const u32 *__restrict__ rows, const u32 *__restrict__ packed, u32 n_rows, u32 M) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (u64)n_rows * M) return;
+    const u32 r = (u32)(i / M), j = (u32)(i % M);
+    const u32 nb = packed[i];
+    const u64 o = (u64)rows[r] * M + j;
+    if (adj_node) adj_node[o] = nb;
+    adj_vec[o] = (nb == ROW_EMPTY || !node_vec) ? nb : node_vec[nb];
 }
 
 template <typename T>
@@ -168,9 +193,9 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
         L.node_vec.resize(L.n);
         for (u32 i = 0; i < L.n; i++) L.node_vec[i] = L.node_ids[i] == COS_ROOT_ID ? n : L.node_ids[i];
         L.nbr.assign((size_t)L.n * L.M, NONE);
-        L.sim.assign((size_t)L.n * L.M, 0.0f);
+        L.key.assign((size_t)L.n * L.M, EMPTY_KEY);
         L.low_idx.assign(L.n, 0);                    // prob_node.rs:140
-        L.low_sim.assign(L.n, metric_min(metric));
+        L.low_key.assign(L.n, order_key(metric, metric_min(metric)));
         L.stamp.assign(L.n, 0);
         if (l > 0) {
             L.child.resize(L.n);
@@ -205,22 +230,32 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     // ---- batch workspace -----------------------------------------------------------------------
     const u32 L1 = Ltop + 1, KEEP = (u32)KEEP_INDEX;
     u32 *d_rows = nullptr, *d_out_ids = nullptr, *d_out_nodes = nullptr, *d_out_counts = nullptr, *d_drows = nullptr, *d_pack = nullptr;
+    (void)d_drows;
     float *d_out_sims = nullptr;
     int32_t *d_status = nullptr;
     u32 *d_vis = nullptr;
-    size_t pack_cap = 0, drows_cap = 0;
+    size_t pack_cap = 0;
     HIP_TRY(dmalloc(d_rows, Bmax));
     HIP_TRY(dmalloc(d_out_ids, (size_t)Bmax * L1 * KEEP));
     HIP_TRY(dmalloc(d_out_nodes, (size_t)Bmax * L1 * KEEP));
     HIP_TRY(dmalloc(d_out_sims, (size_t)Bmax * L1 * KEEP));
     HIP_TRY(dmalloc(d_out_counts, (size_t)Bmax * L1));
     HIP_TRY(dmalloc(d_status, Bmax));
-    std::vector<u32> h_rows(Bmax), h_nodes((size_t)Bmax * L1 * KEEP), h_counts((size_t)Bmax * L1), h_drows, h_pack;
-    std::vector<float> h_sims((size_t)Bmax * L1 * KEEP);
-    std::vector<int32_t> h_status(Bmax);
+    // pinned staging: walk results down, packed dirty rows up
+    u32 *h_rows = nullptr, *h_nodes = nullptr, *h_counts = nullptr, *h_pack = nullptr;
+    float *h_sims = nullptr;
+    int32_t *h_status = nullptr;
+    size_t h_pack_cap = 0;
+    HIP_TRY(hipHostMalloc((void **)&h_rows, (size_t)Bmax * 4));
+    HIP_TRY(hipHostMalloc((void **)&h_nodes, (size_t)Bmax * L1 * KEEP * 4));
+    HIP_TRY(hipHostMalloc((void **)&h_sims, (size_t)Bmax * L1 * KEEP * 4));
+    HIP_TRY(hipHostMalloc((void **)&h_counts, (size_t)Bmax * L1 * 4));
+    HIP_TRY(hipHostMalloc((void **)&h_status, (size_t)Bmax * 4));
     auto cleanup = [&]() {
         void *ptrs[] = {d_rows, d_out_ids, d_out_nodes, d_out_sims, d_out_counts, d_status, d_drows, d_pack, d_vis};
         for (void *p : ptrs) if (p) (void)hipFree(p);
+        void *hp[] = {h_rows, h_nodes, h_sims, h_counts, h_status, h_pack};
+        for (void *p : hp) if (p) (void)hipHostFree(p);
     };
 
     IndexDev dev = cos_make_index_dev(ix);
@@ -230,11 +265,15 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     }
 
     u32 inserted = 0, batch_no = 0;
+    const bool prof = getenv("COS_BUILD_PROFILE") != nullptr;
+    double t_walk = 0, t_link = 0, t_up = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (inserted < n) {
+        const double t0 = now();
         batch_no++;
         const u32 bs = std::min({Bmax, std::max(1u, inserted / 4u), n - inserted});
         for (u32 b = 0; b < bs; b++) h_rows[b] = inserted + b;
-        hipError_t e = hipMemcpyAsync(d_rows, h_rows.data(), (size_t)bs * 4, hipMemcpyHostToDevice, st);
+        hipError_t e = hipMemcpyAsync(d_rows, h_rows, (size_t)bs * 4, hipMemcpyHostToDevice, st);
         if (e == hipSuccess && d_vis) e = hipMemsetAsync(d_vis, 0, (size_t)bs * dev.vis_words_per_query * 4, st);
         WalkArgs wa;
         memset(&wa, 0, sizeof(wa));
@@ -252,10 +291,10 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
         wa.out_counts = d_out_counts;
         wa.out_status = d_status;
         if (e == hipSuccess) e = launch_walk(ix->eng, dev, wa, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_nodes.data(), d_out_nodes, (size_t)bs * L1 * KEEP * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_sims.data(), d_out_sims, (size_t)bs * L1 * KEEP * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_counts.data(), d_out_counts, (size_t)bs * L1 * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status, (size_t)bs * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_nodes, d_out_nodes, (size_t)bs * L1 * KEEP * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_sims, d_out_sims, (size_t)bs * L1 * KEEP * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_counts, d_out_counts, (size_t)bs * L1 * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_status, d_status, (size_t)bs * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
         for (u32 b = 0; b < bs; b++)
@@ -264,42 +303,66 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
                 return cos_fail(h_status[b], "vector %u cannot be indexed (zero norm -> DistanceError::CalculationError)", inserted + b);
             }
 
-        // connect edges level by level, new nodes in id order (create_node_edges, vector_store.rs:923-936)
+        const double t1 = now();
+        t_walk += t1 - t0;
+        // connect edges level by level, new nodes in id order (create_node_edges, vector_store.rs:923-936).  Levels are
+        // independent graphs: level 0 (3/4 of the work) and the upper levels are linked by two host threads.
+        const int32_t kmin = order_key(metric, metric_min(metric)), kmax = order_key(metric, metric_max(metric));
+        auto link_levels = [&](u32 l_begin, u32 l_end) {
+            for (u32 l = l_begin; l < l_end; l++) {
+                LevelBuild &L = lb[l];
+                L.dirty.clear();
+                const u32 slot = Ltop - l;
+                for (u32 b = 0; b < bs; b++) {
+                    const u32 id = inserted + b;
+                    if (max_level[id] < l) continue;
+                    const u32 me = L.cursor++;
+                    const size_t base = ((size_t)b * L1 + slot) * KEEP;
+                    create_node_edges(L, metric, kmin, kmax, me, &h_nodes[base], &h_sims[base], h_counts[(size_t)b * L1 + slot], batch_no);
+                }
+            }
+        };
+        if (Ltop >= 1 && bs >= 64) {
+            std::thread upper(link_levels, 1u, Ltop + 1);
+            link_levels(0u, 1u);
+            upper.join();
+        } else
+            link_levels(0u, Ltop + 1);
+        const double tl1 = now();
+        t_link += tl1 - t1;
+        // scatter the dirtied adjacency rows back to HBM (node indices up; vector rows derived on the device)
         for (u32 l = 0; l <= Ltop; l++) {
             LevelBuild &L = lb[l];
-            L.dirty.clear();
-            for (u32 b = 0; b < bs; b++) {
-                const u32 id = inserted + b;
-                if (max_level[id] < l) continue;
-                const u32 me = L.cursor++;
-                const u32 slot = Ltop - l;
-                const size_t base = ((size_t)b * L1 + slot) * KEEP;
-                create_node_edges(L, metric, me, &h_nodes[base], &h_sims[base], h_counts[(size_t)b * L1 + slot], batch_no);
-            }
-            // scatter the dirtied adjacency rows back to HBM
             const u32 nd = (u32)L.dirty.size();
             if (nd == 0) continue;
-            const size_t need = (size_t)nd * L.M;
+            const size_t need = (size_t)nd * L.M + nd;
             if (need > pack_cap) { if (d_pack) (void)hipFree(d_pack); d_pack = nullptr; pack_cap = need * 2; e = dmalloc(d_pack, pack_cap); if (e != hipSuccess) { cleanup(); HIP_TRY(e); } }
-            if (nd > drows_cap) { if (d_drows) (void)hipFree(d_drows); d_drows = nullptr; drows_cap = (size_t)nd * 2; e = dmalloc(d_drows, drows_cap); if (e != hipSuccess) { cleanup(); HIP_TRY(e); } }
-            h_pack.resize(need);
-            e = hipMemcpyAsync(d_drows, L.dirty.data(), (size_t)nd * 4, hipMemcpyHostToDevice, st);
-            for (int pass = 0; pass < (l == 0 ? 1 : 2) && e == hipSuccess; pass++) {
-                // pass 0: neighbour VECTOR ROWS (adj_vec); pass 1 (levels >= 1): neighbour NODE indices (adj_node)
-                for (u32 i = 0; i < nd; i++)
-                    for (u32 j = 0; j < L.M; j++) {
-                        const u32 nb = L.nbr[(size_t)L.dirty[i] * L.M + j];
-                        h_pack[(size_t)i * L.M + j] = nb == NONE ? ROW_EMPTY : (pass == 0 ? L.node_vec[nb] : nb);
-                    }
-                e = hipMemcpyAsync(d_pack, h_pack.data(), need * 4, hipMemcpyHostToDevice, st);
-                if (e == hipSuccess) e = launch_scatter_rows(pass == 0 ? ix->lv[l].d_adj_vec : ix->lv[l].d_adj_node, d_drows, d_pack, nd, L.M, st);
-                if (e == hipSuccess) e = hipStreamSynchronize(st); // h_pack is reused by the next pass
+            if (need > h_pack_cap) {
+                if (h_pack) (void)hipHostFree(h_pack);
+                h_pack = nullptr;
+                h_pack_cap = need * 2;
+                e = hipHostMalloc((void **)&h_pack, h_pack_cap * 4);
+                if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
             }
+            memcpy(h_pack, L.dirty.data(), (size_t)nd * 4); // [row ids | packed rows]
+            u32 *pk = h_pack + nd;
+            for (u32 i = 0; i < nd; i++) memcpy(pk + (size_t)i * L.M, &L.nbr[(size_t)L.dirty[i] * L.M], (size_t)L.M * 4); // NONE == ROW_EMPTY
+            e = hipMemcpyAsync(d_pack, h_pack, need * 4, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) {
+                const u64 total = (u64)nd * L.M;
+                hipLaunchKernelGGL(scatter_rows2_kernel, dim3((u32)((total + 255) / 256)), dim3(256), 0, st, ix->lv[l].d_adj_vec,
+                                   l == 0 ? (u32 *)nullptr : ix->lv[l].d_adj_node, l == 0 ? (const u32 *)nullptr : (const u32 *)ix->lv[l].d_node_vec,
+                                   d_pack, d_pack + nd, nd, L.M);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(st); // staging buffers are reused by the next level
             if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
         }
+        t_up += now() - tl1;
         inserted += bs;
     }
     cleanup();
+    if (prof) fprintf(stderr, "[cos_index_build] n=%u batches=%u walk+copy %.2fs link %.2fs upload %.2fs\n", n, batch_no, t_walk, t_link, t_up);
 
     // ---- host copy of the graph in the id format (cos_index_download_graph_level) ---------------
     for (u32 l = 0; l <= Ltop; l++) {
