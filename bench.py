@@ -62,11 +62,17 @@ def mixture(n, d, seed, device, centers, sigma=0.8):
 
 
 def bruteforce_top10(X, Q, k=10):
-    """exact cosine top-k (ground truth for recall; independent of the engine under test)."""
+    """exact cosine top-k by torch matmul (independent cross-check of the engine's own ground truth).
+    Column chunks of 1M: torch.topk over multi-million-wide rows was observed to be unreliable."""
     ids = []
     for s in range(0, Q.shape[0], 256):
-        sims = Q[s:s + 256] @ X.T
-        ids.append(sims.topk(k, dim=1).indices)
+        ci, cs = [], []
+        for c in range(0, X.shape[0], 1 << 20):
+            t = (Q[s:s + 256] @ X[c:c + (1 << 20)].T).topk(k, dim=1)
+            ci.append(t.indices + c)
+            cs.append(t.values)
+        ci, cs = torch.cat(ci, 1), torch.cat(cs, 1)
+        ids.append(torch.gather(ci, 1, cs.topk(k, dim=1).indices))
     return torch.cat(ids)
 
 
@@ -84,6 +90,9 @@ def main():
                     "measured recall@10 is >= --recall-target (the metric is QPS AT recall@10 >= 0.95); config.toml default is 256")
     ap.add_argument("--recall-target", type=float, default=0.95)
     ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--visited", default="ref", choices=["ref", "exact"],
+                    help="search-time visited filter: ref = PerformantFixedSet replica (ID parity with the reference), "
+                         "exact = exact visited set (recall mode, not ID-identical); the graph is always built with ref")
     ap.add_argument("--quantization", default="auto", choices=["auto", "range11"], help="auto = sampled values_range; range11 = (-1,1)")
     ap.add_argument("--ef-sweep", default="256", help="comma list of extra ef_search values to time after the main run (256 = config.toml default)")
     ap.add_argument("--build-batch", type=int, default=4096)
@@ -146,6 +155,8 @@ def main():
     t0 = time.time()
     ix.build(args.build_batch)
     build_s = time.time() - t0
+    if args.visited == "exact":
+        ix.set_visited_mode(ca.VISITED_EXACT)
 
     # ---- buffers + streams ------------------------------------------------------------------------
     S = args.inflight
@@ -301,6 +312,7 @@ def main():
         Xh = X.cpu().numpy()
         op = O.HNSWParams(dim=d, storage=O.STORAGE_U8, num_layers=9, ef_construction=128, ef_search=ef, seed=42,
                           range_lo=values_range[0], range_hi=values_range[1])
+        op.visited_mode = O.VISITED_EXACT if args.visited == "exact" else O.VISITED_REF
         oix = O.OracleIndex(op).set_vectors(Xh)
         oix.import_graph(ix.download_graph(), ix.download_root())
         Qh = Q.cpu().numpy()
@@ -327,6 +339,18 @@ def main():
         parity = {"queries": nq, "id_mismatch_queries": int((gi != oids).any(axis=1).sum()),
                   "score_bit_mismatches": int((gs.view(np.uint32) != osc.view(np.uint32)).sum())}
 
+    # HBM traffic of the walk kernel: PMC FETCH_SIZE cannot be read from inside the process; it is taken from the
+    # committed rocprofv3 --pmc pass of this same command (profiles/pmc_traffic.json, written by
+    # scripts/pmc_traffic.py) when the workload / ef / launch shape match, else null.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            for ent in json.load(fh):
+                if (ent["workload"], ent["ef_search"], ent["queries_per_launch"]) == (args.workload, ef, B) and not args.n:
+                    traffic = ent["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     if rank == 0:
         out = {
             "metric": METRIC, "value": qps, "unit": "queries/s", "n_gpus": world, "steps": steps_done, "warmup": n_warm * C,
@@ -334,13 +358,13 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload + ": " + desc, "standard_size": not bool(args.n), "vectors_per_gpu": n, "dim": d,
                        "query_batch": Bc, "batches_per_launch": C, "launches_in_flight": S, "top_k": k, "ef_search": ef, "ef_policy": ("smallest ef with recall@10 >= %.2f" % args.recall_target) if args.ef == "auto" else "fixed", "M": 32, "M0": 64, "num_layers": 9,
-                       "storage": f"u8 (quantization {args.quantization}, values_range {values_range})", "visited": "reference PerformantFixedSet (ID parity mode)",
+                       "storage": f"u8 (quantization {args.quantization}, values_range {values_range})", "visited": "reference PerformantFixedSet (ID parity mode)" if args.visited == "ref" else "exact visited set (recall mode)",
                        "parallelism": f"id-range shards x{world}" + (" + RCCL all-gather top-k merge" if world > 1 else ""),
                        "corpus": f"Gaussian mixture, {n_centers} centres, sigma 0.8/sqrt(d), L2-normalised, seed 42"},
             "recall_at_10": recall, "recall_queries": nrq, "failed_queries": status_bad,
             "single_batch_qps": serial_qps, "ef_selection": ef_table, "ef_sweep": sweep, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64>" % (1 if ef <= 64 else (4 if ef <= 256 else 8)),
+                         "traffic": traffic, "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64>" % (1 if ef <= 64 else (4 if ef <= 256 else 8)),
                          "per_launch": {"algorithmic_bytes": avg_bytes, "avg_ms": avg_ms, "in_flight": overlap,
                                         "evals": float(np.mean([p[2] for p in per])), "expansions": float(np.mean([p[3] for p in per])),
                                         "finalize_ms": float(np.mean([p[4] for p in per])), "prep_ms": float(np.mean([p[5] for p in per])),

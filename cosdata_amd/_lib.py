@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "cos_index_create", "cos_index_destroy", "cos_last_error_string", "cos_device_count",
     "cos_index_upload_vectors", "cos_index_set_root", "cos_index_upload_graph_level", "cos_index_level_count",
     "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build",
-    "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_ef_search",
+    "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_coalescing", "cos_index_set_ef_search",
     "cos_index_set_visited_mode", "cos_index_enable_timing", "cos_index_last_stats", "cos_quantize_batch",
     "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
     "cos_bm25_search_batch", "cos_rrf_fuse_batch", "cos_merge_topk_device",
@@ -104,6 +104,7 @@ def lib():
         "cos_search_batch_device": [vp, vp, u32, u32, vp, vp, vp, vp, vp],
         "cos_ann_search_batch": [vp, vp, u32, vp, vp, vp, vp],
         "cos_index_set_ef_search": [vp, u32],
+        "cos_index_set_coalescing": [vp, u32, u32],
         "cos_index_set_visited_mode": [vp, u32],
         "cos_index_enable_timing": [vp, i32],
         "cos_index_last_stats": [vp, vp, C.POINTER(CosSearchStats)],

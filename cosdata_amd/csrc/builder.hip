@@ -313,7 +313,26 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
                 LevelBuild &L = lb[l];
                 L.dirty.clear();
                 const u32 slot = Ltop - l;
+                // the link is a chain of random row accesses (neighbour slots + keys of every candidate): software-prefetch the
+                // rows of the batch nodes a few positions ahead while the current one is being connected
+                auto prefetch_rows = [&](u32 b) {
+                    if (b >= bs || max_level[inserted + b] < l) return;
+                    const size_t base = ((size_t)b * L1 + slot) * KEEP;
+                    const u32 zn = h_counts[(size_t)b * L1 + slot];
+                    for (u32 i = 0; i < zn; i++) {
+                        const size_t o = (size_t)h_nodes[base + i] * L.M;
+                        for (u32 c = 0; c < L.M; c += 16) { // 64-byte lines
+                            __builtin_prefetch(&L.nbr[o + c], 1, 1);
+                            __builtin_prefetch(&L.key[o + c], 1, 1);
+                        }
+                        __builtin_prefetch(&L.low_key[h_nodes[base + i]], 1, 1);
+                        __builtin_prefetch(&L.low_idx[h_nodes[base + i]], 1, 1);
+                        __builtin_prefetch(&L.stamp[h_nodes[base + i]], 1, 1);
+                    }
+                };
+                for (u32 b = 0; b < 3 && b < bs; b++) prefetch_rows(b);
                 for (u32 b = 0; b < bs; b++) {
+                    prefetch_rows(b + 3);
                     const u32 id = inserted + b;
                     if (max_level[id] < l) continue;
                     const u32 me = L.cursor++;

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -194,6 +196,9 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     ix->have_vectors = false;
     const u64 dim = ix->p.dim;
     if (flags & COS_UPLOAD_BORROW_DEVICE) {
+        // the caller's producer (e.g. a torch kernel on another stream) may still be writing the buffer: our streams
+        // are non-blocking, so drain the device once before the quantize kernel reads it
+        HIP_TRY(hipDeviceSynchronize());
         ix->d_raw = const_cast<float *>(raw);
         ix->raw_borrowed = true;
     } else {
@@ -497,11 +502,10 @@ extern "C" int32_t cos_search_batch_device(cos_index *ix, const float *d_queries
     return run_search(ix, w, d_queries, B, top_k, d_out_ids, d_out_scores, d_out_counts, d_out_status, true, (hipStream_t)stream);
 }
 
-extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,
-                                    uint32_t *out_counts, int32_t *out_status) {
-    int32_t rc = check_search_args(ix, queries, B, top_k);
-    if (rc) return rc;
-    if (!out_ids || !out_scores || !out_counts) return cos_fail(COS_ERR_INVALID, "null output");
+// one launch for a contiguous host batch, on the calling thread's private stream
+static int32_t search_host_once(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,
+                                uint32_t *out_counts, int32_t *out_status) {
+    int32_t rc;
     // host API: a private stream per calling thread so concurrent callers (rayon workers) do not serialise
     static thread_local std::map<cos_index *, hipStream_t> tl_streams;
     hipStream_t st = tl_streams[ix];
@@ -524,6 +528,120 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
     if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
     for (u32 b = 0; b < B; b++)
         if (status[b] != COS_OK) return cos_fail(status[b], "query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", b, status[b]);
+    return COS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Request coalescing for the host API (dynamic batching).  The walk kernel gives every query one
+// wavefront, so a 256-CU chip wants thousands of queries per launch, while the reference's callers
+// (rayon workers, actix handlers: indexes/mod.rs:268-271, tests/rps-test.py) submit a few hundred at a
+// time from many threads.  With coalescing on, concurrent cos_search_batch calls that use the same top_k
+// are fused: the first caller becomes the leader, waits `window_us` for followers (or until `max_queries`
+// are pending), runs ONE launch for all of them and hands every caller its own slice.  Results are
+// identical to un-coalesced calls (queries are independent); errors stay per request.
+// ------------------------------------------------------------------------------------------------
+struct CoalesceReq {
+    const float *queries;
+    u32 B, top_k;
+    u32 *out_ids;
+    float *out_scores;
+    u32 *out_counts;
+    int32_t *out_status;
+    int32_t rc = COS_OK;
+    std::string err;
+    bool done = false;
+};
+
+static int32_t run_coalesced(cos_index *ix, std::vector<CoalesceReq *> &group) {
+    const u32 top_k = group[0]->top_k, dim = ix->p.dim;
+    u32 total = 0;
+    for (auto *r : group) total += r->B;
+    std::vector<float> q((size_t)total * dim);
+    std::vector<u32> ids((size_t)total * top_k), counts(total);
+    std::vector<float> scores((size_t)total * top_k);
+    std::vector<int32_t> status(total, 0);
+    size_t off = 0;
+    for (auto *r : group) { memcpy(q.data() + off * dim, r->queries, (size_t)r->B * dim * 4); off += r->B; }
+    int32_t rc = search_host_once(ix, q.data(), total, top_k, ids.data(), scores.data(), counts.data(), status.data());
+    const std::string err = rc ? std::string(cos_last_error_string()) : std::string();
+    const bool infra_failure = rc != COS_OK && rc != COS_ERR_CALCULATION; // HIP errors etc. hit every request
+    off = 0;
+    for (auto *r : group) {
+        memcpy(r->out_ids, ids.data() + off * top_k, (size_t)r->B * top_k * 4);
+        memcpy(r->out_scores, scores.data() + off * top_k, (size_t)r->B * top_k * 4);
+        memcpy(r->out_counts, counts.data() + off, (size_t)r->B * 4);
+        if (r->out_status) memcpy(r->out_status, status.data() + off, (size_t)r->B * 4);
+        r->rc = infra_failure ? rc : COS_OK;
+        r->err = infra_failure ? err : std::string();
+        if (!infra_failure)
+            for (u32 b = 0; b < r->B; b++)
+                if (status[off + b] != COS_OK) { // the reference fails the whole request of THIS caller (collect::<Result<_>>)
+                    r->rc = status[off + b];
+                    char buf[160];
+                    snprintf(buf, sizeof(buf), "query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", b, status[off + b]);
+                    r->err = buf;
+                    break;
+                }
+        off += r->B;
+    }
+    return rc;
+}
+
+extern "C" int32_t cos_index_set_coalescing(cos_index *ix, uint32_t max_queries, uint32_t window_us) {
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
+    std::lock_guard<std::mutex> g(ix->co_mu);
+    ix->co_max_queries = max_queries;
+    ix->co_window_us = window_us;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,
+                                    uint32_t *out_counts, int32_t *out_status) {
+    int32_t rc = check_search_args(ix, queries, B, top_k);
+    if (rc) return rc;
+    if (!out_ids || !out_scores || !out_counts) return cos_fail(COS_ERR_INVALID, "null output");
+    u32 max_q, window;
+    { std::lock_guard<std::mutex> g(ix->co_mu); max_q = ix->co_max_queries; window = ix->co_window_us; }
+    if (max_q == 0 || B >= max_q) return search_host_once(ix, queries, B, top_k, out_ids, out_scores, out_counts, out_status);
+
+    CoalesceReq me{queries, B, top_k, out_ids, out_scores, out_counts, out_status};
+    std::unique_lock<std::mutex> lk(ix->co_mu);
+    ix->co_pending.push_back(&me);
+    ix->co_cv.notify_all();
+    while (!me.done) {
+        if (!ix->co_leader_active) {
+            // become the leader: collect followers for up to `window` microseconds, then serve one group per round
+            ix->co_leader_active = true;
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window);
+            for (;;) {
+                u32 pend = 0;
+                for (auto *r : ix->co_pending) pend += r->B;
+                if (pend >= max_q || ix->co_cv.wait_until(lk, deadline) == std::cv_status::timeout) break;
+            }
+            std::vector<CoalesceReq *> group, rest;
+            u32 taken = 0;
+            for (auto *r : ix->co_pending) {
+                if (r->top_k == me.top_k && (taken == 0 || taken + r->B <= max_q)) { group.push_back(r); taken += r->B; }
+                else rest.push_back(r);
+            }
+            if (std::find(group.begin(), group.end(), &me) == group.end()) { // never starve the leader itself
+                rest.insert(rest.end(), group.begin(), group.end());
+                group.assign(1, &me);
+                rest.erase(std::remove(rest.begin(), rest.end(), &me), rest.end());
+            }
+            ix->co_pending = rest;
+            lk.unlock();
+            (void)run_coalesced(ix, group);
+            lk.lock();
+            for (auto *r : group) r->done = true;
+            ix->co_leader_active = false;
+            ix->co_cv.notify_all();
+        } else {
+            ix->co_cv.wait(lk);
+        }
+    }
+    lk.unlock();
+    if (me.rc != COS_OK) return cos_fail(me.rc, "%s", me.err.c_str());
     return COS_OK;
 }
 

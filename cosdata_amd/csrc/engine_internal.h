@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -84,6 +85,12 @@ struct cos_index {
     std::mutex mu;                    // guards workspaces map + timing flag
     std::map<void *, Workspace *> ws;
     Workspace *last_ws = nullptr; // most recent batch (cos_index_last_stats with stream == NULL)
+    // host-API request coalescing (cos_index_set_coalescing)
+    std::mutex co_mu;
+    std::condition_variable co_cv;
+    std::vector<struct CoalesceReq *> co_pending;
+    bool co_leader_active = false;
+    u32 co_max_queries = 0, co_window_us = 0;
     bool timing = false;
 };
 

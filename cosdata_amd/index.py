@@ -214,6 +214,10 @@ class HNSWIndex:
         check(_lib.lib().cos_index_set_ef_search(self._h, ef))
         self.hnsw_params.ef_search = ef
 
+    def set_coalescing(self, max_queries: int, window_us: int = 200):
+        """Fuse concurrent batch_search() calls of different threads into one launch (0 = off)."""
+        check(_lib.lib().cos_index_set_coalescing(self._h, max_queries, window_us))
+
     def set_visited_mode(self, mode: int):
         check(_lib.lib().cos_index_set_visited_mode(self._h, mode))
 

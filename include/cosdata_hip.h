@@ -142,6 +142,10 @@ int32_t cos_search_batch_device(cos_index *ix, const float *d_queries, uint32_t 
  * counts [B][num_layers+1], top level first.  Host buffers. */
 int32_t cos_ann_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t *out_ids, float *out_sims,
                              uint32_t *out_counts, int32_t *out_status);
+/* Dynamic batching for the host API: concurrent cos_search_batch calls (rayon workers / request handlers) with
+ * the same top_k are fused into one launch of up to max_queries queries; the first caller waits window_us
+ * for followers.  max_queries = 0 (default) turns it off.  Results are identical to un-coalesced calls. */
+int32_t cos_index_set_coalescing(cos_index *ix, uint32_t max_queries, uint32_t window_us);
 int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef_search);
 int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode);
 /* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
