@@ -296,20 +296,18 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                     u64 m = wmask;
                     while (m && !failed) {
                         uint4 buf[PB64][CH];
-                        int wl[PB64];
-                        float mg[PB64];
                         int cnt = 0;
+                        float magv = 1.0f, dotv = 0.0f; // lane p <- winner p of this block: |v| and the integer dot as f32
+                        u32 nodev = 0;
 #pragma unroll
                         for (int p = 0; p < PB64; p++) {
-                            wl[p] = 0;
-                            mg[p] = 1.0f;
                             if (m) {
                                 const int l = __ffsll((long long)m) - 1;
                                 m &= m - 1;
-                                wl[p] = l;
                                 const u32 row = readlane_u32(nb_vec, l);
+                                const u32 nd = readlane_u32(nb_node, l);
                                 const uint8_t *rp = ix.codes + (u64)row * ix.row_stride;
-                                mg[p] = ix.mags[row];
+                                if (lane == p) { magv = ix.mags[row]; nodev = nd; }
 #pragma unroll
                                 for (int c = 0; c < CH; c++) {
                                     const u32 chunk = (u32)lane + (u32)c * 64u;
@@ -321,24 +319,34 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                         }
 #pragma unroll
                         for (int p = 0; p < PB64; p++) {
-                            if (p >= cnt) break;
-                            u32 acc = 0;
+                            if (p < cnt) {
+                                u32 acc = 0;
 #pragma unroll
-                            for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
-                            acc = group_reduce_add_u32(acc, 64);
-                            const float dotf = (float)acc;
-                            float sim = dotf;
-                            if (metric == 0u) {
-                                const float den = __fmul_rn(qmag, mg[p]);
-                                if (den == 0.0f) { failed = true; break; }
-                                sim = __fdiv_rn(dotf, den);
+                                for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
+                                acc = group_reduce_add_u32(acc, 64);
+                                if (lane == p) dotv = (float)acc; // integer dot `as f32` (RNE)
                             }
-                            const u64 kk = pack_key(metric_key(metric, sim), readlane_u32(nb_node, wl[p]));
-                            const int pos = pool.rank_of(kk);
-                            if (pos < limit) {
-                                pool.insert_at(kk, pos, lane);
-                                if (npool < (u32)(64 * R)) npool++;
-                                if (pos < ahead) window_ok = false;
+                        }
+                        // one vector epilogue for the whole block: cosine_similarity_from_dot_product (cosine.rs:223-235)
+                        float sim = dotv;
+                        bool bad = false;
+                        if (metric == 0u) {
+                            const float den = __fmul_rn(qmag, magv);
+                            bad = lane < cnt && den == 0.0f;
+                            sim = __fdiv_rn(dotv, den);
+                        }
+                        if (__any(bad)) { failed = true; break; }
+                        const u32 keyv = metric_key(metric, sim);
+#pragma unroll
+                        for (int p = 0; p < PB64; p++) {
+                            if (p < cnt) {
+                                const u64 kk = pack_key(readlane_u32(keyv, p), readlane_u32(nodev, p));
+                                const int pos = pool.rank_of(kk);
+                                if (pos < limit) {
+                                    pool.insert_at(kk, pos, lane);
+                                    if (npool < (u32)(64 * R)) npool++;
+                                    if (pos < ahead) window_ok = false;
+                                }
                             }
                         }
                     }
