@@ -11,6 +11,9 @@
 // Compile with -ffp-contract=off: the reference's arithmetic order (fused only where AVX2 FMA is
 // used, x86_64.rs:418-444) is reproduced with explicit __fmaf_rn / __fmul_rn / __fadd_rn.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+
 #include "engine_types.h"
 #include "dot_engines.h"
 
@@ -534,7 +537,10 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
     {
         u32 off = 0;
         for (u32 s = 0; s <= L; s++) {
-            const u32 c = fa.walk_counts[(u64)qi * (L + 1) + s];
+            // a level list is sorted: entries past its first 5k cannot reach the global top 5k (each is preceded by 5k
+            // distinct better nodes), so only min(count, 5k) entries per level take part in the sort
+            u32 c = fa.walk_counts[(u64)qi * (L + 1) + s];
+            if (c > 5u * fa.top_k) c = 5u * fa.top_k;
             const u64 b = ((u64)qi * (L + 1) + s) * KEEP_SEARCH;
             // element index off + j  lives in lane (off+j)/FR, register (off+j)%FR
 #pragma unroll
@@ -583,35 +589,55 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
 
     // exact rerank on raw f32 (vector_store.rs:404-445); 32 candidates per pass (one lane pair each)
     const float mag_query = fa.q_raw_mags[qi];
-    u64 rk[FR];
-#pragma unroll
-    for (int r = 0; r < FR; r++) rk[r] = 0ull;
+    const u32 nout = ncand < fa.top_k ? ncand : fa.top_k;
     const int pair = lane >> 1;
-    for (u32 base = 0; base < ncand; base += 32) {
-        const u32 my = base + (u32)pair;
-        const u32 id = my < ncand ? cand[my] : 0u;
-        const float dp = f32_pair_dot(ix.raw + (u64)id * ix.raw_stride, qf, ix.dim, lane & 1);
-        const float cs = __fdiv_rn(dp, __fmul_rn(mag_query, ix.raw_mags[id]));
-        const u64 key = pack_key(simkey(cs), id); // results.sort_unstable_by(total_cmp) desc; larger id first on ties
-        // scatter into the blocked register layout: element my -> lane my/FR, reg my%FR
-        for (u32 j = 0; j < 32 && base + j < ncand; j++) {
-            const u64 kv = readlane_u64(key, (int)(2 * j));
-            const u32 e = base + j;
-            if ((u32)lane == e / FR) {
+    if (ncand <= 64) {
+        // common case (5k <= 64): survivor j ends in lane j and one 64-key sort finishes the job
+        u64 res[1] = {0ull};
+        for (u32 base = 0; base < ncand; base += 32) {
+            const u32 my = base + (u32)pair;
+            const u32 id = my < ncand ? cand[my] : 0u;
+            const float dp = f32_pair_dot(ix.raw + (u64)id * ix.raw_stride, qf, ix.dim, lane & 1);
+            const float cs = __fdiv_rn(dp, __fmul_rn(mag_query, ix.raw_mags[id]));
+            const u64 key = my < ncand ? pack_key(simkey(cs), id) : 0ull; // total_cmp desc; larger id first on ties
+            const int from = (2 * (lane - (int)base)) & 63;
+            const u32 klo = (u32)__shfl((int)(u32)key, from, 64), khi = (u32)__shfl((int)(u32)(key >> 32), from, 64);
+            if ((u32)lane >= base && (u32)lane < base + 32) res[0] = ((u64)khi << 32) | klo;
+        }
+        bitonic_sort_desc<1>(res, lane);
+        if ((u32)lane < nout) {
+            fa.out_ids[(u64)qi * fa.top_k + lane] = (u32)res[0] + ix.id_base;
+            fa.out_scores[(u64)qi * fa.top_k + lane] = simkey_inv((u32)(res[0] >> 32));
+        }
+    } else {
+        u64 rk[FR];
 #pragma unroll
-                for (int r = 0; r < FR; r++)
-                    if ((e % FR) == (u32)r) rk[r] = kv;
+        for (int r = 0; r < FR; r++) rk[r] = 0ull;
+        for (u32 base = 0; base < ncand; base += 32) {
+            const u32 my = base + (u32)pair;
+            const u32 id = my < ncand ? cand[my] : 0u;
+            const float dp = f32_pair_dot(ix.raw + (u64)id * ix.raw_stride, qf, ix.dim, lane & 1);
+            const float cs = __fdiv_rn(dp, __fmul_rn(mag_query, ix.raw_mags[id]));
+            const u64 key = pack_key(simkey(cs), id);
+            // scatter into the blocked register layout: element my -> lane my/FR, reg my%FR
+            for (u32 j = 0; j < 32 && base + j < ncand; j++) {
+                const u64 kv = readlane_u64(key, (int)(2 * j));
+                const u32 e = base + j;
+                if ((u32)lane == e / FR) {
+#pragma unroll
+                    for (int r = 0; r < FR; r++)
+                        if ((e % FR) == (u32)r) rk[r] = kv;
+                }
             }
         }
-    }
-    bitonic_sort_desc<FR>(rk, lane);
-    const u32 nout = ncand < fa.top_k ? ncand : fa.top_k;
+        bitonic_sort_desc<FR>(rk, lane);
 #pragma unroll
-    for (int r = 0; r < FR; r++) {
-        const u32 e = (u32)lane * FR + r;
-        if (e < nout) {
-            fa.out_ids[(u64)qi * fa.top_k + e] = (u32)rk[r] + ix.id_base;
-            fa.out_scores[(u64)qi * fa.top_k + e] = simkey_inv((u32)(rk[r] >> 32));
+        for (int r = 0; r < FR; r++) {
+            const u32 e = (u32)lane * FR + r;
+            if (e < nout) {
+                fa.out_ids[(u64)qi * fa.top_k + e] = (u32)rk[r] + ix.id_base;
+                fa.out_scores[(u64)qi * fa.top_k + e] = simkey_inv((u32)(rk[r] >> 32));
+            }
         }
     }
     if (lane == 0) {
@@ -683,11 +709,15 @@ hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_strid
     if (B == 0) return hipSuccess;
     FinalizeArgs fa{queries, q_stride, q_raw_mags, walk_ids, walk_sims, walk_counts, walk_status, B, top_k,
                     out_ids, out_scores, out_counts, out_status, out_rerank_rows};
-    const u32 total = (ix.num_layers + 1) * KEEP_SEARCH;
+    const u32 per_level = std::min<u32>(KEEP_SEARCH, 5u * top_k);
+    const u32 total = (ix.num_layers + 1) * per_level;
     dim3 grid(B), block(64);
     if (total <= 64 * 4) {
         size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 4 * 4;
         hipLaunchKernelGGL(finalize_kernel<4>, grid, block, smem, st, ix, fa);
+    } else if (total <= 64 * 8) {
+        size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 8 * 4;
+        hipLaunchKernelGGL(finalize_kernel<8>, grid, block, smem, st, ix, fa);
     } else if (total <= 64 * 16) {
         size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 16 * 4;
         hipLaunchKernelGGL(finalize_kernel<16>, grid, block, smem, st, ix, fa);
