@@ -2,6 +2,7 @@
 // sequential norm, the integer chunk dots and the reference-order f32 dot.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include "device_common.h"
 
 namespace cosdev {
@@ -90,5 +91,24 @@ __device__ __forceinline__ float f32_pair_dot(const float *__restrict__ row, con
     return r;
 }
 
+
+
+// dot_product_f16 (dot_product.rs:13-19): sequential sum of f32(a) * f32(b), no SIMD in the reference.  ONE lane
+// walks one stored row; the query's f16 code is held as f32 in LDS (f32::from(b) is exact).
+__device__ __forceinline__ float f16_lane_dot(const uint8_t *__restrict__ row, const float *__restrict__ q_lds, u32 dim) {
+    float acc = -0.0f; // <f32 as Sum> folds from -0.0
+    u32 i = 0;
+    for (; i + 8 <= dim; i += 8) {
+        const uint4 v = *(const uint4 *)(row + (u64)i * 2);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            acc = __fadd_rn(acc, __fmul_rn(__half2float(__ushort_as_half((unsigned short)(w[k] & 0xFFFFu))), q_lds[i + 2 * k]));
+            acc = __fadd_rn(acc, __fmul_rn(__half2float(__ushort_as_half((unsigned short)(w[k] >> 16))), q_lds[i + 2 * k + 1]));
+        }
+    }
+    for (; i < dim; i++) acc = __fadd_rn(acc, __fmul_rn(__half2float(((const __half *)row)[i]), q_lds[i]));
+    return acc;
+}
 
 } // namespace cosdev

@@ -125,6 +125,9 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
         if (p->metric == COS_METRIC_DOT) return cos_fail(COS_ERR_STORAGE_MISMATCH, "DotProductDistance has no FullPrecisionFP arm (dotproduct.rs:20-64)");
         eng = ENG_F32; row_stride = ((u64)p->dim * 4 + 15) & ~15ull; G = 2;
         break;
+    case COS_STORAGE_F16:
+        eng = ENG_F16; row_stride = ((u64)p->dim * 2 + 15) & ~15ull; G = 1;
+        break;
     default: return cos_fail(COS_ERR_UNIMPLEMENTED, "storage kind %u not supported on the device yet", p->storage);
     }
     int ndev = 0;
@@ -350,6 +353,7 @@ extern "C" size_t cos_code_bytes(uint32_t storage, uint32_t resolution, uint32_t
 static void row_to_reference_layout(int eng, u32 dim, const uint8_t *dev_row, uint8_t *ref_row) {
     if (eng == ENG_U8) memcpy(ref_row, dev_row, dim);
     else if (eng == ENG_F32) memcpy(ref_row, dev_row, (size_t)dim * 4);
+    else if (eng == ENG_F16) memcpy(ref_row, dev_row, (size_t)dim * 2);
     else { // Q2: [chunk][plane][8 B] -> plane-major
         const u32 pb = (dim + 7) / 8;
         for (u32 p = 0; p < 2; p++)

@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
             }
         }
         if (lane == 0) mags[row] = rn; // norm of the ORIGINAL vector (scalar.rs:31-32)
+    } else if constexpr (ENG == ENG_F16) {
+        __half *ch = (__half *)cr;
+        for (u32 i = lane; i < (u32)(row_stride / 2); i += 64) ch[i] = i < dim ? __float2half_rn(xr[i]) : __float2half_rn(0.0f); // f16::from_f32 (RNE)
+        if (lane == 0) mags[row] = rn; // norm of the ORIGINAL vector (scalar.rs:41)
     } else {
         float *cf = (float *)cr;
         for (u32 i = lane; i < (u32)(row_stride / 4); i += 64) cf[i] = i < dim ? xr[i] : 0.0f;
@@ -132,17 +136,24 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
     u32 *vis_slab = exact ? wa.vis_slab + (u64)qi * ix.vis_words_per_query : nullptr;
 
     // ---- engine set-up -------------------------------------------------------------------------
-    const int G = (ENG == ENG_F32) ? 2 : (int)ix.G;
+    constexpr bool FLOAT_ENG = ENG == ENG_F32 || ENG == ENG_F16; // ordered f32 chains instead of integer chunk dots
+    const int G = (ENG == ENG_F32) ? 2 : (ENG == ENG_F16 ? 1 : (int)ix.G);
     const int lig = lane & (G - 1);  // lane in group
     const int grp = lane / G;        // group index
     const int RP = 64 / G;           // rows per pass
     uint4 qreg[CH];
-    if constexpr (ENG != ENG_F32) {
+    if constexpr (!FLOAT_ENG) {
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             u32 chunk = (u32)lig + (u32)c * (u32)G;
             qreg[c] = chunk < ix.nchunks ? *(const uint4 *)(qcode + (u64)chunk * 16) : make_uint4(0, 0, 0, 0);
         }
+    } else if constexpr (ENG == ENG_F16) {
+        const __half *qh = (const __half *)qcode;
+        for (u32 i = lane; i < ix.dim; i += 64) sm.qf[i] = __half2float(qh[i]);
+        __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+        for (int c = 0; c < CH; c++) qreg[c] = make_uint4(0, 0, 0, 0);
     } else {
         const float *qg = (const float *)qcode;
         for (u32 i = lane; i < (u32)(ix.row_stride / 4); i += 64) sm.qf[i] = qg[i];
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
     // distance of ONE row computed by group 0 (entry node); result valid in every lane
     auto single_distance = [&](u32 row, float &sim_out) -> bool {
         float dotf;
-        if constexpr (ENG != ENG_F32) {
+        if constexpr (!FLOAT_ENG) {
             u32 acc = 0;
             if (grp == 0) {
 #pragma unroll
@@ -170,6 +181,9 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
             acc = group_reduce_add_u32(acc, G);
             acc = readlane_u32(acc, 0);
             dotf = (float)acc; // integer dot `as f32` (RNE)
+        } else if constexpr (ENG == ENG_F16) {
+            float d = f16_lane_dot(ix.codes + (u64)row * ix.row_stride, sm.qf, ix.dim);
+            dotf = __uint_as_float(readlane_u32(__float_as_uint(d), 0));
         } else {
             float d = f32_pair_dot((const float *)(ix.codes + (u64)row * ix.row_stride), sm.qf, ix.dim, lane & 1);
             dotf = __uint_as_float(readlane_u32(__float_as_uint(d), 0));
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
 
                 const u64 wmask = __ballot(win);
                 const int W = __popcll(wmask);
-                if constexpr (G64 && ENG != ENG_F32) {
+                if constexpr (G64 && !FLOAT_ENG) {
                     // One code row per wave pass (64 lanes x 16 B cover the row): the winner's row index is
                     // wave-uniform, so it is taken straight from the owning lane with v_readlane, the row base
                     // lives in SGPRs and nothing goes through LDS.  PB64 rows are in flight before the dots.
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                         prow[p] = v ? sm.wl_vec[my] : 0u;
                         pmag[p] = 1.0f;
                         if (v) pmag[p] = ix.mags[prow[p]];
-                        if constexpr (ENG != ENG_F32) {
+                        if constexpr (!FLOAT_ENG) {
 #pragma unroll
                             for (int c = 0; c < CH; c++) {
                                 u32 chunk = (u32)lig + (u32)c * (u32)G;
@@ -387,19 +401,22 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                             }
                         }
                     }
-                    if constexpr (ENG == ENG_F32) {
-                        // every lane pair must run the (uniform-trip-count) dot; invalid pairs read row 0 and are ignored
+                    if constexpr (FLOAT_ENG) {
+                        // every lane (pair) runs the uniform-trip-count dot; lanes without a winner read row 0 and are ignored
 #pragma unroll
                         for (int p = 0; p < PB; p++) {
                             if (base + p * RP >= W) break;
-                            fdot[p] = f32_pair_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 1);
+                            if constexpr (ENG == ENG_F32)
+                                fdot[p] = f32_pair_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 1);
+                            else
+                                fdot[p] = f16_lane_dot(ix.codes + (u64)prow[p] * ix.row_stride, sm.qf, ix.dim);
                         }
                     }
 #pragma unroll
                     for (int p = 0; p < PB; p++) {
                         if (base + p * RP >= W) break; // wave-uniform
                         float dotf;
-                        if constexpr (ENG != ENG_F32) {
+                        if constexpr (!FLOAT_ENG) {
                             u32 acc = 0;
 #pragma unroll
                             for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
@@ -662,6 +679,7 @@ hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u3
     case ENG_U8: hipLaunchKernelGGL(quantize_rows_kernel<ENG_U8>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
     case ENG_Q2: hipLaunchKernelGGL(quantize_rows_kernel<ENG_Q2>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
     case ENG_F32: hipLaunchKernelGGL(quantize_rows_kernel<ENG_F32>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
+    case ENG_F16: hipLaunchKernelGGL(quantize_rows_kernel<ENG_F16>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -672,6 +690,7 @@ size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     size_t b = (size_t)Mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2 + (size_t)LA * 64 * 4 * 2 + (size_t)LA * 8;
     b = (b + 15) & ~(size_t)15;
     if (eng == ENG_F32) b += (size_t)ix.row_stride;
+    if (eng == ENG_F16) b += ((size_t)ix.dim * 4 + 15) & ~(size_t)15;
     return b + 16;
 }
 
@@ -688,7 +707,7 @@ static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStrea
 
 hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     if (wa.B == 0) return hipSuccess;
-    const u32 ch = eng == ENG_F32 ? 1 : (ix.nchunks + ix.G - 1) / ix.G;
+    const u32 ch = (eng == ENG_F32 || eng == ENG_F16) ? 1 : (ix.nchunks + ix.G - 1) / ix.G;
     switch (eng) {
     case ENG_U8:
         if (ch == 1) return ix.G == 64 ? launch_walk_r<ENG_U8, 1, true>(ix, wa, st) : launch_walk_r<ENG_U8, 1, false>(ix, wa, st);
@@ -698,6 +717,7 @@ hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStrea
         if (ch == 1) return ix.G == 64 ? launch_walk_r<ENG_Q2, 1, true>(ix, wa, st) : launch_walk_r<ENG_Q2, 1, false>(ix, wa, st);
         return hipErrorInvalidValue;
     case ENG_F32: return launch_walk_r<ENG_F32, 1, false>(ix, wa, st);
+    case ENG_F16: return launch_walk_r<ENG_F16, 1, false>(ix, wa, st);
     default: return hipErrorInvalidValue;
     }
 }

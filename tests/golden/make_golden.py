@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import oracle as O  # noqa: E402
 
-STORAGES = {"u8": (O.STORAGE_U8, 0), "q2": (O.STORAGE_SUBBYTE, 2), "f32": (O.STORAGE_F32, 0)}
+STORAGES = {"u8": (O.STORAGE_U8, 0), "q2": (O.STORAGE_SUBBYTE, 2), "f32": (O.STORAGE_F32, 0), "f16": (O.STORAGE_F16, 0)}
 
 
 def corpus(n, d, seed):

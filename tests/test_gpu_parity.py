@@ -11,6 +11,7 @@ STORAGES = [
     ("u8", O.STORAGE_U8, 0),
     ("q2", O.STORAGE_SUBBYTE, 2),
     ("f32", O.STORAGE_F32, 0),
+    ("f16", O.STORAGE_F16, 0),
 ]
 
 
