@@ -4,16 +4,16 @@ profiles/pmc_traffic.json: HBM bytes per walk launch, with the gfx950 correction
 (FETCH_SIZE reports 1/2 of a wide 16 B/lane coalesced read; KB units)."""
 import json, os, sqlite3, sys
 
-db_fetch, grid, workload, ef = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
-db_write = sys.argv[5] if len(sys.argv) > 5 else None
+db_fetch, grid, workload, ef, pattern = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+db_write = sys.argv[6] if len(sys.argv) > 6 else None
 def avg(db, counter):
     cur = sqlite3.connect(db).cursor()
-    r = cur.execute("select count(*), avg(value) from counters_collection where kernel_name like '%walk_kernel%' and "
-                    "grid_size/workgroup_size = ? and counter_name = ?", (grid, counter)).fetchone()
+    r = cur.execute("select count(*), avg(value) from counters_collection where kernel_name like ? and "
+                    "grid_size/workgroup_size = ? and counter_name = ?", ("%" + pattern + "%", grid, counter)).fetchone()
     return r
 n, fetch_kb = avg(db_fetch, "FETCH_SIZE")
 wn, write_kb = avg(db_write, "WRITE_SIZE") if db_write else (0, 0.0)
-ent = {"workload": workload, "ef_search": ef, "queries_per_launch": grid, "dispatches": n,
+ent = {"kernel": pattern, "workload": workload, "ef_search": ef, "queries_per_launch": grid, "dispatches": n,
        "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb or 0.0,
        "hbm_bytes_per_launch": (fetch_kb * 2.0 + (write_kb or 0.0)) * 1024.0,
        "note": "FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KB -> bytes"}
