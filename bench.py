@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--visited", default="ref", choices=["ref", "exact"],
                     help="search-time visited filter: ref = PerformantFixedSet replica (ID parity with the reference), "
                          "exact = exact visited set (recall mode, not ID-identical); the graph is always built with ref")
+    ap.add_argument("--ef-construction", type=int, default=128, help="config.toml default 128")
+    ap.add_argument("--build-visited", default="ref", choices=["ref", "exact"], help="visited filter used by the builder's walks")
     ap.add_argument("--quantization", default="auto", choices=["auto", "range11"], help="auto = sampled values_range; range11 = (-1,1)")
     ap.add_argument("--ef-sweep", default="256", help="comma list of extra ef_search values to time after the main run (256 = config.toml default)")
     ap.add_argument("--build-batch", type=int, default=4096)
@@ -148,15 +150,15 @@ def main():
         vr = torch.tensor(values_range, device=dev, dtype=torch.float64)
         dist.broadcast(vr, 0)
         values_range = (float(vr[0].item()), float(vr[1].item()))
-    hp = ca.HNSWHyperParams(num_layers=9, ef_construction=128, ef_search=ef, level_0_neighbors_count=64, neighbors_count=32)
+    hp = ca.HNSWHyperParams(num_layers=9, ef_construction=args.ef_construction, ef_search=ef, level_0_neighbors_count=64, neighbors_count=32)
     ix = ca.HNSWIndex(d, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), values_range, shortlist_size=64,
-                      device=local_rank, id_base=rank * n, seed=42 + rank)
+                      device=local_rank, id_base=rank * n, seed=42 + rank,
+                      visited_mode=ca.VISITED_EXACT if args.build_visited == "exact" else ca.VISITED_REF)
     ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
     t0 = time.time()
     ix.build(args.build_batch)
     build_s = time.time() - t0
-    if args.visited == "exact":
-        ix.set_visited_mode(ca.VISITED_EXACT)
+    ix.set_visited_mode(ca.VISITED_EXACT if args.visited == "exact" else ca.VISITED_REF)
 
     # ---- buffers + streams ------------------------------------------------------------------------
     S = args.inflight
@@ -310,7 +312,7 @@ def main():
         from oracle import oracle as O
         cores = os.cpu_count() or 1
         Xh = X.cpu().numpy()
-        op = O.HNSWParams(dim=d, storage=O.STORAGE_U8, num_layers=9, ef_construction=128, ef_search=ef, seed=42,
+        op = O.HNSWParams(dim=d, storage=O.STORAGE_U8, num_layers=9, ef_construction=args.ef_construction, ef_search=ef, seed=42,
                           range_lo=values_range[0], range_hi=values_range[1])
         op.visited_mode = O.VISITED_EXACT if args.visited == "exact" else O.VISITED_REF
         oix = O.OracleIndex(op).set_vectors(Xh)
@@ -357,7 +359,7 @@ def main():
             "ms_per_step": elapsed / steps_done * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload + ": " + desc, "standard_size": not bool(args.n), "vectors_per_gpu": n, "dim": d,
-                       "query_batch": Bc, "batches_per_launch": C, "launches_in_flight": S, "top_k": k, "ef_search": ef, "ef_policy": ("smallest ef with recall@10 >= %.2f" % args.recall_target) if args.ef == "auto" else "fixed", "M": 32, "M0": 64, "num_layers": 9,
+                       "query_batch": Bc, "batches_per_launch": C, "launches_in_flight": S, "top_k": k, "ef_search": ef, "ef_policy": ("smallest ef with recall@10 >= %.2f" % args.recall_target) if args.ef == "auto" else "fixed", "M": 32, "M0": 64, "num_layers": 9, "ef_construction": args.ef_construction, "build_visited": args.build_visited,
                        "storage": f"u8 (quantization {args.quantization}, values_range {values_range})", "visited": "reference PerformantFixedSet (ID parity mode)" if args.visited == "ref" else "exact visited set (recall mode)",
                        "parallelism": f"id-range shards x{world}" + (" + RCCL all-gather top-k merge" if world > 1 else ""),
                        "corpus": f"Gaussian mixture, {n_centers} centres, sigma 0.8/sqrt(d), L2-normalised, seed 42"},
