@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import cosdata_amd as ca  # noqa: E402
-from cosdata_amd.sharding import allgather_topk, merge_topk_device  # noqa: E402
+from cosdata_amd.sharding import allgather_packed, merge_topk_packed_device, packed_views, packed_words  # noqa: E402
 
 METRIC = "QPS at recall@10≥0.95, 1024-dim dense cosine, 1/2/4/8 MI355X"
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -163,14 +163,16 @@ def main():
     # ---- buffers + streams ------------------------------------------------------------------------
     S = args.inflight
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    o_ids = torch.zeros(S, B, k, dtype=torch.int32, device=dev)
-    o_sc = torch.zeros(S, B, k, dtype=torch.float32, device=dev)
-    o_cnt = torch.zeros(S, B, dtype=torch.int32, device=dev)
+    # the shard's result lives in ONE packed record [ids | scores | counts] so the sharded path exchanges it
+    # with a single all-gather per launch (sharding.py)
+    o_pack = torch.zeros(S, packed_words(B, k), dtype=torch.int32, device=dev)
+    o_views = [packed_views(o_pack[s], B, k) for s in range(S)]
+    o_ids = [v[0] for v in o_views]
+    o_sc = [v[1] for v in o_views]
+    o_cnt = [v[2] for v in o_views]
     o_st = torch.zeros(S, B, dtype=torch.int32, device=dev)
     if dist_on:
-        g_ids = torch.zeros(S, world, B, k, dtype=torch.int32, device=dev)
-        g_sc = torch.zeros(S, world, B, k, dtype=torch.float32, device=dev)
-        g_cnt = torch.zeros(S, world, B, dtype=torch.int32, device=dev)
+        g_pack = torch.zeros(S, world, packed_words(B, k), dtype=torch.int32, device=dev)
         m_ids = torch.zeros(S, B, k, dtype=torch.int32, device=dev)
         m_sc = torch.zeros(S, B, k, dtype=torch.float32, device=dev)
         m_cnt = torch.zeros(S, B, dtype=torch.int32, device=dev)
@@ -184,8 +186,8 @@ def main():
                                st.cuda_stream)
         if dist_on:  # per-shard top-k -> RCCL all-gather over xGMI -> S-way merge
             with torch.cuda.stream(st):
-                allgather_topk(o_ids[s], o_sc[s], o_cnt[s], g_ids[s], g_sc[s], g_cnt[s])
-            merge_topk_device(g_ids[s], g_sc[s], g_cnt[s], m_ids[s], m_sc[s], m_cnt[s], local_rank, st.cuda_stream)
+                allgather_packed(o_pack[s], g_pack[s])
+            merge_topk_packed_device(g_pack[s], B, k, m_ids[s], m_sc[s], m_cnt[s], local_rank, st.cuda_stream)
 
     def sync_all():
         torch.cuda.synchronize(dev)

@@ -25,13 +25,6 @@ namespace {
 
 constexpr u32 NONE = 0xFFFFFFFFu;
 
-__global__ void scatter_rows_kernel(u32 *__restrict__ dst, const u32 *__restrict__ rows, const u32 *__restrict__ packed, u32 n_rows, u32 M) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (u64)n_rows * M) return;
-    const u32 r = (u32)(i / M), j = (u32)(i % M);
-    dst[(u64)rows[r] * M + j] = packed[i];
-}
-
 inline uint64_t splitmix64(uint64_t &st) {
     uint64_t z = (st += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -45,12 +38,6 @@ inline int32_t total_key(float v) {
     memcpy(&b, &v, 4);
     b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
     return b;
-}
-// MetricResult::cmp (models/types.rs:401-411)
-inline int metric_cmp(u32 metric, float a, float b) {
-    int32_t ka = total_key(a), kb = total_key(b);
-    int c = (ka > kb) - (ka < kb);
-    return (metric == COS_METRIC_EUCLIDEAN || metric == COS_METRIC_HAMMING) ? -c : c;
 }
 inline float metric_min(u32 metric) { return metric == COS_METRIC_COSINE ? -1.0f : -INFINITY; }
 inline float metric_max(u32 metric) { return metric == COS_METRIC_COSINE ? 2.0f : INFINITY; }
@@ -141,15 +128,6 @@ template <typename T>
 hipError_t dmalloc(T *&p, size_t count) { return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)); }
 
 } // namespace
-
-namespace cosdev {
-hipError_t launch_scatter_rows(u32 *dst, const u32 *rows, const u32 *packed, u32 n_rows, u32 M, hipStream_t st) {
-    if (n_rows == 0) return hipSuccess;
-    const u64 total = (u64)n_rows * M;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3((u32)((total + 255) / 256)), dim3(256), 0, st, dst, rows, packed, n_rows, M);
-    return hipGetLastError();
-}
-} // namespace cosdev
 
 extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null index");

@@ -742,33 +742,3 @@ extern "C" int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uin
     for (size_t r = 0; r < n; r++) row_to_reference_layout(eng, dim, dev.data() + r * row_stride, (uint8_t *)codes + r * cb);
     return COS_OK;
 }
-
-// ------------------------------------------------------------------------------------------------
-// entry points whose kernels live in other translation units (weak stubs until they are linked in)
-// ------------------------------------------------------------------------------------------------
-#define COS_WEAK_STUB __attribute__((weak))
-extern "C" COS_WEAK_STUB int32_t cos_index_build(cos_index *, uint32_t) { return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_index_build: builder kernels not linked"); }
-extern "C" COS_WEAK_STUB int32_t cos_distance_batch(uint32_t, uint32_t, uint32_t, uint32_t, const void *, const float *, uint32_t, const void *,
-                                                    const float *, uint32_t, const uint32_t *, const uint32_t *, uint32_t, float *, int32_t *) {
-    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_distance_batch: kernels not linked");
-}
-extern "C" COS_WEAK_STUB int32_t cos_bruteforce_topk(cos_index *, const float *, uint32_t, uint32_t, uint32_t *, float *) {
-    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_bruteforce_topk: kernels not linked");
-}
-extern "C" COS_WEAK_STUB int32_t cos_bm25_create(int32_t, const uint32_t *, const uint64_t *, uint32_t, const uint32_t *, const float *, uint32_t,
-                                                 cos_bm25 **) {
-    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_bm25_create: kernels not linked");
-}
-extern "C" COS_WEAK_STUB int32_t cos_bm25_destroy(cos_bm25 *) { return COS_OK; }
-extern "C" COS_WEAK_STUB int32_t cos_bm25_search_batch(cos_bm25 *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t *, float *,
-                                                       uint32_t *) {
-    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_bm25_search_batch: kernels not linked");
-}
-extern "C" COS_WEAK_STUB int32_t cos_rrf_fuse_batch(const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, uint32_t,
-                                                    uint32_t, float, uint32_t, uint32_t *, float *, uint32_t *) {
-    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_rrf_fuse_batch: kernels not linked");
-}
-extern "C" COS_WEAK_STUB int32_t cos_merge_topk_device(const uint32_t *, const float *, const uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t *,
-                                                       float *, uint32_t *, int32_t, void *) {
-    return cos_fail(COS_ERR_UNIMPLEMENTED, "cos_merge_topk_device: kernels not linked");
-}

@@ -23,7 +23,6 @@ int32_t quantize_ref_layout(uint32_t storage, uint32_t res, uint32_t dim, const 
 int32_t distance_ref_layout(uint32_t metric, uint32_t storage, uint32_t res, uint32_t dim, const void *x_codes, const float *x_mags, uint32_t nx,
                             const void *y_codes, const float *y_mags, uint32_t ny, const uint32_t *pair_x, const uint32_t *pair_y, uint32_t n_pairs,
                             float *out, int32_t *status);
-hipError_t launch_scatter_rows(u32 *dst, const u32 *rows, const u32 *packed, u32 n_rows, u32 M, hipStream_t st);
 } // namespace cosdev
 
 using cosdev::u32;

@@ -12,10 +12,13 @@ using namespace cosdev;
 namespace {
 
 // One wave per query: gather S per-shard lists (already sorted, but any order is accepted), sort by
-// (total_cmp score desc, larger id first) and emit the best k.
+// (total_cmp score desc, larger id first) and emit the best k.  Shard s's rows start at s*stride_rows
+// elements in ids/scores and its counts at s*stride_counts in counts, so both the dense [S][B][k] layout
+// and a packed per-shard record [ids B*k | scores B*k | counts B] (ONE all-gather) are accepted.
 template <int R>
 __global__ __launch_bounds__(64) void merge_topk_kernel(const u32 *__restrict__ ids, const float *__restrict__ scores,
-                                                        const u32 *__restrict__ counts, u32 S, u32 B, u32 k, u32 *__restrict__ out_ids,
+                                                        const u32 *__restrict__ counts, u64 stride_rows, u64 stride_counts,
+                                                        u32 S, u32 B, u32 k, u32 *__restrict__ out_ids,
                                                         float *__restrict__ out_scores, u32 *__restrict__ out_counts) {
     const int lane = threadIdx.x;
     const u32 q = blockIdx.x;
@@ -28,13 +31,13 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const u32 *__restrict__ 
         key[r] = 0ull;
         if (e < S * k) {
             const u32 s = e / k, j = e % k;
-            if (j < counts[(u64)s * B + q]) {
-                const u64 off = ((u64)s * B + q) * k + j;
+            if (j < counts[(u64)s * stride_counts + q]) {
+                const u64 off = (u64)s * stride_rows + (u64)q * k + j;
                 key[r] = pack_key(simkey(scores[off]), ids[off]);
             }
         }
     }
-    for (u32 s = 0; s < S; s++) total += counts[(u64)s * B + q];
+    for (u32 s = 0; s < S; s++) total += counts[(u64)s * stride_counts + q];
     bitonic_sort_desc<R>(key, lane);
     const u32 n = total < k ? total : k;
 #pragma unroll
@@ -48,18 +51,16 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const u32 *__restrict__ 
     if (lane == 0) out_counts[q] = n;
 }
 
-} // namespace
-
-extern "C" int32_t cos_merge_topk_device(const uint32_t *d_ids, const float *d_scores, const uint32_t *d_counts, uint32_t S, uint32_t B,
-                                         uint32_t k, uint32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts, int32_t device,
-                                         void *stream) {
+int32_t merge_topk_launch(const uint32_t *d_ids, const float *d_scores, const uint32_t *d_counts, u64 stride_rows, u64 stride_counts,
+                          uint32_t S, uint32_t B, uint32_t k, uint32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts,
+                          int32_t device, void *stream) {
     if (!d_ids || !d_scores || !d_counts || !d_out_ids || !d_out_scores || !d_out_counts || S == 0 || B == 0 || k == 0)
         return cos_fail(COS_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(device));
     const u32 total = S * k;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B), block(64);
-#define LAUNCH(R) hipLaunchKernelGGL(merge_topk_kernel<R>, grid, block, 0, st, d_ids, d_scores, d_counts, S, B, k, d_out_ids, d_out_scores, d_out_counts)
+#define LAUNCH(R) hipLaunchKernelGGL(merge_topk_kernel<R>, grid, block, 0, st, d_ids, d_scores, d_counts, stride_rows, stride_counts, S, B, k, d_out_ids, d_out_scores, d_out_counts)
     if (total <= 64) LAUNCH(1);
     else if (total <= 128) LAUNCH(2);
     else if (total <= 256) LAUNCH(4);
@@ -69,6 +70,22 @@ extern "C" int32_t cos_merge_topk_device(const uint32_t *d_ids, const float *d_s
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
     return COS_OK;
+}
+
+} // namespace
+
+extern "C" int32_t cos_merge_topk_device(const uint32_t *d_ids, const float *d_scores, const uint32_t *d_counts, uint32_t S, uint32_t B,
+                                         uint32_t k, uint32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts, int32_t device,
+                                         void *stream) {
+    return merge_topk_launch(d_ids, d_scores, d_counts, (u64)B * k, B, S, B, k, d_out_ids, d_out_scores, d_out_counts, device, stream);
+}
+
+extern "C" int32_t cos_merge_topk_packed_device(const uint32_t *d_packed, uint32_t S, uint32_t B, uint32_t k, uint32_t *d_out_ids,
+                                                float *d_out_scores, uint32_t *d_out_counts, int32_t device, void *stream) {
+    if (!d_packed) return cos_fail(COS_ERR_INVALID, "bad argument");
+    const u64 rec = (u64)B * (2ull * k + 1ull);
+    return merge_topk_launch(d_packed, reinterpret_cast<const float *>(d_packed + (u64)B * k), d_packed + 2ull * B * k, rec, rec, S, B, k,
+                             d_out_ids, d_out_scores, d_out_counts, device, stream);
 }
 
 // ================================================================================================

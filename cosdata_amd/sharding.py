@@ -43,3 +43,36 @@ def merge_topk_device(g_ids, g_scores, g_counts, out_ids, out_scores, out_counts
     S, B, k = g_ids.shape
     _lib.check(_lib.lib().cos_merge_topk_device(g_ids.data_ptr(), g_scores.data_ptr(), g_counts.data_ptr(), S, B, k,
                                                 out_ids.data_ptr(), out_scores.data_ptr(), out_counts.data_ptr(), device_index, stream))
+
+
+# ---- packed exchange: one collective per batch -----------------------------------------------------------------
+def packed_words(B: int, k: int) -> int:
+    """4-byte words of one shard's packed result record [ids B*k | scores B*k | counts B]."""
+    return B * (2 * k + 1)
+
+
+def packed_views(buf: torch.Tensor, B: int, k: int):
+    """Views (ids u32-as-int32 [B][k], scores f32 [B][k], counts int32 [B]) into one packed int32 record, so the
+    search kernels write straight into the buffer that is exchanged."""
+    assert buf.dtype == torch.int32 and buf.numel() == packed_words(B, k) and buf.is_contiguous()
+    ids = buf[: B * k].view(B, k)
+    scores = buf[B * k: 2 * B * k].view(torch.float32).view(B, k)
+    counts = buf[2 * B * k:]
+    return ids, scores, counts
+
+
+def allgather_packed(buf: torch.Tensor, out: torch.Tensor | None = None):
+    """ONE all-gather of the packed record: [words] -> [S][words].  Three small collectives per batch are
+    latency-bound (tens of microseconds each on xGMI); one keeps the exchange step off the critical path."""
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty(world * buf.numel(), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(out.view(-1), buf)
+    return out.view(world, buf.numel())
+
+
+def merge_topk_packed_device(g_packed, B: int, k: int, out_ids, out_scores, out_counts, device_index: int, stream: int = 0):
+    from . import _lib
+    S = g_packed.shape[0]
+    _lib.check(_lib.lib().cos_merge_topk_packed_device(g_packed.data_ptr(), S, B, k, out_ids.data_ptr(), out_scores.data_ptr(),
+                                                       out_counts.data_ptr(), device_index, stream))

@@ -214,6 +214,13 @@ int32_t cos_merge_topk_device(const uint32_t *d_ids, const float *d_scores, cons
                               uint32_t B, uint32_t k, uint32_t *d_out_ids, float *d_out_scores,
                               uint32_t *d_out_counts, int32_t device, void *stream);
 
+/* Same merge over S packed per-shard records, each B*(2k+1) 4-byte words laid out
+ * [ids B*k | scores B*k (f32 bits) | counts B] — the layout that lets the caller exchange a shard's
+ * whole result with ONE all-gather per batch instead of three. */
+int32_t cos_merge_topk_packed_device(const uint32_t *d_packed, uint32_t S, uint32_t B, uint32_t k,
+                                     uint32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts,
+                                     int32_t device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,7 +53,7 @@ def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from cosdata_amd.sharding import allgather_topk, shard_range
+    from cosdata_amd.sharding import allgather_packed, allgather_topk, packed_views, packed_words, shard_range
     rng = np.random.default_rng(123)
     X = rng.uniform(-1, 1, (1200, 40)).astype(np.float32)
     Q = (X[rng.integers(0, 1200, 16)] + 0.02 * rng.standard_normal((16, 40))).astype(np.float32)
@@ -62,6 +62,15 @@ def _worker(rank, world, port, tmp):
     gids, sc, cnt = _shard_search(X, Q, lo, hi, k)
     g_ids, g_sc, g_cnt = allgather_topk(torch.from_numpy(gids.view(np.int32)), torch.from_numpy(sc), torch.from_numpy(cnt.view(np.int32)))
     assert g_ids.shape == (world, 16, k)
+    # packed exchange (what bench.py uses): ONE collective must carry exactly the same data
+    rec = torch.zeros(packed_words(16, k), dtype=torch.int32)
+    p_ids, p_sc, p_cnt = packed_views(rec, 16, k)
+    p_ids.copy_(torch.from_numpy(gids.view(np.int32))); p_sc.copy_(torch.from_numpy(sc)); p_cnt.copy_(torch.from_numpy(cnt.view(np.int32)))
+    g_rec = allgather_packed(rec)
+    assert g_rec.shape == (world, packed_words(16, k))
+    for s_ in range(world):
+        u_ids, u_sc, u_cnt = packed_views(g_rec[s_].contiguous(), 16, k)
+        assert torch.equal(u_ids, g_ids[s_]) and torch.equal(u_sc.view(torch.int32), g_sc[s_].view(torch.int32)) and torch.equal(u_cnt, g_cnt[s_])
     np.save(os.path.join(tmp, f"gathered_{rank}.npy"), g_ids.numpy())
     m_ids, m_sc, m_cnt = _merge_numpy(g_ids.numpy().view(np.uint32), g_sc.numpy(), g_cnt.numpy().view(np.uint32), k)
     np.savez(os.path.join(tmp, f"merged_{rank}.npz"), ids=m_ids, sc=m_sc, cnt=m_cnt)
@@ -107,7 +116,7 @@ def test_shard_range_partition():
 @pytest.mark.gpu
 def test_merge_kernel_matches_rule():
     import cosdata_amd  # noqa: F401
-    from cosdata_amd.sharding import merge_topk_device
+    from cosdata_amd.sharding import merge_topk_device, merge_topk_packed_device
     rng = np.random.default_rng(5)
     for S, B, k in [(2, 33, 10), (8, 256, 10), (4, 7, 50), (8, 5, 100)]:
         sc = rng.choice(np.linspace(0.1, 0.9, 23).astype(np.float32), (S, B, k))  # many ties
@@ -121,9 +130,15 @@ def test_merge_kernel_matches_rule():
         o_c = torch.zeros(B, dtype=torch.int32, device=dev)
         merge_topk_device(t(ids, np.int32), t(sc, np.float32), t(cnt, np.int32), o_i, o_s, o_c, 0, 0)
         torch.cuda.synchronize()
-        gc = o_c.cpu().numpy().view(np.uint32)
-        assert np.array_equal(gc, exp[2])
-        for b in range(B):
-            c = int(gc[b])
-            assert np.array_equal(o_i.cpu().numpy().view(np.uint32)[b, :c], exp[0][b, :c])
-            assert np.array_equal(o_s.cpu().numpy()[b, :c], exp[1][b, :c])
+        # packed per-shard records [ids | scores | counts] through cos_merge_topk_packed_device
+        packed = np.concatenate([ids.reshape(S, -1).view(np.int32), sc.reshape(S, -1).view(np.int32), cnt.view(np.int32)], axis=1)
+        p_i = torch.zeros_like(o_i); p_s = torch.zeros_like(o_s); p_c = torch.zeros_like(o_c)
+        merge_topk_packed_device(torch.from_numpy(np.ascontiguousarray(packed)).to(dev), B, k, p_i, p_s, p_c, 0, 0)
+        torch.cuda.synchronize()
+        for (r_i, r_s, r_c) in [(o_i, o_s, o_c), (p_i, p_s, p_c)]:
+            gc = r_c.cpu().numpy().view(np.uint32)
+            assert np.array_equal(gc, exp[2])
+            for b in range(B):
+                c = int(gc[b])
+                assert np.array_equal(r_i.cpu().numpy().view(np.uint32)[b, :c], exp[0][b, :c])
+                assert np.array_equal(r_s.cpu().numpy()[b, :c], exp[1][b, :c])
