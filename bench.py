@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--build-batch", type=int, default=4096)
     ap.add_argument("--recall-queries", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-probe", action="store_true", help="skip the empirical HBM ceiling probes (cos_hbm_probe)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -355,6 +356,22 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
+    # empirical HBM ceilings on THIS part: streaming read and the walk's own access pattern — random
+    # gathers of d-byte rows over a buffer the size of the code array — measured after the timed region
+    empirical = None
+    if rank == 0 and not args.no_hbm_probe:
+        import ctypes as C_
+        g = C_.c_double(0.0)
+        empirical = {}
+        for name, kind, nbytes, rb in (("stream_read", 0, 4 << 30, 0), ("stream_copy", 1, 2 << 30, 0),
+                                       ("row_gather", 2, max(n * d, 1 << 20), d)):
+            ca._lib.check(lib.cos_hbm_probe(local_rank, kind, nbytes, rb, 3, C_.byref(g)))
+            empirical[name + "_GBps"] = g.value
+        empirical["row_gather_row_bytes"] = d
+        empirical["row_gather_buffer_bytes"] = n * d
+        empirical["frac_of_row_gather"] = achieved / empirical["row_gather_GBps"]
+        empirical["frac_of_stream_read"] = achieved / empirical["stream_read_GBps"]
+
     if rank == 0:
         out = {
             "metric": METRIC, "value": qps, "unit": "queries/s", "n_gpus": world, "steps": steps_done, "warmup": n_warm * C,
@@ -368,7 +385,7 @@ def main():
             "recall_at_10": recall, "recall_queries": nrq, "failed_queries": status_bad,
             "single_batch_qps": serial_qps, "ef_selection": ef_table, "ef_sweep": sweep, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64>" % (1 if ef <= 64 else (4 if ef <= 256 else 8)),
+                         "traffic": traffic, "empirical": empirical, "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64>" % (1 if ef <= 64 else (4 if ef <= 256 else 8)),
                          "per_launch": {"algorithmic_bytes": avg_bytes, "avg_ms": avg_ms, "in_flight": overlap,
                                         "evals": float(np.mean([p[2] for p in per])), "expansions": float(np.mean([p[3] for p in per])),
                                         "finalize_ms": float(np.mean([p[4] for p in per])), "prep_ms": float(np.mean([p[5] for p in per])),

@@ -101,6 +101,12 @@ int32_t cos_index_create(const cos_params *params, cos_index **out);
 int32_t cos_index_destroy(cos_index *ix);
 const char *cos_last_error_string(void);
 int32_t cos_device_count(int32_t *out);
+/* Diagnostic (not a reference interface): empirical HBM ceilings for the roofline report, SURVEY.md 8(d).
+ * kind 0 = streaming read, 1 = streaming copy (read+write bytes), 2 = random gather of row_bytes-sized rows
+ * (the walk's access pattern; row_bytes multiple of 16, <= 1024).  Allocates buffer_bytes (x2 for copy),
+ * times `iters` launches with HIP events, returns GB/s (1e9 B/s). */
+int32_t cos_hbm_probe(int32_t device, uint32_t kind, uint64_t buffer_bytes, uint32_t row_bytes, uint32_t iters,
+                      double *out_gbps);
 
 /* ---- data upload (host side of the snapshot; the Rust host walks its graph once) ------------ */
 /* Collection::index_embeddings' raw f32 values (collection.rs:368, get_raw_emb_by_internal_id) for
