@@ -101,8 +101,8 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
     auto pow2 = [](u32 v) { return v && !(v & (v - 1)); };
     if (!pow2(p->neighbors_count) || !pow2(p->level0_neighbors_count) || p->neighbors_count > 256 || p->level0_neighbors_count > 256)
         return cos_fail(COS_ERR_INVALID, "neighbors_count / level_0_neighbors_count must be powers of two <= 256 (PerformantFixedSet, fixedset.rs)");
-    if (p->num_layers + 1 > (u32)MAX_LEVELS || (p->num_layers + 1) * KEEP_SEARCH > 1024)
-        return cos_fail(COS_ERR_UNIMPLEMENTED, "num_layers > 9 not supported on the device");
+    if (p->num_layers + 1 > (u32)MAX_LEVELS || (p->num_layers + 1) * KEEP_SEARCH > 2048)
+        return cos_fail(COS_ERR_UNIMPLEMENTED, "num_layers > 15 not supported on the device");
     if (std::min(p->neighbors_count, p->shortlist_size) > 64 || std::min(p->level0_neighbors_count, p->shortlist_size) > 64)
         return cos_fail(COS_ERR_UNIMPLEMENTED, "more than 64 scanned neighbour slots per node not supported on the device");
     if (p->ef_search > 512 || p->ef_construction > 512) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
