@@ -211,7 +211,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     (void)d_drows;
     float *d_out_sims = nullptr;
     int32_t *d_status = nullptr;
-    u32 *d_vis = nullptr;
+    VisTab vtab; // EXACT build mode: visited hash sets of the batch walks
     size_t pack_cap = 0;
     HIP_TRY(dmalloc(d_rows, Bmax));
     HIP_TRY(dmalloc(d_out_ids, (size_t)Bmax * L1 * KEEP));
@@ -230,17 +230,13 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     HIP_TRY(hipHostMalloc((void **)&h_counts, (size_t)Bmax * L1 * 4));
     HIP_TRY(hipHostMalloc((void **)&h_status, (size_t)Bmax * 4));
     auto cleanup = [&]() {
-        void *ptrs[] = {d_rows, d_out_ids, d_out_nodes, d_out_sims, d_out_counts, d_status, d_drows, d_pack, d_vis};
+        void *ptrs[] = {d_rows, d_out_ids, d_out_nodes, d_out_sims, d_out_counts, d_status, d_drows, d_pack, vtab.bits, vtab.log};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         void *hp[] = {h_rows, h_nodes, h_sims, h_counts, h_status, h_pack};
         for (void *p : hp) if (p) (void)hipHostFree(p);
     };
 
     IndexDev dev = cos_make_index_dev(ix);
-    if (dev.visited_mode == COS_VISITED_EXACT) {
-        hipError_t e = dmalloc(d_vis, (size_t)Bmax * dev.vis_words_per_query);
-        if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
-    }
 
     u32 inserted = 0, batch_no = 0;
     const bool prof = getenv("COS_BUILD_PROFILE") != nullptr;
@@ -252,14 +248,16 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
         const u32 bs = std::min({Bmax, std::max(1u, inserted / 4u), n - inserted});
         for (u32 b = 0; b < bs; b++) h_rows[b] = inserted + b;
         hipError_t e = hipMemcpyAsync(d_rows, h_rows, (size_t)bs * 4, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess && d_vis) e = hipMemsetAsync(d_vis, 0, (size_t)bs * dev.vis_words_per_query * 4, st);
         WalkArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.qcodes = ix->d_codes;
         wa.qmags = ix->d_mags;
         wa.q_rows = d_rows;
         wa.self_ids = d_rows; // the new node's id is pre-inserted in the visited filter (vector_store.rs:807)
-        wa.vis_slab = d_vis;
+        if (dev.visited_mode == COS_VISITED_EXACT) {
+            const int32_t vrc = vis_tab_prepare(vtab, ix, Bmax, ix->p.ef_construction, st, wa);
+            if (vrc) { cleanup(); return vrc; }
+        }
         wa.B = bs;
         wa.ef = ix->p.ef_construction;
         wa.keep = KEEP;

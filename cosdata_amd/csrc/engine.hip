@@ -74,7 +74,6 @@ IndexDev cos_make_index_dev(const cos_index *ix) {
     d.nchunks = ix->nchunks;
     d.G = ix->G;
     d.id_base = ix->p.id_base;
-    u32 off = 0;
     for (u32 l = 0; l <= ix->p.num_layers; l++) {
         const LevelHost &h = ix->lv[l];
         d.lv[l].adj_vec = h.d_adj_vec;
@@ -84,10 +83,7 @@ IndexDev cos_make_index_dev(const cos_index *ix) {
         d.lv[l].n = h.n;
         d.lv[l].M = h.M;
         d.lv[l].root_idx = h.n ? h.n - 1 : 0;
-        d.lv[l].vis_word_off = off;
-        off += (h.n + 31) / 32;
     }
-    d.vis_words_per_query = off;
     return d;
 }
 
@@ -162,7 +158,7 @@ static void free_level(LevelHost &l) {
 }
 static void free_ws(Workspace *w) {
     void *ptrs[] = {w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
-                    w->rerank_rows, w->vis_slab, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status};
+                    w->rerank_rows, w->vis.bits, w->vis.log, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : w->ev) if (e) (void)hipEventDestroy(e);
     delete w;
@@ -408,6 +404,45 @@ static hipError_t regrow(T *&p, size_t count) {
     return hipMalloc((void **)&p, count * sizeof(T));
 }
 
+int32_t vis_tab_prepare(VisTab &vt, const cos_index *ix, u32 B, u32 ef, hipStream_t st, WalkArgs &wa) {
+    const u32 M = std::max(ix->p.level0_neighbors_count, ix->p.neighbors_count);
+    // a level inserts its entry node plus at most M neighbours per pop, and pops at most ef times
+    const u64 log_cap = (u64)ef * M + 2;
+    u32 max_nodes = 0;
+    for (const LevelHost &l : ix->lv) max_nodes = std::max(max_nodes, l.n);
+    const u32 words = (max_nodes + 31) / 32 + 1;
+    if (log_cap > 0xFFFFFFFFull) return cos_fail(COS_ERR_INVALID, "ef too large");
+    const size_t need_bits = (size_t)B * words, need_log = (size_t)B * log_cap;
+    if (need_bits > vt.bits_cap || need_log > vt.log_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (need_bits > vt.bits_cap) {
+            if (vt.bits) HIP_TRY(hipFree(vt.bits));
+            vt.bits = nullptr;
+            vt.bits_cap = 0;
+            HIP_TRY(hipMalloc((void **)&vt.bits, need_bits * 4));
+            vt.bits_cap = need_bits;
+        }
+        if (need_log > vt.log_cap) {
+            if (vt.log) HIP_TRY(hipFree(vt.log));
+            vt.log = nullptr;
+            vt.log_cap = 0;
+            HIP_TRY(hipMalloc((void **)&vt.log, need_log * 4));
+            vt.log_cap = need_log;
+        }
+    }
+    // the per-query stride may change (other B / graph), which is harmless: the whole allocation is all-zero between launches
+    if (!vt.zeroed || vt.zeroed_cap != vt.bits_cap) {
+        HIP_TRY(hipMemsetAsync(vt.bits, 0, vt.bits_cap * 4, st));
+        vt.zeroed = true;
+        vt.zeroed_cap = vt.bits_cap;
+    }
+    wa.vis_bits = vt.bits;
+    wa.vis_log = vt.log;
+    wa.vis_words_per_query = words;
+    wa.vis_log_cap = (u32)log_cap;
+    return COS_OK;
+}
+
 static int32_t get_workspace(cos_index *ix, void *stream_key, u32 B, u32 top_k, bool host_api, Workspace **out) {
     std::lock_guard<std::mutex> g(ix->mu);
     Workspace *&w = ix->ws[stream_key];
@@ -430,7 +465,6 @@ static int32_t get_workspace(cos_index *ix, void *stream_key, u32 B, u32 top_k, 
         HIP_TRY(regrow(w->d_out_status, cap));
         w->capB = cap;
         w->cap_topk = 0;
-        w->vis_slab_words = 0;
     }
     if (host_api && (size_t)top_k * w->capB > (size_t)w->cap_topk * w->capB) {
         HIP_TRY(regrow(w->d_out_ids, (size_t)w->capB * top_k));
@@ -448,24 +482,18 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     IndexDev dev = cos_make_index_dev(ix);
     bool timed;
     { std::lock_guard<std::mutex> g(ix->mu); timed = ix->timing; }
+    WalkArgs wa;
+    memset(&wa, 0, sizeof(wa));
     if (dev.visited_mode == COS_VISITED_EXACT) {
-        size_t need = (size_t)B * dev.vis_words_per_query;
-        if (need > w->vis_slab_words) {
-            HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(regrow(w->vis_slab, need));
-            w->vis_slab_words = need;
-        }
-        HIP_TRY(hipMemsetAsync(w->vis_slab, 0, need * 4, st));
+        int32_t rc = vis_tab_prepare(w->vis, ix, B, ix->p.ef_search, st, wa);
+        if (rc) return rc;
     }
     if (timed) HIP_TRY(hipEventRecord(w->ev[0], st));
     HIP_TRY(launch_quantize_rows(ix->eng, d_queries, ix->p.dim, B, ix->p.dim, ix->p.range_lo, ix->p.range_hi, w->q_codes, ix->row_stride,
                                  w->q_mags, w->q_raw_mags, st));
     if (timed) HIP_TRY(hipEventRecord(w->ev[1], st));
-    WalkArgs wa;
-    memset(&wa, 0, sizeof(wa));
     wa.qcodes = w->q_codes;
     wa.qmags = w->q_mags;
-    wa.vis_slab = w->vis_slab;
     wa.B = B;
     wa.ef = ix->p.ef_search;
     wa.keep = KEEP_SEARCH;

@@ -46,6 +46,17 @@ struct LevelHost {
     bool host_valid = false; // node_ids/nbr_ids mirror the device arrays
 };
 
+// EXACT-mode visited filters of one stream (WalkArgs::vis_bits / vis_log).  The bitset is zeroed once, when it is
+// (re)allocated; afterwards every walk level undoes its own bits.
+struct VisTab {
+    u32 *bits = nullptr, *log = nullptr;
+    size_t bits_cap = 0, log_cap = 0; // allocated u32 words
+    bool zeroed = false;
+    size_t zeroed_cap = 0;
+};
+// sizes/allocates the filter for B queries at beam width ef and fills wa.vis_*
+int32_t vis_tab_prepare(VisTab &vt, const cos_index *ix, u32 B, u32 ef, hipStream_t st, cosdev::WalkArgs &wa);
+
 struct Workspace {
     u32 capB = 0, cap_topk = 0;
     uint8_t *q_codes = nullptr;
@@ -55,8 +66,7 @@ struct Workspace {
     int32_t *walk_status = nullptr;
     u64 *stats = nullptr;       // [B][4]
     u64 *rerank_rows = nullptr; // [B]
-    u32 *vis_slab = nullptr;
-    size_t vis_slab_words = 0;
+    VisTab vis; // EXACT mode visited filters
     // host-API staging (device)
     float *d_queries = nullptr;
     u32 *d_out_ids = nullptr, *d_out_counts = nullptr;

@@ -14,7 +14,6 @@ struct LevelDev {
     u32 n;
     u32 M;
     u32 root_idx;
-    u32 vis_word_off; // EXACT mode: offset (in u32 words) of this level's bitset inside a query's slab
 };
 
 struct IndexDev {
@@ -34,7 +33,6 @@ struct IndexDev {
     u32 nchunks;   // 16-byte chunks per code row (integer engines)
     u32 G;         // lanes per row (power of two, integer engines)
     u32 id_base;
-    u32 vis_words_per_query; // EXACT mode slab size (u32 words)
     LevelDev lv[MAX_LEVELS];
 };
 
@@ -43,7 +41,13 @@ struct WalkArgs {
     const float *qmags;
     const u32 *q_rows;   // optional: query b reads row q_rows[b] of qcodes/qmags (builder: corpus rows)
     const u32 *self_ids; // optional: id pre-inserted in the visited filter (default COS_QUERY_ID)
-    u32 *vis_slab;       // EXACT mode: [B][vis_words_per_query], zeroed before launch
+    // EXACT mode: per-query bitset [B][vis_words_per_query] (one bit per node of the level being walked) that is all-zero
+    // between levels and launches, plus the undo log [B][vis_log_cap] of the words a level set: a level clears exactly
+    // what it touched, so nothing is memset per launch (the slab would be B x N/8 bytes).
+    u32 *vis_bits;
+    u32 *vis_log;
+    u32 vis_words_per_query;
+    u32 vis_log_cap;     // >= ef * max(M) + 2
     u32 B;
     u32 ef;
     u32 keep;            // 100 (search) / 64 (indexing)

@@ -103,7 +103,7 @@ struct WalkSmem {
     float *qf;    // F32 engine: the query vector
 };
 
-template <int ENG, int CH, int R, bool G64>
+template <int ENG, int CH, int R, bool G64, bool EXACT>
 __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkArgs wa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x;
@@ -132,8 +132,11 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
     const u32 N = ix.n;
     const u32 L = ix.num_layers;
     const u32 metric = ix.metric;
-    const bool exact = ix.visited_mode != 0;
-    u32 *vis_slab = exact ? wa.vis_slab + (u64)qi * ix.vis_words_per_query : nullptr;
+    constexpr bool exact = EXACT; // compile-time: the REF kernels carry none of the hash-set code
+    // EXACT mode: this query's bitset (one bit per node of the level being walked; all-zero between levels) and the undo log
+    // of the words it set, so the filter is cleared by touching only what the level touched (no per-launch memset)
+    u32 *vis = exact ? wa.vis_bits + (u64)qi * wa.vis_words_per_query : sm.vis;
+    u32 *vlog = exact ? wa.vis_log + (u64)qi * wa.vis_log_cap : nullptr;
 
     // ---- engine set-up -------------------------------------------------------------------------
     constexpr bool FLOAT_ENG = ENG == ENG_F32 || ENG == ENG_F16; // ordered f32 chains instead of integer chunk dots
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
         const u32 M = lv.M;
         const u32 slots = M < ix.shortlist ? M : ix.shortlist;
         const u32 bitmask = 64u * M - 1u;
-        u32 *vis = exact ? (vis_slab + lv.vis_word_off) : sm.vis;
         const u32 out_slot = L - (u32)level;
+        u32 nlog = 0; // EXACT mode: entries of the undo log (wave-uniform)
 
         // fresh visited filter, pre-seeded with the query / new-node id (vector_store.rs:266-271, :807)
         if (!exact) {
@@ -228,10 +231,14 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
             const u32 eid = erow == N ? COS_ROOT_ID : erow;
             if (lane == 0) {
                 if (!exact) { u32 b = eid & bitmask; sm.vis[b >> 5] |= 1u << (b & 31); }
-                else atomicOr(&vis[entry >> 5], 1u << (entry & 31));
+                else {
+                    atomicOr(&vis[entry >> 5], 1u << (entry & 31));
+                    vlog[0] = entry >> 5;
+                }
             }
             pool.insert_at(pack_key(metric_key(metric, s0), entry), 0, lane);
             npool = 1;
+            if (exact) nlog = 1;
         }
 
         bool failed = false;
@@ -299,8 +306,13 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                     bool pre = false;
                     if (valid) pre = (__hip_atomic_load(&vis[nb_node >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (nb_node & 31)) & 1u;
                     win = valid && !pre;
-                    if (!__any(win)) continue;
-                    if (win) atomicOr(&vis[nb_node >> 5], 1u << (nb_node & 31));
+                    const u64 em = __ballot(win);
+                    if (!em) continue;
+                    if (win) {
+                        atomicOr(&vis[nb_node >> 5], 1u << (nb_node & 31));                    // fire and forget
+                        vlog[nlog + (u32)__popcll(em & ((1ull << lane) - 1ull))] = nb_node >> 5;   // undo log, in slot order
+                    }
+                    nlog += (u32)__popcll(em);
                 }
 
                 const u64 wmask = __ballot(win);
@@ -456,6 +468,19 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                 if (failed || !window_ok) break;
             }
             if (failed) break;
+        }
+        if (exact) {
+            // undo: zero exactly the words this level set (whole words belong to this query), leaving the bitset all-zero
+            // for the next level / launch.  One wave owns the filter and its vector-memory operations reach L2 in issue
+            // order, so waiting for the outstanding ones (no cache write-back fence) orders set -> clear -> next test.
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __builtin_amdgcn_s_waitcnt(0);
+            for (u32 i = lane; i < nlog; i += 64) {
+                const u32 w = __hip_atomic_load(&vlog[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&vis[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __builtin_amdgcn_s_waitcnt(0);
         }
         if (failed) { status = COS_ERR_CALCULATION; break; }
 
@@ -698,10 +723,17 @@ template <int ENG, int CH, bool G64>
 static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     const size_t smem = walk_smem_bytes(ix, wa.ef, ENG);
     dim3 grid(wa.B), block(64);
-    if (wa.ef <= 64) hipLaunchKernelGGL((walk_kernel<ENG, CH, 1, G64>), grid, block, smem, st, ix, wa);
-    else if (wa.ef <= 256) hipLaunchKernelGGL((walk_kernel<ENG, CH, 4, G64>), grid, block, smem, st, ix, wa);
-    else if (wa.ef <= 512) hipLaunchKernelGGL((walk_kernel<ENG, CH, 8, G64>), grid, block, smem, st, ix, wa);
+    const bool exact = ix.visited_mode != 0;
+#define WALK(R_)                                                                                                          \
+    do {                                                                                                                  \
+        if (exact) hipLaunchKernelGGL((walk_kernel<ENG, CH, R_, G64, true>), grid, block, smem, st, ix, wa);              \
+        else hipLaunchKernelGGL((walk_kernel<ENG, CH, R_, G64, false>), grid, block, smem, st, ix, wa);                   \
+    } while (0)
+    if (wa.ef <= 64) WALK(1);
+    else if (wa.ef <= 256) WALK(4);
+    else if (wa.ef <= 512) WALK(8);
     else return hipErrorInvalidValue;
+#undef WALK
     return hipGetLastError();
 }
 
