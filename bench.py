@@ -296,7 +296,12 @@ def main():
 
     # ---- optional ef_search sweep (same index, same launch shape): QPS and recall per ef ----------------------
     sweep = []
-    for ef2 in [int(v) for v in args.ef_sweep.split(",") if v]:
+    main_mode = ca.VISITED_EXACT if args.visited == "exact" else ca.VISITED_REF
+    for tok in [v for v in args.ef_sweep.split(",") if v]:   # "256" or "ref:256" / "exact:64" (other visited filter, same graph)
+        mode_name, _, efs = tok.rpartition(":")
+        ef2 = int(efs)
+        mode2 = {"": main_mode, "ref": ca.VISITED_REF, "exact": ca.VISITED_EXACT}[mode_name]
+        ix.set_visited_mode(mode2)
         rec2 = measure_recall(ef2)
         for i in range(n_warm):
             step(i)
@@ -305,8 +310,10 @@ def main():
         for i in range(n_launch):
             step(i)
         sync_all()
-        sweep.append({"ef_search": ef2, "qps": n_launch * C * Bc / (time.perf_counter() - t2), "recall_at_10": rec2})
+        sweep.append({"ef_search": ef2, "visited": "exact" if mode2 == ca.VISITED_EXACT else "ref",
+                      "qps": n_launch * C * Bc / (time.perf_counter() - t2), "recall_at_10": rec2})
     ix.set_ef_search(ef)
+    ix.set_visited_mode(main_mode)
 
     # ---- CPU baseline: the oracle (C restatement of the Rust path) on this box's host cores ----------
     cpu = None

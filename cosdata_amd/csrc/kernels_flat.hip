@@ -24,18 +24,25 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BK + 1; // +1 float pad: conflict-free ds_read_b32 column reads
+constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4; // 36-float rows: 16 B aligned, conflict-free ds_read/ds_write_b128
 constexpr int SEL = 64;                                  // survivors per query
+constexpr size_t GEMM_SMEM = 2ull * (BM + BN) * LDT * sizeof(float); // double-buffered Q and X panels: 73 728 B -> 2 workgroups per CU
 
+// S = Q . X^T on v_mfma_f32_32x32x2_f32.  128x128 tile per 4-wave workgroup (each wave 64x64 = 2x2 MFMA blocks), K panels
+// of 32 double-buffered in LDS: panel p+1 travels HBM -> registers while panel p is multiplied, then registers -> LDS, one
+// barrier per panel.  A lane's MFMA operand for k-step s of an 8-wide k block is element s of ONE ds_read_b128
+// (k = 4*(lane>>5) + s): the k permutation is the same for both operands, so the sum is unchanged.
+template <bool VEC>
 __global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q, u64 q_stride, const float *__restrict__ qmags, u32 B,
                                                      const float *__restrict__ X, u64 x_stride, const float *__restrict__ xmags, u32 n0,
                                                      u32 n_chunk, u32 dim, float *__restrict__ scores /*[B][n_chunk_padded]*/, u64 s_stride) {
-    __shared__ float As[BM * LDT];
-    __shared__ float Bs[BN * LDT];
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); remap so that each XCD
-    // walks a contiguous strip of candidate tiles and re-uses the query panel in its own L2.
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); remap so that each XCD walks a
+    // contiguous strip of the tile sequence, and order the sequence query-tile-fastest: the tiles_m workgroups that share
+    // one 128-row X tile run back to back on one XCD, so X streams from HBM once and is re-used from that XCD's L2
+    // (the query panel, a few MB, stays in L2 / Infinity Cache).
     const u32 tiles_n = gridDim.x, tiles_m = gridDim.y;
     u32 wg = blockIdx.y * tiles_n + blockIdx.x;
     const u32 total = tiles_n * tiles_m;
@@ -43,7 +50,7 @@ __global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q
         const u32 q = total / 8, r = total % 8, xcd = wg % 8, idx = wg / 8;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; // bijective for any total
     }
-    const u32 tn = wg % tiles_n, tm = wg / tiles_n;
+    const u32 tm = wg % tiles_m, tn = wg / tiles_m;
     const u32 row0 = tm * BM, col0 = tn * BN;
 
     f32x16 acc[2][2];
@@ -54,29 +61,64 @@ __global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    const int lr = tid >> 1, lc = (tid & 1) * 8; // staging: thread -> (row, 8 consecutive k)
-    for (u32 k0 = 0; k0 < dim; k0 += BK) {
-        {
-            const u32 qr = row0 + lr;
-            const float *src = Q + (u64)qr * q_stride + k0 + lc;
+    // staging: 8 consecutive lanes fetch one row's 128 B of the panel (float4 each), 32 rows per pass, 4 passes per operand
+    const int sr = tid >> 3, sc = (tid & 7) * 4;
+    float4 ra[4], rb[4];
+    auto fetch = [&](u32 k0) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) As[lr * LDT + lc + e] = (qr < B && k0 + lc + e < dim) ? src[e] : 0.0f;
-            const u32 xr = col0 + lr;
-            const float *srx = X + (u64)(n0 + xr) * x_stride + k0 + lc;
+        for (int i = 0; i < 4; i++) {
+            const u32 qr = row0 + i * 32 + sr, xr = col0 + i * 32 + sr, k = k0 + sc;
+            const float *pa = Q + (u64)qr * q_stride + k;
+            const float *pb = X + (u64)(n0 + xr) * x_stride + k;
+            if constexpr (VEC) { // dim % 4 == 0 and 16 B aligned rows
+                ra[i] = (qr < B && k < dim) ? *(const float4 *)pa : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = (xr < n_chunk && k < dim) ? *(const float4 *)pb : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                float a[4], b[4];
 #pragma unroll
-            for (int e = 0; e < 8; e++) Bs[lr * LDT + lc + e] = (xr < n_chunk && k0 + lc + e < dim) ? srx[e] : 0.0f;
+                for (int e = 0; e < 4; e++) {
+                    a[e] = (qr < B && k + e < dim) ? pa[e] : 0.f;
+                    b[e] = (xr < n_chunk && k + e < dim) ? pb[e] : 0.f;
+                }
+                ra[i] = make_float4(a[0], a[1], a[2], a[3]);
+                rb[i] = make_float4(b[0], b[1], b[2], b[3]);
+            }
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
+        float *As = gsm + (size_t)buf * (BM + BN) * LDT, *Bs = As + BM * LDT;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int kq = kk + (lane >> 5);
-            const float a0 = As[(wr * 64 + (lane & 31)) * LDT + kq], a1 = As[(wr * 64 + 32 + (lane & 31)) * LDT + kq];
-            const float b0 = Bs[(wc * 64 + (lane & 31)) * LDT + kq], b1 = Bs[(wc * 64 + 32 + (lane & 31)) * LDT + kq];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int i = 0; i < 4; i++) {
+            *(float4 *)(As + (i * 32 + sr) * LDT + sc) = ra[i];
+            *(float4 *)(Bs + (i * 32 + sr) * LDT + sc) = rb[i];
         }
+    };
+
+    const u32 npanels = (dim + BK - 1) / BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int orow = lane & 31, okq = (lane >> 5) * 4;
+    for (u32 p = 0; p < npanels; p++) {
+        if (p + 1 < npanels) fetch((p + 1) * BK);
+        const float *As = gsm + (size_t)(p & 1) * (BM + BN) * LDT, *Bs = As + BM * LDT;
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 8) {
+            const float4 a0 = *(const float4 *)(As + (wr * 64 + orow) * LDT + kb + okq);
+            const float4 a1 = *(const float4 *)(As + (wr * 64 + 32 + orow) * LDT + kb + okq);
+            const float4 b0 = *(const float4 *)(Bs + (wc * 64 + orow) * LDT + kb + okq);
+            const float4 b1 = *(const float4 *)(Bs + (wc * 64 + 32 + orow) * LDT + kb + okq);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (p + 1 < npanels) stash((p + 1) & 1); // the other buffer: last read before the previous barrier
         __syncthreads();
     }
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -344,10 +386,15 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
     // |q| in the reference's sequential order (vector_store.rs:414): reuse the F32 quantize kernel's raw_mags output
     if (e == hipSuccess) e = launch_quantize_rows(ENG_F32, d_q, dim, B, dim, 0.f, 0.f, d_codes, ((u64)dim * 4 + 15) & ~15ull, d_dummy, d_qm, st);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)flat_gemm_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)flat_gemm_f32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
     for (u32 n0 = 0; n0 < n && e == hipSuccess; n0 += chunk) {
         const u32 nc = std::min(chunk, n - n0);
         dim3 grid((nc + BN - 1) / BN, (B + BM - 1) / BM);
-        hipLaunchKernelGGL(flat_gemm_f32, grid, dim3(256), 0, st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim, ix->d_raw_mags, n0, nc, dim, d_scores, s_stride);
+        // float4 staging needs 16 B aligned rows: dim % 4 == 0 (hipMalloc'd bases are 256 B aligned; a borrowed raw pointer is checked)
+        const bool vec = dim % 4 == 0 && ((uintptr_t)ix->d_raw & 15) == 0;
+        if (vec) hipLaunchKernelGGL(flat_gemm_f32<true>, grid, dim3(256), GEMM_SMEM, st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim, ix->d_raw_mags, n0, nc, dim, d_scores, s_stride);
+        else hipLaunchKernelGGL(flat_gemm_f32<false>, grid, dim3(256), GEMM_SMEM, st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim, ix->d_raw_mags, n0, nc, dim, d_scores, s_stride);
         e = hipGetLastError();
         if (e == hipSuccess) {
             hipLaunchKernelGGL(flat_select, dim3(B), dim3(64), 0, st, d_scores, s_stride, B, n0, nc, d_pool);
