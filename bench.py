@@ -96,7 +96,9 @@ def main():
     ap.add_argument("--ef-construction", type=int, default=128, help="config.toml default 128")
     ap.add_argument("--build-visited", default="ref", choices=["ref", "exact"], help="visited filter used by the builder's walks")
     ap.add_argument("--quantization", default="auto", choices=["auto", "range11"], help="auto = sampled values_range; range11 = (-1,1)")
-    ap.add_argument("--ef-sweep", default="256", help="comma list of extra ef_search values to time after the main run (256 = config.toml default)")
+    ap.add_argument("--ef-sweep", default="256,exact:32,exact:64",
+                    help="comma list of extra settings timed after the main run on the same graph: '256' = ef_search 256 (config.toml "
+                         "default) with the main visited filter; 'exact:32' / 'ref:128' = that ef with the named visited filter")
     ap.add_argument("--build-batch", type=int, default=4096)
     ap.add_argument("--recall-queries", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
