@@ -15,7 +15,7 @@ constexpr int KEEP_SEARCH = 100;       // vector_store.rs:1194 (search)
 constexpr int KEEP_INDEX = 64;         // vector_store.rs:1194 (indexing)
 constexpr int MAX_LEVELS = 16;
 
-enum : int { ENG_U8 = 0, ENG_Q2 = 1, ENG_F32 = 2, ENG_F16 = 3 };
+enum : int { ENG_U8 = 0, ENG_Q2 = 1, ENG_F32 = 2, ENG_F16 = 3, ENG_Q1 = 4, ENG_Q3 = 5 }; // Q1/Q2/Q3 = SubByte resolution 1/2/3
 
 // f32::total_cmp as an unsigned key: a < b (total order)  <=>  simkey(a) < simkey(b)
 __device__ __forceinline__ u32 simkey(float v) {

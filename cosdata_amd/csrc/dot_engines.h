@@ -22,6 +22,12 @@ __device__ __forceinline__ u32 rust_f32_as_usize_low2(float v) { // low 2 bits o
     if (v >= 18446744073709551616.0f) return 3u;
     return (u32)((u64)v & 3ull);
 }
+__device__ __forceinline__ u32 rust_f32_as_usize_low(float v, u32 mask) { // low bits of `v as usize` (saturating, NaN -> 0)
+    if (!(v == v)) return 0;
+    if (v <= 0.0f) return 0;
+    if (v >= 18446744073709551616.0f) return mask;
+    return (u32)((u64)v & (u64)mask);
+}
 __device__ __forceinline__ float rust_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
 __device__ __forceinline__ float rust_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
 
@@ -55,6 +61,24 @@ __device__ __forceinline__ u32 chunk_dot<ENG_Q2>(uint4 q, uint4 y, u32 acc) { //
     u32 lsbs = (u32)__popcll(xl & yl), carry = (u32)__popcll(mid1 & mid2);
     u32 msbs = (u32)__popcll(xm & ym), mid = (u32)__popcll(mid1 ^ mid2);
     return acc + (msbs << 2) + (carry << 2) + (mid << 1) + lsbs;
+}
+
+template <>
+__device__ __forceinline__ u32 chunk_dot<ENG_Q1>(uint4 q, uint4 y, u32 acc) { // dot_product_binary (dot_product.rs:21-33): 128 dims per chunk
+    return acc + (u32)__popc(q.x & y.x) + (u32)__popc(q.y & y.y) + (u32)__popc(q.z & y.z) + (u32)__popc(q.w & y.w);
+}
+template <>
+__device__ __forceinline__ u32 chunk_dot<ENG_Q3>(uint4 q, uint4 y, u32 acc) { // dot_product_octal (dot_product.rs:64-90): 32 dims per chunk
+    // chunk = [plane0 | plane1 | plane2 | 0] of the same 32 dims; the reference's digit is (p2<<2)|(p1<<1)|p0 on the planes
+    // AS STORED (plane 0 is the level's MSB, multiplied as the LSB — same quirk as quaternary):
+    // sum_dims x*y = sum_{i,j} 2^(i+j) popcount(x_i & y_j)
+    const u32 x0 = q.x, x1 = q.y, x2 = q.z, y0 = y.x, y1 = y.y, y2 = y.z;
+    u32 s = (u32)__popc(x0 & y0);
+    s += ((u32)__popc(x0 & y1) + (u32)__popc(x1 & y0)) << 1;
+    s += ((u32)__popc(x0 & y2) + (u32)__popc(x1 & y1) + (u32)__popc(x2 & y0)) << 2;
+    s += ((u32)__popc(x1 & y2) + (u32)__popc(x2 & y1)) << 3;
+    s += (u32)__popc(x2 & y2) << 4;
+    return acc + s;
 }
 
 // reference-order f32 dot (dot_product_f32_simd, x86_64.rs:418-444) by a PAIR of lanes:

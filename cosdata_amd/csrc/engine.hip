@@ -113,9 +113,13 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
         if ((nchunks + G - 1) / G > 2) return cos_fail(COS_ERR_UNIMPLEMENTED, "u8 dim > 2048 not supported on the device");
         break;
     case COS_STORAGE_SUBBYTE:
-        if (p->resolution != 2) return cos_fail(COS_ERR_UNIMPLEMENTED, "device walk implements SubByte resolution 2 (quaternary)");
-        eng = ENG_Q2; nchunks = (p->dim + 63) / 64; row_stride = (u64)nchunks * 16; G = std::min(64u, pow2ceil(nchunks));
-        if (nchunks > 64) return cos_fail(COS_ERR_UNIMPLEMENTED, "quaternary dim > 4096 not supported on the device");
+        // one 16 B chunk holds every plane of 128 / 64 / 32 dims for binary / quaternary / octal
+        if (p->resolution == 1) { eng = ENG_Q1; nchunks = (p->dim + 127) / 128; }
+        else if (p->resolution == 2) { eng = ENG_Q2; nchunks = (p->dim + 63) / 64; }
+        else if (p->resolution == 3) { eng = ENG_Q3; nchunks = (p->dim + 31) / 32; }
+        else return cos_fail(COS_ERR_CALCULATION, "SubByte resolution %u: the reference's distance arms return CalculationError (cosine.rs:147-154)", p->resolution);
+        row_stride = (u64)nchunks * 16; G = std::min(64u, pow2ceil(nchunks));
+        if (nchunks > 64) return cos_fail(COS_ERR_UNIMPLEMENTED, "SubByte dim > %u not supported on the device", 64u * (128u >> (p->resolution - 1)));
         break;
     case COS_STORAGE_F32:
         if (p->metric == COS_METRIC_DOT) return cos_fail(COS_ERR_STORAGE_MISMATCH, "DotProductDistance has no FullPrecisionFP arm (dotproduct.rs:20-64)");
@@ -350,10 +354,15 @@ static void row_to_reference_layout(int eng, u32 dim, const uint8_t *dev_row, ui
     if (eng == ENG_U8) memcpy(ref_row, dev_row, dim);
     else if (eng == ENG_F32) memcpy(ref_row, dev_row, (size_t)dim * 4);
     else if (eng == ENG_F16) memcpy(ref_row, dev_row, (size_t)dim * 2);
-    else { // Q2: [chunk][plane][8 B] -> plane-major
+    else if (eng == ENG_Q1) memcpy(ref_row, dev_row, (dim + 7) / 8); // one plane, already contiguous
+    else if (eng == ENG_Q2) { // [chunk][plane][8 B] -> plane-major
         const u32 pb = (dim + 7) / 8;
         for (u32 p = 0; p < 2; p++)
             for (u32 b = 0; b < pb; b++) ref_row[(size_t)p * pb + b] = dev_row[(size_t)(b / 8) * 16 + p * 8 + (b % 8)];
+    } else { // Q3: [chunk][plane][4 B] (+4 B pad) -> plane-major
+        const u32 pb = (dim + 7) / 8;
+        for (u32 p = 0; p < 3; p++)
+            for (u32 b = 0; b < pb; b++) ref_row[(size_t)p * pb + b] = dev_row[(size_t)(b / 4) * 16 + p * 4 + (b % 4)];
     }
 }
 
@@ -747,7 +756,9 @@ extern "C" int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uin
     int eng;
     u64 row_stride;
     if (storage == COS_STORAGE_U8) { eng = ENG_U8; row_stride = ((u64)dim + 15) & ~15ull; }
+    else if (storage == COS_STORAGE_SUBBYTE && resolution == 1) { eng = ENG_Q1; row_stride = (u64)((dim + 127) / 128) * 16; }
     else if (storage == COS_STORAGE_SUBBYTE && resolution == 2) { eng = ENG_Q2; row_stride = (u64)((dim + 63) / 64) * 16; }
+    else if (storage == COS_STORAGE_SUBBYTE && resolution == 3) { eng = ENG_Q3; row_stride = (u64)((dim + 31) / 32) * 16; }
     else if (storage == COS_STORAGE_F32) { eng = ENG_F32; row_stride = ((u64)dim * 4 + 15) & ~15ull; }
     else if (storage == COS_STORAGE_F16 || (storage == COS_STORAGE_SUBBYTE && resolution >= 1 && resolution <= 8)) { eng = -1; row_stride = 0; }
     else return cos_fail(COS_ERR_INVALID, "unknown storage kind / resolution");

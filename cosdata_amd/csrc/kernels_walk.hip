@@ -74,6 +74,31 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
             }
         }
         if (lane == 0) mags[row] = rn; // norm of the ORIGINAL vector (scalar.rs:31-32)
+    } else if constexpr (ENG == ENG_Q1) {
+        // binary: one plane, level = floor((x+1)/1.0) & 1 (common.rs:226-275 with resolution 1); 128 dims per 16 B chunk
+        const u32 nch = (u32)(row_stride / 16);
+        for (u32 c = 0; c < 2 * nch; c++) {
+            const u32 i = c * 64 + lane;
+            u32 lvl = 0;
+            if (i < dim) lvl = rust_f32_as_usize_low(floorf(__fdiv_rn(__fadd_rn(xr[i], 1.0f), 1.0f)), 1u);
+            const u64 p0 = __ballot(lvl & 1u);
+            if (lane == 0) *(u64 *)(cr + (u64)c * 8) = p0;
+        }
+        if (lane == 0) mags[row] = rn;
+    } else if constexpr (ENG == ENG_Q3) {
+        // octal: three planes, MSB first; 32 dims per 16 B chunk [p0 | p1 | p2 | 0]; one ballot covers two chunks
+        const u32 nch = (u32)(row_stride / 16);
+        for (u32 c = 0; c < nch; c += 2) {
+            const u32 i = c * 32 + lane;
+            u32 lvl = 0;
+            if (i < dim) lvl = rust_f32_as_usize_low(floorf(__fdiv_rn(__fadd_rn(xr[i], 1.0f), 0.25f)), 7u); // step = 2/8
+            const u64 p0 = __ballot((lvl >> 2) & 1u), p1 = __ballot((lvl >> 1) & 1u), p2 = __ballot(lvl & 1u);
+            if (lane == 0) {
+                *(uint4 *)(cr + (u64)c * 16) = make_uint4((u32)p0, (u32)p1, (u32)p2, 0u);
+                if (c + 1 < nch) *(uint4 *)(cr + (u64)(c + 1) * 16) = make_uint4((u32)(p0 >> 32), (u32)(p1 >> 32), (u32)(p2 >> 32), 0u);
+            }
+        }
+        if (lane == 0) mags[row] = rn;
     } else if constexpr (ENG == ENG_F16) {
         __half *ch = (__half *)cr;
         for (u32 i = lane; i < (u32)(row_stride / 2); i += 64) ch[i] = i < dim ? __float2half_rn(xr[i]) : __float2half_rn(0.0f); // f16::from_f32 (RNE)
@@ -579,10 +604,11 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
     {
         u32 off = 0;
         for (u32 s = 0; s <= L; s++) {
-            // a level list is sorted: entries past its first 5k cannot reach the global top 5k (each is preceded by 5k
-            // distinct better nodes), so only min(count, 5k) entries per level take part in the sort
+            // a level list is sorted: entries past its first 5k+1 cannot reach the global top 5k (each is preceded by 5k
+            // distinct better non-root nodes — one of the first 5k+1 may be the root, which is filtered), so only
+            // min(count, 5k+1) entries per level take part in the sort
             u32 c = fa.walk_counts[(u64)qi * (L + 1) + s];
-            if (c > 5u * fa.top_k) c = 5u * fa.top_k;
+            if (c > 5u * fa.top_k + 1u) c = 5u * fa.top_k + 1u;
             const u64 b = ((u64)qi * (L + 1) + s) * KEEP_SEARCH;
             // element index off + j  lives in lane (off+j)/FR, register (off+j)%FR
 #pragma unroll
@@ -705,6 +731,8 @@ hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u3
     case ENG_Q2: hipLaunchKernelGGL(quantize_rows_kernel<ENG_Q2>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
     case ENG_F32: hipLaunchKernelGGL(quantize_rows_kernel<ENG_F32>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
     case ENG_F16: hipLaunchKernelGGL(quantize_rows_kernel<ENG_F16>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
+    case ENG_Q1: hipLaunchKernelGGL(quantize_rows_kernel<ENG_Q1>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
+    case ENG_Q3: hipLaunchKernelGGL(quantize_rows_kernel<ENG_Q3>, grid, block, 0, st, x, x_stride, n, dim, lo, hi, codes, row_stride, mags, raw_mags); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -748,6 +776,12 @@ hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStrea
     case ENG_Q2:
         if (ch == 1) return ix.G == 64 ? launch_walk_r<ENG_Q2, 1, true>(ix, wa, st) : launch_walk_r<ENG_Q2, 1, false>(ix, wa, st);
         return hipErrorInvalidValue;
+    case ENG_Q1:
+        if (ch == 1) return ix.G == 64 ? launch_walk_r<ENG_Q1, 1, true>(ix, wa, st) : launch_walk_r<ENG_Q1, 1, false>(ix, wa, st);
+        return hipErrorInvalidValue;
+    case ENG_Q3:
+        if (ch == 1) return ix.G == 64 ? launch_walk_r<ENG_Q3, 1, true>(ix, wa, st) : launch_walk_r<ENG_Q3, 1, false>(ix, wa, st);
+        return hipErrorInvalidValue;
     case ENG_F32: return launch_walk_r<ENG_F32, 1, false>(ix, wa, st);
     case ENG_F16: return launch_walk_r<ENG_F16, 1, false>(ix, wa, st);
     default: return hipErrorInvalidValue;
@@ -761,7 +795,7 @@ hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_strid
     if (B == 0) return hipSuccess;
     FinalizeArgs fa{queries, q_stride, q_raw_mags, walk_ids, walk_sims, walk_counts, walk_status, B, top_k,
                     out_ids, out_scores, out_counts, out_status, out_rerank_rows};
-    const u32 per_level = std::min<u32>(KEEP_SEARCH, 5u * top_k);
+    const u32 per_level = std::min<u32>(KEEP_SEARCH, 5u * top_k + 1u);
     const u32 total = (ix.num_layers + 1) * per_level;
     dim3 grid(B), block(64);
     if (total <= 64 * 4) {

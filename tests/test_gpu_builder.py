@@ -17,7 +17,7 @@ def _device_index(X, storage, res, **kw):
     return dix
 
 
-@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2), (O.STORAGE_F32, 0), (O.STORAGE_F16, 0)])
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2), (O.STORAGE_F32, 0), (O.STORAGE_F16, 0), (O.STORAGE_SUBBYTE, 1), (O.STORAGE_SUBBYTE, 3)])
 @pytest.mark.parametrize("n,dim,bs", [(1500, 96, 64), (4000, 128, 512)])
 def test_device_build_equals_oracle_batched(storage, res, n, dim, bs):
     X = H.clustered_corpus(n, dim, n_centers=16, seed=9)

@@ -12,6 +12,8 @@ STORAGES = [
     ("q2", O.STORAGE_SUBBYTE, 2),
     ("f32", O.STORAGE_F32, 0),
     ("f16", O.STORAGE_F16, 0),
+    ("bin", O.STORAGE_SUBBYTE, 1),
+    ("oct", O.STORAGE_SUBBYTE, 3),
 ]
 
 
@@ -27,6 +29,19 @@ def test_quantize_matches_oracle(name, storage, res, dim):
     ocodes, omags = O.quantize_batch(x, storage, res, -1.0, 1.0)
     assert np.array_equal(codes, ocodes)
     assert np.array_equal(mags.view(np.uint32), omags.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,storage,res", STORAGES)
+@pytest.mark.parametrize("dim", [100, 768])
+def test_resident_codes_match_oracle(name, storage, res, dim):
+    """cos_index_download_codes: the codes the index holds in HBM (device layout -> reference layout), root row last."""
+    X = H.uniform_corpus(300, dim, seed=17) * 1.1
+    oix = H.oracle_index(X, storage, res, num_layers=2, ef_construction=16, ef_search=16)
+    dix = H.device_index_from_oracle(oix, X)
+    codes, mags = dix.download_codes()
+    ocodes, omags = O.quantize_batch(np.vstack([X, oix.root_raw()[None, :]]), storage, res, -1.0, 1.0)
+    assert np.array_equal(np.asarray(codes).reshape(301, -1), np.ascontiguousarray(ocodes).view(np.uint8).reshape(301, -1))
+    assert np.array_equal(np.asarray(mags).view(np.uint32), omags.view(np.uint32))
 
 
 def _assert_same_search(oix, dix, Q, top_k):
