@@ -13,7 +13,10 @@ un-coalesced 256-query batch at a time is reported alongside (`single_batch_qps`
 Default workload = BASELINE.json configs[1]: 1M x 768 dense cosine HNSW, query batch 256, one GPU
 (`--workload c4shard` = one 12.5M x 1024 shard of configs[3]).  N > 1: one process per GPU, every
 rank owns an independent shard (ID-range partition, weak scaling), queries are replicated, and each
-step ends with the RCCL all-gather of the per-shard top-k + the S-way merge kernel.
+step ends with the RCCL all-gather of the per-shard top-k + the S-way merge kernel.  The job's corpus grows with N
+(N x vectors_per_gpu) while every rank does the same work per step, so `value` counts the units ALL ranks processed:
+N x (queries searched over one shard) per second — the weak-scaling aggregate; the rate at which merged answers over
+the N-times-larger corpus come out is reported next to it as `merged_qps` (= value / N).
 
 Synthetic data (no network): a seeded Gaussian-mixture corpus, L2-normalised, generated on the
 device; queries are fresh draws from the same mixture.  recall@10 is measured against exact
@@ -298,7 +301,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     steps_done = n_launch * C
-    qps = steps_done * Bc / elapsed
+    merged_qps = steps_done * Bc / elapsed   # answers over the global (world x n) corpus per second
+    qps = merged_qps * world                  # units all ranks processed: every rank searched its shard for every query
 
     # per-launch walk-kernel figures: HIP events recorded by the library on the launch stream
     row_bytes = d + 4  # u8 code row + f32 norm per distance evaluation
@@ -418,6 +422,10 @@ def main():
                        "parallelism": f"id-range shards x{world}" + (" + RCCL all-gather top-k merge" if world > 1 else ""),
                        "corpus": f"Gaussian mixture, {n_centers} centres, sigma 0.8/sqrt(d), L2-normalised, seed 42"},
             "recall_at_10": recall, "recall_queries": nrq, "failed_queries": status_bad,
+            "merged_qps": merged_qps, "global_corpus_vectors": n * world,
+            "value_note": ("n_gpus == 1: value = queries/s over the whole corpus" if world == 1 else
+                           "weak scaling: value = shard-level queries/s summed over ranks (every query is searched on every shard); "
+                           "merged_qps = answers/s over the global corpus = value / n_gpus"),
             "single_batch_qps": serial_qps, "ef_selection": ef_table, "ef_sweep": sweep, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "empirical": empirical, "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64>" % (1 if ef <= 64 else (4 if ef <= 256 else 8)),
