@@ -115,6 +115,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or force_dist
+    # stdout carries exactly ONE JSON line: libraries that print banners through C stdio (RCCL prints its version block on
+    # fd 1 at exit) are pointed at stderr, the JSON line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -437,7 +442,7 @@ def main():
                                  "launches / timed wall time = bytes/avg_ms x in_flight (launches on different streams overlap)"},
             "flat_scan_ground_truth": flat, "result_properties": props, "cpu_baseline": cpu, "parity_vs_oracle": parity,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
