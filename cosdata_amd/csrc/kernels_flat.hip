@@ -4,7 +4,7 @@
 // Used for recall ground truth and as the exhaustive per-shard mode.  Pipeline per N-chunk:
 //   flat_gemm_f32      128x128 tile per workgroup (4 waves, 2x2 MFMA tiles of 32x32 per wave), LDS-staged K panels,
 //                      epilogue divides by |q|*|x| and writes cosine scores [B][chunk]
-//   flat_select        one wave per query keeps a running top-64 (sorted register pool, threshold filter)
+//   flat_select_*      waves per (query, segment) keep a top-64 (sorted register pool, threshold filter); merged per query
 //   flat_rescore       exact reference-order re-score (dot_product_f32_simd order) of the 64 survivors -> top-k
 // MFMA accumulation order differs from the reference's 8-lane tree in the last ulp, so the GEMM only
 // GENERATES candidates (64 >= 2k with margin); the returned ids/scores come from the reference-order kernel
@@ -136,19 +136,48 @@ __global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q
         }
 }
 
-// one wave per query: fold a chunk of scores into the running top-SEL pool (keys = (simkey(score), global id))
-__global__ __launch_bounds__(64) void flat_select(const float *__restrict__ scores, u64 s_stride, u32 B, u32 n0, u32 n_chunk, u64 *__restrict__ pool_mem /*[B][64]*/) {
+// Selection of the SEL best of a chunk in two steps so that a small query batch still fills the chip:
+//   flat_select_segments  grid (B, S): one wave per (query, segment of the chunk) keeps the segment's top-SEL
+//                         (sorted register pool, ballot threshold filter) -> part[B][S][SEL]
+//   flat_select_merge     one wave per query folds the S sorted partial lists into the running pool[B][SEL]
+// keys = (simkey(score), global id): ties go to the larger id, like everywhere else.
+__global__ __launch_bounds__(64) void flat_select_segments(const float *__restrict__ scores, u64 s_stride, u32 B, u32 n0, u32 n_chunk, u32 seg_len,
+                                                           u64 *__restrict__ part /*[B][S][64]*/) {
+    const int lane = threadIdx.x;
+    const u32 q = blockIdx.x, seg = blockIdx.y, S = gridDim.y;
+    if (q >= B) return;
+    Pool<1> pool;
+    pool.clear();
+    u64 thr = 0ull; // SEL-th best so far (0 while not full)
+    const float *sr = scores + (u64)q * s_stride;
+    const u32 c0 = seg * seg_len, c1 = (c0 + seg_len < n_chunk) ? c0 + seg_len : n_chunk;
+    for (u32 c = c0; c < c1; c += 64) {
+        const u32 col = c + lane;
+        u64 key = 0ull;
+        if (col < c1) key = pack_key(simkey(sr[col]), n0 + col);
+        u64 m = __ballot(key > thr);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const u64 kk = readlane_u64(key, l);
+            if (kk > thr) {
+                pool.insert_at(kk, pool.rank_of(kk), lane);
+                thr = readlane_u64(pool.e[0], SEL - 1);
+            }
+        }
+    }
+    part[((u64)q * S + seg) * SEL + lane] = pool.e[0];
+}
+
+__global__ __launch_bounds__(64) void flat_select_merge(const u64 *__restrict__ part, u32 B, u32 S, u64 *__restrict__ pool_mem /*[B][64]*/) {
     const int lane = threadIdx.x;
     const u32 q = blockIdx.x;
     if (q >= B) return;
     Pool<1> pool;
     pool.e[0] = pool_mem[(u64)q * SEL + lane];
-    u64 thr = readlane_u64(pool.e[0], SEL - 1); // current SEL-th best (0 while not full)
-    const float *sr = scores + (u64)q * s_stride;
-    for (u32 c = 0; c < n_chunk; c += 64) {
-        const u32 col = c + lane;
-        u64 key = 0ull;
-        if (col < n_chunk) key = pack_key(simkey(sr[col]), n0 + col);
+    u64 thr = readlane_u64(pool.e[0], SEL - 1);
+    for (u32 sgm = 0; sgm < S; sgm++) {
+        const u64 key = part[((u64)q * S + sgm) * SEL + lane];
         u64 m = __ballot(key > thr);
         while (m) {
             const int l = __ffsll((long long)m) - 1;
@@ -161,6 +190,30 @@ __global__ __launch_bounds__(64) void flat_select(const float *__restrict__ scor
         }
     }
     pool_mem[(u64)q * SEL + lane] = pool.e[0];
+}
+
+// segments per query: enough waves to fill 256 CUs x 8, at least 4096 candidates per segment
+static u32 select_segments(u32 B, u32 n_chunk) {
+    u32 S = (4096 + B - 1) / B;
+    const u32 max_s = (n_chunk + 4095) / 4096;
+    if (S > max_s) S = max_s;
+    if (S > 64) S = 64;
+    return S ? S : 1;
+}
+static hipError_t launch_select(const float *d_scores, u64 s_stride, u32 B, u32 n0, u32 nc, u64 *d_part, u32 S, u64 *d_pool, hipStream_t st) {
+    const u32 seg_len = ((nc + S - 1) / S + 63) / 64 * 64;
+    hipLaunchKernelGGL(flat_select_segments, dim3(B, S), dim3(64), 0, st, d_scores, s_stride, B, n0, nc, seg_len, d_part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(flat_select_merge, dim3(B), dim3(64), 0, st, (const u64 *)d_part, B, S, d_pool);
+    return hipGetLastError();
+}
+
+// any zero among n floats -> *flag = 1 (cosine zero-norm screening without copying the norms to the host)
+__global__ void any_zero_kernel(const float *__restrict__ v, u32 n, u32 *__restrict__ flag) {
+    bool z = false;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) z |= (v[i] == 0.0f);
+    if (__any(z) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 // exact re-score of the survivors in the reference order, sort, top-k
@@ -370,11 +423,13 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     chunk = std::min(n, std::max<u32>(chunk, BN));
     const u64 s_stride = ((u64)chunk + 63) & ~63ull;
     float *d_q = nullptr, *d_qm = nullptr, *d_scores = nullptr, *d_os = nullptr, *d_dummy = nullptr;
-    u64 *d_pool = nullptr;
+    u64 *d_pool = nullptr, *d_part = nullptr;
     u32 *d_oi = nullptr;
     uint8_t *d_codes = nullptr;
     hipStream_t st = ix->own_stream;
+    const u32 S = select_segments(B, chunk);
     hipError_t e = hipMalloc(&d_q, (size_t)B * dim * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_part, (size_t)B * S * SEL * 8);
     if (e == hipSuccess) e = hipMalloc(&d_qm, (size_t)B * 4);
     if (e == hipSuccess) e = hipMalloc(&d_dummy, (size_t)B * 4);
     if (e == hipSuccess) e = hipMalloc(&d_codes, (size_t)B * (((size_t)dim * 4 + 15) & ~(size_t)15));
@@ -396,10 +451,7 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
         if (vec) hipLaunchKernelGGL(flat_gemm_f32<true>, grid, dim3(256), GEMM_SMEM, st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim, ix->d_raw_mags, n0, nc, dim, d_scores, s_stride);
         else hipLaunchKernelGGL(flat_gemm_f32<false>, grid, dim3(256), GEMM_SMEM, st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim, ix->d_raw_mags, n0, nc, dim, d_scores, s_stride);
         e = hipGetLastError();
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(flat_select, dim3(B), dim3(64), 0, st, d_scores, s_stride, B, n0, nc, d_pool);
-            e = hipGetLastError();
-        }
+        if (e == hipSuccess) e = launch_select(d_scores, s_stride, B, n0, nc, d_part, S, d_pool, st);
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(flat_rescore, dim3(B), dim3(64), (((size_t)dim * 4 + 15) & ~(size_t)15), st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim,
@@ -409,7 +461,7 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_oi, (size_t)B * k * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_os, (size_t)B * k * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    void *ptrs[] = {d_q, d_qm, d_dummy, d_codes, d_scores, d_pool, d_oi, d_os};
+    void *ptrs[] = {d_q, d_qm, d_dummy, d_codes, d_scores, d_pool, d_part, d_oi, d_os};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     HIP_TRY(e);
     return COS_OK;
@@ -434,10 +486,14 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     hipStream_t st = ix->own_stream;
     float *d_q = nullptr, *d_qm = nullptr, *d_qrm = nullptr, *d_scores = nullptr, *d_os = nullptr;
     uint8_t *d_qc = nullptr;
-    u32 *d_qs = nullptr, *d_cs = nullptr, *d_oi = nullptr, *d_oc = nullptr;
-    u64 *d_pool = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    u32 *d_qs = nullptr, *d_cs = nullptr, *d_oi = nullptr, *d_oc = nullptr, *d_zero = nullptr;
+    u64 *d_pool = nullptr, *d_part = nullptr;
+    std::vector<hipEvent_t> evs; // (start, stop) of every GEMM launch, read after the last one
+    const u32 S = select_segments(B, chunk);
     hipError_t e = hipMalloc(&d_q, (size_t)B * dim * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_part, (size_t)B * S * SEL * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_zero, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(d_zero, 0, 4, st);
     if (e == hipSuccess) e = hipMalloc(&d_qm, (size_t)B * 4);
     if (e == hipSuccess) e = hipMalloc(&d_qrm, (size_t)B * 4);
     if (e == hipSuccess) e = hipMalloc(&d_qc, (size_t)B * ix->row_stride);
@@ -448,8 +504,6 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     if (e == hipSuccess) e = hipMalloc(&d_oi, (size_t)B * top_k * 4);
     if (e == hipSuccess) e = hipMalloc(&d_os, (size_t)B * top_k * 4);
     if (e == hipSuccess) e = hipMalloc(&d_oc, (size_t)B * 4);
-    if (e == hipSuccess) e = hipEventCreate(&ev0);
-    if (e == hipSuccess) e = hipEventCreate(&ev1);
     if (e == hipSuccess) e = hipMemcpyAsync(d_q, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
     if (e == hipSuccess) e = launch_quantize_rows(ix->eng, d_q, dim, B, dim, ix->p.range_lo, ix->p.range_hi, d_qc, ix->row_stride, d_qm, d_qrm, st);
@@ -460,36 +514,33 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     }
     // zero-norm screening (cosine): the reference aborts a search on the first zero denominator it meets; an
     // exhaustive scan meets every vector, so any zero |q| or zero |v| is a CalculationError for the call.
-    std::vector<float> hq(B), hm;
-    if (e == hipSuccess) e = hipMemcpyAsync(hq.data(), d_qm, (size_t)B * 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && ix->p.metric == COS_METRIC_COSINE) { hm.resize(n); e = hipMemcpyAsync(hm.data(), ix->d_mags, (size_t)n * 4, hipMemcpyDeviceToHost, st); }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    bool zero = false;
+    u32 hzero = 0;
     if (e == hipSuccess && ix->p.metric == COS_METRIC_COSINE) {
-        for (float v : hq) zero |= (v == 0.0f);
-        for (float v : hm) zero |= (v == 0.0f);
+        hipLaunchKernelGGL(any_zero_kernel, dim3(64), dim3(256), 0, st, (const float *)d_qm, B, d_zero);
+        hipLaunchKernelGGL(any_zero_kernel, dim3(1024), dim3(256), 0, st, (const float *)ix->d_mags, n, d_zero);
+        e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(&hzero, d_zero, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    const bool zero = hzero != 0;
     float gemm_ms = 0.f;
     u32 launches = 0;
     if (e == hipSuccess && !zero) {
         for (u32 n0 = 0; n0 < n && e == hipSuccess; n0 += chunk) {
             const u32 nc = std::min(chunk, n - n0);
             dim3 grid((nc + CN - 1) / CN, (B + CM - 1) / CM);
-            e = hipEventRecord(ev0, st);
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            e = hipEventCreate(&ev0);
+            if (e == hipSuccess) { evs.push_back(ev0); e = hipEventCreate(&ev1); }
+            if (e == hipSuccess) { evs.push_back(ev1); e = hipEventRecord(ev0, st); }
+            if (e != hipSuccess) break;
             if (ix->eng == ENG_U8)
                 hipLaunchKernelGGL(flat_codes_gemm_i8<ENG_U8>, grid, dim3(512), 0, st, d_qc, d_qm, d_qs, B, ix->d_codes, ix->d_mags, d_cs, ix->row_stride, n0, nc, kdims, ix->p.metric, d_scores, s_stride);
             else
                 hipLaunchKernelGGL(flat_codes_gemm_i8<ENG_Q2>, grid, dim3(512), 0, st, d_qc, d_qm, d_qs, B, ix->d_codes, ix->d_mags, d_cs, ix->row_stride, n0, nc, kdims, ix->p.metric, d_scores, s_stride);
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(ev1, st);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(flat_select, dim3(B), dim3(64), 0, st, d_scores, s_stride, B, n0, nc, d_pool);
-                e = hipGetLastError();
-            }
-            if (e == hipSuccess) e = hipEventSynchronize(ev1);
-            float ms = 0.f;
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
-            gemm_ms += ms;
+            if (e == hipSuccess) e = launch_select(d_scores, s_stride, B, n0, nc, d_part, S, d_pool, st);
             launches++;
         }
         if (e == hipSuccess) {
@@ -501,6 +552,11 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
         if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_os, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_oc, (size_t)B * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        for (size_t i = 0; i + 1 < evs.size() && e == hipSuccess; i += 2) {
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
+            gemm_ms += ms;
+        }
     }
     if (stats) {
         stats->gemm_ms = gemm_ms;
@@ -508,10 +564,9 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
         stats->int8_ops = 2.0 * (double)B * (double)n * (double)kdims;
         stats->code_bytes = (double)n * (double)ix->row_stride * (double)((B + CM - 1) / CM);
     }
-    void *ptrs[] = {d_q, d_qm, d_qrm, d_qc, d_qs, d_cs, d_scores, d_pool, d_oi, d_os, d_oc};
+    void *ptrs[] = {d_q, d_qm, d_qrm, d_qc, d_qs, d_cs, d_scores, d_pool, d_part, d_zero, d_oi, d_os, d_oc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
+    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
     HIP_TRY(e);
     if (zero) return cos_fail(COS_ERR_CALCULATION, "zero-norm query or stored vector: DistanceError::CalculationError (cosine.rs:228-232)");
     return COS_OK;

@@ -51,6 +51,9 @@ out = {"config": f"c3: {n} x {d} quaternary (SubByte 2), flat scan of the codes,
                 "int8_peak_tops_dense": 5000.0, "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall,
                 "qps_end_to_end": B / wall, "recall_at_10_vs_f32_bruteforce": rec_flat, "upload_quantize_s": t_up}}
 del ix
+if a.walk_n <= 0:   # flat scan only
+    print(json.dumps(out))
+    sys.exit(0)
 # (ii) HNSW walk with quaternary distance on a 1M subset
 m = min(a.walk_n, n)
 Xs = X[:m].contiguous()
