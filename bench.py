@@ -369,12 +369,15 @@ def main():
         probe = oix.search_batch(Qh[:max(64, cores)], k, threads=cores)
         rate = max(64, cores) / (time.perf_counter() - t2)
         nq = int(min(Qh.shape[0], max(256, rate * args.cpu_seconds)))
+        # bounded sample: the distinct queries of the workload, repeated until about --cpu-seconds of wall time are spent
+        reps = int(max(1, min(16, round(rate * args.cpu_seconds / nq))))
         t2 = time.perf_counter()
-        oids, osc, ocnt = oix.search_batch(Qh[:nq], k, threads=cores)[:3]
+        for _ in range(reps):
+            oids, osc, ocnt = oix.search_batch(Qh[:nq], k, threads=cores)[:3]
         cpu_s = time.perf_counter() - t2
-        cpu = {"value": nq / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
-               "sample": f"{nq} queries of the same workload ({cpu_s:.1f} s wall), C/AVX2 restatement of the Rust path "
-                         f"(oracle/), one OpenMP thread per core like batch_search's rayon fan-out"}
+        cpu = {"value": reps * nq / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
+               "sample": f"{reps} passes over {nq} queries of the same workload ({cpu_s:.1f} s wall on {cores} threads), C/AVX2 "
+                         f"restatement of the Rust path (oracle/), one OpenMP thread per core like batch_search's rayon fan-out"}
         # free parity check on the same sample: GPU ids/scores vs oracle
         gi = np.zeros((nq, k), np.uint32)
         gs = np.zeros((nq, k), np.float32)
