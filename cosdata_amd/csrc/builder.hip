@@ -207,34 +207,39 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
 
     // ---- batch workspace -----------------------------------------------------------------------
     const u32 L1 = Ltop + 1, KEEP = (u32)KEEP_INDEX;
-    u32 *d_rows = nullptr, *d_out_ids = nullptr, *d_out_nodes = nullptr, *d_out_counts = nullptr, *d_drows = nullptr, *d_pack = nullptr;
-    (void)d_drows;
+    u32 *d_rows = nullptr, *d_out_ids = nullptr, *d_out_nodes = nullptr, *d_out_counts = nullptr, *d_pack = nullptr;
     float *d_out_sims = nullptr;
     int32_t *d_status = nullptr;
-    VisTab vtab; // EXACT build mode: visited hash sets of the batch walks
+    VisTab vtab; // EXACT build mode: visited filters of the batch walks
     size_t pack_cap = 0;
-    HIP_TRY(dmalloc(d_rows, Bmax));
-    HIP_TRY(dmalloc(d_out_ids, (size_t)Bmax * L1 * KEEP));
-    HIP_TRY(dmalloc(d_out_nodes, (size_t)Bmax * L1 * KEEP));
-    HIP_TRY(dmalloc(d_out_sims, (size_t)Bmax * L1 * KEEP));
-    HIP_TRY(dmalloc(d_out_counts, (size_t)Bmax * L1));
-    HIP_TRY(dmalloc(d_status, Bmax));
     // pinned staging: walk results down, packed dirty rows up
     u32 *h_rows = nullptr, *h_nodes = nullptr, *h_counts = nullptr, *h_pack = nullptr;
     float *h_sims = nullptr;
     int32_t *h_status = nullptr;
     size_t h_pack_cap = 0;
-    HIP_TRY(hipHostMalloc((void **)&h_rows, (size_t)Bmax * 4));
-    HIP_TRY(hipHostMalloc((void **)&h_nodes, (size_t)Bmax * L1 * KEEP * 4));
-    HIP_TRY(hipHostMalloc((void **)&h_sims, (size_t)Bmax * L1 * KEEP * 4));
-    HIP_TRY(hipHostMalloc((void **)&h_counts, (size_t)Bmax * L1 * 4));
-    HIP_TRY(hipHostMalloc((void **)&h_status, (size_t)Bmax * 4));
     auto cleanup = [&]() {
-        void *ptrs[] = {d_rows, d_out_ids, d_out_nodes, d_out_sims, d_out_counts, d_status, d_drows, d_pack, vtab.bits, vtab.log};
+        void *ptrs[] = {d_rows, d_out_ids, d_out_nodes, d_out_sims, d_out_counts, d_status, d_pack, vtab.bits, vtab.log};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         void *hp[] = {h_rows, h_nodes, h_sims, h_counts, h_status, h_pack};
         for (void *p : hp) if (p) (void)hipHostFree(p);
     };
+#define BUILD_TRY(expr)                                                                                                    \
+    do {                                                                                                                   \
+        hipError_t _be = (expr);                                                                                           \
+        if (_be != hipSuccess) { cleanup(); HIP_TRY(_be); }                                                                \
+    } while (0)
+    BUILD_TRY(dmalloc(d_rows, Bmax));
+    BUILD_TRY(dmalloc(d_out_ids, (size_t)Bmax * L1 * KEEP));
+    BUILD_TRY(dmalloc(d_out_nodes, (size_t)Bmax * L1 * KEEP));
+    BUILD_TRY(dmalloc(d_out_sims, (size_t)Bmax * L1 * KEEP));
+    BUILD_TRY(dmalloc(d_out_counts, (size_t)Bmax * L1));
+    BUILD_TRY(dmalloc(d_status, Bmax));
+    BUILD_TRY(hipHostMalloc((void **)&h_rows, (size_t)Bmax * 4));
+    BUILD_TRY(hipHostMalloc((void **)&h_nodes, (size_t)Bmax * L1 * KEEP * 4));
+    BUILD_TRY(hipHostMalloc((void **)&h_sims, (size_t)Bmax * L1 * KEEP * 4));
+    BUILD_TRY(hipHostMalloc((void **)&h_counts, (size_t)Bmax * L1 * 4));
+    BUILD_TRY(hipHostMalloc((void **)&h_status, (size_t)Bmax * 4));
+#undef BUILD_TRY
 
     IndexDev dev = cos_make_index_dev(ix);
 

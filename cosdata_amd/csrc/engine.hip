@@ -35,6 +35,7 @@ int32_t cos_fail(int32_t code, const char *fmt, ...) {
 extern "C" const char *cos_last_error_string(void) { return g_err.c_str(); }
 
 extern "C" int32_t cos_device_count(int32_t *out) {
+    if (!out) return cos_fail(COS_ERR_INVALID, "null argument");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { *out = 0; return cos_fail(COS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
@@ -197,6 +198,8 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     if (ix->d_mags) (void)hipFree(ix->d_mags);
     ix->d_raw = nullptr; ix->d_raw_mags = nullptr; ix->d_codes = nullptr; ix->d_mags = nullptr;
     ix->have_vectors = false;
+    ix->have_root = false;
+    for (auto &l : ix->lv) free_level(l); // a graph refers to vector rows: new vectors invalidate it
     const u64 dim = ix->p.dim;
     if (flags & COS_UPLOAD_BORROW_DEVICE) {
         // the caller's producer (e.g. a torch kernel on another stream) may still be writing the buffer: our streams
@@ -228,16 +231,15 @@ extern "C" int32_t cos_index_set_root(cos_index *ix, const float *root_raw) {
     int32_t rc = cos_set_device(ix);
     if (rc) return rc;
     ix->root_raw.assign(root_raw, root_raw + ix->p.dim);
-    float *d_tmp = nullptr, *d_dummy = nullptr;
-    HIP_TRY(hipMalloc(&d_tmp, (size_t)ix->p.dim * 4));
-    HIP_TRY(hipMalloc(&d_dummy, 4));
-    HIP_TRY(hipMemcpy(d_tmp, root_raw, (size_t)ix->p.dim * 4, hipMemcpyHostToDevice));
-    hipError_t e = launch_quantize_rows(ix->eng, d_tmp, ix->p.dim, 1, ix->p.dim, ix->p.range_lo, ix->p.range_hi,
+    float *d_tmp = nullptr; // [dim] staged root + 1 float for the unused raw-norm output
+    HIP_TRY(hipMalloc(&d_tmp, ((size_t)ix->p.dim + 1) * 4));
+    float *d_dummy = d_tmp + ix->p.dim;
+    hipError_t e = hipMemcpy(d_tmp, root_raw, (size_t)ix->p.dim * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_quantize_rows(ix->eng, d_tmp, ix->p.dim, 1, ix->p.dim, ix->p.range_lo, ix->p.range_hi,
                                         ix->d_codes + (size_t)ix->n * ix->row_stride, ix->row_stride, ix->d_mags + ix->n, d_dummy,
                                         ix->own_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ix->own_stream);
     (void)hipFree(d_tmp);
-    (void)hipFree(d_dummy);
     HIP_TRY(e);
     ix->have_root = true;
     return COS_OK;
