@@ -31,6 +31,16 @@ __device__ __forceinline__ u32 rust_f32_as_usize_low(float v, u32 mask) { // low
 __device__ __forceinline__ float rust_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
 __device__ __forceinline__ float rust_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
 
+// IEEE division with x86's NaN convention.  The reference runs on x86-64 (its SIMD paths are AVX2), where an invalid
+// operation (0/0, inf/inf) yields the NEGATIVE default NaN 0xFFC00000; gfx950 yields 0x7FC00000.  f32::total_cmp puts the
+// two at opposite ends of the order (a zero raw vector would rank first instead of last in finalize_ann_results), so the
+// quotient of two non-NaN operands is canonicalised to the x86 pattern.
+__device__ __forceinline__ float x86_div(float a, float b) {
+    float r = __fdiv_rn(a, b);
+    if (r != r && a == a && b == b) r = __uint_as_float(0xFFC00000u);
+    return r;
+}
+
 // sqrt(sequential, non-fused sum of x*x): scalar.rs:31,41,45 / vector_store.rs:414,426.  Executed by ONE lane.
 __device__ __forceinline__ float seq_norm(const float *x, u32 n) {
     float acc = -0.0f;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const u32 row = row0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < B && col < n_chunk) scores[(u64)row * s_stride + col] = acc[i][j][r] / (qmags[row] * xm);
+                if (row < B && col < n_chunk) scores[(u64)row * s_stride + col] = x86_div(acc[i][j][r], qmags[row] * xm);
             }
         }
 }
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64) void flat_rescore(const float *__restrict__ Q, 
         const bool valid = __shfl((int)(u32)(mine >> 32), src, 64) != 0;
         const u32 row = valid ? sid : 0u;
         const float dp = f32_pair_dot(X + (u64)row * x_stride, qf, dim, lane & 1);
-        const float cs = dp / (mq * xmags[row]); // dp / (mag_query * mag_raw), vector_store.rs:427
+        const float cs = x86_div(dp, mq * xmags[row]); // dp / (mag_query * mag_raw), vector_store.rs:427
         const u64 key = valid ? pack_key(simkey(cs), sid) : 0ull;
         // survivor base + j was computed by lanes 2j and 2j+1 -> hand it to lane base + j
         const int from = (2 * (lane - base)) & 63;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64) void flat_rerank_top5k(const float *__restrict_
         const bool valid = (u32)src < ncand;
         const u32 row = valid ? sid : 0u;
         const float dp = f32_pair_dot(X + (u64)row * x_stride, qf, dim, lane & 1);
-        const float cs = dp / (mq * xmags[row]);
+        const float cs = x86_div(dp, mq * xmags[row]);
         const u64 key = valid ? pack_key(simkey(cs), sid) : 0ull;
         const int from = (2 * (lane - base)) & 63;
         const u32 klo = (u32)__shfl((int)(u32)key, from, 64), khi = (u32)__shfl((int)(u32)(key >> 32), from, 64);

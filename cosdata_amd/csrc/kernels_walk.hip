@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
             const u32 my = base + (u32)pair;
             const u32 id = my < ncand ? cand[my] : 0u;
             const float dp = f32_pair_dot(ix.raw + (u64)id * ix.raw_stride, qf, ix.dim, lane & 1);
-            const float cs = __fdiv_rn(dp, __fmul_rn(mag_query, ix.raw_mags[id]));
+            const float cs = x86_div(dp, __fmul_rn(mag_query, ix.raw_mags[id])); // 0/0 (zero raw vector or query) -> x86's -NaN
             const u64 key = my < ncand ? pack_key(simkey(cs), id) : 0ull; // total_cmp desc; larger id first on ties
             const int from = (2 * (lane - (int)base)) & 63;
             const u32 klo = (u32)__shfl((int)(u32)key, from, 64), khi = (u32)__shfl((int)(u32)(key >> 32), from, 64);
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
             const u32 my = base + (u32)pair;
             const u32 id = my < ncand ? cand[my] : 0u;
             const float dp = f32_pair_dot(ix.raw + (u64)id * ix.raw_stride, qf, ix.dim, lane & 1);
-            const float cs = __fdiv_rn(dp, __fmul_rn(mag_query, ix.raw_mags[id]));
+            const float cs = x86_div(dp, __fmul_rn(mag_query, ix.raw_mags[id])); // 0/0 (zero raw vector or query) -> x86's -NaN
             const u64 key = pack_key(simkey(cs), id);
             // scatter into the blocked register layout: element my -> lane my/FR, reg my%FR
             for (u32 j = 0; j < 32 && base + j < ncand; j++) {

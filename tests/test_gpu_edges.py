@@ -108,3 +108,26 @@ def test_c1_config_build_and_search():
         _assert_same_search(oix, dix, Q, k)
     ids = dix.batch_search(Q, 5)[0]
     assert (ids[:, 0] == np.arange(100)).mean() >= 0.9   # a corpus vector (nearly always) finds itself; uniform high-d data is adversarial
+
+
+def test_zero_raw_vectors_and_zero_query_follow_x86_nan_order():
+    """finalize_ann_results divides by |q|*|raw| without a zero check (vector_store.rs:425-427): a zero raw vector (or query)
+    gives 0/0.  On x86-64, the reference's platform, that is the NEGATIVE default NaN, which f32::total_cmp sorts below
+    everything — the zero vector drops to the end of the rerank.  The device must reproduce ids AND the 0xFFC00000 bits."""
+    X = H.clustered_corpus(2000, 64, n_centers=6, seed=4)
+    X[[5, 700, 1500]] = 0.0          # u8 codes 127...: valid quantized norm, reachable by the walk, |raw| = 0
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=3, ef_construction=32, ef_search=64)
+    dix = H.device_index_from_oracle(oix, X)
+    Q = H.queries_from(X, 12, seed=9)
+    Q[3] = 0.0                       # |q| = 0 in the rerank: every score is 0/0
+    Q[4] = X[1] * 1e-3               # tiny but non-zero
+    _assert_same_walk(oix, dix, Q)
+    _assert_same_search(oix, dix, Q, 10)
+    _assert_same_search(oix, dix, Q, 400)   # returns every candidate: the zero vectors must close each list with -NaN
+    ids, sc, cnt = dix.batch_search(Q, 400)
+    assert all(int(ids[b, int(cnt[b]) - 1]) in (5, 700, 1500) for b in range(12) if b != 3)
+    assert (sc[3, :int(cnt[3])].view(np.uint32) == 0xFFC00000).all()
+    keep = [i for i in range(12) if i != 3]
+    bi, bs = dix.bruteforce_topk(Q[keep], 10)
+    oi, osc = O.bruteforce_topk(X, Q[keep], 10, threads=4)
+    assert np.array_equal(bi, oi) and np.array_equal(bs.view(np.uint32), osc.view(np.uint32))
