@@ -339,3 +339,28 @@ def test_auto_quantization_sampler_thresholds():
     assert O.sample_values_range(xs, 1.0)[1] == np.float32(0.025)
     xs[0, 2] = 0.7                                                                                      # 1.5 % above every threshold
     assert O.sample_values_range(xs, 1.0)[1] == 1.0
+
+
+def test_zero_raw_vector_gets_x86_negative_nan_and_ranks_last():
+    """finalize_ann_results (vector_store.rs:425-427) divides by |q|*|raw| unchecked: 0/0 on x86-64 — the platform of the
+    reference's AVX2 paths — is the negative default NaN, which f32::total_cmp orders below every number.  The oracle gets
+    this from the host FPU; the device canonicalises to the same bits (x86_div in cosdata_amd/csrc/dot_engines.h)."""
+    import platform
+    if platform.machine() not in ("x86_64", "AMD64"):
+        pytest.skip("the NaN sign of an invalid operation is the x86 convention")
+    from tests import helpers as H
+    X = H.clustered_corpus(1200, 48, n_centers=5, seed=4)
+    X[[7, 500]] = 0.0
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=2, ef_construction=32, ef_search=64)
+    Q = H.queries_from(X, 6, seed=9)
+    ids, sc, cnt = oix.search_batch(Q, 300, threads=2)[:3]
+    seen = 0
+    for b in range(6):
+        c = int(cnt[b])
+        zpos = [j for j in range(c) if int(ids[b, j]) in (7, 500)]
+        seen += len(zpos)
+        assert all(j >= c - len(zpos) for j in zpos)                       # they close the list
+        assert all(sc[b, j:j + 1].view(np.uint32)[0] == 0xFFC00000 for j in zpos)
+        finite = sc[b, :c - len(zpos)]
+        assert np.all(np.isfinite(finite)) and np.all(finite[:-1] >= finite[1:])
+    assert seen > 0
