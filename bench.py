@@ -37,7 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import cosdata_amd as ca  # noqa: E402
-from cosdata_amd.sharding import allgather_packed, merge_topk_packed_device, packed_views, packed_words  # noqa: E402
+from cosdata_amd.sharding import (allgather_packed, global_topk_by_score, merge_topk_packed_device, packed_views,  # noqa: E402
+                                  packed_words)
 
 METRIC = "QPS at recall@10≥0.95, 1024-dim dense cosine, 1/2/4/8 MI355X"
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -229,12 +230,7 @@ def main():
         import torch.distributed as dist
         loc = (local_ids_global - rank * n).clamp_(0, n - 1)
         sims = torch.einsum("qd,qkd->qk", Q[:nrq], X[loc])   # exact cosine of the k returned rows only (unit-norm corpus)
-        all_ids = [torch.zeros_like(local_ids_global) for _ in range(world)]
-        all_s = [torch.zeros_like(sims) for _ in range(world)]
-        dist.all_gather(all_ids, local_ids_global.contiguous())
-        dist.all_gather(all_s, sims.contiguous())
-        ci, cs = torch.cat(all_ids, 1), torch.cat(all_s, 1)
-        return torch.gather(ci, 1, cs.topk(k, dim=1).indices)
+        return global_topk_by_score(local_ids_global, sims, k)
 
     gt = merge_global(gt_local + rank * n) if dist_on else gt_local
 

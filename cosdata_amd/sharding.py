@@ -76,3 +76,15 @@ def merge_topk_packed_device(g_packed, B: int, k: int, out_ids, out_scores, out_
     S = g_packed.shape[0]
     _lib.check(_lib.lib().cos_merge_topk_packed_device(g_packed.data_ptr(), S, B, k, out_ids.data_ptr(), out_scores.data_ptr(),
                                                        out_counts.data_ptr(), device_index, stream))
+
+
+def global_topk_by_score(ids_global: torch.Tensor, scores: torch.Tensor, k: int) -> torch.Tensor:
+    """Recall bookkeeping for S shards (not on the query path): every rank contributes its [Q][k'] candidate ids (global)
+    with their exact scores; returns the [Q][k] ids of the best scores over all shards, identical on every rank."""
+    world = dist.get_world_size()
+    all_ids = [torch.zeros_like(ids_global) for _ in range(world)]
+    all_s = [torch.zeros_like(scores) for _ in range(world)]
+    dist.all_gather(all_ids, ids_global.contiguous())
+    dist.all_gather(all_s, scores.contiguous())
+    ci, cs = torch.cat(all_ids, 1), torch.cat(all_s, 1)
+    return torch.gather(ci, 1, cs.topk(k, dim=1).indices)

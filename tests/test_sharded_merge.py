@@ -142,3 +142,50 @@ def test_merge_kernel_matches_rule():
                 c = int(gc[b])
                 assert np.array_equal(r_i.cpu().numpy().view(np.uint32)[b, :c], exp[0][b, :c])
                 assert np.array_equal(r_s.cpu().numpy()[b, :c], exp[1][b, :c])
+
+
+def _recall_worker(rank, world, port, tmp):
+    """bench.py's recall bookkeeping for N > 1, on CPU: per-shard exact top-k (global ids) -> global_topk_by_score ->
+    every rank holds the same global ground truth, equal to the single-process brute force over the whole corpus."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cosdata_amd.sharding import global_topk_by_score, shard_range
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 900, 24, 10, 5
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    lo, hi = shard_range(n, world, rank)
+    lid, _ = O.bruteforce_topk(np.ascontiguousarray(X[lo:hi]), Q, k)
+    gids = torch.from_numpy(lid.astype(np.int64) + lo)
+    Xt, Qt = torch.from_numpy(X), torch.from_numpy(Q)
+    sims = torch.einsum("qd,qkd->qk", Qt, Xt[gids])           # what bench.py::merge_global computes
+    merged = global_topk_by_score(gids, sims, k)
+    np.save(os.path.join(tmp, f"gt_{rank}.npy"), merged.numpy())
+    r = torch.tensor([0.5 + rank])                            # the ef decision is broadcast from rank 0
+    dist.broadcast(r, 0)
+    assert float(r.item()) == 0.5
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)       # timed region: MAX over ranks
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t.item()) == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_ground_truth_merge_gloo(tmp_path):
+    world = 2
+    mp.spawn(_recall_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "gt_0.npy"), np.load(tmp_path / "gt_1.npy")
+    assert np.array_equal(a, b)
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((900, 24)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = rng.standard_normal((10, 24)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    gt, _ = O.bruteforce_topk(X, Q, 5)
+    assert all(set(a[i].tolist()) == set(gt[i].tolist()) for i in range(10))
