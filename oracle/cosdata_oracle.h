@@ -124,6 +124,8 @@ int coso_index_set_vectors(coso_index *ix, const float *raw, uint32_t n);
 int coso_index_build(coso_index *ix);
 /* Batch-synchronous schedule (CPU statement of the device builder, cosdata_amd/csrc/builder.hip). */
 int coso_index_build_batched(coso_index *ix, uint32_t batch_size);
+/* prototype of the round-synchronous link schedule; stats[4] = rounds, (batch,level) pairs, nodes, first-round nodes */
+int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uint64_t *stats);
 /* Flat export/import (the same arrays include/cosdata_hip.h uploads). */
 uint32_t coso_index_level_count(const coso_index *ix, uint32_t level);
 int coso_index_export_level(const coso_index *ix, uint32_t level, uint32_t *node_ids /*[n_l]*/,

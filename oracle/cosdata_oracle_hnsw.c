@@ -621,6 +621,186 @@ int coso_index_build_batched(coso_index *ix, uint32_t batch_size) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * PROTOTYPE (not yet mirrored by the device builder): round-synchronous link schedule, the plan of
+ * DESIGN.md §10.1 for moving the link phase to the GPU.  Walks and node creation are those of
+ * coso_index_build_batched.  Per level, the batch's nodes are linked in ROUNDS: pending nodes, in
+ * id order, claim {self} + their candidates; a node runs in the current round iff it is the first
+ * claimer of every row it claimed (a blocked node keeps its claims, so nodes that conflict keep
+ * their id order).  Rows outside a node's own claim are only ever touched through evictions
+ * (the evictee drops its back edge, prob_node.rs:271-279): those removals are queued and applied
+ * in (evictor id, occurrence) order when the round ends.  Runnable nodes of a round touch disjoint
+ * rows, so they can execute concurrently; the result does not depend on their interleaving.
+ * stats[0] = rounds summed over (batch, level), stats[1] = (batch, level) pairs with >= 1 node,
+ * stats[2] = nodes linked, stats[3] = nodes that ran in the first round of their (batch, level).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint32_t old_idx, target; } evict_t;
+
+static int add_neighbor_deferred(level_t *L, int metric, uint32_t self, uint32_t nbr, float dist, uint32_t *evicted) {
+    const uint32_t M = L->M;
+    uint32_t lowest_idx = L->low_idx[self];
+    float lowest_sim = L->low_sim[self];
+    *evicted = IDX_NONE;
+    if (coso_metric_cmp(metric, dist, lowest_sim) <= 0) return -1;
+    uint32_t *nb = L->nbr + (size_t)self * M;
+    float *ns = L->nbr_sim + (size_t)self * M;
+    int ok = (nb[lowest_idx] == IDX_NONE) || coso_metric_cmp(metric, dist, ns[lowest_idx]) > 0;
+    uint32_t old = IDX_NONE;
+    if (ok) { old = nb[lowest_idx]; nb[lowest_idx] = nbr; ns[lowest_idx] = dist; }
+    uint32_t nl = 0;
+    float nsim = metric_max(metric);
+    for (uint32_t j = 0; j < M; j++) {
+        if (nb[j] == IDX_NONE) { nsim = metric_min(metric); nl = j; break; }
+        if (coso_metric_cmp(metric, ns[j], nsim) < 0) { nsim = ns[j]; nl = j; }
+    }
+    L->low_idx[self] = (uint8_t)nl;
+    L->low_sim[self] = nsim;
+    if (!ok) return -1;
+    *evicted = old; /* the caller removes `self` from old's row now (own claim) or at the end of the round */
+    return (int)lowest_idx;
+}
+
+int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uint64_t *stats) {
+    if (!ix || !ix->codes) return COSO_ERR_INVALID;
+    const uint32_t Ltop = ix->p.num_layers, L1 = Ltop + 1;
+    const uint32_t Bmax = batch_size ? batch_size : 4096u;
+    const int metric = (int)ix->p.metric;
+    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
+    uint64_t st[4] = {0, 0, 0, 0};
+    for (uint32_t l = 0; l <= Ltop; l++) level_free(&ix->lv[l]);
+    for (uint32_t i = 0; i < ix->p.dim; i++) ix->root_raw[i] = ix->p.range_lo + rand_f32(&rng) * (ix->p.range_hi - ix->p.range_lo);
+    int rc = coso_index_set_root_raw(ix, ix->root_raw);
+    if (rc != COSO_OK) return rc;
+    for (uint32_t l = 0; l <= Ltop; l++) {
+        uint32_t r = level_append(&ix->lv[l], COSO_ROOT_ID, metric);
+        ix->lv[l].root_idx = r;
+        if (l > 0) ix->lv[l].child[r] = ix->lv[l - 1].root_idx;
+    }
+    double *pv = (double *)malloc(L1 * sizeof(double));
+    uint8_t *pl = (uint8_t *)malloc(L1);
+    coso_level_probs(4.0, (int)Ltop, pv, pl);
+    uint8_t *max_level = (uint8_t *)malloc(ix->n ? ix->n : 1);
+    for (uint32_t id = 0; id < ix->n; id++) max_level[id] = (uint8_t)coso_max_insert_level((double)rand_f32(&rng), pv, pl, (int)L1);
+    scratch_t *s = scratch_new(ix);
+    zent *z = (zent *)malloc((size_t)Bmax * L1 * KEEP_INDEX * sizeof(zent));
+    uint32_t *zn = (uint32_t *)malloc((size_t)Bmax * L1 * 4);
+    uint32_t *me = (uint32_t *)malloc((size_t)Bmax * L1 * 4);
+    /* claim table per node index of a level (level 0 is the largest: n + 1 nodes) */
+    uint32_t *claim_round = (uint32_t *)calloc((size_t)ix->n + 2, 4), *claim_owner = (uint32_t *)calloc((size_t)ix->n + 2, 4);
+    uint32_t round_id = 0;
+    uint32_t *pending = (uint32_t *)malloc((size_t)Bmax * 4), *next = (uint32_t *)malloc((size_t)Bmax * 4);
+    evict_t *q = (evict_t *)malloc((size_t)Bmax * 2 * KEEP_INDEX * sizeof(evict_t));
+    uint32_t inserted = 0;
+    while (inserted < ix->n && rc == COSO_OK) {
+        uint32_t bs = inserted / 4u;
+        if (bs < 1) bs = 1;
+        if (bs > Bmax) bs = Bmax;
+        if (bs > ix->n - inserted) bs = ix->n - inserted;
+        for (uint32_t b = 0; b < bs && rc == COSO_OK; b++) { /* 1. walks on the snapshot (as coso_index_build_batched) */
+            const uint32_t id = inserted + b, row = id;
+            const uint8_t *code = ix->codes + (size_t)row * ix->cb;
+            uint32_t entry = ix->lv[Ltop].root_idx;
+            for (int level = (int)Ltop; level >= 0; level--) {
+                zent *zz = z + ((size_t)b * L1 + (uint32_t)level) * KEEP_INDEX;
+                int cnt = walk_level(ix, (uint32_t)level, entry, code, ix->mags[row], id, ix->p.ef_construction, KEEP_INDEX, s, NULL);
+                if (cnt < 0) { rc = -cnt; break; }
+                if (cnt == 0) {
+                    float d;
+                    rc = node_distance(ix, code, ix->mags[row], row_of(ix, ix->lv[level].node_id[entry]), &d);
+                    if (rc != COSO_OK) break;
+                    zz[0].idx = entry; zz[0].sim = d; cnt = 1;
+                } else
+                    for (int i = 0; i < cnt; i++) { zz[i].idx = s->res[i].idx; zz[i].sim = s->res[i].sim; }
+                zn[(size_t)b * L1 + (uint32_t)level] = (uint32_t)cnt;
+                if (level > 0) entry = ix->lv[level].child[zz[0].idx];
+            }
+        }
+        if (rc != COSO_OK) break;
+        for (uint32_t b = 0; b < bs; b++) { /* 2. nodes of the batch */
+            const uint32_t id = inserted + b;
+            uint32_t parent = IDX_NONE;
+            for (int level = (int)max_level[id]; level >= 0; level--) {
+                uint32_t m = level_append(&ix->lv[level], id, metric);
+                me[(size_t)b * L1 + (uint32_t)level] = m;
+                if (parent != IDX_NONE) ix->lv[level + 1].child[parent] = m;
+                parent = m;
+            }
+        }
+        for (uint32_t l = 0; l <= Ltop; l++) { /* 3. rounds */
+            level_t *L = &ix->lv[l];
+            uint32_t np = 0;
+            for (uint32_t b = 0; b < bs; b++) if (max_level[inserted + b] >= l) pending[np++] = b;
+            if (np == 0) continue;
+            st[1]++;
+            st[2] += np;
+            int first = 1;
+            while (np > 0) {
+                round_id++;
+                st[0]++;
+                uint32_t nn = 0, qn = 0;
+                for (uint32_t k = 0; k < np; k++) {
+                    const uint32_t b = pending[k], node = me[(size_t)b * L1 + l];
+                    const zent *zz = z + ((size_t)b * L1 + l) * KEEP_INDEX;
+                    const int cnt = (int)zn[(size_t)b * L1 + l];
+                    int runnable = 1;
+                    if (!greedy) {
+                        /* ordered: claim {self} + candidates; first claimer of a row in this round owns it, blocked nodes keep
+                         * their claims so that conflicting nodes are linked in id order */
+                        for (int i = -1; i < cnt; i++) {
+                            const uint32_t r = i < 0 ? node : zz[i].idx;
+                            if (claim_round[r] == round_id) { if (claim_owner[r] != b) runnable = 0; }
+                            else { claim_round[r] = round_id; claim_owner[r] = b; }
+                        }
+                    } else {
+                        /* greedy: only RUNNING nodes hold claims (maximal independent set in id order); conflicting nodes may
+                         * be linked out of id order, still deterministic */
+                        for (int i = -1; i < cnt && runnable; i++) {
+                            const uint32_t r = i < 0 ? node : zz[i].idx;
+                            if (claim_round[r] == round_id && claim_owner[r] != b) runnable = 0;
+                        }
+                        if (runnable)
+                            for (int i = -1; i < cnt; i++) {
+                                const uint32_t r = i < 0 ? node : zz[i].idx;
+                                claim_round[r] = round_id; claim_owner[r] = b;
+                            }
+                    }
+                    if (!runnable) { next[nn++] = b; continue; }
+                    if (first) st[3]++;
+                    /* create_node_edges (vector_store.rs:976-1074) with evictions outside the own claim queued */
+                    uint32_t succ = 0;
+                    for (int i = 0; i < cnt; i++) {
+                        if (succ >= L->M) break;
+                        uint32_t ev;
+                        int r = add_neighbor_deferred(L, metric, node, zz[i].idx, zz[i].sim, &ev);
+                        if (ev != IDX_NONE) {
+                            if (claim_round[ev] == round_id && claim_owner[ev] == b) remove_neighbor_by_idx(L, ev, node);
+                            else { q[qn].old_idx = ev; q[qn].target = node; qn++; }
+                        }
+                        if (r >= 0) {
+                            int r2 = add_neighbor_deferred(L, metric, zz[i].idx, node, zz[i].sim, &ev);
+                            if (ev != IDX_NONE) {
+                                if (claim_round[ev] == round_id && claim_owner[ev] == b) remove_neighbor_by_idx(L, ev, zz[i].idx);
+                                else { q[qn].old_idx = ev; q[qn].target = zz[i].idx; qn++; }
+                            }
+                            if (r2 >= 0) succ++;
+                            else if (L->nbr[(size_t)node * L->M + (uint32_t)r] == zz[i].idx) L->nbr[(size_t)node * L->M + (uint32_t)r] = IDX_NONE;
+                        }
+                    }
+                }
+                for (uint32_t e = 0; e < qn; e++) remove_neighbor_by_idx(L, q[e].old_idx, q[e].target); /* end of round */
+                uint32_t *t = pending; pending = next; next = t;
+                np = nn;
+                first = 0;
+            }
+        }
+        inserted += bs;
+    }
+    if (stats) memcpy(stats, st, sizeof(st));
+    free(z); free(zn); free(me); free(max_level); free(pv); free(pl); free(claim_round); free(claim_owner); free(pending); free(next); free(q);
+    scratch_free(s);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * flat export / import: node ids ascending with the root (u32::MAX) last; neighbour slots as
  * internal ids, COSO_SLOT_EMPTY for null pointers.  Slot order is preserved.
  * ---------------------------------------------------------------------------------------- */

@@ -78,6 +78,7 @@ def lib():
         "coso_index_set_vectors": (C.c_int, [vp, vp, C.c_uint32]),
         "coso_index_build": (C.c_int, [vp]),
         "coso_index_build_batched": (C.c_int, [vp, C.c_uint32]),
+        "coso_index_build_rounds": (C.c_int, [vp, C.c_uint32, C.c_int, vp]),
         "coso_index_level_count": (C.c_uint32, [vp, C.c_uint32]),
         "coso_index_export_level": (C.c_int, [vp, C.c_uint32, vp, vp, vp]),
         "coso_index_import_level": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
@@ -274,6 +275,14 @@ class OracleIndex:
         if rc != OK:
             raise ValueError(f"build_batched status {rc}")
         return self
+
+    def build_rounds(self, batch_size=0, greedy=False):
+        """prototype: round-synchronous link schedule; returns (self, stats dict)"""
+        st = np.zeros(4, np.uint64)
+        rc = lib().coso_index_build_rounds(self._h, batch_size, 1 if greedy else 0, st.ctypes.data_as(C.c_void_p))
+        if rc != OK:
+            raise ValueError(f"build_rounds status {rc}")
+        return self, {"rounds": int(st[0]), "batch_levels": int(st[1]), "nodes": int(st[2]), "first_round_nodes": int(st[3])}
 
     @property
     def n(self):

@@ -364,3 +364,29 @@ def test_zero_raw_vector_gets_x86_negative_nan_and_ranks_last():
         finite = sc[b, :c - len(zpos)]
         assert np.all(np.isfinite(finite)) and np.all(finite[:-1] >= finite[1:])
     assert seen > 0
+
+
+def test_round_synchronous_link_prototype():
+    """the round-synchronous link schedule (oracle prototype for the device link phase) is deterministic,
+    links every node, and yields the same graph quality as the id-order replay of coso_index_build_batched."""
+    from tests import helpers as H
+    X = H.clustered_corpus(4000, 32, n_centers=40, seed=3)
+    Q = H.queries_from(X, 64, seed=5)
+    gt, _ = O.bruteforce_topk(X, Q, 10, threads=2)
+    kw = dict(dim=32, num_layers=4, ef_construction=48, ef_search=48, seed=9)
+
+    def recall(ix):
+        ids = ix.search_batch(Q, 10, threads=2)[0]
+        return float(np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(len(Q))]))
+
+    base = recall(O.OracleIndex(O.HNSWParams(**kw)).set_vectors(X).build_batched(128))
+    for greedy in (False, True):
+        a, sa = O.OracleIndex(O.HNSWParams(**kw)).set_vectors(X).build_rounds(128, greedy=greedy)
+        b, sb = O.OracleIndex(O.HNSWParams(**kw)).set_vectors(X).build_rounds(128, greedy=greedy)
+        assert sa == sb
+        for (ia, na), (ib, nb) in zip(a.export_graph(), b.export_graph()):
+            assert np.array_equal(ia, ib) and np.array_equal(na, nb)              # deterministic
+        assert sa["nodes"] >= 4000 and sa["rounds"] >= sa["batch_levels"] and sa["first_round_nodes"] <= sa["nodes"]
+        assert abs(recall(a) - base) <= 0.02, (recall(a), base)
+        deg = np.mean((a.export_graph()[0][1] != 0xFFFFFFFD).sum(axis=1))
+        assert deg > 16
