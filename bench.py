@@ -137,6 +137,11 @@ def main():
     Bc, k = args.batch, args.top_k                # Bc = client batch (a "step"); B = queries per launch
     ef = 256 if args.ef == "auto" else int(args.ef)
     C = max(1, args.coalesce)
+    # time EXACTLY --steps client batches: use the largest launch size (in client batches) that divides --steps, unless that
+    # would shrink launches below a quarter of --coalesce (then the step count is rounded up to whole launches and reported)
+    div = max(c for c in range(1, C + 1) if args.steps % c == 0)
+    if div * 4 >= C:
+        C = div
     B = Bc * C
     n_launch = (args.steps + C - 1) // C
     n_warm = (args.warmup + C - 1) // C
