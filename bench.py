@@ -80,6 +80,32 @@ def bruteforce_top10(X, Q, k=10):
     return torch.cat(ids)
 
 
+def effective_cores():
+    """CPU cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (os.cpu_count() reports
+    the host's logical CPUs even inside a container limited to a few of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:   # cgroup v1
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0 and per > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -358,7 +384,7 @@ def main():
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        cores = os.cpu_count() or 1
+        cores = effective_cores()
         Xh = X.cpu().numpy()
         op = O.HNSWParams(dim=d, storage=O.STORAGE_U8, num_layers=9, ef_construction=args.ef_construction, ef_search=ef, seed=42,
                           range_lo=values_range[0], range_hi=values_range[1])
@@ -379,8 +405,9 @@ def main():
             oix.search_batch(Qh[:nq], k, threads=cores)
         cpu_s = time.perf_counter() - t2
         cpu = {"value": reps * nq / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
-               "sample": f"{reps} passes over {nq} queries of the same workload ({cpu_s:.1f} s wall on {cores} threads), C/AVX2 "
-                         f"restatement of the Rust path (oracle/), one OpenMP thread per core like batch_search's rayon fan-out"}
+               "sample": f"{reps} passes over {nq} queries of the same workload ({cpu_s:.1f} s wall on {cores} threads = usable "
+                         f"cores: affinity/cgroup quota; host reports {os.cpu_count()} logical CPUs), C/AVX2 restatement of the Rust "
+                         f"path (oracle/), one OpenMP thread per core like batch_search's rayon fan-out"}
         # free parity check on the same sample: GPU ids/scores vs oracle
         gi = np.zeros((nq, k), np.uint32)
         gs = np.zeros((nq, k), np.float32)
