@@ -30,6 +30,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / hipIpcGetMemHandle fail in legacy mode); the variable is
+# normally exported already — keep it if the launcher dropped it.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
