@@ -84,6 +84,17 @@ def bruteforce_top10(X, Q, k=10):
     return torch.cat(ids)
 
 
+def launch_shape(steps: int, warmup: int, coalesce: int):
+    """(client batches per launch, timed launches, warm-up launches).  To time EXACTLY `steps` client batches the launch size
+    is the largest divisor of `steps` not above `coalesce` — unless that would shrink launches below a quarter of `coalesce`
+    (then the step count is rounded up to whole launches and the JSON line reports the number actually timed)."""
+    C = max(1, coalesce)
+    div = max(c for c in range(1, C + 1) if steps % c == 0)
+    if div * 4 >= C:
+        C = div
+    return C, (steps + C - 1) // C, (warmup + C - 1) // C
+
+
 def effective_cores():
     """CPU cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (os.cpu_count() reports
     the host's logical CPUs even inside a container limited to a few of them)."""
@@ -166,15 +177,8 @@ def main():
         n = args.n
     Bc, k = args.batch, args.top_k                # Bc = client batch (a "step"); B = queries per launch
     ef = 256 if args.ef == "auto" else int(args.ef)
-    C = max(1, args.coalesce)
-    # time EXACTLY --steps client batches: use the largest launch size (in client batches) that divides --steps, unless that
-    # would shrink launches below a quarter of --coalesce (then the step count is rounded up to whole launches and reported)
-    div = max(c for c in range(1, C + 1) if args.steps % c == 0)
-    if div * 4 >= C:
-        C = div
+    C, n_launch, n_warm = launch_shape(args.steps, args.warmup, args.coalesce)
     B = Bc * C
-    n_launch = (args.steps + C - 1) // C
-    n_warm = (args.warmup + C - 1) // C
     t_setup = time.time()
 
     # ---- synthetic shard + queries (resident in HBM) -------------------------------------------
