@@ -48,6 +48,11 @@ class CosSearchStats(C.Structure):
     ]
 
 
+class CosTimingSummary(C.Structure):
+    _fields_ = [("launches", C.c_uint32), ("prep_ms_sum", C.c_float), ("walk_ms_sum", C.c_float), ("finalize_ms_sum", C.c_float),
+                ("walk_ms_min", C.c_float), ("walk_ms_max", C.c_float)]
+
+
 class CosFlatStats(C.Structure):
     _fields_ = [("gemm_ms", C.c_float), ("gemm_launches", C.c_uint32), ("int8_ops", C.c_double), ("code_bytes", C.c_double)]
 
@@ -73,7 +78,7 @@ ABI_SYMBOLS = [
     "cos_index_upload_vectors", "cos_index_set_root", "cos_index_upload_graph_level", "cos_index_level_count",
     "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build",
     "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_coalescing", "cos_index_set_ef_search",
-    "cos_index_set_visited_mode", "cos_index_enable_timing", "cos_index_last_stats", "cos_quantize_batch",
+    "cos_index_set_visited_mode", "cos_index_enable_timing", "cos_index_last_stats", "cos_index_timing_summary", "cos_quantize_batch",
     "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
     "cos_bm25_search_batch", "cos_rrf_fuse_batch", "cos_merge_topk_device", "cos_merge_topk_packed_device", "cos_hbm_probe",
 ]
@@ -108,6 +113,7 @@ def lib():
         "cos_index_set_visited_mode": [vp, u32],
         "cos_index_enable_timing": [vp, i32],
         "cos_index_last_stats": [vp, vp, C.POINTER(CosSearchStats)],
+        "cos_index_timing_summary": [vp, vp, C.POINTER(CosTimingSummary)],
         "cos_quantize_batch": [u32, u32, u32, f32, f32, vp, u32, vp, vp],
         "cos_sample_values_range": [vp, u32, u32, f32, C.POINTER(f32), C.POINTER(f32)],
         "cos_distance_batch": [u32, u32, u32, u32, vp, vp, u32, vp, vp, u32, vp, vp, u32, vp, vp],

@@ -174,6 +174,7 @@ extern "C" int32_t cos_index_destroy(cos_index *ix) {
     (void)hipSetDevice(ix->p.device);
     (void)hipDeviceSynchronize();
     for (auto &kv : ix->ws) free_ws(kv.second);
+    for (auto &kv : ix->thread_streams) if (kv.second) (void)hipStreamDestroy(kv.second);
     for (auto &l : ix->lv) free_level(l);
     if (ix->d_raw && !ix->raw_borrowed) (void)hipFree(ix->d_raw);
     if (ix->d_raw_mags) (void)hipFree(ix->d_raw_mags);
@@ -201,6 +202,19 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     ix->have_root = false;
     for (auto &l : ix->lv) free_level(l); // a graph refers to vector rows: new vectors invalidate it
     const u64 dim = ix->p.dim;
+    struct Rollback { // a failed upload leaves the handle empty instead of half-populated
+        cos_index *ix;
+        bool armed = true;
+        ~Rollback() {
+            if (!armed) return;
+            if (ix->d_raw && !ix->raw_borrowed) (void)hipFree(ix->d_raw);
+            if (ix->d_raw_mags) (void)hipFree(ix->d_raw_mags);
+            if (ix->d_codes) (void)hipFree(ix->d_codes);
+            if (ix->d_mags) (void)hipFree(ix->d_mags);
+            ix->d_raw = nullptr; ix->d_raw_mags = nullptr; ix->d_codes = nullptr; ix->d_mags = nullptr;
+            ix->raw_borrowed = false;
+        }
+    } rollback{ix};
     if (flags & COS_UPLOAD_BORROW_DEVICE) {
         // the caller's producer (e.g. a torch kernel on another stream) may still be writing the buffer: our streams
         // are non-blocking, so drain the device once before the quantize kernel reads it
@@ -219,6 +233,7 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     HIP_TRY(launch_quantize_rows(ix->eng, ix->d_raw, dim, n, ix->p.dim, ix->p.range_lo, ix->p.range_hi, ix->d_codes, ix->row_stride,
                                  ix->d_mags, ix->d_raw_mags, ix->own_stream));
     HIP_TRY(hipStreamSynchronize(ix->own_stream));
+    rollback.armed = false;
     ix->n = n;
     ix->have_vectors = true;
     ix->have_root = false;
@@ -231,16 +246,13 @@ extern "C" int32_t cos_index_set_root(cos_index *ix, const float *root_raw) {
     int32_t rc = cos_set_device(ix);
     if (rc) return rc;
     ix->root_raw.assign(root_raw, root_raw + ix->p.dim);
-    float *d_tmp = nullptr; // [dim] staged root + 1 float for the unused raw-norm output
-    HIP_TRY(hipMalloc(&d_tmp, ((size_t)ix->p.dim + 1) * 4));
-    float *d_dummy = d_tmp + ix->p.dim;
-    hipError_t e = hipMemcpy(d_tmp, root_raw, (size_t)ix->p.dim * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_quantize_rows(ix->eng, d_tmp, ix->p.dim, 1, ix->p.dim, ix->p.range_lo, ix->p.range_hi,
-                                        ix->d_codes + (size_t)ix->n * ix->row_stride, ix->row_stride, ix->d_mags + ix->n, d_dummy,
-                                        ix->own_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ix->own_stream);
-    (void)hipFree(d_tmp);
-    HIP_TRY(e);
+    DevBuf tmp; // [dim] staged root + 1 float for the unused raw-norm output
+    HIP_TRY(tmp.alloc(((size_t)ix->p.dim + 1) * 4));
+    float *d_tmp = tmp.as<float>(), *d_dummy = d_tmp + ix->p.dim;
+    HIP_TRY(hipMemcpy(d_tmp, root_raw, (size_t)ix->p.dim * 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_quantize_rows(ix->eng, d_tmp, ix->p.dim, 1, ix->p.dim, ix->p.range_lo, ix->p.range_hi,
+                                 ix->d_codes + (size_t)ix->n * ix->row_stride, ix->row_stride, ix->d_mags + ix->n, d_dummy, ix->own_stream));
+    HIP_TRY(hipStreamSynchronize(ix->own_stream));
     ix->have_root = true;
     return COS_OK;
 }
@@ -383,24 +395,29 @@ extern "C" int32_t cos_index_download_codes(const cos_index *ix, void *codes, fl
 }
 
 extern "C" int32_t cos_index_download_root(const cos_index *ix, float *root_raw) {
-    if (!ix || !ix->have_root) return cos_fail(COS_ERR_NOT_READY, "no root");
+    if (!ix || !root_raw) return cos_fail(COS_ERR_INVALID, "null argument");
+    if (!ix->have_root) return cos_fail(COS_ERR_NOT_READY, "no root");
     memcpy(root_raw, ix->root_raw.data(), (size_t)ix->p.dim * 4);
     return COS_OK;
 }
 
 extern "C" int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef) {
-    if (!ix || ef > 512) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
+    if (ef > 512) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
+    std::lock_guard<std::mutex> g(ix->mu); // searches snapshot ef / visited mode under the same lock (run_search)
     ix->p.ef_search = ef;
     return COS_OK;
 }
 extern "C" int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode) {
     if (!ix || mode > 1) return cos_fail(COS_ERR_INVALID, "bad visited mode");
+    std::lock_guard<std::mutex> g(ix->mu);
     ix->p.visited_mode = mode;
     return COS_OK;
 }
 extern "C" int32_t cos_index_enable_timing(cos_index *ix, int32_t on) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (on && !ix->timing) for (auto &kv : ix->ws) kv.second->ev_count = 0; // a new measurement window
     ix->timing = on != 0;
     return COS_OK;
 }
@@ -482,7 +499,10 @@ static int32_t get_workspace(cos_index *ix, void *stream_key, u32 B, u32 top_k, 
         HIP_TRY(regrow(w->d_out_scores, (size_t)w->capB * top_k));
         w->cap_topk = top_k;
     }
-    if (!w->ev[0]) for (auto &e : w->ev) HIP_TRY(hipEventCreate(&e));
+    if (w->ev.empty()) {
+        w->ev.assign((size_t)Workspace::EV_RING * 4, nullptr);
+        for (auto &e : w->ev) HIP_TRY(hipEventCreate(&e));
+    }
     *out = w;
     return COS_OK;
 }
@@ -492,21 +512,28 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
                           u32 *d_out_counts, int32_t *d_out_status, bool do_finalize, hipStream_t st) {
     IndexDev dev = cos_make_index_dev(ix);
     bool timed;
-    { std::lock_guard<std::mutex> g(ix->mu); timed = ix->timing; }
+    u32 ef;
+    { // one consistent snapshot of the knobs cos_index_set_* may change from another thread
+        std::lock_guard<std::mutex> g(ix->mu);
+        timed = ix->timing;
+        ef = ix->p.ef_search;
+        dev.visited_mode = ix->p.visited_mode;
+    }
     WalkArgs wa;
     memset(&wa, 0, sizeof(wa));
     if (dev.visited_mode == COS_VISITED_EXACT) {
-        int32_t rc = vis_tab_prepare(w->vis, ix, B, ix->p.ef_search, st, wa);
+        int32_t rc = vis_tab_prepare(w->vis, ix, B, ef, st, wa);
         if (rc) return rc;
     }
-    if (timed) HIP_TRY(hipEventRecord(w->ev[0], st));
+    hipEvent_t *ev = &w->ev[(size_t)(w->ev_count % Workspace::EV_RING) * 4];
+    if (timed) HIP_TRY(hipEventRecord(ev[0], st));
     HIP_TRY(launch_quantize_rows(ix->eng, d_queries, ix->p.dim, B, ix->p.dim, ix->p.range_lo, ix->p.range_hi, w->q_codes, ix->row_stride,
                                  w->q_mags, w->q_raw_mags, st));
-    if (timed) HIP_TRY(hipEventRecord(w->ev[1], st));
+    if (timed) HIP_TRY(hipEventRecord(ev[1], st));
     wa.qcodes = w->q_codes;
     wa.qmags = w->q_mags;
     wa.B = B;
-    wa.ef = ix->p.ef_search;
+    wa.ef = ef;
     wa.keep = KEEP_SEARCH;
     wa.out_ids = w->walk_ids;
     wa.out_sims = w->walk_sims;
@@ -514,12 +541,12 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     wa.out_status = w->walk_status;
     wa.out_stats = w->stats;
     HIP_TRY(launch_walk(ix->eng, dev, wa, st));
-    if (timed) HIP_TRY(hipEventRecord(w->ev[2], st));
+    if (timed) HIP_TRY(hipEventRecord(ev[2], st));
     if (do_finalize) {
         HIP_TRY(launch_finalize(dev, d_queries, ix->p.dim, w->q_raw_mags, w->walk_ids, w->walk_sims, w->walk_counts, w->walk_status, B, top_k,
                                 d_out_ids, d_out_scores, d_out_counts, d_out_status, w->rerank_rows, st));
     }
-    if (timed) HIP_TRY(hipEventRecord(w->ev[3], st));
+    if (timed) { HIP_TRY(hipEventRecord(ev[3], st)); w->ev_count++; }
     w->lastB = B;
     w->timed = timed;
     { std::lock_guard<std::mutex> g(ix->mu); ix->last_ws = w; }
@@ -545,17 +572,24 @@ extern "C" int32_t cos_search_batch_device(cos_index *ix, const float *d_queries
     return run_search(ix, w, d_queries, B, top_k, d_out_ids, d_out_scores, d_out_counts, d_out_status, true, (hipStream_t)stream);
 }
 
+// host API: a private stream (and, through it, a private workspace) per calling thread, so concurrent callers (rayon
+// workers, indexes/mod.rs:268-271) neither serialise nor share staging buffers.  The streams belong to the handle and
+// die with it (cos_index_destroy).
+static int32_t thread_stream(cos_index *ix, hipStream_t *out) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    hipStream_t &st = ix->thread_streams[std::this_thread::get_id()];
+    if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *out = st;
+    return COS_OK;
+}
+
 // one launch for a contiguous host batch, on the calling thread's private stream
 static int32_t search_host_once(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,
                                 uint32_t *out_counts, int32_t *out_status) {
     int32_t rc;
-    // host API: a private stream per calling thread so concurrent callers (rayon workers) do not serialise
-    static thread_local std::map<cos_index *, hipStream_t> tl_streams;
-    hipStream_t st = tl_streams[ix];
-    if (!st) {
-        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        tl_streams[ix] = st;
-    }
+    hipStream_t st;
+    rc = thread_stream(ix, &st);
+    if (rc) return rc;
     Workspace *w;
     rc = get_workspace(ix, (void *)st, B, top_k, true, &w);
     if (rc) return rc;
@@ -692,7 +726,10 @@ extern "C" int32_t cos_ann_search_batch(cos_index *ix, const float *queries, uin
                                         uint32_t *out_counts, int32_t *out_status) {
     int32_t rc = check_search_args(ix, queries, B, 1);
     if (rc) return rc;
-    hipStream_t st = ix->own_stream;
+    if (!out_ids || !out_sims || !out_counts) return cos_fail(COS_ERR_INVALID, "null output");
+    hipStream_t st;
+    rc = thread_stream(ix, &st); // same per-thread stream + workspace as cos_search_batch: thread-safe on a shared handle
+    if (rc) return rc;
     Workspace *w;
     rc = get_workspace(ix, (void *)st, B, 1, true, &w);
     if (rc) return rc;
@@ -728,11 +765,12 @@ extern "C" int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_
         if (!w) return cos_fail(COS_ERR_NOT_READY, "no batch has run on this stream");
     }
     if (w->lastB == 0) return cos_fail(COS_ERR_NOT_READY, "no batch has run on this stream");
-    if (w->timed) {
-        HIP_TRY(hipEventSynchronize(w->ev[3]));
-        HIP_TRY(hipEventElapsedTime(&out->prep_ms, w->ev[0], w->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&out->walk_ms, w->ev[1], w->ev[2]));
-        HIP_TRY(hipEventElapsedTime(&out->finalize_ms, w->ev[2], w->ev[3]));
+    if (w->timed && w->ev_count) {
+        hipEvent_t *ev = &w->ev[(size_t)((w->ev_count - 1) % Workspace::EV_RING) * 4];
+        HIP_TRY(hipEventSynchronize(ev[3]));
+        HIP_TRY(hipEventElapsedTime(&out->prep_ms, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&out->walk_ms, ev[1], ev[2]));
+        HIP_TRY(hipEventElapsedTime(&out->finalize_ms, ev[2], ev[3]));
     } else {
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -745,6 +783,37 @@ extern "C" int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_
         out->adj_bytes += st[(size_t)b * 4 + 2];
         out->reserved += (uint32_t)st[(size_t)b * 4 + 3]; // walk rounds (lookahead windows issued)
         out->rerank_rows += rr[b];
+    }
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_timing_summary(cos_index *ix, void *stream, cos_timing_summary *out) {
+    if (!ix || !out) return cos_fail(COS_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    Workspace *w = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        auto it = ix->ws.find(stream);
+        if (it != ix->ws.end()) w = it->second;
+    }
+    if (!w || w->ev_count == 0) return cos_fail(COS_ERR_NOT_READY, "no timed batch has run on this stream");
+    const u32 n = std::min(w->ev_count, Workspace::EV_RING);
+    out->launches = n;
+    out->walk_ms_min = 1e30f;
+    for (u32 i = 0; i < n; i++) {
+        hipEvent_t *ev = &w->ev[(size_t)((w->ev_count - 1 - i) % Workspace::EV_RING) * 4];
+        float a = 0, b = 0, c = 0;
+        HIP_TRY(hipEventSynchronize(ev[3]));
+        HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
+        HIP_TRY(hipEventElapsedTime(&c, ev[2], ev[3]));
+        out->prep_ms_sum += a;
+        out->walk_ms_sum += b;
+        out->finalize_ms_sum += c;
+        out->walk_ms_min = std::min(out->walk_ms_min, b);
+        out->walk_ms_max = std::max(out->walk_ms_max, b);
     }
     return COS_OK;
 }
@@ -767,18 +836,15 @@ extern "C" int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uin
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
     if (eng < 0) return quantize_ref_layout(storage, resolution, dim, x, n, codes, mags);
-    float *d_x = nullptr, *d_m = nullptr;
-    uint8_t *d_c = nullptr;
-    HIP_TRY(hipMalloc(&d_x, (size_t)n * dim * 4));
-    HIP_TRY(hipMalloc(&d_m, (size_t)n * 4));
-    HIP_TRY(hipMalloc(&d_c, (size_t)n * row_stride));
-    hipError_t e = hipMemcpy(d_x, x, (size_t)n * dim * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_quantize_rows(eng, d_x, dim, n, dim, lo, hi, d_c, row_stride, d_m, nullptr, 0);
+    DevBuf bx, bm, bc;
+    HIP_TRY(bx.alloc((size_t)n * dim * 4));
+    HIP_TRY(bm.alloc((size_t)n * 4));
+    HIP_TRY(bc.alloc((size_t)n * row_stride));
+    HIP_TRY(hipMemcpy(bx.p, x, (size_t)n * dim * 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_quantize_rows(eng, bx.as<float>(), dim, n, dim, lo, hi, bc.as<uint8_t>(), row_stride, bm.as<float>(), nullptr, 0));
     std::vector<uint8_t> dev((size_t)n * row_stride);
-    if (e == hipSuccess) e = hipMemcpy(dev.data(), d_c, dev.size(), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(mags, d_m, (size_t)n * 4, hipMemcpyDeviceToHost);
-    (void)(void)hipFree(d_x); (void)hipFree(d_m); (void)hipFree(d_c);
-    HIP_TRY(e);
+    HIP_TRY(hipMemcpy(dev.data(), bc.p, dev.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mags, bm.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     const size_t cb = cos_code_bytes(storage, resolution, dim);
     for (size_t r = 0; r < n; r++) row_to_reference_layout(eng, dim, dev.data() + r * row_stride, (uint8_t *)codes + r * cb);
     return COS_OK;

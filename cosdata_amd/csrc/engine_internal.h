@@ -6,6 +6,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cosdata_hip.h"
@@ -34,6 +35,17 @@ int32_t cos_fail(int32_t code, const char *fmt, ...);
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) return cos_fail(COS_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
+
+// scoped device allocation: temporaries of an entry point are released on every return path
+struct DevBuf {
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T> T *as() const { return (T *)p; }
+};
 
 // ------------------------------------------------------------------------------------------------
 // handle
@@ -72,7 +84,11 @@ struct Workspace {
     u32 *d_out_ids = nullptr, *d_out_counts = nullptr;
     float *d_out_scores = nullptr;
     int32_t *d_out_status = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // timing: a ring of event quadruples (before prep | after prep | after walk | after finalize), one per launch, so a
+    // run of launches can be summarised afterwards without synchronising between them (cos_index_timing_summary)
+    static constexpr u32 EV_RING = 128;
+    std::vector<hipEvent_t> ev; // [EV_RING][4]
+    u32 ev_count = 0;           // timed launches since timing was switched on (ring position = ev_count % EV_RING)
     u32 lastB = 0;
     bool timed = false;
 };
@@ -90,9 +106,10 @@ struct cos_index {
     u32 nchunks = 0, G = 1;
     std::vector<float> root_raw;
     std::vector<LevelHost> lv;
-    hipStream_t own_stream = nullptr; // host API stream
-    std::mutex mu;                    // guards workspaces map + timing flag
+    hipStream_t own_stream = nullptr; // uploads / builder stream (exclusive entry points)
+    std::mutex mu;                    // guards the workspace + thread-stream maps, the timing flag, ef_search and visited_mode
     std::map<void *, Workspace *> ws;
+    std::map<std::thread::id, hipStream_t> thread_streams; // host-API searches: one private stream per calling thread, owned here
     Workspace *last_ws = nullptr; // most recent batch (cos_index_last_stats with stream == NULL)
     // host-API request coalescing (cos_index_set_coalescing)
     std::mutex co_mu;

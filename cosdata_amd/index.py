@@ -23,7 +23,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import CosdataError, CosFlatStats, CosParams, CosSearchStats, check
+from ._lib import CosdataError, CosFlatStats, CosParams, CosSearchStats, CosTimingSummary, check
 
 ROOT_ID, QUERY_ID, SLOT_EMPTY = 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFFFD
 VISITED_REF, VISITED_EXACT = 0, 1
@@ -145,7 +145,8 @@ class HNSWIndex:
     # ---- uploads ----------------------------------------------------------------------------
     def upload_vectors(self, raw):
         raw = _c(raw, np.float32)
-        assert raw.ndim == 2 and raw.shape[1] == self.dim
+        if raw.ndim != 2 or raw.shape[1] != self.dim:
+            raise CosdataError(_lib.ERR_INVALID, f"vectors must be [n][{self.dim}] f32, got shape {tuple(raw.shape)}")
         check(_lib.lib().cos_index_upload_vectors(self._h, _p(raw), raw.shape[0], 0))
         self.n = raw.shape[0]
         return self
@@ -157,8 +158,17 @@ class HNSWIndex:
         self._keepalive = keepalive
         return self
 
+    def _queries(self, queries) -> np.ndarray:
+        """[B][dim] contiguous f32; a wrong dimension is an error, never an out-of-bounds host read on the C side."""
+        q = _c(np.atleast_2d(queries), np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise CosdataError(_lib.ERR_INVALID, f"queries must be [B][{self.dim}] f32, got shape {tuple(q.shape)}")
+        return q
+
     def set_root(self, root_raw):
         r = _c(root_raw, np.float32)
+        if r.size != self.dim:
+            raise CosdataError(_lib.ERR_INVALID, f"root vector must hold {self.dim} values, got {r.size}")
         check(_lib.lib().cos_index_set_root(self._h, _p(r)))
         return self
 
@@ -225,7 +235,7 @@ class HNSWIndex:
         """IndexOps::batch_search: [B][dim] raw f32 -> (ids [B][k], scores [B][k], counts [B]).
         Raises CosdataError (status 2 = CalculationError) if any query fails, like the
         reference's collect::<Result<_>>; return_status=True returns per-query statuses instead."""
-        q = _c(np.atleast_2d(queries), np.float32)
+        q = self._queries(queries)
         B = q.shape[0]
         ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
         scores = np.zeros((B, top_k), np.float32)
@@ -251,7 +261,7 @@ class HNSWIndex:
 
     def ann_search_batch(self, queries):
         """ann_search's per-level lists before finalisation: ids/sims [B][L+1][100], counts [B][L+1]."""
-        q = _c(np.atleast_2d(queries), np.float32)
+        q = self._queries(queries)
         B, L1 = q.shape[0], self.hnsw_params.num_layers + 1
         ids = np.zeros((B, L1, 100), np.uint32)
         sims = np.zeros((B, L1, 100), np.float32)
@@ -268,9 +278,15 @@ class HNSWIndex:
         check(_lib.lib().cos_index_last_stats(self._h, C.c_void_p(stream), C.byref(st)))
         return st
 
+    def timing_summary(self, stream: int) -> CosTimingSummary:
+        """HIP-event times of the launches enqueued on `stream` since enable_timing(True)."""
+        st = CosTimingSummary()
+        check(_lib.lib().cos_index_timing_summary(self._h, C.c_void_p(stream), C.byref(st)))
+        return st
+
     def flat_search(self, queries, top_k: int, with_stats: bool = False):
         """Exhaustive search over the quantized codes (i8 MFMA GEMM) + exact rerank of the best 5k."""
-        q = _c(np.atleast_2d(queries), np.float32)
+        q = self._queries(queries)
         B = q.shape[0]
         ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
         scores = np.zeros((B, top_k), np.float32)
@@ -280,7 +296,7 @@ class HNSWIndex:
         return (ids, scores, counts, st) if with_stats else (ids, scores, counts)
 
     def bruteforce_topk(self, queries, k: int):
-        q = _c(np.atleast_2d(queries), np.float32)
+        q = self._queries(queries)
         ids = np.zeros((q.shape[0], k), np.uint32)
         scores = np.zeros((q.shape[0], k), np.float32)
         check(_lib.lib().cos_bruteforce_topk(self._h, _p(q), q.shape[0], k, _p(ids), _p(scores)))

@@ -157,6 +157,14 @@ int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode);
 /* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
 int32_t cos_index_enable_timing(cos_index *ix, int32_t on);
 int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out);
+/* HIP-event times of the (up to 128 most recent) launches enqueued on `stream` since cos_index_enable_timing(1):
+ * sums / extremes per kernel, read after the fact so the measured launches are never synchronised in between. */
+typedef struct {
+    uint32_t launches;
+    float prep_ms_sum, walk_ms_sum, finalize_ms_sum;
+    float walk_ms_min, walk_ms_max;
+} cos_timing_summary;
+int32_t cos_index_timing_summary(cos_index *ix, void *stream, cos_timing_summary *out);
 
 /* ---- operators (L1 of SURVEY.md §1) --------------------------------------------------------- */
 /* QuantizationMetric::quantize (models/types.rs:504) for n vectors; codes in the REFERENCE layout

@@ -119,6 +119,11 @@ void coso_index_destroy(coso_index *ix);
 /* Give the index its corpus: raw f32 [n][dim] (borrowed, must outlive the index).
  * Quantizes every vector with the index storage (ScalarQuantization::quantize). */
 int coso_index_set_vectors(coso_index *ix, const float *raw, uint32_t n);
+/* Corpora whose raw f32 table does not fit in host memory: allocate the code table, quantize chunks of rows as they are
+ * streamed in (same ScalarQuantization::quantize), and give the exact rerank a subset of raw rows (ids ascending, borrowed). */
+int coso_index_alloc_vectors(coso_index *ix, uint32_t n);
+int coso_index_quantize_rows(coso_index *ix, uint32_t start, const float *raw_chunk, uint32_t m);
+int coso_index_set_raw_subset(coso_index *ix, const uint32_t *ids_sorted, const float *rows, uint32_t m);
 /* Deterministic single-threaded builder with reference edge semantics (App. A.4).
  * Inserts ids [0, n) in order.  Creates the root first (random vector in values_range). */
 int coso_index_build(coso_index *ix);
@@ -153,6 +158,9 @@ typedef struct {
 int coso_search_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k,
                       uint32_t *out_ids, float *out_scores, uint32_t *out_counts, int32_t *out_status,
                       coso_stats *stats /*[B] or NULL*/, int threads);
+/* walk + remove_duplicates_and_filter only: out_ids [B][5*top_k] = the candidates whose raw rows the rerank reads */
+int coso_candidates_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                          uint32_t *out_counts, int threads);
 /* Raw walk output before finalisation: ann_search's concatenated per-level lists.
  * out_ids/out_sims: [ (num_layers+1) * 100 ]; returns count or negative status. */
 int coso_ann_search(const coso_index *ix, const float *query, uint32_t *out_ids, float *out_sims,

@@ -38,6 +38,11 @@ struct coso_index {
     float *root_raw;
     level_t *lv; /* [num_layers+1] */
     int has_root;
+    /* corpora too large for a host copy of the raw f32 table (bench.py --workload c4shard): the rerank reads the raw rows of
+     * the few candidates it needs from a caller-provided subset (ids ascending) instead of ix->raw */
+    const uint32_t *sub_ids;
+    const float *sub_rows;
+    uint32_t sub_n;
 };
 
 typedef struct {
@@ -128,6 +133,48 @@ int coso_index_set_vectors(coso_index *ix, const float *raw, uint32_t n) {
         coso_quantize(ix->root_raw, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo,
                       ix->p.range_hi, ix->codes + (size_t)n * ix->cb, &ix->mags[n]);
     return rc;
+}
+
+/* Chunked variant of coso_index_set_vectors for corpora whose raw f32 table does not fit in host memory: allocate the code
+ * table, then quantize chunks of rows as they are streamed in; ix->raw stays NULL (see coso_index_set_raw_subset). */
+int coso_index_alloc_vectors(coso_index *ix, uint32_t n) {
+    if (!ix) return COSO_ERR_INVALID;
+    free(ix->codes); free(ix->mags);
+    ix->n = n;
+    ix->raw = NULL;
+    ix->codes = (uint8_t *)calloc((size_t)n + 1, ix->cb);
+    ix->mags = (float *)calloc((size_t)n + 1, sizeof(float));
+    return ix->codes && ix->mags ? COSO_OK : COSO_ERR_INVALID;
+}
+int coso_index_quantize_rows(coso_index *ix, uint32_t start, const float *raw_chunk, uint32_t m) {
+    if (!ix || !ix->codes || (uint64_t)start + m > ix->n) return COSO_ERR_INVALID;
+    int rc = COSO_OK;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)m; i++) {
+        int r = coso_quantize(raw_chunk + (size_t)i * ix->p.dim, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution,
+                              ix->p.range_lo, ix->p.range_hi, ix->codes + ((size_t)start + (size_t)i) * ix->cb, &ix->mags[start + i]);
+        if (r != COSO_OK) rc = r;
+    }
+    return rc;
+}
+int coso_index_set_raw_subset(coso_index *ix, const uint32_t *ids_sorted, const float *rows, uint32_t m) {
+    if (!ix) return COSO_ERR_INVALID;
+    for (uint32_t i = 1; i < m; i++)
+        if (ids_sorted[i] <= ids_sorted[i - 1]) return COSO_ERR_INVALID;
+    ix->sub_ids = ids_sorted;
+    ix->sub_rows = rows;
+    ix->sub_n = m;
+    return COSO_OK;
+}
+/* raw f32 row of an internal id for the exact rerank: the full table, or the caller's subset (NULL if absent) */
+static const float *raw_row(const coso_index *ix, uint32_t id) {
+    if (ix->raw) return ix->raw + (size_t)id * ix->p.dim;
+    uint32_t lo = 0, hi = ix->sub_n;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (ix->sub_ids[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    return (lo < ix->sub_n && ix->sub_ids[lo] == id) ? ix->sub_rows + (size_t)lo * ix->p.dim : NULL;
 }
 
 const float *coso_index_root_raw(const coso_index *ix) { return ix->root_raw; }
@@ -331,8 +378,9 @@ static int cmp_fent_desc(const void *a, const void *b) {
 }
 
 /* search_internal (indexes/hnsw/mod.rs:390-440) for one query */
+/* candidates_only: stop after remove_duplicates_and_filter and return the <= 5k ids the rerank would read (out_ids [5k]) */
 static int search_one(const coso_index *ix, const float *q, uint32_t top_k, scratch_t *s, hent *all, fent *f, uint32_t *out_ids,
-                      float *out_scores, uint32_t *out_count, coso_stats *st) {
+                      float *out_scores, uint32_t *out_count, coso_stats *st, int candidates_only) {
     float qmag;
     int rc = coso_quantize(q, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo, ix->p.range_hi,
                            s->qcode, &qmag);
@@ -354,12 +402,18 @@ static int search_one(const coso_index *ix, const float *q, uint32_t top_k, scra
     m = w;
     qsort(all, (size_t)m, sizeof(hent), cmp_hent_desc);
     if ((uint32_t)m > 5 * top_k) m = (int)(5 * top_k);
+    if (candidates_only) {
+        for (int i = 0; i < m; i++) out_ids[i] = all[i].id;
+        *out_count = (uint32_t)m;
+        return COSO_OK;
+    }
     /* finalize_ann_results (vector_store.rs:404-445): exact cosine on RAW f32, norm recomputed per candidate */
     const int d = (int)ix->p.dim;
     float mag_query = coso_seq_norm_f32(q, d);
     for (int i = 0; i < m; i++) {
         uint32_t id = all[i].id;
-        const float *rv = ix->raw + (size_t)id * d;
+        const float *rv = raw_row(ix, id);
+        if (!rv) return COSO_ERR_INVALID; /* raw subset does not cover this candidate */
         float dp = coso_dot_f32(q, rv, d);
         float mag_raw = coso_seq_norm_f32(rv, d);
         float cs = dp / (mag_query * mag_raw);
@@ -375,7 +429,7 @@ static int search_one(const coso_index *ix, const float *q, uint32_t top_k, scra
 
 int coso_search_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
                       float *out_scores, uint32_t *out_counts, int32_t *out_status, coso_stats *stats, int threads) {
-    if (!ix || !ix->raw || top_k == 0) return COSO_ERR_INVALID;
+    if (!ix || (!ix->raw && !ix->sub_rows) || top_k == 0) return COSO_ERR_INVALID;
     int first_err = COSO_OK;
     if (threads < 1) threads = 1;
 #pragma omp parallel num_threads(threads)
@@ -388,7 +442,7 @@ int coso_search_batch(const coso_index *ix, const float *queries, uint32_t B, ui
             coso_stats st = {0, 0, 0};
             uint32_t cnt = 0;
             int rc = search_one(ix, queries + (size_t)b * ix->p.dim, top_k, s, all, fbuf, out_ids + (size_t)b * top_k,
-                                out_scores + (size_t)b * top_k, &cnt, &st);
+                                out_scores + (size_t)b * top_k, &cnt, &st, 0);
             out_counts[b] = rc == COSO_OK ? cnt : 0;
             if (out_status) out_status[b] = rc;
             if (stats) stats[b] = st;
@@ -399,6 +453,33 @@ int coso_search_batch(const coso_index *ix, const float *queries, uint32_t B, ui
         }
         free(all);
         free(fbuf);
+        scratch_free(s);
+    }
+    return first_err;
+}
+
+/* walk + remove_duplicates_and_filter only: the <= 5*top_k ids per query whose raw rows finalize_ann_results reads
+ * (out_ids [B][5*top_k]).  Lets a caller that cannot hold the raw table on the host fetch exactly those rows. */
+int coso_candidates_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                          uint32_t *out_counts, int threads) {
+    if (!ix || top_k == 0) return COSO_ERR_INVALID;
+    int first_err = COSO_OK;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        scratch_t *s = scratch_new(ix);
+        hent *all = (hent *)malloc((size_t)(ix->p.num_layers + 1) * KEEP_SEARCH * sizeof(hent));
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            uint32_t cnt = 0;
+            int rc = search_one(ix, queries + (size_t)b * ix->p.dim, top_k, s, all, NULL, out_ids + (size_t)b * 5 * top_k, NULL, &cnt, NULL, 1);
+            out_counts[b] = rc == COSO_OK ? cnt : 0;
+            if (rc != COSO_OK) {
+#pragma omp critical
+                if (first_err == COSO_OK) first_err = rc;
+            }
+        }
+        free(all);
         scratch_free(s);
     }
     return first_err;

@@ -76,6 +76,10 @@ def lib():
         "coso_index_create": (vp, [P(Params)]),
         "coso_index_destroy": (None, [vp]),
         "coso_index_set_vectors": (C.c_int, [vp, vp, C.c_uint32]),
+        "coso_index_alloc_vectors": (C.c_int, [vp, C.c_uint32]),
+        "coso_index_quantize_rows": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32]),
+        "coso_index_set_raw_subset": (C.c_int, [vp, vp, vp, C.c_uint32]),
+        "coso_candidates_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
         "coso_index_build": (C.c_int, [vp]),
         "coso_index_build_batched": (C.c_int, [vp, C.c_uint32]),
         "coso_index_build_rounds": (C.c_int, [vp, C.c_uint32, C.c_int, vp]),
@@ -264,6 +268,38 @@ class OracleIndex:
             raise ValueError(f"set_vectors status {rc}")
         return self
 
+    # ---- corpora without a host copy of the raw table (bench.py --workload c4shard) ----
+    def alloc_vectors(self, n):
+        self._raw = None
+        self._n = int(n)
+        rc = lib().coso_index_alloc_vectors(self._h, self._n)
+        if rc != OK:
+            raise ValueError(f"alloc_vectors status {rc}")
+        return self
+
+    def quantize_rows(self, start, raw_chunk):
+        x = _c(raw_chunk, np.float32)
+        rc = lib().coso_index_quantize_rows(self._h, int(start), _p(x), x.shape[0])
+        if rc != OK:
+            raise ValueError(f"quantize_rows status {rc}")
+
+    def set_raw_subset(self, ids_sorted, rows):
+        self._sub = (_c(ids_sorted, np.uint32), _c(rows, np.float32))  # borrowed by the C side: keep alive
+        rc = lib().coso_index_set_raw_subset(self._h, _p(self._sub[0]), _p(self._sub[1]), self._sub[0].size)
+        if rc != OK:
+            raise ValueError(f"set_raw_subset status {rc}")
+
+    def candidates_batch(self, queries, top_k, threads=1):
+        """ids [B][5k] (+ counts [B]) of the candidates whose raw rows the exact rerank reads"""
+        q = _c(queries, np.float32)
+        B = q.shape[0]
+        ids = np.full((B, 5 * top_k), 0xFFFFFFFF, np.uint32)
+        counts = np.zeros(B, np.uint32)
+        rc = lib().coso_candidates_batch(self._h, _p(q), B, top_k, _p(ids), _p(counts), threads)
+        if rc != OK:
+            raise ValueError(f"candidates status {rc}")
+        return ids, counts
+
     def build(self):
         rc = lib().coso_index_build(self._h)
         if rc != OK:
@@ -286,7 +322,7 @@ class OracleIndex:
 
     @property
     def n(self):
-        return 0 if self._raw is None else self._raw.shape[0]
+        return getattr(self, "_n", 0) if self._raw is None else self._raw.shape[0]
 
     def level_M(self, level):
         return self.params.level0_neighbors_count if level == 0 else self.params.neighbors_count

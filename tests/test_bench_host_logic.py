@@ -1,23 +1,37 @@
-"""Host-side logic of bench.py that needs no GPU: launch shaping (exactly K timed steps) and the usable-core count."""
+"""Host-side logic of bench.py that needs no GPU: the ef selection rule (selection set / confidence bound) and the
+usable-core count."""
 import os
 import sys
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def test_launch_shape_times_exactly_k_steps_when_it_can():
+def test_recall_stats_mean_stderr_lower_bound():
     import bench
-    assert bench.launch_shape(1024, 64, 32) == (32, 32, 2)          # default: 32 launches of 32 client batches
-    for steps in (32, 64, 100, 50, 1000, 20, 96, 8):
-        C, n_launch, _ = bench.launch_shape(steps, 64, 32)
-        assert C * n_launch == steps and C * 4 >= 32, (steps, C, n_launch)
-    for steps in (53, 5, 1, 31 * 7 + 0):                            # no usable divisor: rounded up to whole launches
-        C, n_launch, _ = bench.launch_shape(steps, 64, 32)
-        assert C * n_launch >= steps and (C * n_launch - steps) < C
-    C, n_launch, n_warm = bench.launch_shape(1024, 0, 32)
-    assert n_warm == 0
-    assert bench.launch_shape(10, 3, 1) == (1, 10, 3)               # coalescing off
+    hits = np.array([10, 9, 10, 8, 10, 10, 9, 10])
+    mean, se, lower = bench.recall_stats(hits, 10)
+    assert abs(mean - 0.95) < 1e-12
+    assert abs(se - (hits / 10).std(ddof=1) / np.sqrt(8)) < 1e-12
+    assert abs(lower - (mean - 1.645 * se)) < 1e-12
+    assert bench.recall_stats([10], 10) == (1.0, 0.0, 1.0)
+
+
+def test_select_ef_takes_the_smallest_ef_whose_lower_bound_clears_the_target():
+    import bench
+    table = {32: (0.93, 0.001, 0.928), 48: (0.9505, 0.001, 0.9489), 64: (0.955, 0.001, 0.9534), 96: (0.97, 0.001, 0.968)}
+    asked = []
+
+    def measure(ef):
+        asked.append(ef)
+        return table[ef]
+    ef, rows = bench.select_ef([32, 48, 64, 96], measure, 0.95)
+    assert ef == 64 and asked == [32, 48, 64]          # 48 has mean >= 0.95 but not with 95 % confidence; 96 is never tried
+    assert [r["ef_search"] for r in rows] == [32, 48, 64] and rows[-1]["lower95"] == 0.9534
+    ef, rows = bench.select_ef([32, 48], measure, 0.95)  # nothing qualifies: the largest candidate is used
+    assert ef == 48 and len(rows) == 2
 
 
 def test_effective_cores_is_bounded_by_affinity():
