@@ -11,8 +11,12 @@
 
 #include "../../include/cosdata_hip.h"
 #include "engine_types.h"
+#include "link_types.h"
 
 namespace cosdev {
+hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st);
+hipError_t launch_link_round(const LinkArgs &a, u32 maxM, const u32 *pend, const u32 *pcount, u32 *next, u32 *next_count, u32 *evq, u32 *evq_count,
+                             u32 count_ub, u32 round, hipStream_t st);
 hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
                                 u64 row_stride, float *mags, float *raw_mags, hipStream_t st);
 hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);

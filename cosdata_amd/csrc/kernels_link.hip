@@ -1,0 +1,324 @@
+// kernels_link.hip — the builder's link phase on the device.
+//   create_node_edges                 vector_store.rs:976-1074
+//   ProbNode::add_neighbor            models/prob_node.rs:210-283   (replace-lowest slot, cached lowest index/similarity)
+//   remove_neighbor_by_id             models/prob_node.rs:285-306   (evictee drops its back edge, cache NOT refreshed)
+//   remove_neighbor_by_index_and_id   vector_store.rs:1050-1067     (roll the forward half back when the back edge is refused)
+//
+// Schedule: ROUND-SYNCHRONOUS (oracle/cosdata_oracle_hnsw.c:coso_index_build_rounds, ordered variant, is the CPU statement;
+// the tests assert identical graphs).  The nodes a batch adds to one level are linked in rounds.  Every pending node claims
+// {itself} + its walk candidates; the first claimer of a row in batch order owns it for the round — on the device that is ONE
+// atomicMax per (node, row) on a tag (round << 13 | 8191 - batch position), no scan — and a node runs iff it owns every row it
+// claimed.  Runnable nodes touch disjoint rows, so one wavefront per node executes the literal sequential create_node_edges
+// on its rows (a row's M slots <-> the lanes) with no synchronisation between waves.  The only rows touched outside a node's
+// own claim are those of nodes it EVICTS from a candidate's row (the evictee must drop its back edge): those removals are
+// queued and applied by evict_kernel after every runnable node of the round has finished, exactly like the oracle applies
+// them at the end of the round (they commute: an (evictee, target) pair exists at most once).  Blocked nodes go to the next
+// round.  All levels of a batch share the rounds (levels are independent graphs).
+//
+// HBM-bound bookkeeping (integer compares, 256 B rows); no MFMA.  Rows of the link state are read and written with
+// agent-scope relaxed atomics so a wave re-reading a row it modified earlier in the same launch sees its own stores.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "engine_types.h"
+#include "link_types.h"
+
+using namespace cosdev;
+
+namespace {
+
+constexpr u32 NONE = 0xFFFFFFFFu;
+constexpr int32_t EMPTY_KEY = INT32_MIN; // below every real key: the first-minimum scan finds the first empty slot
+
+template <typename T>
+__device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a value loaded by lane 0 and broadcast: per-node scalars (lowest cache) are always read and written by lane 0
+template <typename T>
+__device__ __forceinline__ u32 ld_uniform_u32(const T *p, int lane) {
+    u32 v = 0;
+    if (lane == 0) v = (u32)ld(p);
+    return readlane_u32(v, 0);
+}
+
+// MetricResult order as a signed key (models/types.rs:401-411): a < b  <=>  order_key(a) < order_key(b)
+__device__ __forceinline__ int32_t order_key(u32 metric, float v) {
+    int32_t b = (int32_t)__float_as_uint(v);
+    b ^= (int32_t)(((u32)(b >> 31)) >> 1);
+    return (metric == 1u || metric == 2u) ? ~b : b;
+}
+
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const u64 o = shfl_xor_u64(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// One row of a level (M slots: slot j lives in lane j % 64, register j / 64) — the wave-level mirror of ProbNode.neighbors.
+template <int SL>
+struct Row {
+    u32 nb[SL];
+    int32_t nk[SL];
+    __device__ __forceinline__ void load(const LinkLevelDev &lv, u32 node, int lane) {
+#pragma unroll
+        for (int s = 0; s < SL; s++) {
+            const u32 j = (u32)lane + 64u * s;
+            nb[s] = NONE;
+            nk[s] = EMPTY_KEY;
+            if (j < lv.M) {
+                nb[s] = ld(&lv.adj_node[(u64)node * lv.M + j]);
+                nk[s] = ld(&lv.key[(u64)node * lv.M + j]);
+            }
+        }
+    }
+    __device__ __forceinline__ void store_slot(const LinkLevelDev &lv, u32 node, u32 slot, int lane) const {
+#pragma unroll
+        for (int s = 0; s < SL; s++) {
+            const u32 j = (u32)lane + 64u * s;
+            if (j == slot) {
+                const u64 o = (u64)node * lv.M + j;
+                st(&lv.adj_node[o], nb[s]);
+                if (lv.adj_vec != lv.adj_node) st(&lv.adj_vec[o], nb[s] == NONE ? NONE : lv.node_vec[nb[s]]);
+                st(&lv.key[o], nk[s]);
+            }
+        }
+    }
+    __device__ __forceinline__ void store_all(const LinkLevelDev &lv, u32 node, int lane) const {
+#pragma unroll
+        for (int s = 0; s < SL; s++) {
+            const u32 j = (u32)lane + 64u * s;
+            if (j < lv.M) {
+                const u64 o = (u64)node * lv.M + j;
+                st(&lv.adj_node[o], nb[s]);
+                if (lv.adj_vec != lv.adj_node) st(&lv.adj_vec[o], nb[s] == NONE ? NONE : lv.node_vec[nb[s]]);
+                st(&lv.key[o], nk[s]);
+            }
+        }
+    }
+    // (neighbour, key) of one slot, wave-uniform
+    __device__ __forceinline__ void get(u32 slot, u32 &n_out, int32_t &k_out) const {
+        u32 n = NONE;
+        int32_t k = EMPTY_KEY;
+#pragma unroll
+        for (int s = 0; s < SL; s++)
+            if ((slot >> 6) == (u32)s) { n = nb[s]; k = nk[s]; }
+        n_out = (u32)__shfl((int)n, (int)(slot & 63u), 64);
+        k_out = __shfl(k, (int)(slot & 63u), 64);
+    }
+    __device__ __forceinline__ void set(u32 slot, u32 n, int32_t k, int lane) {
+#pragma unroll
+        for (int s = 0; s < SL; s++)
+            if ((u32)lane + 64u * s == slot) { nb[s] = n; nk[s] = k; }
+    }
+    // prob_node.rs:245-259: the scan starts from MetricResult::max; the first empty slot wins outright (its key is below every
+    // real key), otherwise the first strictly-smallest similarity; no slot below max -> (0, max)
+    __device__ __forceinline__ void lowest(u32 M, int32_t kmin, int32_t kmax, int lane, u32 &idx_out, int32_t &key_out) const {
+        u64 best = ~0ull;
+#pragma unroll
+        for (int s = 0; s < SL; s++) {
+            const u32 j = (u32)lane + 64u * s;
+            if (j < M) {
+                const u64 v = ((u64)((u32)nk[s] ^ 0x80000000u) << 32) | j; // signed order -> unsigned order; ties: smaller index
+                best = v < best ? v : best;
+            }
+        }
+        best = wave_min_u64(best);
+        const int32_t mn = (int32_t)((u32)(best >> 32) ^ 0x80000000u);
+        if (mn < kmax) { idx_out = (u32)best; key_out = mn == EMPTY_KEY ? kmin : mn; }
+        else { idx_out = 0; key_out = kmax; }
+    }
+    // first slot holding `target` (remove_neighbor_by_id scans in slot order), or NONE
+    __device__ __forceinline__ u32 find(u32 target, u32 M, int lane) const {
+        u32 found = NONE;
+#pragma unroll
+        for (int s = SL - 1; s >= 0; s--) {
+            const u32 j = (u32)lane + 64u * s;
+            const u64 m = __ballot(j < M && nb[s] == target);
+            if (m) found = (u32)(__ffsll((long long)m) - 1) + 64u * s;
+        }
+        return found;
+    }
+};
+
+// ProbNode::add_neighbor on a row held in registers.  Returns the slot (or -1); `evicted` = the neighbour that was replaced.
+// The caller owns the row's cached (lowest index, lowest key) and gets them updated.
+template <int SL>
+__device__ __forceinline__ int add_neighbor(Row<SL> &row, u32 M, int32_t kmin, int32_t kmax, u32 &low_idx, int32_t &low_key, u32 nbr, int32_t dist,
+                                            int lane, u32 &evicted) {
+    evicted = NONE;
+    if (dist <= low_key) return -1;                                     // :222-225
+    const u32 slot = low_idx;
+    u32 old_n;
+    int32_t old_k;
+    row.get(slot, old_n, old_k);
+    const bool ok = old_n == NONE || dist > old_k;                      // :227-243
+    if (ok) row.set(slot, nbr, dist, lane);
+    row.lowest(M, kmin, kmax, lane, low_idx, low_key);                  // :245-262 (refreshed whether or not the slot was taken)
+    if (!ok) return -1;
+    evicted = old_n;
+    return (int)slot;
+}
+
+// ---- phase 1 of a round: claims ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void claim_kernel(const LinkArgs a, const u32 *__restrict__ pend, const u32 *__restrict__ pcount, u32 *next_count,
+                                                    u32 *evq_count, u32 round) {
+    const u32 count = *pcount;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *next_count = 0; *evq_count = 0; } // consumed by the previous round; refilled by link_kernel
+    const u32 per = KEEP_INDEX + 1;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 e_idx = (u32)(t / per), i = (u32)(t % per);
+    if (e_idx >= count) return;
+    const u32 e = pend[e_idx], level = e >> 16, b = e & 0xFFFFu;
+    const LinkLevelDev &lv = a.lv[level];
+    const u32 slot = a.L1 - 1 - level;
+    u32 r;
+    if (i == 0) r = a.me[(u64)b * a.L1 + level];
+    else {
+        if (i - 1 >= a.z_counts[(u64)b * a.L1 + slot]) return;
+        r = a.z_nodes[((u64)b * a.L1 + slot) * KEEP_INDEX + (i - 1)];
+    }
+    atomicMax(&lv.owner[r], (round << 13) | (8191u - b));
+}
+
+// ---- phase 2: one wave per pending node; runnable nodes execute create_node_edges on their rows ---------------------
+template <int SL>
+__global__ __launch_bounds__(64) void link_kernel(const LinkArgs a, const u32 *__restrict__ pend, const u32 *__restrict__ pcount, u32 *__restrict__ next,
+                                                  u32 *next_count, u32 *__restrict__ evq, u32 *evq_count, u32 round) {
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= *pcount) return;
+    const u32 e = pend[blockIdx.x], level = e >> 16, b = e & 0xFFFFu;
+    const LinkLevelDev lv = a.lv[level];
+    const u32 M = lv.M, slotz = a.L1 - 1 - level;
+    const u32 node = a.me[(u64)b * a.L1 + level];
+    const u32 cnt = a.z_counts[(u64)b * a.L1 + slotz];
+    const u64 zb = ((u64)b * a.L1 + slotz) * KEEP_INDEX;
+    const u32 cz = (u32)lane < cnt ? a.z_nodes[zb + lane] : NONE;
+    const float cs = (u32)lane < cnt ? a.z_sims[zb + lane] : 0.0f;
+    const u32 tag = (round << 13) | (8191u - b);
+    bool mine = true;
+    if ((u32)lane < cnt) mine = ld(&lv.owner[cz]) == tag;
+    const bool runnable = __all(mine) && ld_uniform_u32(&lv.owner[node], lane) == tag;
+    if (!runnable) { // blocked by an earlier node of the batch: next round
+        if (lane == 0) next[atomicAdd(next_count, 1u)] = e;
+        return;
+    }
+
+    Row<SL> self;
+    self.load(lv, node, lane);
+    u32 s_low_idx = ld_uniform_u32(&lv.low_idx[node], lane);
+    int32_t s_low_key = (int32_t)ld_uniform_u32(&lv.low_key[node], lane);
+    const u32 node_vec = lv.adj_vec != lv.adj_node ? lv.node_vec[node] : node;
+
+    // evictee `old` drops its back edge to `target`: now if the row is in this node's claim, else at the end of the round
+    auto drop_back_edge = [&](u32 old, u32 target) {
+        const bool own = ld_uniform_u32(&lv.owner[old], lane) == tag;
+        if (own) {
+            Row<SL> r;
+            r.load(lv, old, lane);
+            const u32 j = r.find(target, M, lane);
+            if (j != NONE) { r.set(j, NONE, EMPTY_KEY, lane); r.store_slot(lv, old, j, lane); }
+        } else if (lane == 0) {
+            const u32 q = atomicAdd(evq_count, 1u);
+            evq[3 * (u64)q + 0] = level;
+            evq[3 * (u64)q + 1] = old;
+            evq[3 * (u64)q + 2] = target;
+        }
+    };
+
+    u32 succ = 0;
+    for (u32 i = 0; i < cnt; i++) { // walk results in descending order until M edges succeeded (vector_store.rs:995-1074)
+        if (succ >= M) break;
+        const u32 c = readlane_u32(cz, (int)i);
+        const int32_t dk = order_key(a.metric, __uint_as_float(readlane_u32(__float_as_uint(cs), (int)i)));
+        u32 ev;
+        const int r = add_neighbor<SL>(self, M, a.kmin, a.kmax, s_low_idx, s_low_key, c, dk, lane, ev);
+        if (ev != NONE) drop_back_edge(ev, node);
+        if (r < 0) continue;
+        // the back edge on the candidate's row
+        u32 c_low_idx = ld_uniform_u32(&lv.low_idx[c], lane);
+        int32_t c_low_key = (int32_t)ld_uniform_u32(&lv.low_key[c], lane);
+        int r2 = -1;
+        if (dk > c_low_key) {
+            Row<SL> cr;
+            cr.load(lv, c, lane);
+            r2 = add_neighbor<SL>(cr, M, a.kmin, a.kmax, c_low_idx, c_low_key, node, dk, lane, ev);
+            if (r2 >= 0) { // the slot written holds `node`: derive its vector row here (node_vec of a level >= 1)
+#pragma unroll
+                for (int s = 0; s < SL; s++) {
+                    const u32 j = (u32)lane + 64u * s;
+                    if (j == (u32)r2) {
+                        const u64 o = (u64)c * M + j;
+                        st(&lv.adj_node[o], node);
+                        if (lv.adj_vec != lv.adj_node) st(&lv.adj_vec[o], node_vec);
+                        st(&lv.key[o], dk);
+                    }
+                }
+            }
+            if (lane == 0) { st(&lv.low_idx[c], (uint8_t)c_low_idx); st(&lv.low_key[c], c_low_key); }
+            if (ev != NONE) drop_back_edge(ev, c);
+        }
+        if (r2 >= 0) succ++;
+        else { // remove_neighbor_by_index_and_id: the forward half is rolled back if the slot still holds the candidate
+            u32 cur_n;
+            int32_t cur_k;
+            self.get((u32)r, cur_n, cur_k);
+            if (cur_n == c) self.set((u32)r, NONE, EMPTY_KEY, lane);
+        }
+    }
+    self.store_all(lv, node, lane);
+    if (lane == 0) { st(&lv.low_idx[node], (uint8_t)s_low_idx); st(&lv.low_key[node], s_low_key); }
+}
+
+// ---- phase 3: evictees outside the evictor's claim drop their back edges ---------------------------------------------
+__global__ __launch_bounds__(256) void evict_kernel(const LinkArgs a, const u32 *__restrict__ evq, const u32 *__restrict__ evq_count) {
+    const u32 n = *evq_count;
+    for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (u64)gridDim.x * blockDim.x) {
+        const u32 level = evq[3 * q], old = evq[3 * q + 1], target = evq[3 * q + 2];
+        const LinkLevelDev &lv = a.lv[level];
+        for (u32 j = 0; j < lv.M; j++) {
+            const u64 o = (u64)old * lv.M + j;
+            if (lv.adj_node[o] == target) {
+                lv.adj_node[o] = NONE;
+                if (lv.adj_vec != lv.adj_node) lv.adj_vec[o] = NONE;
+                lv.key[o] = EMPTY_KEY;
+                break;
+            }
+        }
+    }
+}
+
+__global__ void fill_i32_kernel(int32_t *p, u64 n, int32_t v) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = v;
+}
+
+} // namespace
+
+namespace cosdev {
+
+hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const u32 blocks = (u32)std::min<u64>((n + 255) / 256, 65535);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, st, p, n, v);
+    return hipGetLastError();
+}
+
+// one round over at most `count_ub` pending entries (the true count is read on the device from pcount)
+hipError_t launch_link_round(const LinkArgs &a, u32 maxM, const u32 *pend, const u32 *pcount, u32 *next, u32 *next_count, u32 *evq, u32 *evq_count,
+                             u32 count_ub, u32 round, hipStream_t st) {
+    if (count_ub == 0) return hipSuccess;
+    const u64 threads = (u64)count_ub * (KEEP_INDEX + 1);
+    hipLaunchKernelGGL(claim_kernel, dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, a, pend, pcount, next_count, evq_count, round);
+    if (maxM <= 64) hipLaunchKernelGGL(link_kernel<1>, dim3(count_ub), dim3(64), 0, st, a, pend, pcount, next, next_count, evq, evq_count, round);
+    else if (maxM <= 128) hipLaunchKernelGGL(link_kernel<2>, dim3(count_ub), dim3(64), 0, st, a, pend, pcount, next, next_count, evq, evq_count, round);
+    else hipLaunchKernelGGL(link_kernel<4>, dim3(count_ub), dim3(64), 0, st, a, pend, pcount, next, next_count, evq, evq_count, round);
+    const u32 eblocks = std::min<u32>(1024u, std::max<u32>(1u, count_ub / 2u));
+    hipLaunchKernelGGL(evict_kernel, dim3(eblocks), dim3(256), 0, st, a, evq, evq_count);
+    return hipGetLastError();
+}
+
+} // namespace cosdev
