@@ -81,6 +81,7 @@ ABI_SYMBOLS = [
     "cos_index_set_visited_mode", "cos_index_enable_timing", "cos_index_last_stats", "cos_index_timing_summary", "cos_quantize_batch",
     "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
     "cos_bm25_search_batch", "cos_rrf_fuse_batch", "cos_merge_topk_device", "cos_merge_topk_packed_device", "cos_hbm_probe",
+    "cos_shardset_unique_id", "cos_shardset_create", "cos_shardset_destroy", "cos_shardset_search_batch", "cos_shardset_exchange_device",
 ]
 
 
@@ -126,6 +127,11 @@ def lib():
         "cos_merge_topk_device": [vp, vp, vp, u32, u32, u32, vp, vp, vp, i32, vp],
         "cos_merge_topk_packed_device": [vp, u32, u32, u32, vp, vp, vp, i32, vp],
         "cos_hbm_probe": [i32, u32, C.c_uint64, u32, u32, C.POINTER(C.c_double)],
+        "cos_shardset_unique_id": [vp],
+        "cos_shardset_create": [vp, u32, u32, u32, vp, C.POINTER(vp)],
+        "cos_shardset_destroy": [vp],
+        "cos_shardset_search_batch": [vp, vp, u32, u32, vp, vp, vp],
+        "cos_shardset_exchange_device": [vp, vp, u32, u32, vp, vp, vp, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

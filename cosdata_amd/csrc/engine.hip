@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -135,6 +136,7 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
     if (p->device < 0 || p->device >= ndev) return cos_fail(COS_ERR_INVALID, "device %d out of range (%d visible)", p->device, ndev);
     cos_index *ix = new cos_index();
+    if (const char *e = getenv("COS_WALK_CHAIN_MIN_B")) ix->chain_min_B = (u32)strtoul(e, nullptr, 10); // experiments: 0 = always, 4294967295 = never
     ix->p = *p;
     ix->eng = eng;
     ix->row_stride = row_stride;
@@ -166,6 +168,7 @@ static void free_ws(Workspace *w) {
                     w->rerank_rows, w->vis.bits, w->vis.log, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : w->ev) if (e) (void)hipEventDestroy(e);
+    if (w->walk_done) (void)hipEventDestroy(w->walk_done);
     delete w;
 }
 
@@ -344,10 +347,30 @@ extern "C" int32_t cos_index_level_count(const cos_index *ix, uint32_t level, ui
     return COS_OK;
 }
 
-extern "C" int32_t cos_index_download_graph_level(const cos_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids) {
+// A level built on the device has no id-format host copy until somebody asks for one: node indices -> internal ids.
+static int32_t materialize_host_level(cos_index *ix, u32 level) {
+    LevelHost &L = ix->lv[level];
+    if (L.host_valid) return COS_OK;
+    if (L.n == 0 || L.node_ids.size() != L.n || !L.d_adj_vec) return cos_fail(COS_ERR_NOT_READY, "level %u not resident", level);
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    std::vector<u32> adj((size_t)L.n * L.M);
+    HIP_TRY(hipMemcpy(adj.data(), level == 0 ? L.d_adj_vec : L.d_adj_node, adj.size() * 4, hipMemcpyDeviceToHost));
+    L.nbr_ids.resize(adj.size());
+    for (size_t i = 0; i < adj.size(); i++) L.nbr_ids[i] = adj[i] == ROW_EMPTY ? COS_SLOT_EMPTY : L.node_ids[adj[i]]; // level 0: node index = vector row
+    L.host_valid = true;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_download_graph_level(const cos_index *ix_, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids) {
+    cos_index *ix = const_cast<cos_index *>(ix_);
     if (!ix || level > ix->p.num_layers) return cos_fail(COS_ERR_INVALID, "bad argument");
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        const int32_t rc = materialize_host_level(ix, level);
+        if (rc) return rc;
+    }
     const LevelHost &L = ix->lv[level];
-    if (!L.host_valid) return cos_fail(COS_ERR_NOT_READY, "level %u not resident", level);
     if (node_ids) memcpy(node_ids, L.node_ids.data(), L.node_ids.size() * 4);
     if (nbr_ids) memcpy(nbr_ids, L.nbr_ids.data(), L.nbr_ids.size() * 4);
     return COS_OK;
@@ -503,6 +526,7 @@ static int32_t get_workspace(cos_index *ix, void *stream_key, u32 B, u32 top_k, 
         w->ev.assign((size_t)Workspace::EV_RING * 4, nullptr);
         for (auto &e : w->ev) HIP_TRY(hipEventCreate(&e));
     }
+    if (!w->walk_done) HIP_TRY(hipEventCreateWithFlags(&w->walk_done, hipEventDisableTiming));
     *out = w;
     return COS_OK;
 }
@@ -540,7 +564,15 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     wa.out_counts = w->walk_counts;
     wa.out_status = w->walk_status;
     wa.out_stats = w->stats;
-    HIP_TRY(launch_walk(ix->eng, dev, wa, st));
+    if (B >= ix->chain_min_B) { // walk chain (engine_internal.h): wait for the previous big walk, whichever stream it ran on
+        std::lock_guard<std::mutex> g(ix->chain_mu);
+        if (ix->chain_ev && ix->chain_ev != w->walk_done) HIP_TRY(hipStreamWaitEvent(st, ix->chain_ev, 0));
+        if (timed) HIP_TRY(hipEventRecord(ev[1], st)); // the kernel's own duration: after the wait
+        HIP_TRY(launch_walk(ix->eng, dev, wa, st));
+        HIP_TRY(hipEventRecord(w->walk_done, st));
+        ix->chain_ev = w->walk_done;
+    } else
+        HIP_TRY(launch_walk(ix->eng, dev, wa, st));
     if (timed) HIP_TRY(hipEventRecord(ev[2], st));
     if (do_finalize) {
         HIP_TRY(launch_finalize(dev, d_queries, ix->p.dim, w->q_raw_mags, w->walk_ids, w->walk_sims, w->walk_counts, w->walk_status, B, top_k,

@@ -93,6 +93,7 @@ struct Workspace {
     static constexpr u32 EV_RING = 128;
     std::vector<hipEvent_t> ev; // [EV_RING][4]
     u32 ev_count = 0;           // timed launches since timing was switched on (ring position = ev_count % EV_RING)
+    hipEvent_t walk_done = nullptr; // recorded after this workspace's walk kernel (walk chain, see cos_index::chain_*)
     u32 lastB = 0;
     bool timed = false;
 };
@@ -122,6 +123,13 @@ struct cos_index {
     bool co_leader_active = false;
     u32 co_max_queries = 0, co_window_us = 0;
     bool timing = false;
+    // Walk chain: a launch big enough to fill the chip several times over (>= chain_min_B queries) gains nothing from sharing
+    // it with ANOTHER stream's walk — two co-running walks only stretch each other — but its prologue/epilogue (quantize,
+    // finalize: short kernels) do hide well under a neighbour's walk.  So big walks of different streams are ordered one after
+    // the other with an event, while everything else of a launch stays free to overlap.
+    std::mutex chain_mu;
+    hipEvent_t chain_ev = nullptr; // walk_done of the most recent chained walk
+    u32 chain_min_B = 16384;
 };
 
 

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "engine_types.h"
 #include "dot_engines.h"
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
 
 constexpr int PB = 4; // code rows in flight per lane group before the dots are consumed
 constexpr int LA = 4; // lookahead window: adjacency rows prefetched per round
-constexpr int PB64 = 4; // G = 64 path: code rows in flight per wave
+// G = 64 path: code rows in flight per wave = template parameter PB64 (4: throughput launches, 8: launches too small to fill
+// the chip, where one wave per CU lives on memory-level parallelism and the extra 16 VGPRs cost no occupancy that matters)
 
 // ------------------------------------------------------------------------------------------------
 // walk kernel
@@ -128,7 +130,7 @@ struct WalkSmem {
     float *qf;    // F32 engine: the query vector
 };
 
-template <int ENG, int CH, int R, bool G64, bool EXACT>
+template <int ENG, int CH, int R, bool G64, bool EXACT, int PB64 = 4>
 __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkArgs wa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x;
@@ -747,13 +749,30 @@ size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     return b + 16;
 }
 
+// rows in flight per wave on the G = 64 u8 path: 8 when the launch cannot fill the chip anyway (few waves per CU: latency
+// bound, memory-level parallelism is all there is), 4 otherwise.  COS_WALK_PB=4|8 overrides the policy (experiments).
+static int walk_pb_policy(u32 B) {
+    static const int forced = [] { const char *e = getenv("COS_WALK_PB"); return e ? atoi(e) : 0; }();
+    if (forced == 4 || forced == 8) return forced;
+    return B <= 2048 ? 8 : 4;
+}
+
 template <int ENG, int CH, bool G64>
 static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     const size_t smem = walk_smem_bytes(ix, wa.ef, ENG);
     dim3 grid(wa.B), block(64);
     const bool exact = ix.visited_mode != 0;
+    constexpr bool HAS_PB8 = ENG == ENG_U8 && G64 && CH == 1; // the headline path (u8, 513..1024 dims)
+    const bool pb8 = HAS_PB8 && walk_pb_policy(wa.B) == 8;
 #define WALK(R_)                                                                                                          \
     do {                                                                                                                  \
+        if constexpr (HAS_PB8) {                                                                                          \
+            if (pb8) {                                                                                                    \
+                if (exact) hipLaunchKernelGGL((walk_kernel<ENG, CH, R_, G64, true, 8>), grid, block, smem, st, ix, wa);   \
+                else hipLaunchKernelGGL((walk_kernel<ENG, CH, R_, G64, false, 8>), grid, block, smem, st, ix, wa);        \
+                break;                                                                                                    \
+            }                                                                                                             \
+        }                                                                                                                 \
         if (exact) hipLaunchKernelGGL((walk_kernel<ENG, CH, R_, G64, true>), grid, block, smem, st, ix, wa);              \
         else hipLaunchKernelGGL((walk_kernel<ENG, CH, R_, G64, false>), grid, block, smem, st, ix, wa);                   \
     } while (0)

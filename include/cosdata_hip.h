@@ -235,6 +235,35 @@ int32_t cos_merge_topk_packed_device(const uint32_t *d_packed, uint32_t S, uint3
                                      uint32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts,
                                      int32_t device, void *stream);
 
+/* ---- sharded serving --------------------------------------------------------- */
+/* A shard set = the S id-range shards of one collection (cos_index handles, cos_params.id_base = first id of the shard) plus
+ * the exchange step between them: ONE all-gather of the packed per-shard records (RCCL over xGMI) and the S-way merge.
+ * It stands behind the same caller as cos_search_batch — IndexOps::batch_search (indexes/mod.rs:260-272), a single process —
+ * so the Rust host gets merged global top-k lists from one call.  Two deployments:
+ *   - every shard in this process (n_local == world_size, unique_id NULL): communicators via ncclCommInitAll, the per-batch
+ *     collective is a group of S ncclAllGather calls, one per device; cos_shardset_search_batch is the entry point;
+ *   - one process per GPU (n_local == 1 < world_size): rank `first_rank` of a world_size communicator built from the
+ *     ncclUniqueId one process obtained with cos_shardset_unique_id and handed to the others; the per-batch entry point is
+ *     cos_shardset_exchange_device (all-gather + merge enqueued on the caller's stream).
+ * Shards that share one device are exchanged with device copies (no communicator can span them). */
+typedef struct cos_shardset cos_shardset;
+#define COS_SHARDSET_UNIQUE_ID_BYTES 128
+int32_t cos_shardset_unique_id(uint8_t *out /* [COS_SHARDSET_UNIQUE_ID_BYTES] */);
+int32_t cos_shardset_create(cos_index *const *shards, uint32_t n_local, uint32_t first_rank, uint32_t world_size,
+                            const uint8_t *unique_id, cos_shardset **out);
+int32_t cos_shardset_destroy(cos_shardset *ss); /* the cos_index handles stay owned by the caller */
+/* queries [B][dim] raw f32 (host) -> merged global top-k over every shard: out_ids [B][top_k] global internal ids,
+ * out_scores exact cosine, out_counts [B].  Order: score desc by total_cmp, larger id first on ties.  Any failing query on
+ * any shard fails the call (first error), like cos_search_batch.  Thread-safe; batches are serialised per shard set. */
+int32_t cos_shardset_search_batch(cos_shardset *ss, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                                  float *out_scores, uint32_t *out_counts);
+/* Process-per-GPU exchange, all pointers DEVICE memory, enqueued on `stream`: d_packed_local = this shard's packed record
+ * (B*(2*top_k+1) words, written by cos_search_batch_device on the same stream) -> d_gathered [world_size][words] ->
+ * merged d_out_* on every rank.  Every rank must call it the same number of times in the same order. */
+int32_t cos_shardset_exchange_device(cos_shardset *ss, const uint32_t *d_packed_local, uint32_t B, uint32_t top_k,
+                                     uint32_t *d_gathered, uint32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts,
+                                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

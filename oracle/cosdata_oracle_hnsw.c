@@ -942,14 +942,17 @@ int coso_index_import_level(coso_index *ix, uint32_t level, uint32_t n_nodes, co
     int dense = 1; /* level 0 holds ids 0..n-2 then the root: id -> index without searching */
     for (uint32_t i = 0; i + 1 < n_nodes; i++)
         if (node_ids[i] != i) { dense = 0; break; }
-    for (uint32_t i = 0; i < n_nodes; i++)
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int64_t i = 0; i < (int64_t)n_nodes; i++)
         for (uint32_t j = 0; j < L->M; j++) {
             uint32_t nid = nbr_ids[(size_t)i * L->M + j];
             if (nid == COSO_SLOT_EMPTY) continue;
             uint32_t k = dense ? (nid == COSO_ROOT_ID ? n_nodes - 1 : (nid < n_nodes - 1 ? nid : IDX_NONE)) : find_sorted(L->node_id, L->n, nid);
-            if (k == IDX_NONE) return COSO_ERR_INVALID;
+            if (k == IDX_NONE) { bad = 1; continue; }
             L->nbr[(size_t)i * L->M + j] = k;
         }
+    if (bad) return COSO_ERR_INVALID;
     int rc = resolve_children(ix, level);
     if (rc == COSO_OK) rc = resolve_children(ix, level + 1);
     return rc;

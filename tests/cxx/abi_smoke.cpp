@@ -19,6 +19,11 @@ int main() {
     rc = cos_index_create(&p, &ix);
     if (rc != COS_ERR_INVALID) { printf("FAIL pow2 rc=%d\n", rc); return 1; }
     p.neighbors_count = 32;
+    // shard set: argument contract (no GPU needed)
+    cos_shardset *ss = nullptr;
+    if (cos_shardset_create(nullptr, 0, 0, 0, nullptr, &ss) != COS_ERR_INVALID || ss != nullptr) { printf("FAIL shardset null list\n"); return 1; }
+    if (cos_shardset_search_batch(nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr) != COS_ERR_INVALID) { printf("FAIL shardset search args\n"); return 1; }
+    if (cos_shardset_destroy(nullptr) != COS_OK) { printf("FAIL shardset destroy(null)\n"); return 1; }
     int ndev = -1;
     int rcd = cos_device_count(&ndev);
     rc = cos_index_create(&p, &ix);
@@ -33,6 +38,44 @@ int main() {
     float q[96] = {0}; unsigned ids[4]; float sc[4]; unsigned cnt;
     rc = cos_search_batch(ix, q, 1, 4, ids, sc, &cnt, nullptr); // nothing uploaded yet
     if (rc != COS_ERR_NOT_READY) { printf("FAIL not-ready rc=%d\n", rc); return 1; }
+    // two shards of one collection on this device behind ONE call: build both on the device, search through the shard set
+    {
+        const unsigned n = 600, d = 96, B = 8, k = 5;
+        static float X[2][600 * 96], Q[8 * 96];
+        unsigned long long st = 88172645463325252ull;
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (float)((st >> 40) & 0xFFFFFF) / 16777216.0f * 2.0f - 1.0f; };
+        for (auto &sh : X) for (float &v : sh) v = rnd();
+        for (unsigned b = 0; b < B; b++) for (unsigned j = 0; j < d; j++) Q[b * d + j] = X[b & 1][(b * 37) * d + j] + 0.01f * rnd();
+        cos_index *sh[2] = {nullptr, nullptr};
+        p.num_layers = 3; p.ef_construction = 32; p.ef_search = 32;
+        for (int s = 0; s < 2; s++) {
+            p.id_base = s * n; p.seed = 7 + s;
+            if (cos_index_create(&p, &sh[s]) != COS_OK || cos_index_upload_vectors(sh[s], X[s], n, COS_UPLOAD_DEFAULT) != COS_OK ||
+                cos_index_build(sh[s], 128) != COS_OK) { printf("FAIL shard %d: %s\n", s, cos_last_error_string()); return 1; }
+        }
+        if (cos_shardset_create(sh, 2, 0, 2, nullptr, &ss) != COS_OK) { printf("FAIL shardset create: %s\n", cos_last_error_string()); return 1; }
+        unsigned mi[8 * 5], mc[8], si[8 * 5], sc_[8]; float ms[8 * 5], ssc[8 * 5];
+        if (cos_shardset_search_batch(ss, Q, B, k, mi, ms, mc) != COS_OK) { printf("FAIL shardset search: %s\n", cos_last_error_string()); return 1; }
+        bool seen[2] = {false, false};
+        for (unsigned b = 0; b < B; b++) {
+            if (mc[b] != k) { printf("FAIL merged count %u\n", mc[b]); return 1; }
+            for (unsigned j = 0; j < k; j++) {
+                if (mi[b * k + j] >= 2 * n) { printf("FAIL merged id out of range\n"); return 1; }
+                if (j && ms[b * k + j] > ms[b * k + j - 1]) { printf("FAIL merged scores not sorted\n"); return 1; }
+                seen[mi[b * k + j] / n] = true;
+            }
+            // the merged head must be the better of the two shards' own heads
+            float best = -2.f;
+            for (int s = 0; s < 2; s++) {
+                if (cos_search_batch(sh[s], Q + b * d, 1, k, si, ssc, sc_, nullptr) != COS_OK) { printf("FAIL shard search\n"); return 1; }
+                if (ssc[0] > best) best = ssc[0];
+            }
+            if (ms[b * k] != best) { printf("FAIL merged head %g != best shard head %g\n", ms[b * k], best); return 1; }
+        }
+        if (!seen[0] || !seen[1]) { printf("FAIL a shard never contributed\n"); return 1; }
+        cos_shardset_destroy(ss);
+        cos_index_destroy(sh[0]); cos_index_destroy(sh[1]);
+    }
     cos_index_destroy(ix);
     printf("OK device\n");
     return 0;

@@ -87,13 +87,13 @@ def test_single_layer_and_deep_hierarchy():
 def test_c1_config_build_and_search():
     """BASELINE configs[0] (tests/test.py:73-88 of the reference): 10k x 768 uniform(-1,1), num_layers 7,
     ef_construction 512, ef_search 256, M 32 / M0 64, queries = corpus vectors, top_k 5 and 10 — built on the
-    device AND by the oracle's batched builder; graphs, walks and results must be identical."""
+    device AND by the oracle's statement of the same schedule (build_rounds); graphs, walks and results must be identical."""
     import cosdata_amd as ca
     n, d = 10000, 768
     X = H.uniform_corpus(n, d, seed=42)
     p = O.HNSWParams(dim=d, num_layers=7, ef_construction=512, ef_search=256, seed=42)
     oix = O.OracleIndex(p).set_vectors(X)
-    oix.build_batched(256)
+    oix.build_rounds(256, greedy=False)
     hp = ca.HNSWHyperParams(num_layers=7, ef_construction=512, ef_search=256, level_0_neighbors_count=64, neighbors_count=32)
     dix = ca.HNSWIndex(d, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), (-1.0, 1.0), 64, seed=42)
     dix.upload_vectors(X)

@@ -390,3 +390,27 @@ def test_round_synchronous_link_prototype():
         assert abs(recall(a) - base) <= 0.02, (recall(a), base)
         deg = np.mean((a.export_graph()[0][1] != 0xFFFFFFFD).sum(axis=1))
         assert deg > 16
+
+
+def test_streamed_quantize_and_raw_subset_equal_the_full_table_path():
+    """bench.py --workload c4shard cannot hold the raw f32 corpus on the host: the oracle then quantizes streamed chunks
+    (coso_index_quantize_rows) and reranks from a subset of raw rows (coso_index_set_raw_subset).  Same answers, bit for bit."""
+    from tests import helpers as H
+    X = H.clustered_corpus(3000, 64, seed=1)
+    oix = H.oracle_index(X, num_layers=3, ef_construction=32, ef_search=32)
+    Q = H.queries_from(X, 50)
+    want = oix.search_batch(Q, 10, threads=2)
+    o2 = O.OracleIndex(O.HNSWParams(dim=64, num_layers=3, ef_construction=32, ef_search=32)).alloc_vectors(3000)
+    for s in range(0, 3000, 700):
+        o2.quantize_rows(s, X[s:s + 700])
+    o2.import_graph(oix.export_graph(), oix.root_raw())
+    assert np.array_equal(o2.codes(), oix.codes()) and np.array_equal(o2.mags().view(np.uint32), oix.mags().view(np.uint32))
+    ids, cnt = o2.candidates_batch(Q, 10, threads=2)
+    assert (cnt <= 50).all() and (cnt > 0).all()
+    u = np.unique(ids[ids != 0xFFFFFFFF])
+    o2.set_raw_subset(u, X[u])
+    got = o2.search_batch(Q, 10, threads=2)
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    o2.set_raw_subset(u[:-1], X[u[:-1]])                      # a candidate without its raw row is an error, never a guess
+    with pytest.raises(ValueError):
+        o2.search_batch(Q, 10, threads=2)
