@@ -132,12 +132,14 @@ def effective_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64, help="timed steps; one step = one coalesced launch of --coalesce x --batch queries")
-    ap.add_argument("--warmup", type=int, default=8, help="untimed warm-up steps (launches)")
+    ap.add_argument("--steps", type=int, default=24, help="timed steps; one step = one coalesced launch of --coalesce x --batch queries")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed warm-up steps (launches)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override vectors per GPU (marks the run as non-standard)")
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--coalesce", type=int, default=32, help="client batches fused per launch (dynamic batching)")
+    ap.add_argument("--coalesce", type=int, default=128, help="client batches fused per launch (dynamic batching); 128 x 256 = 32768 queries "
+                    "refill the chip's 7168 wave slots several times over, so one launch runs the walk kernel at 0.9 of the HBM roof "
+                    "(8192-query launches: 0.71 — every wave is resident at once and the chip drains as they finish)")
     ap.add_argument("--inflight", type=int, default=2, help="launches kept in flight (HIP streams)")
     ap.add_argument("--ef", default="auto", help="ef_search: an integer, or 'auto' = smallest of 32,48,64,96,128,192,256,384,512 whose recall@10 "
                     "on the SELECTION query set clears --recall-target with 95 %% confidence (the metric is QPS AT recall@10 >= 0.95); "

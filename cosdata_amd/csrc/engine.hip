@@ -403,6 +403,43 @@ static void row_to_reference_layout(int eng, u32 dim, const uint8_t *dev_row, ui
     }
 }
 
+// reference layout -> device layout for one row (inverse of row_to_reference_layout); dev_row is zero-filled by the caller
+static void row_to_device_layout(int eng, u32 dim, const uint8_t *ref_row, uint8_t *dev_row) {
+    if (eng == ENG_U8) memcpy(dev_row, ref_row, dim);
+    else if (eng == ENG_F32) memcpy(dev_row, ref_row, (size_t)dim * 4);
+    else if (eng == ENG_F16) memcpy(dev_row, ref_row, (size_t)dim * 2);
+    else if (eng == ENG_Q1) memcpy(dev_row, ref_row, (dim + 7) / 8);
+    else if (eng == ENG_Q2) {
+        const u32 pb = (dim + 7) / 8;
+        for (u32 p = 0; p < 2; p++)
+            for (u32 b = 0; b < pb; b++) dev_row[(size_t)(b / 8) * 16 + p * 8 + (b % 8)] = ref_row[(size_t)p * pb + b];
+    } else {
+        const u32 pb = (dim + 7) / 8;
+        for (u32 p = 0; p < 3; p++)
+            for (u32 b = 0; b < pb; b++) dev_row[(size_t)(b / 4) * 16 + p * 4 + (b % 4)] = ref_row[(size_t)p * pb + b];
+    }
+}
+
+// The root as the reference STORED it (a quantized Storage + mag, read from prop.data by ref_index_reader.hip): written
+// straight into row N.  The raw f32 root is not known on this path (cos_index_download_root returns zeros); the walk only
+// ever reads the root's code and norm, and the rerank never sees the root (common.rs:397).
+int32_t cos_set_root_code(cos_index *ix, const uint8_t *ref_code, float mag) {
+    if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before the root");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    std::vector<uint8_t> dev(ix->row_stride, 0);
+    row_to_device_layout(ix->eng, ix->p.dim, ref_code, dev.data());
+    HIP_TRY(hipMemcpy(ix->d_codes + (size_t)ix->n * ix->row_stride, dev.data(), dev.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->d_mags + ix->n, &mag, 4, hipMemcpyHostToDevice));
+    ix->root_raw.assign(ix->p.dim, 0.0f);
+    ix->have_root = true;
+    return COS_OK;
+}
+
+int32_t cos_push_level_ids(cos_index *ix, u32 level, std::vector<u32> &&node_ids, std::vector<u32> &&nbr_ids) {
+    return cos_index_upload_graph_level(ix, level, (u32)node_ids.size(), node_ids.data(), nbr_ids.data());
+}
+
 extern "C" int32_t cos_index_download_codes(const cos_index *ix, void *codes, float *mags) {
     if (!ix || !ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "no vectors resident");
     HIP_TRY(hipSetDevice(ix->p.device));

@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
 
 constexpr int PB = 4; // code rows in flight per lane group before the dots are consumed
 constexpr int LA = 4; // lookahead window: adjacency rows prefetched per round
-// G = 64 path: code rows in flight per wave = template parameter PB64 (4: throughput launches, 8: launches too small to fill
-// the chip, where one wave per CU lives on memory-level parallelism and the extra 16 VGPRs cost no occupancy that matters)
+// G = 64 path: code rows in flight per wave = template parameter PB64.  An expansion discovers ~7 new neighbours on average:
+// with 4 rows in flight that is two dependent HBM round trips per pop, with 8 it is one.  Measured on c2 (profiles/
+// r02_c2_launch_shape_sweep_pb8.jsonl): 8 is faster at every launch size (+6 % at ef 64, +2 % at ef 256; the 16 extra VGPRs do
+// not change the occupancy, which the 106 SGPRs pin at 7 waves/SIMD), so 8 is the default where the variant exists.
 
 // ------------------------------------------------------------------------------------------------
 // walk kernel
@@ -749,12 +751,11 @@ size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     return b + 16;
 }
 
-// rows in flight per wave on the G = 64 u8 path: 8 when the launch cannot fill the chip anyway (few waves per CU: latency
-// bound, memory-level parallelism is all there is), 4 otherwise.  COS_WALK_PB=4|8 overrides the policy (experiments).
+// rows in flight per wave on the G = 64 u8 path (see PB64 above); COS_WALK_PB=4|8 overrides the default (experiments)
 static int walk_pb_policy(u32 B) {
     static const int forced = [] { const char *e = getenv("COS_WALK_PB"); return e ? atoi(e) : 0; }();
     if (forced == 4 || forced == 8) return forced;
-    return B <= 2048 ? 8 : 4;
+    return 8;
 }
 
 template <int ENG, int CH, bool G64>

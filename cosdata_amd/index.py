@@ -214,6 +214,11 @@ class HNSWIndex:
         check(_lib.lib().cos_index_download_codes(self._h, _p(codes), _p(mags)))
         return codes, mags
 
+    def load_reference_dir(self, dense_hnsw_dir: str, root_ptr_offset: int, verify_codes: bool = False):
+        """graph (+ root code) of an index persisted by the reference server -> this handle; vectors must be uploaded first"""
+        check(_lib.lib().cos_index_load_reference_dir(self._h, dense_hnsw_dir.encode(), root_ptr_offset, 1 if verify_codes else 0))
+        return self
+
     def build(self, batch_size: int = 0):
         """vector_store::index_embeddings on the device."""
         check(_lib.lib().cos_index_build(self._h, batch_size))

@@ -127,6 +127,25 @@ int32_t cos_index_download_graph_level(const cos_index *ix, uint32_t level, uint
 int32_t cos_index_download_codes(const cos_index *ix, void *codes, float *mags);
 int32_t cos_index_download_root(const cos_index *ix, float *root_raw);
 
+/* Load the graph of an index the reference server persisted (its `<collection>/dense_hnsw/` directory: {k}.index node records,
+ * nodes.ptr, prop.data — models/serializer/hnsw/node.rs:19-101, neighbors.rs:22-61, latest_node.rs:18-44,
+ * models/file_persist.rs:58-108) into the handle: every level's node ids and neighbour ids in slot order (as
+ * cos_index_upload_graph_level would receive them) plus the root's stored code.  The raw vectors must already be resident
+ * (cos_index_upload_vectors: the files hold only quantized codes, the exact rerank needs raw f32); root_ptr_offset =
+ * HNSWIndexData.root_vec_ptr_offset (indexes/hnsw/mod.rs:47-57, kept in LMDB by the host).  COS_LOAD_VERIFY_CODES also
+ * compares every stored Storage with the device's own quantization of the uploaded vector (StorageMismatch on a difference).
+ * Collections with a metadata schema are refused (Unimplemented).  Format parity is UNPINNED: no reference-written file
+ * exists in this image; see cosdata_amd/csrc/ref_index_reader.hip. */
+#define COS_LOAD_DEFAULT 0u
+#define COS_LOAD_VERIFY_CODES 1u
+int32_t cos_index_load_reference_dir(cos_index *ix, const char *dense_hnsw_dir, uint32_t root_ptr_offset, uint32_t flags);
+/* Host-only views of the same directory (no device needed): node count per level, then one level as the flat arrays
+ * cos_index_upload_graph_level takes (node_ids ascending, root last; nbr_ids [n][M_level], COS_SLOT_EMPTY = null slot). */
+int32_t cos_reference_dir_level_counts(const char *dense_hnsw_dir, uint32_t num_layers, uint32_t neighbors_count,
+                                       uint32_t level0_neighbors_count, uint32_t *level_counts /* [num_layers + 1] */);
+int32_t cos_reference_dir_read_level(const char *dense_hnsw_dir, uint32_t num_layers, uint32_t neighbors_count,
+                                     uint32_t level0_neighbors_count, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids);
+
 /* vector_store::index_embeddings (vector_store.rs:714) on the device: builds every level for the
  * uploaded vectors with the reference's edge semantics, batch-synchronously. */
 int32_t cos_index_build(cos_index *ix, uint32_t batch_size);

@@ -1,0 +1,105 @@
+"""The reference's on-disk dense index: tests/ref_index_writer.py (writer, from the serializer sources) ->
+libcosdata_hip's reader.  The host-only views run without a GPU; loading into a device handle is a GPU test."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+from tests.ref_index_writer import cbor_f32, write_dense_hnsw_dir
+
+
+def _oracle(storage, res, n=700, dim=40, **kw):
+    X = H.uniform_corpus(n, dim, seed=3) * 0.9
+    hp = dict(num_layers=3, ef_construction=24, ef_search=24, neighbors_count=8, level0_neighbors_count=16)
+    hp.update(kw)
+    return X, H.oracle_index(X, storage, res, **hp), hp
+
+
+def _read_dir(path, hp):
+    from cosdata_amd import _lib
+    L = _lib.lib()
+    Ltop, M, M0 = hp["num_layers"], hp["neighbors_count"], hp["level0_neighbors_count"]
+    counts = np.zeros(Ltop + 1, np.uint32)
+    _lib.check(L.cos_reference_dir_level_counts(path.encode(), Ltop, M, M0, counts.ctypes.data_as(C.c_void_p)))
+    out = []
+    for l in range(Ltop + 1):
+        ids = np.zeros(counts[l], np.uint32)
+        nbr = np.zeros((counts[l], M0 if l == 0 else M), np.uint32)
+        _lib.check(L.cos_reference_dir_read_level(path.encode(), Ltop, M, M0, l, ids.ctypes.data_as(C.c_void_p), nbr.ctypes.data_as(C.c_void_p)))
+        out.append((ids, nbr))
+    return out
+
+
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2), (O.STORAGE_F16, 0), (O.STORAGE_F32, 0)])
+@pytest.mark.parametrize("min_size", [1 << 62, 4096])
+def test_written_directory_reads_back_identically(tmp_path, storage, res, min_size):
+    X, oix, hp = _oracle(storage, res)
+    g = oix.export_graph()
+    d = str(tmp_path / "dense_hnsw")
+    write_dense_hnsw_dir(d, g, oix.codes(), oix.mags(), storage, res, X.shape[1], index_file_min_size=min_size)
+    if min_size == 4096:
+        assert os.path.exists(os.path.join(d, "3.index"))       # records spread over several index files
+    got = _read_dir(d, hp)
+    for (gi, gn), (ei, en) in zip(got, g):
+        assert np.array_equal(gi, ei) and np.array_equal(gn, en)
+
+
+def test_reader_rejects_damaged_directories(tmp_path):
+    from cosdata_amd import _lib
+    X, oix, hp = _oracle(O.STORAGE_U8, 0, n=120)
+    d = str(tmp_path / "dense_hnsw")
+    write_dense_hnsw_dir(d, oix.export_graph(), oix.codes(), oix.mags(), O.STORAGE_U8, 0, X.shape[1])
+    counts = np.zeros(4, np.uint32)
+    args = lambda M=8, M0=16, L=3: (d.encode(), L, M, M0, counts.ctypes.data_as(C.c_void_p))
+    L = _lib.lib()
+    assert L.cos_reference_dir_level_counts(*args()) == 0 and counts[0] == 121
+    assert L.cos_reference_dir_level_counts(*args(M0=32)) == _lib.ERR_INVALID           # other hyper-parameters than the file's
+    assert L.cos_reference_dir_level_counts(*args(L=2)) == _lib.ERR_INVALID             # a node above num_layers
+    raw = open(os.path.join(d, "0.index"), "rb").read()
+    open(os.path.join(d, "0.index"), "wb").write(raw[:len(raw) // 2])                   # truncated index file
+    assert L.cos_reference_dir_level_counts(*args()) == _lib.ERR_INVALID
+    open(os.path.join(d, "0.index"), "wb").write(raw)
+    p = bytearray(open(os.path.join(d, "prop.data"), "rb").read())
+    p[0] = 0x1F                                                                          # not a CBOR map
+    open(os.path.join(d, "prop.data"), "wb").write(bytes(p))
+    assert L.cos_reference_dir_level_counts(*args()) == _lib.ERR_INVALID
+    assert L.cos_reference_dir_level_counts(b"/nonexistent", 3, 8, 16, counts.ctypes.data_as(C.c_void_p)) == _lib.ERR_INVALID
+
+
+def test_cbor_float_encoding_follows_serde_cbor():
+    assert cbor_f32(1.0) == b"\xf9\x3c\x00"                 # lossless as half
+    assert cbor_f32(0.1)[0] == 0xFA and len(cbor_f32(0.1)) == 5
+    assert cbor_f32(np.inf) == b"\xf9\x7c\x00"
+    assert cbor_f32(65504.0)[0] == 0xF9 and cbor_f32(65505.0)[0] == 0xFA
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2), (O.STORAGE_SUBBYTE, 3), (O.STORAGE_F16, 0), (O.STORAGE_F32, 0)])
+def test_loaded_directory_searches_like_the_oracle(tmp_path, storage, res):
+    """write the oracle's index in the reference's format, load it into a device handle (vectors uploaded separately, stored
+    codes verified against the device's own quantization) and search: ids/scores bit-exact vs the oracle"""
+    import cosdata_amd as ca
+    from tests.test_gpu_parity import _assert_same_search, _assert_same_walk
+    X, oix, hp = _oracle(storage, res, n=2500, dim=96, num_layers=4, neighbors_count=32, level0_neighbors_count=64, ef_construction=48, ef_search=64)
+    d = str(tmp_path / "dense_hnsw")
+    root_ptr = write_dense_hnsw_dir(d, oix.export_graph(), oix.codes(), oix.mags(), storage, res, 96, index_file_min_size=1 << 20)
+    h = ca.HNSWHyperParams(num_layers=4, ef_construction=48, ef_search=64)
+    dix = ca.HNSWIndex(96, h, ca.DistanceMetric.Cosine, ca.StorageType(ca.StorageKind(storage), res), (-1.0, 1.0))
+    dix.upload_vectors(X).load_reference_dir(d, root_ptr, verify_codes=True)
+    for (gi, gn), (ei, en) in zip(dix.download_graph(), oix.export_graph()):
+        assert np.array_equal(gi, ei) and np.array_equal(gn, en)
+    Q = H.queries_from(X, 24, seed=5)
+    _assert_same_walk(oix, dix, Q)
+    _assert_same_search(oix, dix, Q, 10)
+    # a stored code that differs from the device's quantization is reported, not ignored
+    X2 = X.copy()
+    X2[17] *= -1.0
+    dix2 = ca.HNSWIndex(96, h, ca.DistanceMetric.Cosine, ca.StorageType(ca.StorageKind(storage), res), (-1.0, 1.0))
+    with pytest.raises(ca.CosdataError) as ei:
+        dix2.upload_vectors(X2).load_reference_dir(d, root_ptr, verify_codes=True)
+    assert ei.value.status == 1
+    with pytest.raises(ca.CosdataError):                       # a ptr offset that is not the root's
+        dix2.load_reference_dir(d, root_ptr + 8)
