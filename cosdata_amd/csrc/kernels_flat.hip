@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(64) void flat_select_segments(const float *__restri
     part[((u64)q * S + seg) * SEL + lane] = pool.e[0];
 }
 
-__global__ __launch_bounds__(64) void flat_select_merge(const u64 *__restrict__ part, u32 B, u32 S, u64 *__restrict__ pool_mem /*[B][64]*/) {
+__global__ __launch_bounds__(64) void flat_select_merge(const u64 *__restrict__ part, u32 B, u32 S, u64 *__restrict__ pool_mem /*[B][64]*/,
+                                                        u64 *__restrict__ thr_out /*optional [B]: the SEL-th best key so far (0 while the pool is not full)*/) {
     const int lane = threadIdx.x;
     const u32 q = blockIdx.x;
     if (q >= B) return;
@@ -190,6 +192,37 @@ __global__ __launch_bounds__(64) void flat_select_merge(const u64 *__restrict__ 
         }
     }
     pool_mem[(u64)q * SEL + lane] = pool.e[0];
+    if (thr_out && lane == 0) thr_out[q] = thr;
+}
+
+// Fused scans (flat_codes_gemm_i8<ENG, true>): the GEMM epilogue appended only the candidates that beat the query's
+// threshold to app[B][cap]; one wave per query folds them into the pool, publishes the new threshold and clears the counter.
+// A counter above `cap` means entries were dropped: the flag makes the host repeat the search on the unfused path.
+__global__ __launch_bounds__(64) void flat_select_append(const u64 *__restrict__ app, u32 *__restrict__ app_cnt, u32 cap, u32 B, u64 *__restrict__ pool_mem,
+                                                         u64 *__restrict__ thr_out, u32 *__restrict__ overflow) {
+    const int lane = threadIdx.x;
+    const u32 q = blockIdx.x;
+    if (q >= B) return;
+    Pool<1> pool;
+    pool.e[0] = pool_mem[(u64)q * SEL + lane];
+    u64 thr = readlane_u64(pool.e[0], SEL - 1);
+    u32 cnt = app_cnt[q];
+    if (cnt > cap) { if (lane == 0) atomicOr(overflow, 1u); cnt = cap; }
+    for (u32 c = 0; c < cnt; c += 64) {
+        const u64 key = c + lane < cnt ? app[(u64)q * cap + c + lane] : 0ull;
+        u64 m = __ballot(key > thr);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const u64 kk = readlane_u64(key, l);
+            if (kk > thr) {
+                pool.insert_at(kk, pool.rank_of(kk), lane);
+                thr = readlane_u64(pool.e[0], SEL - 1);
+            }
+        }
+    }
+    pool_mem[(u64)q * SEL + lane] = pool.e[0];
+    if (lane == 0) { thr_out[q] = thr; app_cnt[q] = 0; }
 }
 
 // segments per query: enough waves to fill 256 CUs x 8, at least 4096 candidates per segment
@@ -200,12 +233,13 @@ static u32 select_segments(u32 B, u32 n_chunk) {
     if (S > 64) S = 64;
     return S ? S : 1;
 }
-static hipError_t launch_select(const float *d_scores, u64 s_stride, u32 B, u32 n0, u32 nc, u64 *d_part, u32 S, u64 *d_pool, hipStream_t st) {
+static hipError_t launch_select(const float *d_scores, u64 s_stride, u32 B, u32 n0, u32 nc, u64 *d_part, u32 S, u64 *d_pool, hipStream_t st,
+                                u64 *d_thr = nullptr) {
     const u32 seg_len = ((nc + S - 1) / S + 63) / 64 * 64;
     hipLaunchKernelGGL(flat_select_segments, dim3(B, S), dim3(64), 0, st, d_scores, s_stride, B, n0, nc, seg_len, d_part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(flat_select_merge, dim3(B), dim3(64), 0, st, (const u64 *)d_part, B, S, d_pool);
+    hipLaunchKernelGGL(flat_select_merge, dim3(B), dim3(64), 0, st, (const u64 *)d_part, B, S, d_pool, d_thr);
     return hipGetLastError();
 }
 
@@ -290,12 +324,36 @@ __device__ __forceinline__ uint4 stage16(const uint8_t *__restrict__ row, u32 k0
     return o;
 }
 
-template <int ENG>
+// queries' quaternary planes -> the i8 digits the GEMM multiplies, once per batch ([B][kdims] bytes): the scan kernel then
+// stages the query operand with plain 16 B copies instead of re-expanding it for every one of the N / 128 candidate tiles
+__global__ void expand_q2_digits_kernel(const uint8_t *__restrict__ qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *__restrict__ digits) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 pieces = kdims / 16;
+    if (t >= (u64)B * pieces) return;
+    const u32 q = (u32)(t / pieces), k0 = (u32)(t % pieces) * 16;
+    const u32 code_k = (u32)(row_stride / 16) * 64;
+    *(uint4 *)(digits + (u64)q * kdims + k0) = stage16<ENG_Q2>(qcodes + (u64)q * row_stride, k0, k0 < code_k);
+}
+
+// Threshold-filtered epilogue (FUSED): instead of writing the [B][chunk] score matrix to HBM for a second kernel to select from
+// (10 GB written + 10 GB re-read per 256 x 10M scan against 1.9 GB of codes), every score is compared with its query's current
+// SEL-th best key and only the rare survivors are appended to app[B][cap] through a per-query counter.  A reciprocal-based
+// estimate (4 VALU ops) screens the elements; the exact IEEE quotient — the value that is ranked — is formed only for those
+// within 4e-6 of the threshold or above it, so results are identical to the unfused path.
+struct FusedOut {
+    const u64 *thr;   // [B] SEL-th best (key) so far; 0 = pool not full yet, everything passes
+    u64 *app;         // [B][cap]
+    u32 *app_cnt;     // [B]
+    u32 cap;
+    const uint8_t *qdigits; // ENG_Q2: [B][kdims] pre-expanded query digits (expand_q2_digits_kernel)
+};
+
+template <int ENG, bool FUSED>
 __global__ __launch_bounds__(512) void flat_codes_gemm_i8(const uint8_t *__restrict__ qcodes, const float *__restrict__ qmags,
                                                           const u32 *__restrict__ qsums, u32 B, const uint8_t *__restrict__ codes,
                                                           const float *__restrict__ mags, const u32 *__restrict__ csums, u64 row_stride,
                                                           u32 n0, u32 n_chunk, u32 kdims /*padded to 64*/, u32 metric,
-                                                          float *__restrict__ scores, u64 s_stride) {
+                                                          float *__restrict__ scores, u64 s_stride, const FusedOut fo) {
     __shared__ __attribute__((aligned(16))) unsigned char As[CM * CLD];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[CN * CLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -315,7 +373,10 @@ __global__ __launch_bounds__(512) void flat_codes_gemm_i8(const uint8_t *__restr
             for (int h = 0; h < 2; h++) {
                 const int piece = tid * 2 + h, r = piece >> 2, kq = (piece & 3) * 16;
                 const u32 qr = row0 + r;
-                *(uint4 *)(As + r * CLD + kq) = stage16<ENG>(qcodes + (u64)qr * row_stride, k0 + kq, qr < B && k0 + kq < code_k);
+                if constexpr (FUSED && ENG == ENG_Q2)
+                    *(uint4 *)(As + r * CLD + kq) = qr < B ? *(const uint4 *)(fo.qdigits + (u64)qr * kdims + k0 + kq) : make_uint4(0, 0, 0, 0);
+                else
+                    *(uint4 *)(As + r * CLD + kq) = stage16<ENG>(qcodes + (u64)qr * row_stride, k0 + kq, qr < B && k0 + kq < code_k);
             }
             const int r = tid >> 2, kq = (tid & 3) * 16;
             const u32 xr = col0 + r;
@@ -333,6 +394,48 @@ __global__ __launch_bounds__(512) void flat_codes_gemm_i8(const uint8_t *__restr
             acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
+    }
+    if constexpr (FUSED) {
+        // per-row filter state in LDS (the operand panels are dead: the k loop ended with a barrier)
+        u64 *thr_key = (u64 *)As;                         // [CM]
+        float *thr_lo = (float *)(As + CM * 8);           // [CM] score a candidate must reach to be worth the exact quotient
+        float *rq = (float *)(As + CM * 12);              // [CM] ~1/|q|
+        for (int idx = tid; idx < CM; idx += 512) {
+            const u32 row = row0 + idx;
+            const u64 k = row < B ? fo.thr[row] : ~0ull;
+            thr_key[idx] = k;
+            thr_lo[idx] = k == 0ull ? -1.0f : simkey_inv((u32)(k >> 32)) * (1.0f - 4e-6f); // scores of u8 / quaternary codes are >= 0
+            rq[idx] = row < B ? __builtin_amdgcn_rcpf(qmags[row]) : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const u32 col = col0 + wc * 64 + j * 32 + (lane & 31);
+                const bool cv = col < n_chunk;
+                const float xm = cv ? mags[n0 + col] : 1.0f;
+                const float rx = __builtin_amdgcn_rcpf(xm);
+                const int cs = (ENG == ENG_U8 && cv) ? (int)csums[n0 + col] : 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int rl = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const u32 row = row0 + rl;
+                    int dot = acc[i][j][r];
+                    if constexpr (ENG == ENG_U8) dot += 128 * (int)qsums[row < B ? row : 0] + 128 * cs - 16384 * (int)kdims;
+                    const float dotf = (float)(u32)dot;
+                    const float est = metric == 0u ? dotf * rx * rq[rl] : dotf;
+                    if (row < B && cv && est >= thr_lo[rl]) {
+                        const float sc = metric == 0u ? __fdiv_rn(dotf, __fmul_rn(qmags[row], xm)) : dotf;
+                        const u64 key = pack_key(simkey(sc), n0 + col);
+                        if (key > thr_key[rl]) {
+                            const u32 pos = atomicAdd(&fo.app_cnt[row], 1u);
+                            if (pos < fo.cap) fo.app[(u64)row * fo.cap + pos] = key;
+                        }
+                    }
+                }
+            }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -480,74 +583,126 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     if (rc) return rc;
     const u32 dim = ix->p.dim, n = ix->n;
     const u32 kdims = ix->eng == ENG_U8 ? (u32)((ix->row_stride + 63) / 64 * 64) : (u32)(ix->row_stride / 16) * 64;
-    u32 chunk = (u32)std::min<u64>(1u << 20, ((1ull << 31) / B / 4) / CN * CN);
+    // Scan schedule.  The first candidates (SEED of them) go through the unfused path — score matrix + segmented selection —
+    // and seed every query's threshold; from then on chunks grow 8x (128 K, 1 M, 4 M ...) and the fused GEMM appends only what
+    // beats the threshold: a chunk 8x the size of everything seen before lets ~64 * 8 entries per query through, an eighth of
+    // the append capacity.  An adversarially ordered corpus can still overflow it; that is detected on the device and the
+    // call is repeated on the unfused path, so the result never depends on the shortcut.  COS_FLAT_UNFUSED=1 forces that path.
+    const bool allow_fused = getenv("COS_FLAT_UNFUSED") == nullptr;
+    constexpr u32 SEED = 16384, APP_CAP = 4096;
+    u32 chunk = (u32)std::min<u64>(1u << 20, ((1ull << 31) / B / 4) / CN * CN); // unfused: the [B][chunk] score buffer stays <= 2 GiB
     chunk = std::min(n, std::max<u32>(chunk, CN));
-    const u64 s_stride = ((u64)chunk + 63) & ~63ull;
     hipStream_t st = ix->own_stream;
     float *d_q = nullptr, *d_qm = nullptr, *d_qrm = nullptr, *d_scores = nullptr, *d_os = nullptr;
-    uint8_t *d_qc = nullptr;
-    u32 *d_qs = nullptr, *d_cs = nullptr, *d_oi = nullptr, *d_oc = nullptr, *d_zero = nullptr;
-    u64 *d_pool = nullptr, *d_part = nullptr;
+    uint8_t *d_qc = nullptr, *d_qd = nullptr;
+    u32 *d_qs = nullptr, *d_cs = nullptr, *d_oi = nullptr, *d_oc = nullptr, *d_zero = nullptr, *d_appcnt = nullptr;
+    u64 *d_pool = nullptr, *d_part = nullptr, *d_thr = nullptr, *d_app = nullptr;
     std::vector<hipEvent_t> evs; // (start, stop) of every GEMM launch, read after the last one
-    const u32 S = select_segments(B, chunk);
-    hipError_t e = hipMalloc(&d_q, (size_t)B * dim * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_part, (size_t)B * S * SEL * 8);
-    if (e == hipSuccess) e = hipMalloc(&d_zero, 4);
-    if (e == hipSuccess) e = hipMemsetAsync(d_zero, 0, 4, st);
-    if (e == hipSuccess) e = hipMalloc(&d_qm, (size_t)B * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_qrm, (size_t)B * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_qc, (size_t)B * ix->row_stride);
-    if (e == hipSuccess) e = hipMalloc(&d_qs, (size_t)B * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_cs, ((size_t)n + 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_scores, (size_t)B * s_stride * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_pool, (size_t)B * SEL * 8);
-    if (e == hipSuccess) e = hipMalloc(&d_oi, (size_t)B * top_k * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_os, (size_t)B * top_k * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_oc, (size_t)B * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_q, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
-    if (e == hipSuccess) e = launch_quantize_rows(ix->eng, d_q, dim, B, dim, ix->p.range_lo, ix->p.range_hi, d_qc, ix->row_stride, d_qm, d_qrm, st);
-    if (e == hipSuccess && ix->eng == ENG_U8) {
-        hipLaunchKernelGGL(code_sums_kernel, dim3((B + 3) / 4), dim3(256), 0, st, d_qc, ix->row_stride, B, d_qs);
-        hipLaunchKernelGGL(code_sums_kernel, dim3((n + 3) / 4), dim3(256), 0, st, ix->d_codes, ix->row_stride, n, d_cs);
-        e = hipGetLastError();
-    }
-    // zero-norm screening (cosine): the reference aborts a search on the first zero denominator it meets; an
-    // exhaustive scan meets every vector, so any zero |q| or zero |v| is a CalculationError for the call.
-    u32 hzero = 0;
-    if (e == hipSuccess && ix->p.metric == COS_METRIC_COSINE) {
-        hipLaunchKernelGGL(any_zero_kernel, dim3(64), dim3(256), 0, st, (const float *)d_qm, B, d_zero);
-        hipLaunchKernelGGL(any_zero_kernel, dim3(1024), dim3(256), 0, st, (const float *)ix->d_mags, n, d_zero);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(&hzero, d_zero, 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    const bool zero = hzero != 0;
     float gemm_ms = 0.f;
     u32 launches = 0;
-    if (e == hipSuccess && !zero) {
-        for (u32 n0 = 0; n0 < n && e == hipSuccess; n0 += chunk) {
-            const u32 nc = std::min(chunk, n - n0);
+    double streamed = 0.0;
+    bool zero = false;
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 2 && e == hipSuccess; attempt++) {
+        const bool fused = allow_fused && attempt == 0 && n > SEED;
+        const u32 first = fused ? SEED : chunk;                              // size of the (unfused) first chunk
+        const u64 s_stride = ((u64)std::min(first, n) + 63) & ~63ull;
+        const u32 S = select_segments(B, std::min(first, n));
+        if (attempt == 0) {
+            e = hipMalloc(&d_q, (size_t)B * dim * 4);
+            if (e == hipSuccess) e = hipMalloc(&d_zero, 8);
+            if (e == hipSuccess) e = hipMemsetAsync(d_zero, 0, 8, st);
+            if (e == hipSuccess) e = hipMalloc(&d_qm, (size_t)B * 4);
+            if (e == hipSuccess) e = hipMalloc(&d_qrm, (size_t)B * 4);
+            if (e == hipSuccess) e = hipMalloc(&d_qc, (size_t)B * ix->row_stride);
+            if (e == hipSuccess) e = hipMalloc(&d_qd, (size_t)B * kdims);
+            if (e == hipSuccess) e = hipMalloc(&d_qs, (size_t)B * 4);
+            if (e == hipSuccess) e = hipMalloc(&d_cs, ((size_t)n + 1) * 4);
+            if (e == hipSuccess) e = hipMalloc(&d_pool, (size_t)B * SEL * 8);
+            if (e == hipSuccess) e = hipMalloc(&d_thr, (size_t)B * 8);
+            if (e == hipSuccess) e = hipMalloc(&d_app, (size_t)B * APP_CAP * 8);
+            if (e == hipSuccess) e = hipMalloc(&d_appcnt, (size_t)B * 4);
+            if (e == hipSuccess) e = hipMalloc(&d_oi, (size_t)B * top_k * 4);
+            if (e == hipSuccess) e = hipMalloc(&d_os, (size_t)B * top_k * 4);
+            if (e == hipSuccess) e = hipMalloc(&d_oc, (size_t)B * 4);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_q, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = launch_quantize_rows(ix->eng, d_q, dim, B, dim, ix->p.range_lo, ix->p.range_hi, d_qc, ix->row_stride, d_qm, d_qrm, st);
+            if (e == hipSuccess && ix->eng == ENG_U8) {
+                hipLaunchKernelGGL(code_sums_kernel, dim3((B + 3) / 4), dim3(256), 0, st, d_qc, ix->row_stride, B, d_qs);
+                hipLaunchKernelGGL(code_sums_kernel, dim3((n + 3) / 4), dim3(256), 0, st, ix->d_codes, ix->row_stride, n, d_cs);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess && ix->eng == ENG_Q2) {
+                const u64 pieces = (u64)B * (kdims / 16);
+                hipLaunchKernelGGL(expand_q2_digits_kernel, dim3((u32)((pieces + 255) / 256)), dim3(256), 0, st, d_qc, ix->row_stride, B, kdims, d_qd);
+                e = hipGetLastError();
+            }
+            // zero-norm screening (cosine): the reference aborts a search on the first zero denominator it meets; an
+            // exhaustive scan meets every vector, so any zero |q| or zero |v| is a CalculationError for the call.
+            u32 hzero = 0;
+            if (e == hipSuccess && ix->p.metric == COS_METRIC_COSINE) {
+                hipLaunchKernelGGL(any_zero_kernel, dim3(64), dim3(256), 0, st, (const float *)d_qm, B, d_zero);
+                hipLaunchKernelGGL(any_zero_kernel, dim3(1024), dim3(256), 0, st, (const float *)ix->d_mags, n, d_zero);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&hzero, d_zero, 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            zero = hzero != 0;
+            if (zero) break;
+        }
+        if (d_scores) (void)hipFree(d_scores);
+        if (d_part) (void)hipFree(d_part);
+        d_scores = nullptr; d_part = nullptr;
+        if (e == hipSuccess) e = hipMalloc(&d_scores, (size_t)B * s_stride * 4);
+        if (e == hipSuccess) e = hipMalloc(&d_part, (size_t)B * S * SEL * 8);
+        if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_thr, 0, (size_t)B * 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_appcnt, 0, (size_t)B * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_zero + 1, 0, 4, st); // overflow flag of the fused path
+        FusedOut fo{d_thr, d_app, d_appcnt, APP_CAP, d_qd};
+        u32 n0 = 0, seen = 0;
+        while (n0 < n && e == hipSuccess) {
+            const bool use_fused = fused && n0 > 0;
+            u32 nc = use_fused ? std::min<u64>((u64)seen * 8, 1ull << 22) : first;
+            nc = std::min(nc, n - n0);
             dim3 grid((nc + CN - 1) / CN, (B + CM - 1) / CM);
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             e = hipEventCreate(&ev0);
             if (e == hipSuccess) { evs.push_back(ev0); e = hipEventCreate(&ev1); }
             if (e == hipSuccess) { evs.push_back(ev1); e = hipEventRecord(ev0, st); }
             if (e != hipSuccess) break;
-            if (ix->eng == ENG_U8)
-                hipLaunchKernelGGL(flat_codes_gemm_i8<ENG_U8>, grid, dim3(512), 0, st, d_qc, d_qm, d_qs, B, ix->d_codes, ix->d_mags, d_cs, ix->row_stride, n0, nc, kdims, ix->p.metric, d_scores, s_stride);
-            else
-                hipLaunchKernelGGL(flat_codes_gemm_i8<ENG_Q2>, grid, dim3(512), 0, st, d_qc, d_qm, d_qs, B, ix->d_codes, ix->d_mags, d_cs, ix->row_stride, n0, nc, kdims, ix->p.metric, d_scores, s_stride);
-            if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess) e = hipEventRecord(ev1, st);
-            if (e == hipSuccess) e = launch_select(d_scores, s_stride, B, n0, nc, d_part, S, d_pool, st);
-            launches++;
-        }
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(flat_rerank_top5k, dim3(B), dim3(64), (((size_t)dim * 4 + 15) & ~(size_t)15), st, d_q, (u64)dim, d_qrm, B, ix->d_raw, (u64)dim,
-                               ix->d_raw_mags, dim, d_pool, 5 * top_k, top_k, ix->p.id_base, d_oi, d_os, d_oc);
+#define FLAT_ARGS d_qc, d_qm, d_qs, B, ix->d_codes, ix->d_mags, d_cs, ix->row_stride, n0, nc, kdims, ix->p.metric, d_scores, s_stride, fo
+            if (ix->eng == ENG_U8) {
+                if (use_fused) hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, true>), grid, dim3(512), 0, st, FLAT_ARGS);
+                else hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, false>), grid, dim3(512), 0, st, FLAT_ARGS);
+            } else {
+                if (use_fused) hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_Q2, true>), grid, dim3(512), 0, st, FLAT_ARGS);
+                else hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_Q2, false>), grid, dim3(512), 0, st, FLAT_ARGS);
+            }
+#undef FLAT_ARGS
             e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(ev1, st);
+            if (e == hipSuccess) {
+                if (use_fused) {
+                    hipLaunchKernelGGL(flat_select_append, dim3(B), dim3(64), 0, st, (const u64 *)d_app, d_appcnt, APP_CAP, B, d_pool, d_thr, d_zero + 1);
+                    e = hipGetLastError();
+                } else
+                    e = launch_select(d_scores, s_stride, B, n0, nc, d_part, S, d_pool, st, d_thr);
+            }
+            launches++;
+            streamed += (double)nc * (double)ix->row_stride * (double)((B + CM - 1) / CM);
+            n0 += nc;
+            seen += nc;
         }
+        u32 hover = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&hover, d_zero + 1, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess || !fused || hover == 0) break; // done; otherwise the append buffer overflowed: repeat unfused
+    }
+    if (e == hipSuccess && !zero) {
+        hipLaunchKernelGGL(flat_rerank_top5k, dim3(B), dim3(64), (((size_t)dim * 4 + 15) & ~(size_t)15), st, d_q, (u64)dim, d_qrm, B, ix->d_raw, (u64)dim,
+                           ix->d_raw_mags, dim, d_pool, 5 * top_k, top_k, ix->p.id_base, d_oi, d_os, d_oc);
+        e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_oi, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_os, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_oc, (size_t)B * 4, hipMemcpyDeviceToHost, st);
@@ -562,9 +717,9 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
         stats->gemm_ms = gemm_ms;
         stats->gemm_launches = launches;
         stats->int8_ops = 2.0 * (double)B * (double)n * (double)kdims;
-        stats->code_bytes = (double)n * (double)ix->row_stride * (double)((B + CM - 1) / CM);
+        stats->code_bytes = streamed;
     }
-    void *ptrs[] = {d_q, d_qm, d_qrm, d_qc, d_qs, d_cs, d_scores, d_pool, d_part, d_zero, d_oi, d_os, d_oc};
+    void *ptrs[] = {d_q, d_qm, d_qrm, d_qc, d_qd, d_qs, d_cs, d_scores, d_pool, d_part, d_zero, d_oi, d_os, d_oc, d_thr, d_app, d_appcnt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
     HIP_TRY(e);

@@ -68,3 +68,43 @@ def test_flat_code_scan_zero_norm_is_calculation_error():
     with pytest.raises(ca.CosdataError) as ei:
         ix.flat_search(X[:4], 5)
     assert ei.value.status == 2
+
+
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2)])
+@pytest.mark.parametrize("n,dim,B,k", [(70000, 96, 70, 10), (40000, 768, 260, 12)])
+def test_flat_code_scan_fused_epilogue_matches_oracle(storage, res, n, dim, B, k):
+    """n above the 16384-candidate seed chunk: the remaining chunks run the threshold-filtered (fused) epilogue — survivors are
+    appended per query instead of a [B][chunk] score matrix — and the answer must still be the oracle's, bit for bit."""
+    import cosdata_amd as ca
+    X = H.clustered_corpus(n, dim, n_centers=40, sigma=0.2, seed=23)
+    Q = np.concatenate([H.queries_from(X, B - 2, noise=0.05, seed=8), H.uniform_corpus(2, dim, seed=77)])
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType(ca.StorageKind(storage), res))
+    ix.upload_vectors(X)
+    ids, sc, cnt, st = ix.flat_search(Q, k, with_stats=True)
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, storage=storage, resolution=res, num_layers=3)).set_vectors(X)
+    oids, osc, ocnt = oix.flat_search_batch(Q, k, threads=8)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    assert st.gemm_launches >= 2
+
+
+def test_flat_code_scan_fused_overflow_falls_back_exactly():
+    """adversarial order: every later vector is closer to the query than all earlier ones, so everything beats the running
+    threshold and the per-query append buffer overflows — the scan must notice and repeat on the unfused path (same answer)"""
+    import cosdata_amd as ca
+    n, dim = 60000, 64
+    rng = np.random.default_rng(4)
+    q = rng.standard_normal(dim).astype(np.float32)
+    q /= np.linalg.norm(q)
+    noise = rng.standard_normal((n, dim)).astype(np.float32)
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    w = np.linspace(0.0, 1.0, n, dtype=np.float32)[:, None]            # later rows lean further towards q
+    X = (w * q[None, :] + (1.0 - w) * noise).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    X *= 0.9
+    Q = np.stack([q * 0.9, -q * 0.9, X[100], X[59000]]).astype(np.float32)
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType.UnsignedByte())
+    ix.upload_vectors(X)
+    ids, sc, cnt = ix.flat_search(Q, 10)
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, num_layers=3)).set_vectors(X)
+    oids, osc, ocnt = oix.flat_search_batch(Q, 10, threads=8)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
