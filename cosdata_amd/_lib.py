@@ -76,7 +76,8 @@ _lib = None
 ABI_SYMBOLS = [
     "cos_index_create", "cos_index_destroy", "cos_last_error_string", "cos_device_count",
     "cos_index_upload_vectors", "cos_index_set_root", "cos_index_upload_graph_level", "cos_index_level_count",
-    "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build", "cos_index_load_reference_dir", "cos_reference_dir_level_counts", "cos_reference_dir_read_level",
+    "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build", "cos_index_enable_metadata", "cos_index_upload_meta_nodes", "cos_index_upload_meta_graph_level", "cos_search_filtered_batch",
+    "cos_ann_search_filtered_batch", "cos_index_load_reference_dir", "cos_reference_dir_level_counts", "cos_reference_dir_read_level",
     "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_coalescing", "cos_index_set_ef_search",
     "cos_index_set_visited_mode", "cos_index_enable_timing", "cos_index_last_stats", "cos_index_timing_summary", "cos_quantize_batch",
     "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
@@ -107,6 +108,11 @@ def lib():
         "cos_index_download_root": [vp, vp],
         "cos_index_build": [vp, u32],
         "cos_index_load_reference_dir": [vp, C.c_char_p, u32, u32],
+        "cos_index_enable_metadata": [vp, u32, u32],
+        "cos_index_upload_meta_nodes": [vp, u32, vp, vp],
+        "cos_index_upload_meta_graph_level": [vp, u32, u32, vp, vp],
+        "cos_search_filtered_batch": [vp, vp, u32, vp, vp, u32, vp, vp, vp, vp],
+        "cos_ann_search_filtered_batch": [vp, vp, u32, vp, vp, vp, vp, vp, vp],
         "cos_reference_dir_level_counts": [C.c_char_p, u32, u32, u32, vp],
         "cos_reference_dir_read_level": [C.c_char_p, u32, u32, u32, u32, vp, vp],
         "cos_search_batch": [vp, vp, u32, u32, vp, vp, vp, vp],

@@ -118,7 +118,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
         H.nbr_ids.clear();
         H.node_ids.clear();
         for (u32 id = 0; id < n; id++)
-            if (max_level[id] >= l) H.node_ids.push_back(id);
+            if (max_level[id] >= l) H.node_ids.push_back(id * ix->id_stride); // internal id of vector row `id`
         H.node_ids.push_back(COS_ROOT_ID);
         const u32 nl = (u32)H.node_ids.size(), M = H.M;
         maxM = std::max(maxM, M);
@@ -128,7 +128,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
             std::vector<u32> node_vec(nl), child(nl);
             const std::vector<u32> &D = ix->lv[l - 1].node_ids;
             for (u32 i = 0; i < nl; i++) {
-                node_vec[i] = H.node_ids[i] == COS_ROOT_ID ? n : H.node_ids[i];
+                node_vec[i] = H.node_ids[i] == COS_ROOT_ID ? n : H.node_ids[i] / ix->id_stride;
                 child[i] = (u32)(std::lower_bound(D.begin(), D.end(), H.node_ids[i]) - D.begin()); // same id one level down (vector_store.rs:897-903)
             }
             HIP_TRY(hipMalloc((void **)&H.d_adj_node, (size_t)nl * M * 4));

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -76,6 +77,10 @@ IndexDev cos_make_index_dev(const cos_index *ix) {
     d.nchunks = ix->nchunks;
     d.G = ix->G;
     d.id_base = ix->p.id_base;
+    d.id_stride = ix->id_stride;
+    d.mbits = ix->meta.d_mbits;
+    d.mmags = ix->meta.d_mmags;
+    d.mdim = ix->meta.mdim;
     for (u32 l = 0; l <= ix->p.num_layers; l++) {
         const LevelHost &h = ix->lv[l];
         d.lv[l].adj_vec = h.d_adj_vec;
@@ -152,11 +157,32 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
     return COS_OK;
 }
 
+// the pseudo-root component as the walk kernels see it: every level (0 included) maps node -> id / vector row / metadata row
+IndexDev cos_make_meta_dev(const cos_index *ix) {
+    IndexDev d = cos_make_index_dev(ix);
+    for (u32 l = 0; l <= ix->p.num_layers; l++) {
+        const LevelHost &h = ix->meta.lv[l];
+        d.lv[l].adj_vec = h.d_adj_vec;
+        d.lv[l].adj_node = h.d_adj_node;
+        d.lv[l].node_vec = h.d_node_vec;
+        d.lv[l].child = h.d_child;
+        d.lv[l].node_id = h.d_node_id;
+        d.lv[l].node_meta = h.d_node_meta;
+        d.lv[l].n = h.n;
+        d.lv[l].M = h.M;
+        d.lv[l].root_idx = h.root_idx;
+    }
+    return d;
+}
+
 static void free_level(LevelHost &l) {
     if (l.d_adj_vec) (void)hipFree(l.d_adj_vec);
     if (l.d_adj_node) (void)hipFree(l.d_adj_node);
     if (l.d_node_vec) (void)hipFree(l.d_node_vec);
     if (l.d_child) (void)hipFree(l.d_child);
+    if (l.d_node_id) (void)hipFree(l.d_node_id);
+    if (l.d_node_meta) (void)hipFree(l.d_node_meta);
+    l.d_node_id = l.d_node_meta = nullptr;
     l.d_adj_vec = l.d_adj_node = l.d_node_vec = l.d_child = nullptr;
     l.n = 0;
     l.node_ids.clear();
@@ -179,6 +205,9 @@ extern "C" int32_t cos_index_destroy(cos_index *ix) {
     for (auto &kv : ix->ws) free_ws(kv.second);
     for (auto &kv : ix->thread_streams) if (kv.second) (void)hipStreamDestroy(kv.second);
     for (auto &l : ix->lv) free_level(l);
+    for (auto &l : ix->meta.lv) free_level(l);
+    if (ix->meta.d_mbits) (void)hipFree(ix->meta.d_mbits);
+    if (ix->meta.d_mmags) (void)hipFree(ix->meta.d_mmags);
     if (ix->d_raw && !ix->raw_borrowed) (void)hipFree(ix->d_raw);
     if (ix->d_raw_mags) (void)hipFree(ix->d_raw_mags);
     if (ix->d_codes) (void)hipFree(ix->d_codes);
@@ -204,6 +233,7 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     ix->have_vectors = false;
     ix->have_root = false;
     for (auto &l : ix->lv) free_level(l); // a graph refers to vector rows: new vectors invalidate it
+    for (auto &l : ix->meta.lv) free_level(l);
     const u64 dim = ix->p.dim;
     struct Rollback { // a failed upload leaves the handle empty instead of half-populated
         cos_index *ix;
@@ -229,10 +259,12 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
         HIP_TRY(hipMemcpy(ix->d_raw, raw, (size_t)n * dim * 4, hipMemcpyHostToDevice));
         ix->raw_borrowed = false;
     }
-    HIP_TRY(hipMalloc(&ix->d_raw_mags, ((size_t)n + 1) * 4));
-    HIP_TRY(hipMalloc(&ix->d_codes, ((size_t)n + 1) * ix->row_stride));
-    HIP_TRY(hipMalloc(&ix->d_mags, ((size_t)n + 1) * 4));
-    HIP_TRY(hipMemsetAsync(ix->d_codes + (size_t)n * ix->row_stride, 0, ix->row_stride, ix->own_stream));
+    // rows [0, n) = vectors, row n = the root, row n + 1 = the vector shared by the pseudo nodes of a metadata collection
+    HIP_TRY(hipMalloc(&ix->d_raw_mags, ((size_t)n + 2) * 4));
+    HIP_TRY(hipMalloc(&ix->d_codes, ((size_t)n + 2) * ix->row_stride));
+    HIP_TRY(hipMalloc(&ix->d_mags, ((size_t)n + 2) * 4));
+    HIP_TRY(hipMemsetAsync(ix->d_codes + (size_t)n * ix->row_stride, 0, 2 * ix->row_stride, ix->own_stream));
+    HIP_TRY(hipMemsetAsync(ix->d_mags + n, 0, 8, ix->own_stream));
     HIP_TRY(launch_quantize_rows(ix->eng, ix->d_raw, dim, n, ix->p.dim, ix->p.range_lo, ix->p.range_hi, ix->d_codes, ix->row_stride,
                                  ix->d_mags, ix->d_raw_mags, ix->own_stream));
     HIP_TRY(hipStreamSynchronize(ix->own_stream));
@@ -261,7 +293,7 @@ extern "C" int32_t cos_index_set_root(cos_index *ix, const float *root_raw) {
 }
 
 // id -> vector row (root = row n)
-static inline u32 row_of(const cos_index *ix, u32 id) { return id == COS_ROOT_ID ? ix->n : id; }
+static inline u32 row_of(const cos_index *ix, u32 id) { return id == COS_ROOT_ID ? ix->n : id / ix->id_stride; }
 
 static int32_t push_level_to_device(cos_index *ix, u32 level) {
     LevelHost &L = ix->lv[level];
@@ -327,7 +359,8 @@ extern "C" int32_t cos_index_upload_graph_level(cos_index *ix, uint32_t level, u
     if (rc) return rc;
     for (u32 i = 0; i < n_nodes; i++) {
         if (i && node_ids[i] <= node_ids[i - 1]) return cos_fail(COS_ERR_INVALID, "level %u: node_ids must be strictly ascending", level);
-        if (node_ids[i] != COS_ROOT_ID && node_ids[i] >= ix->n) return cos_fail(COS_ERR_INVALID, "level %u: node id %u out of range", level, node_ids[i]);
+        if (node_ids[i] != COS_ROOT_ID && (node_ids[i] % ix->id_stride != 0 || node_ids[i] / ix->id_stride >= ix->n))
+            return cos_fail(COS_ERR_INVALID, "level %u: node id %u is not the base id of a resident vector (ids are vector row x %u)", level, node_ids[i], ix->id_stride);
     }
     if (node_ids[n_nodes - 1] != COS_ROOT_ID) return cos_fail(COS_ERR_INVALID, "level %u: the root (0xFFFFFFFF) must be the last node", level);
     if (level == 0 && n_nodes != ix->n + 1) return cos_fail(COS_ERR_INVALID, "level 0 must hold every vector plus the root (%u nodes, expected %u)", n_nodes, ix->n + 1);
@@ -885,6 +918,218 @@ extern "C" int32_t cos_index_timing_summary(cos_index *ix, void *stream, cos_tim
         out->walk_ms_max = std::max(out->walk_ms_max, b);
     }
     return COS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// metadata-filtered search: the pseudo-root component and cos_search_filtered_batch
+// ------------------------------------------------------------------------------------------------
+static constexpr u32 PSEUDO_LO = 0xFFFFFEFEu, PSEUDO_HI = 0xFFFFFFFDu; // u32::MAX - 257 (pseudo_root_id, metadata/mod.rs:217) ..= u32::MAX - 2
+
+extern "C" int32_t cos_index_enable_metadata(cos_index *ix, uint32_t mdim, uint32_t max_replicas_per_node) {
+    if (!ix || mdim == 0 || mdim > 64 || max_replicas_per_node == 0) return cos_fail(COS_ERR_INVALID, "metadata dimensions must be in [1, 64] and max_replicas_per_node >= 1");
+    if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before enabling the metadata component");
+    if ((u64)ix->n * max_replicas_per_node >= PSEUDO_LO) return cos_fail(COS_ERR_INVALID, "replica ids would run into the reserved id range");
+    if (ix->p.id_base != 0) return cos_fail(COS_ERR_UNIMPLEMENTED, "metadata collections are not sharded (id_base must be 0)");
+    for (auto &l : ix->lv)
+        if (l.n) return cos_fail(COS_ERR_INVALID, "enable the metadata component before uploading / building the base graph: it changes the id of every vector (row x max_replicas)");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    ix->id_stride = max_replicas_per_node;
+    ix->meta.mdim = mdim;
+    ix->meta.lv.resize(ix->p.num_layers + 1);
+    for (u32 l = 0; l <= ix->p.num_layers; l++) ix->meta.lv[l].M = l == 0 ? ix->p.level0_neighbors_count : ix->p.neighbors_count;
+    // the pseudo nodes' vector: all zeros (pseudo_node_vector, metadata/mod.rs:211-214), quantized like any other vector -> row n + 1
+    DevBuf z;
+    HIP_TRY(z.alloc(((size_t)ix->p.dim + 1) * 4));
+    HIP_TRY(hipMemsetAsync(z.p, 0, ((size_t)ix->p.dim + 1) * 4, ix->own_stream));
+    HIP_TRY(launch_quantize_rows(ix->eng, z.as<float>(), ix->p.dim, 1, ix->p.dim, ix->p.range_lo, ix->p.range_hi,
+                                 ix->d_codes + ((size_t)ix->n + 1) * ix->row_stride, ix->row_stride, ix->d_mags + ix->n + 1, z.as<float>() + ix->p.dim, ix->own_stream));
+    HIP_TRY(hipStreamSynchronize(ix->own_stream));
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_upload_meta_nodes(cos_index *ix, uint32_t n_nodes, const uint32_t *node_ids, const int32_t *mbits) {
+    if (!ix || !node_ids || !mbits || n_nodes == 0) return cos_fail(COS_ERR_INVALID, "null/empty node table");
+    if (!ix->meta.mdim) return cos_fail(COS_ERR_NOT_READY, "cos_index_enable_metadata first");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    const u32 md = ix->meta.mdim;
+    for (u32 i = 0; i < n_nodes; i++) {
+        if (i && node_ids[i] <= node_ids[i - 1]) return cos_fail(COS_ERR_INVALID, "node ids must be strictly ascending");
+        const bool pseudo = node_ids[i] >= PSEUDO_LO && node_ids[i] <= PSEUDO_HI;
+        if (!pseudo && node_ids[i] / ix->id_stride >= ix->n) return cos_fail(COS_ERR_INVALID, "replica id %u has no resident vector", node_ids[i]);
+    }
+    std::vector<float> mags(n_nodes);
+    for (u32 i = 0; i < n_nodes; i++) { // Metadata::from (types.rs:112-126): sqrt of the sequential sum of squares
+        float acc = -0.0f;
+        for (u32 j = 0; j < md; j++) { const float x = (float)mbits[(size_t)i * md + j]; acc = acc + x * x; }
+        mags[i] = sqrtf(acc);
+    }
+    if (ix->meta.d_mbits) (void)hipFree(ix->meta.d_mbits);
+    if (ix->meta.d_mmags) (void)hipFree(ix->meta.d_mmags);
+    ix->meta.d_mbits = nullptr; ix->meta.d_mmags = nullptr;
+    for (auto &l : ix->meta.lv) free_level(l);
+    HIP_TRY(hipMalloc((void **)&ix->meta.d_mbits, (size_t)n_nodes * md * 4));
+    HIP_TRY(hipMalloc((void **)&ix->meta.d_mmags, (size_t)n_nodes * 4));
+    HIP_TRY(hipMemcpy(ix->meta.d_mbits, mbits, (size_t)n_nodes * md * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->meta.d_mmags, mags.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice));
+    ix->meta.node_ids.assign(node_ids, node_ids + n_nodes);
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_upload_meta_graph_level(cos_index *ix, uint32_t level, uint32_t n_nodes, const uint32_t *node_ids, const uint32_t *nbr_ids) {
+    if (!ix || !node_ids || !nbr_ids || n_nodes == 0) return cos_fail(COS_ERR_INVALID, "null/empty level");
+    if (ix->meta.node_ids.empty()) return cos_fail(COS_ERR_NOT_READY, "cos_index_upload_meta_nodes first");
+    if (level > ix->p.num_layers) return cos_fail(COS_ERR_INVALID, "bad level");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    LevelHost &L = ix->meta.lv[level];
+    const u32 M = L.M, n = ix->n;
+    const std::vector<u32> &tab = ix->meta.node_ids;
+    if (node_ids[0] != PSEUDO_LO && !std::binary_search(node_ids, node_ids + n_nodes, PSEUDO_LO)) return cos_fail(COS_ERR_INVALID, "level %u: the pseudo root (u32::MAX - 257) must be a node of every level", level);
+    std::vector<u32> adj_vec((size_t)n_nodes * M), adj_node((size_t)n_nodes * M), node_vec(n_nodes), node_meta(n_nodes);
+    u32 root_idx = 0;
+    for (u32 i = 0; i < n_nodes; i++) {
+        if (i && node_ids[i] <= node_ids[i - 1]) return cos_fail(COS_ERR_INVALID, "level %u: node_ids must be strictly ascending", level);
+        auto it = std::lower_bound(tab.begin(), tab.end(), node_ids[i]);
+        if (it == tab.end() || *it != node_ids[i]) return cos_fail(COS_ERR_INVALID, "level %u: node %u is not in the node table", level, node_ids[i]);
+        node_meta[i] = (u32)(it - tab.begin());
+        node_vec[i] = (node_ids[i] >= PSEUDO_LO && node_ids[i] <= PSEUDO_HI) ? n + 1 : node_ids[i] / ix->id_stride;
+        if (node_ids[i] == PSEUDO_LO) root_idx = i;
+    }
+    for (u32 i = 0; i < n_nodes; i++)
+        for (u32 j = 0; j < M; j++) {
+            const u32 id = nbr_ids[(size_t)i * M + j];
+            if (id == COS_SLOT_EMPTY) { adj_vec[(size_t)i * M + j] = adj_node[(size_t)i * M + j] = ROW_EMPTY; continue; }
+            const uint32_t *it = std::lower_bound(node_ids, node_ids + n_nodes, id);
+            if (it == node_ids + n_nodes || *it != id) return cos_fail(COS_ERR_INVALID, "level %u: neighbour id %u of node %u is not a node of this level", level, id, node_ids[i]);
+            adj_node[(size_t)i * M + j] = (u32)(it - node_ids);
+            adj_vec[(size_t)i * M + j] = node_vec[it - node_ids];
+        }
+    free_level(L);
+    L.M = M;
+    auto up = [&](u32 *&dst, const std::vector<u32> &src) -> hipError_t {
+        hipError_t e = hipMalloc((void **)&dst, std::max<size_t>(src.size(), 1) * 4);
+        return e == hipSuccess ? hipMemcpy(dst, src.data(), src.size() * 4, hipMemcpyHostToDevice) : e;
+    };
+    std::vector<u32> ids(node_ids, node_ids + n_nodes);
+    HIP_TRY(up(L.d_adj_vec, adj_vec));
+    HIP_TRY(up(L.d_adj_node, adj_node));
+    HIP_TRY(up(L.d_node_vec, node_vec));
+    HIP_TRY(up(L.d_node_id, ids));
+    HIP_TRY(up(L.d_node_meta, node_meta));
+    L.node_ids = std::move(ids);
+    L.n = n_nodes;
+    L.root_idx = root_idx;
+    // child links: the same replica one level down; resolved for this level and the one above once both are resident
+    for (u32 lv = level; lv <= std::min(level + 1, ix->p.num_layers); lv++) {
+        if (lv == 0) continue;
+        LevelHost &U = ix->meta.lv[lv], &D = ix->meta.lv[lv - 1];
+        if (U.n == 0 || D.n == 0) continue;
+        std::vector<u32> child(U.n);
+        for (u32 i = 0; i < U.n; i++) {
+            auto it = std::lower_bound(D.node_ids.begin(), D.node_ids.end(), U.node_ids[i]);
+            if (it == D.node_ids.end() || *it != U.node_ids[i]) return cos_fail(COS_ERR_INVALID, "node %u of level %u is missing on level %u", U.node_ids[i], lv, lv - 1);
+            child[i] = (u32)(it - D.node_ids.begin());
+        }
+        if (U.d_child) (void)hipFree(U.d_child);
+        U.d_child = nullptr;
+        HIP_TRY(up(U.d_child, child));
+    }
+    return COS_OK;
+}
+
+static bool meta_ready(const cos_index *ix) {
+    if (!ix->meta.mdim || ix->meta.lv.size() != ix->p.num_layers + 1) return false;
+    for (u32 l = 0; l <= ix->p.num_layers; l++)
+        if (ix->meta.lv[l].n == 0 || (l > 0 && !ix->meta.lv[l].d_child)) return false;
+    return ix->have_vectors;
+}
+
+// quantize -> filtered walk (pseudo-root component) -> [finalize]; host buffers.  per-level lists when out_lvl_* are given.
+static int32_t search_filtered_host(cos_index *ix, const float *queries, u32 B, const u32 *f_off, const int8_t *f_dims, u32 top_k, u32 *out_ids,
+                                    float *out_scores, u32 *out_counts, int32_t *out_status, u32 *lvl_ids, float *lvl_sims, u32 *lvl_counts) {
+    if (!ix || !queries || !f_off || !f_dims || B == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    if (!meta_ready(ix)) return cos_fail(COS_ERR_NOT_READY, "the metadata component needs its node table and every graph level before a filtered search");
+    u32 ef, vmode;
+    { std::lock_guard<std::mutex> g(ix->mu); ef = ix->p.ef_search; vmode = ix->p.visited_mode; }
+    if (vmode != COS_VISITED_REF) return cos_fail(COS_ERR_UNIMPLEMENTED, "filtered search implements the reference's PerformantFixedSet filter only");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    const u32 md = ix->meta.mdim, nf = f_off[B], L1 = ix->p.num_layers + 1;
+    for (u32 b = 0; b < B; b++)
+        if (f_off[b + 1] < f_off[b] || f_off[b + 1] == f_off[b]) return cos_fail(COS_ERR_INVALID, "query %u has no filter (an unfiltered query goes through cos_search_batch)", b);
+    std::vector<int32_t> fd((size_t)nf * md);
+    std::vector<float> fm(nf);
+    for (u32 f = 0; f < nf; f++) { // Metadata::from(&QueryFilterDimensions) (types.rs:128-147)
+        float acc = -0.0f;
+        for (u32 j = 0; j < md; j++) { const int32_t v = f_dims[(size_t)f * md + j]; fd[(size_t)f * md + j] = v; const float x = (float)v; acc = acc + x * x; }
+        fm[f] = sqrtf(acc);
+    }
+    hipStream_t st;
+    rc = thread_stream(ix, &st);
+    if (rc) return rc;
+    Workspace *w;
+    rc = get_workspace(ix, (void *)st, B, top_k ? top_k : 1, true, &w);
+    if (rc) return rc;
+    DevBuf d_fd, d_fm, d_fo;
+    HIP_TRY(d_fd.alloc(fd.size() * 4));
+    HIP_TRY(d_fm.alloc(fm.size() * 4));
+    HIP_TRY(d_fo.alloc(((size_t)B + 1) * 4));
+    HIP_TRY(hipMemcpyAsync(d_fd.p, fd.data(), fd.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_fm.p, fm.data(), fm.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_fo.p, f_off, ((size_t)B + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(w->d_queries, queries, (size_t)B * ix->p.dim * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_quantize_rows(ix->eng, w->d_queries, ix->p.dim, B, ix->p.dim, ix->p.range_lo, ix->p.range_hi, w->q_codes, ix->row_stride, w->q_mags,
+                                 w->q_raw_mags, st));
+    IndexDev dev = cos_make_meta_dev(ix);
+    dev.visited_mode = COS_VISITED_REF;
+    WalkArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.qcodes = w->q_codes;
+    wa.qmags = w->q_mags;
+    wa.B = B;
+    wa.ef = ef;
+    wa.keep = KEEP_SEARCH;
+    wa.out_ids = w->walk_ids;
+    wa.out_sims = w->walk_sims;
+    wa.out_counts = w->walk_counts;
+    wa.out_status = w->walk_status;
+    wa.f_dims = d_fd.as<int32_t>();
+    wa.f_mags = d_fm.as<float>();
+    wa.f_off = d_fo.as<u32>();
+    HIP_TRY(launch_walk_meta(ix->eng, dev, wa, st));
+    std::vector<int32_t> status(B);
+    if (lvl_ids) {
+        HIP_TRY(hipMemcpyAsync(lvl_ids, w->walk_ids, (size_t)B * L1 * KEEP_SEARCH * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(lvl_sims, w->walk_sims, (size_t)B * L1 * KEEP_SEARCH * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(lvl_counts, w->walk_counts, (size_t)B * L1 * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(status.data(), w->walk_status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    } else {
+        HIP_TRY(launch_finalize(dev, w->d_queries, ix->p.dim, w->q_raw_mags, w->walk_ids, w->walk_sims, w->walk_counts, w->walk_status, B, top_k, w->d_out_ids,
+                                w->d_out_scores, w->d_out_counts, w->d_out_status, w->rerank_rows, st));
+        HIP_TRY(hipMemcpyAsync(out_ids, w->d_out_ids, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_scores, w->d_out_scores, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_counts, w->d_out_counts, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(status.data(), w->d_out_status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
+    for (u32 b = 0; b < B; b++)
+        if (status[b] != COS_OK) return cos_fail(status[b], "filtered query %u failed with status %d", b, status[b]);
+    return COS_OK;
+}
+
+extern "C" int32_t cos_search_filtered_batch(cos_index *ix, const float *queries, uint32_t B, const uint32_t *filter_offsets, const int8_t *filter_dims,
+                                             uint32_t top_k, uint32_t *out_ids, float *out_scores, uint32_t *out_counts, int32_t *out_status) {
+    if (!out_ids || !out_scores || !out_counts || top_k == 0 || top_k > 1024) return cos_fail(COS_ERR_INVALID, "bad argument");
+    return search_filtered_host(ix, queries, B, filter_offsets, filter_dims, top_k, out_ids, out_scores, out_counts, out_status, nullptr, nullptr, nullptr);
+}
+
+extern "C" int32_t cos_ann_search_filtered_batch(cos_index *ix, const float *queries, uint32_t B, const uint32_t *filter_offsets, const int8_t *filter_dims,
+                                                 uint32_t *out_ids, float *out_sims, uint32_t *out_counts, int32_t *out_status) {
+    if (!out_ids || !out_sims || !out_counts) return cos_fail(COS_ERR_INVALID, "null output");
+    return search_filtered_host(ix, queries, B, filter_offsets, filter_dims, 0, nullptr, nullptr, nullptr, out_status, out_ids, out_sims, out_counts);
 }
 
 // ------------------------------------------------------------------------------------------------

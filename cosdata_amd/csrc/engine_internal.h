@@ -20,6 +20,7 @@ hipError_t launch_link_round(const LinkArgs &a, u32 maxM, const u32 *pend, const
 hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
                                 u64 row_stride, float *mags, float *raw_mags, hipStream_t st);
 hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
+hipError_t launch_walk_meta(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
                            u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
@@ -58,7 +59,9 @@ struct LevelHost {
     std::vector<u32> node_ids; // ascending, root last
     std::vector<u32> nbr_ids;  // [n][M] internal ids / COS_SLOT_EMPTY
     u32 *d_adj_vec = nullptr, *d_adj_node = nullptr, *d_node_vec = nullptr, *d_child = nullptr;
+    u32 *d_node_id = nullptr, *d_node_meta = nullptr; // pseudo-root component only (metadata-filtered search)
     u32 n = 0, M = 0;
+    u32 root_idx = 0;        // pseudo-root component: node index of the pseudo root (base graph: the root is the last node)
     bool host_valid = false; // node_ids/nbr_ids mirror the device arrays
 };
 
@@ -98,6 +101,16 @@ struct Workspace {
     bool timed = false;
 };
 
+// The pseudo-root component of a collection with a metadata schema: pseudo nodes + Metadata replicas, a graph of
+// its own next to the base graph.  Node table = level 0 of the component, ascending replica id.
+struct MetaGraph {
+    u32 mdim = 0;                 // metadata dimensions per node (0 = the index has no metadata schema)
+    std::vector<u32> node_ids;    // [n_meta] ascending
+    int32_t *d_mbits = nullptr;   // [n_meta][mdim]
+    float *d_mmags = nullptr;     // [n_meta]
+    std::vector<LevelHost> lv;    // [num_layers + 1]
+};
+
 struct cos_index {
     cos_params p;
     int eng = -1;
@@ -111,6 +124,8 @@ struct cos_index {
     u32 nchunks = 0, G = 1;
     std::vector<float> root_raw;
     std::vector<LevelHost> lv;
+    u32 id_stride = 1; // internal id of vector row r = r * id_stride (max_replica_per_node with a metadata schema, else 1)
+    MetaGraph meta;
     hipStream_t own_stream = nullptr; // uploads / builder stream (exclusive entry points)
     std::mutex mu;                    // guards the workspace + thread-stream maps, the timing flag, ef_search and visited_mode
     std::map<void *, Workspace *> ws;
@@ -134,4 +149,5 @@ struct cos_index {
 
 
 cosdev::IndexDev cos_make_index_dev(const cos_index *ix);
+cosdev::IndexDev cos_make_meta_dev(const cos_index *ix);
 int32_t cos_set_device(const cos_index *ix);

@@ -14,6 +14,9 @@ struct LevelDev {
     u32 n;
     u32 M;
     u32 root_idx;
+    // pseudo-root component (metadata-filtered search): nodes are replicas, not vectors
+    const u32 *node_id;   // [n] internal (replica) id of a node; nullptr on the base graph (id = vector row * id_stride)
+    const u32 *node_meta; // [n] row of the node's metadata dimensions in IndexDev::mbits
 };
 
 struct IndexDev {
@@ -33,6 +36,12 @@ struct IndexDev {
     u32 nchunks;   // 16-byte chunks per code row (integer engines)
     u32 G;         // lanes per row (power of two, integer engines)
     u32 id_base;
+    u32 id_stride; // internal id of vector row r = r * id_stride: max_replica_per_node on collections with a metadata schema
+                   // (ids are reserved per embedding, collection.rs:445-468), 1 otherwise
+    // metadata dimensions of the pseudo-root component's nodes (types.rs:106-147)
+    const int32_t *mbits; // [n_meta][mdim]
+    const float *mmags;   // [n_meta]
+    u32 mdim;
     LevelDev lv[MAX_LEVELS];
 };
 
@@ -57,6 +66,10 @@ struct WalkArgs {
     u32 *out_nodes;      // optional [B][L+1][keep] node index within the level (builder)
     u32 *out_counts;     // [B][L+1]
     int32_t *out_status; // [B]
+    // metadata-filtered search: the filters of query b are rows [f_off[b], f_off[b+1]) of f_dims[][mdim] (values -1/0/1)
+    const int32_t *f_dims;
+    const float *f_mags;
+    const u32 *f_off;
     u64 *out_stats;      // [B][4]: evals, expansions, adj_bytes, reserved
 };
 

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
     }
 
     const u32 qrow = wa.q_rows ? wa.q_rows[qi] : qi;
-    const u32 self_id = wa.self_ids ? wa.self_ids[qi] : COS_QUERY_ID;
+    const u32 self_id = wa.self_ids ? wa.self_ids[qi] * ix.id_stride : COS_QUERY_ID; // self_ids are vector rows
     const uint8_t *qcode = wa.qcodes + (u64)qrow * ix.row_stride;
     const float qmag = wa.qmags[qrow];
     const u32 N = ix.n;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
             float s0;
             n_evals++;
             if (!single_distance(erow, s0)) { status = COS_ERR_CALCULATION; break; }
-            const u32 eid = erow == N ? COS_ROOT_ID : erow;
+            const u32 eid = erow == N ? COS_ROOT_ID : erow * ix.id_stride;
             if (lane == 0) {
                 if (!exact) { u32 b = eid & bitmask; sm.vis[b >> 5] |= 1u << (b & 31); }
                 else {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                 bool win;
                 if (!exact) {
                     // PerformantFixedSet: bucket=(id>>6)&(M-1), bit=id&63  <=> linear bit id & (64M-1)
-                    const u32 id = nb_vec == N ? COS_ROOT_ID : nb_vec;
+                    const u32 id = nb_vec == N ? COS_ROOT_ID : nb_vec * ix.id_stride;
                     const u32 bit = id & bitmask;
                     const u32 word = bit >> 5, msk = 1u << (bit & 31);
                     const bool pre = valid && (sm.vis[word] & msk);
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
             if (e < cnt) {
                 const u32 nd = (u32)rk[r];
                 const u32 vrow = lv.node_vec ? lv.node_vec[nd] : nd;
-                wa.out_ids[obase + e] = vrow == N ? COS_ROOT_ID : vrow;
+                wa.out_ids[obase + e] = vrow == N ? COS_ROOT_ID : vrow * ix.id_stride;
                 wa.out_sims[obase + e] = metric_key_inv(metric, (u32)(rk[r] >> 32));
                 if (wa.out_nodes) wa.out_nodes[obase + e] = nd;
             }
@@ -622,7 +622,9 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
                     const u32 j = e - off;
                     const u32 id = fa.walk_ids[b + j];
                     const float sv = fa.walk_sims[b + j];
-                    k[r] = id == COS_ROOT_ID ? 0ull : pack_key(metric_key(metric, sv), id); // root filtered (common.rs:397)
+                    // root filtered (common.rs:397); so are the pseudo nodes of a metadata collection (common.rs:400-402)
+                    const bool drop = id == COS_ROOT_ID || (ix.mdim != 0u && id >= 0xFFFFFEFEu && id <= 0xFFFFFFFDu);
+                    k[r] = drop ? 0ull : pack_key(metric_key(metric, sv), id);
                 }
             }
             off += c;
@@ -669,8 +671,9 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
         for (u32 base = 0; base < ncand; base += 32) {
             const u32 my = base + (u32)pair;
             const u32 id = my < ncand ? cand[my] : 0u;
-            const float dp = f32_pair_dot(ix.raw + (u64)id * ix.raw_stride, qf, ix.dim, lane & 1);
-            const float cs = x86_div(dp, __fmul_rn(mag_query, ix.raw_mags[id])); // 0/0 (zero raw vector or query) -> x86's -NaN
+            const u32 rrow = id / ix.id_stride; // raw embedding of an id = its base id (collection.rs:368-384)
+            const float dp = f32_pair_dot(ix.raw + (u64)rrow * ix.raw_stride, qf, ix.dim, lane & 1);
+            const float cs = x86_div(dp, __fmul_rn(mag_query, ix.raw_mags[rrow])); // 0/0 (zero raw vector or query) -> x86's -NaN
             const u64 key = my < ncand ? pack_key(simkey(cs), id) : 0ull; // total_cmp desc; larger id first on ties
             const int from = (2 * (lane - (int)base)) & 63;
             const u32 klo = (u32)__shfl((int)(u32)key, from, 64), khi = (u32)__shfl((int)(u32)(key >> 32), from, 64);
@@ -688,8 +691,9 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
         for (u32 base = 0; base < ncand; base += 32) {
             const u32 my = base + (u32)pair;
             const u32 id = my < ncand ? cand[my] : 0u;
-            const float dp = f32_pair_dot(ix.raw + (u64)id * ix.raw_stride, qf, ix.dim, lane & 1);
-            const float cs = x86_div(dp, __fmul_rn(mag_query, ix.raw_mags[id])); // 0/0 (zero raw vector or query) -> x86's -NaN
+            const u32 rrow = id / ix.id_stride;
+            const float dp = f32_pair_dot(ix.raw + (u64)rrow * ix.raw_stride, qf, ix.dim, lane & 1);
+            const float cs = x86_div(dp, __fmul_rn(mag_query, ix.raw_mags[rrow])); // 0/0 (zero raw vector or query) -> x86's -NaN
             const u64 key = pack_key(simkey(cs), id);
             // scatter into the blocked register layout: element my -> lane my/FR, reg my%FR
             for (u32 j = 0; j < 32 && base + j < ncand; j++) {

@@ -275,6 +275,55 @@ class HNSWIndex:
         check(_lib.lib().cos_ann_search_batch(self._h, _p(q), B, _p(ids), _p(sims), _p(counts), _p(status)))
         return ids, sims, counts
 
+    # ---- metadata-filtered search (pseudo-root component) ---------------------------------------
+    def enable_metadata(self, mdim: int, max_replicas_per_node: int):
+        check(_lib.lib().cos_index_enable_metadata(self._h, mdim, max_replicas_per_node))
+        self.mdim = mdim
+        return self
+
+    def upload_meta_graph(self, node_ids, mbits, levels):
+        """node table (ascending replica ids, mbits [n][mdim]) + the component's levels [(node_ids, nbr_ids), ...]"""
+        ids, mb = _c(node_ids, np.uint32), _c(mbits, np.int32)
+        assert mb.shape == (ids.size, self.mdim)
+        check(_lib.lib().cos_index_upload_meta_nodes(self._h, ids.size, _p(ids), _p(mb)))
+        for l, (lid, nbr) in enumerate(levels):
+            lid, nbr = _c(lid, np.uint32), _c(nbr, np.uint32)
+            assert nbr.shape == (lid.size, self.level_M(l))
+            check(_lib.lib().cos_index_upload_meta_graph_level(self._h, l, lid.size, _p(lid), _p(nbr)))
+        return self
+
+    def _filters(self, filter_offsets, filter_dims):
+        off, fd = _c(filter_offsets, np.uint32), _c(np.atleast_2d(filter_dims), np.int8)
+        if fd.shape[1] != self.mdim or off[-1] != fd.shape[0]:
+            raise CosdataError(_lib.ERR_INVALID, f"filters must be [F][{self.mdim}] i8 with offsets ending at F")
+        return off, fd
+
+    def search_filtered(self, queries, filter_offsets, filter_dims, top_k: int, return_status: bool = False):
+        """search_internal with a Filter: (replica ids [B][k], exact cosine scores, counts)"""
+        q = self._queries(queries)
+        off, fd = self._filters(filter_offsets, filter_dims)
+        B = q.shape[0]
+        ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+        scores = np.zeros((B, top_k), np.float32)
+        counts = np.zeros(B, np.uint32)
+        status = np.zeros(B, np.int32)
+        rc = _lib.lib().cos_search_filtered_batch(self._h, _p(q), B, _p(off), _p(fd), top_k, _p(ids), _p(scores), _p(counts), _p(status))
+        if return_status:
+            return ids, scores, counts, rc, status
+        check(rc)
+        return ids, scores, counts
+
+    def ann_search_filtered(self, queries, filter_offsets, filter_dims):
+        q = self._queries(queries)
+        off, fd = self._filters(filter_offsets, filter_dims)
+        B, L1 = q.shape[0], self.hnsw_params.num_layers + 1
+        ids = np.zeros((B, L1, 100), np.uint32)
+        sims = np.zeros((B, L1, 100), np.float32)
+        counts = np.zeros((B, L1), np.uint32)
+        status = np.zeros(B, np.int32)
+        check(_lib.lib().cos_ann_search_filtered_batch(self._h, _p(q), B, _p(off), _p(fd), _p(ids), _p(sims), _p(counts), _p(status)))
+        return ids, sims, counts
+
     def enable_timing(self, on: bool = True):
         check(_lib.lib().cos_index_enable_timing(self._h, 1 if on else 0))
 

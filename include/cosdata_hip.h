@@ -185,6 +185,33 @@ typedef struct {
 } cos_timing_summary;
 int32_t cos_index_timing_summary(cos_index *ix, void *stream, cos_timing_summary *out);
 
+/* ---- metadata-filtered search ------------------------------------------------ */
+/* Collections with a metadata schema index every embedding several times (metadata/mod.rs:128-146, vector_store.rs:484-640):
+ * a Base replica under the main root and one Metadata replica per field combination under the PSEUDO root, next to the pseudo
+ * nodes created with the index (api_service.rs:135-210).  A search with a Filter starts at the pseudo root and walks that second
+ * component once per QueryFilterDimensions with one shared visited filter per level (indexes/hnsw/mod.rs:413-423,
+ * vector_store.rs:273-313); the distance depends on the kinds of node and query (distance/cosine.rs:36-102).  Schema -> dimension
+ * encoding (metadata/schema.rs, query_filtering.rs) stays on the host; the device takes the numeric form.
+ * Ids: an embedding reserves max_replicas_per_node consecutive internal ids (collection.rs:445-468): vector row r has base id
+ * r * max_replicas_per_node (also in the BASE graph from now on), replica i = base + i; pseudo root = u32::MAX - 257, pseudo
+ * nodes follow it.  Returned ids are replica ids; scores are the exact cosine against the embedding's raw vector. */
+int32_t cos_index_enable_metadata(cos_index *ix, uint32_t mdim /* <= 64 */, uint32_t max_replicas_per_node);
+/* node table of the pseudo-root component: ascending replica ids (pseudo root and pseudo nodes last), mbits [n_nodes][mdim] */
+int32_t cos_index_upload_meta_nodes(cos_index *ix, uint32_t n_nodes, const uint32_t *node_ids, const int32_t *mbits);
+/* one level of the component, same conventions as cos_index_upload_graph_level (the pseudo root is on every level) */
+int32_t cos_index_upload_meta_graph_level(cos_index *ix, uint32_t level, uint32_t n_nodes, const uint32_t *node_ids,
+                                          const uint32_t *nbr_ids);
+/* HNSWIndex::search_internal with DenseSearchInput(query, Some(filter)): the filters of query b are rows
+ * [filter_offsets[b], filter_offsets[b+1]) of filter_dims[][mdim] (values -1 / 0 / 1, filter_encoded_dimensions'
+ * output).  Host buffers; error behaviour as cos_search_batch. */
+int32_t cos_search_filtered_batch(cos_index *ix, const float *queries, uint32_t B, const uint32_t *filter_offsets,
+                                  const int8_t *filter_dims, uint32_t top_k, uint32_t *out_ids, float *out_scores,
+                                  uint32_t *out_counts, int32_t *out_status);
+/* the filtered ann_search's per-level lists before finalisation (layout of cos_ann_search_batch) */
+int32_t cos_ann_search_filtered_batch(cos_index *ix, const float *queries, uint32_t B, const uint32_t *filter_offsets,
+                                      const int8_t *filter_dims, uint32_t *out_ids, float *out_sims, uint32_t *out_counts,
+                                      int32_t *out_status);
+
 /* ---- operators (L1 of SURVEY.md §1) --------------------------------------------------------- */
 /* QuantizationMetric::quantize (models/types.rs:504) for n vectors; codes in the REFERENCE layout
  * (u8: dim bytes; SubByte: resolution planes x ceil(dim/8) bytes plane-major, plane 0 = MSB;

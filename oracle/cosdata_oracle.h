@@ -172,6 +172,23 @@ int coso_flat_search_batch(const coso_index *ix, const float *queries, uint32_t 
 int coso_bruteforce_topk(const float *raw, uint32_t n, uint32_t dim, const float *queries, uint32_t B,
                          uint32_t k, uint32_t *out_ids, float *out_scores, int threads);
 
+/* ---- metadata-filtered search: the pseudo-root component ---- */
+/* mdim metadata dimensions per node, `max_replicas` internal ids reserved per embedding (base id = vector row * max_replicas,
+ * replica i = base id + i; pseudo nodes: u32::MAX - 257 (the pseudo root) .. u32::MAX - 2).  Call after set_vectors. */
+int coso_meta_enable(coso_index *ix, uint32_t mdim, uint32_t max_replicas);
+/* node table: ascending replica ids (pseudo root + pseudo nodes last), metadata dimensions mbits[n][mdim] */
+int coso_meta_set_nodes(coso_index *ix, uint32_t n_nodes, const uint32_t *ids_sorted, const int32_t *mbits);
+/* builds the component with the reference's index-side rules; max_levels[n_nodes] = the level drawn per node (table order) */
+int coso_meta_build(coso_index *ix, const uint8_t *max_levels);
+uint32_t coso_meta_level_count(const coso_index *ix, uint32_t level);
+int coso_meta_export_level(const coso_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids);
+/* search_internal with a filter: filters of query b = rows [filter_off[b], filter_off[b+1]) of filter_dims[][mdim] (-1/0/1) */
+int coso_search_filtered_batch(const coso_index *ix, const float *queries, uint32_t B, const uint32_t *filter_off, const int32_t *filter_dims,
+                               uint32_t top_k, uint32_t *out_ids, float *out_scores, uint32_t *out_counts, int32_t *out_status, int threads);
+int coso_ann_search_filtered(const coso_index *ix, const float *query, const int32_t *filter_dims, uint32_t nf, uint32_t *out_ids, float *out_sims,
+                             uint32_t *level_counts);
+void coso_pseudo_level_probs(int num_levels, int num_pseudo_nodes, double *values, uint8_t *levels); /* metadata/mod.rs:182-209 */
+
 /* ---- BM25 + RRF (config c5) ---- */
 float coso_bm25_idf(uint32_t documents_count, uint32_t containing);
 float coso_bm25_tf(uint32_t count, uint32_t doc_len, float avg_len, float k1, float b);

@@ -43,6 +43,15 @@ struct coso_index {
     const uint32_t *sub_ids;
     const float *sub_rows;
     uint32_t sub_n;
+    /* metadata-filtered search: the pseudo-root component — pseudo nodes and the Metadata replicas — is a second
+     * graph with its own levels and entry point (the pseudo root); its nodes carry metadata dimensions (types.rs:106-147) */
+    uint32_t mdim, replicas;  /* metadata dimensions; max_replica_per_node (ids of one embedding: base .. base + replicas - 1) */
+    uint32_t n_meta;
+    uint32_t *meta_id;        /* [n_meta] ascending replica ids (incl. the pseudo root u32::MAX - 257 and the pseudo nodes) */
+    int32_t *meta_mbits;      /* [n_meta][mdim] */
+    float *meta_mdims;        /* [n_meta][mdim] the same as f32 (cosine_similarity_mdims converts) */
+    float *meta_mag;          /* [n_meta] */
+    level_t *mlv;             /* [num_layers+1] */
 };
 
 typedef struct {
@@ -79,7 +88,10 @@ static inline int hent_gt(const hent *a, const hent *b) {
     return a->key > b->key || (a->key == b->key && a->id > b->id);
 }
 
-static inline uint32_t row_of(const coso_index *ix, uint32_t id) { return id == COSO_ROOT_ID ? ix->n : id; }
+/* vector row of an internal id: with a metadata schema every embedding reserves `replicas` ids (collection.rs:445-468) and the
+ * Base node of vector row r has id r * replicas; without one (replicas == 0) id == row */
+static inline uint32_t row_of(const coso_index *ix, uint32_t id) { return id == COSO_ROOT_ID ? ix->n : (ix->replicas > 1 ? id / ix->replicas : id); }
+static inline uint32_t id_of_row(const coso_index *ix, uint32_t row) { return ix->replicas > 1 ? row * ix->replicas : row; }
 static inline uint32_t level_M(const coso_index *ix, uint32_t level) {
     return level == 0 ? ix->p.level0_neighbors_count : ix->p.neighbors_count;
 }
@@ -112,6 +124,8 @@ static void level_free(level_t *L) {
 void coso_index_destroy(coso_index *ix) {
     if (!ix) return;
     for (uint32_t l = 0; l <= ix->p.num_layers; l++) level_free(&ix->lv[l]);
+    if (ix->mlv) for (uint32_t l = 0; l <= ix->p.num_layers; l++) level_free(&ix->mlv[l]);
+    free(ix->mlv); free(ix->meta_id); free(ix->meta_mbits); free(ix->meta_mdims); free(ix->meta_mag);
     free(ix->lv); free(ix->codes); free(ix->mags); free(ix->root_raw); free(ix);
 }
 
@@ -120,8 +134,8 @@ int coso_index_set_vectors(coso_index *ix, const float *raw, uint32_t n) {
     free(ix->codes); free(ix->mags);
     ix->n = n;
     ix->raw = raw;
-    ix->codes = (uint8_t *)calloc((size_t)n + 1, ix->cb);
-    ix->mags = (float *)calloc((size_t)n + 1, sizeof(float));
+    ix->codes = (uint8_t *)calloc((size_t)n + 2, ix->cb); /* row n = root, row n + 1 = the pseudo nodes' vector (f4a) */
+    ix->mags = (float *)calloc((size_t)n + 2, sizeof(float));
     int rc = COSO_OK;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; i++) {
@@ -142,8 +156,8 @@ int coso_index_alloc_vectors(coso_index *ix, uint32_t n) {
     free(ix->codes); free(ix->mags);
     ix->n = n;
     ix->raw = NULL;
-    ix->codes = (uint8_t *)calloc((size_t)n + 1, ix->cb);
-    ix->mags = (float *)calloc((size_t)n + 1, sizeof(float));
+    ix->codes = (uint8_t *)calloc((size_t)n + 2, ix->cb);
+    ix->mags = (float *)calloc((size_t)n + 2, sizeof(float));
     return ix->codes && ix->mags ? COSO_OK : COSO_ERR_INVALID;
 }
 int coso_index_quantize_rows(coso_index *ix, uint32_t start, const float *raw_chunk, uint32_t m) {
@@ -412,7 +426,7 @@ static int search_one(const coso_index *ix, const float *q, uint32_t top_k, scra
     float mag_query = coso_seq_norm_f32(q, d);
     for (int i = 0; i < m; i++) {
         uint32_t id = all[i].id;
-        const float *rv = raw_row(ix, id);
+        const float *rv = raw_row(ix, row_of(ix, id));
         if (!rv) return COSO_ERR_INVALID; /* raw subset does not cover this candidate */
         float dp = coso_dot_f32(q, rv, d);
         float mag_raw = coso_seq_norm_f32(rv, d);
@@ -611,10 +625,10 @@ int coso_index_build(coso_index *ix) {
     uint8_t *pl = (uint8_t *)malloc(Ltop + 1);
     coso_level_probs(4.0, (int)Ltop, pv, pl); /* api_service.rs:109 */
     scratch_t *s = scratch_new(ix);
-    for (uint32_t id = 0; id < ix->n && rc == COSO_OK; id++) {
+    for (uint32_t r = 0; r < ix->n && rc == COSO_OK; r++) {
         double x = (double)rand_f32(&rng);
         int max_level = coso_max_insert_level(x, pv, pl, (int)Ltop + 1);
-        rc = index_embedding(ix, id, IDX_NONE, ix->lv[Ltop].root_idx, (int)Ltop, max_level, s);
+        rc = index_embedding(ix, id_of_row(ix, r), IDX_NONE, ix->lv[Ltop].root_idx, (int)Ltop, max_level, s);
     }
     scratch_free(s);
     free(pv); free(pl);
@@ -658,7 +672,7 @@ int coso_index_build_batched(coso_index *ix, uint32_t batch_size) {
         if (bs > ix->n - inserted) bs = ix->n - inserted;
         /* 1. walks on the snapshot */
         for (uint32_t b = 0; b < bs && rc == COSO_OK; b++) {
-            const uint32_t id = inserted + b, row = id;
+            const uint32_t row = inserted + b, id = id_of_row(ix, row);
             const uint8_t *code = ix->codes + (size_t)row * ix->cb;
             uint32_t entry = ix->lv[Ltop].root_idx;
             for (int level = (int)Ltop; level >= 0; level--) {
@@ -679,9 +693,9 @@ int coso_index_build_batched(coso_index *ix, uint32_t batch_size) {
         if (rc != COSO_OK) break;
         /* 2. create the nodes of the batch (child links top-down) */
         for (uint32_t b = 0; b < bs; b++) {
-            const uint32_t id = inserted + b;
+            const uint32_t id = id_of_row(ix, inserted + b);
             uint32_t parent = IDX_NONE;
-            for (int level = (int)max_level[id]; level >= 0; level--) {
+            for (int level = (int)max_level[inserted + b]; level >= 0; level--) {
                 uint32_t m = level_append(&ix->lv[level], id, (int)ix->p.metric);
                 me[(size_t)b * L1 + (uint32_t)level] = m;
                 if (parent != IDX_NONE) ix->lv[level + 1].child[parent] = m;
@@ -777,7 +791,7 @@ int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uin
         if (bs > Bmax) bs = Bmax;
         if (bs > ix->n - inserted) bs = ix->n - inserted;
         for (uint32_t b = 0; b < bs && rc == COSO_OK; b++) { /* 1. walks on the snapshot (as coso_index_build_batched) */
-            const uint32_t id = inserted + b, row = id;
+            const uint32_t row = inserted + b, id = id_of_row(ix, row);
             const uint8_t *code = ix->codes + (size_t)row * ix->cb;
             uint32_t entry = ix->lv[Ltop].root_idx;
             for (int level = (int)Ltop; level >= 0; level--) {
@@ -797,9 +811,9 @@ int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uin
         }
         if (rc != COSO_OK) break;
         for (uint32_t b = 0; b < bs; b++) { /* 2. nodes of the batch */
-            const uint32_t id = inserted + b;
+            const uint32_t id = id_of_row(ix, inserted + b);
             uint32_t parent = IDX_NONE;
-            for (int level = (int)max_level[id]; level >= 0; level--) {
+            for (int level = (int)max_level[inserted + b]; level >= 0; level--) {
                 uint32_t m = level_append(&ix->lv[level], id, metric);
                 me[(size_t)b * L1 + (uint32_t)level] = m;
                 if (parent != IDX_NONE) ix->lv[level + 1].child[parent] = m;
@@ -1045,4 +1059,447 @@ int coso_bruteforce_topk(const float *raw, uint32_t n, uint32_t dim, const float
     }
     free(mags);
     return COSO_OK;
+}
+
+/* ==========================================================================================
+ * Metadata-filtered search — CPU restatement.
+ *   ReplicaNodeKind / VectorData::replica_node_kind     models/types.rs:171-251
+ *   Metadata (mag, mbits)                               models/types.rs:106-147
+ *   CosineSimilarity::calculate, (node kind, query kind) arms      distance/cosine.rs:36-102
+ *   cosine_similarity_mdims                             distance/cosine.rs:243-262
+ *   ann_search with query_filter_dims                   vector_store.rs:256-402 (one walk per QueryFilterDimensions, ONE
+ *                                                       visited filter per level, drop -1.0, sort desc, take 100)
+ *   search_internal: filtered queries start at the pseudo root     indexes/hnsw/mod.rs:413-423
+ *   remove_duplicates_and_filter drops pseudo nodes     models/common.rs:381-412
+ *   raw embedding of a replica = base id = id - id % max_replica_per_node     models/collection.rs:368-384
+ *   index side: replicas / pseudo nodes, edge refusal   vector_store.rs:484-640, 1017-1041; metadata/mod.rs:182-217
+ * What stays on the host in the reference and here: schema -> dimensions (metadata/schema.rs, query_filtering.rs).  This
+ * component works on the numeric form: per node a replica id and its metadata dimensions, per query a list of filter dimension
+ * vectors in {-1, 0, 1}.  Vector rows: replica id / replicas for embeddings (ids are reserved `replicas` at a time,
+ * collection.rs:445-468), row n + 1 for every pseudo node (they share the pseudo root's all-zero vector, api_service.rs:143-158).
+ * ========================================================================================== */
+#define PSEUDO_LO 0xFFFFFEFEu /* u32::MAX - 257: pseudo_root_id() (metadata/mod.rs:217-224) */
+#define PSEUDO_HI 0xFFFFFFFDu /* u32::MAX - 2 */
+enum { KIND_BASE = 0, KIND_PSEUDO = 1, KIND_METADATA = 2 };
+
+static int meta_index(const coso_index *ix, uint32_t id) {
+    uint32_t lo = 0, hi = ix->n_meta;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (ix->meta_id[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    return (lo < ix->n_meta && ix->meta_id[lo] == id) ? (int)lo : -1;
+}
+static inline uint32_t meta_row_of(const coso_index *ix, uint32_t id) {
+    return (id >= PSEUDO_LO && id <= PSEUDO_HI) ? ix->n + 1 : id / ix->replicas;
+}
+/* VectorData::replica_node_kind (types.rs:219-241): `has_id` = the VectorData carries an id (stored nodes, new nodes being
+ * indexed); a search query has none */
+static int kind_of(float mmag, int has_id, uint32_t id) {
+    if (mmag == 0.0f) return KIND_BASE;
+    if (has_id && id >= PSEUDO_LO && id <= PSEUDO_HI) return KIND_PSEUDO;
+    return KIND_METADATA;
+}
+
+int coso_meta_enable(coso_index *ix, uint32_t mdim, uint32_t max_replicas) {
+    if (!ix || !ix->codes || mdim == 0 || max_replicas == 0) return COSO_ERR_INVALID;
+    ix->mdim = mdim;
+    ix->replicas = max_replicas;
+    float *z = (float *)calloc(ix->p.dim, sizeof(float)); /* pseudo_node_vector: all zeros (metadata/mod.rs:211-214) */
+    int rc = coso_quantize(z, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo, ix->p.range_hi,
+                           ix->codes + ((size_t)ix->n + 1) * ix->cb, &ix->mags[ix->n + 1]);
+    free(z);
+    if (!ix->mlv) {
+        ix->mlv = (level_t *)calloc(ix->p.num_layers + 1, sizeof(level_t));
+        for (uint32_t l = 0; l <= ix->p.num_layers; l++) { ix->mlv[l].M = level_M(ix, l); ix->mlv[l].root_idx = IDX_NONE; }
+    }
+    return rc;
+}
+
+/* node table of the component: ascending replica ids (embedding replicas, then the pseudo root u32::MAX - 257 and the pseudo
+ * nodes after it), mbits [n][mdim].  mag = sqrt(sum of squares) like Metadata::from (types.rs:112-126). */
+int coso_meta_set_nodes(coso_index *ix, uint32_t n_nodes, const uint32_t *ids_sorted, const int32_t *mbits) {
+    if (!ix || !ix->mdim || !ids_sorted || !mbits) return COSO_ERR_INVALID;
+    for (uint32_t i = 1; i < n_nodes; i++)
+        if (ids_sorted[i] <= ids_sorted[i - 1]) return COSO_ERR_INVALID;
+    free(ix->meta_id); free(ix->meta_mbits); free(ix->meta_mdims); free(ix->meta_mag);
+    const uint32_t md = ix->mdim;
+    ix->n_meta = n_nodes;
+    ix->meta_id = (uint32_t *)malloc((size_t)n_nodes * 4 + 4);
+    ix->meta_mbits = (int32_t *)malloc((size_t)n_nodes * md * 4 + 4);
+    ix->meta_mdims = (float *)malloc((size_t)n_nodes * md * 4 + 4);
+    ix->meta_mag = (float *)malloc((size_t)n_nodes * 4 + 4);
+    memcpy(ix->meta_id, ids_sorted, (size_t)n_nodes * 4);
+    memcpy(ix->meta_mbits, mbits, (size_t)n_nodes * md * 4);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (!(ids_sorted[i] >= PSEUDO_LO && ids_sorted[i] <= PSEUDO_HI) && ids_sorted[i] / ix->replicas >= ix->n) return COSO_ERR_INVALID;
+        for (uint32_t j = 0; j < md; j++) ix->meta_mdims[(size_t)i * md + j] = (float)mbits[(size_t)i * md + j];
+        ix->meta_mag[i] = coso_seq_norm_f32(ix->meta_mdims + (size_t)i * md, (int)md);
+    }
+    return COSO_OK;
+}
+
+/* the query side of a distance: the quantized vector + (optional) metadata dimensions */
+typedef struct {
+    const uint8_t *code;
+    float mag;
+    const int32_t *mbits; /* NULL = no metadata */
+    const float *mdims;
+    float mmag;
+    int kind;             /* KIND_* of the query / new node */
+} qdesc;
+
+/* CosineSimilarity::calculate / DotProductDistance on (stored node y, query x) — distance/cosine.rs:36-102 */
+static int meta_distance(const coso_index *ix, const qdesc *q, uint32_t node_id, float *out) {
+    const int k = meta_index(ix, node_id);
+    if (k < 0) return COSO_ERR_INVALID;
+    const uint32_t md = ix->mdim;
+    const int ykind = kind_of(ix->meta_mag[k], 1, node_id), xkind = q->kind;
+    const uint32_t row = meta_row_of(ix, node_id);
+    if (ix->p.metric != COSO_METRIC_COSINE) /* other metrics do not look at the node kinds at all */
+        return coso_distance((int)ix->p.metric, (int)ix->p.storage, (int)ix->p.resolution, (int)ix->p.dim, q->code, q->mag,
+                             ix->codes + (size_t)row * ix->cb, ix->mags[row], out);
+    if (ykind == KIND_PSEUDO && xkind == KIND_PSEUDO) { /* cosine_similarity_mdims */
+        float dp = coso_dot_f32(q->mdims, ix->meta_mdims + (size_t)k * md, (int)md);
+        float den = q->mmag * ix->meta_mag[k];
+        if (den == 0.0f) return COSO_ERR_CALCULATION;
+        *out = dp / den;
+        return COSO_OK;
+    }
+    if (ykind == KIND_PSEUDO && xkind == KIND_METADATA) { /* exact mbits match -> 1.0, anything else -> -1.0 */
+        *out = memcmp(q->mbits, ix->meta_mbits + (size_t)k * md, (size_t)md * 4) == 0 ? 1.0f : -1.0f;
+        return COSO_OK;
+    }
+    if (ykind == KIND_BASE && xkind == KIND_BASE)
+        return coso_distance(COSO_METRIC_COSINE, (int)ix->p.storage, (int)ix->p.resolution, (int)ix->p.dim, q->code, q->mag,
+                             ix->codes + (size_t)row * ix->cb, ix->mags[row], out);
+    if (ykind == KIND_METADATA && xkind == KIND_METADATA) {
+        float dp = coso_dot_f32(q->mdims, ix->meta_mdims + (size_t)k * md, (int)md);
+        float den = q->mmag * ix->meta_mag[k];
+        if (den == 0.0f) return COSO_ERR_CALCULATION;
+        if (dp / den > 0.99f)
+            return coso_distance(COSO_METRIC_COSINE, (int)ix->p.storage, (int)ix->p.resolution, (int)ix->p.dim, q->code, q->mag,
+                                 ix->codes + (size_t)row * ix->cb, ix->mags[row], out);
+        *out = -1.0f;
+        return COSO_OK;
+    }
+    if (ykind == KIND_BASE && xkind == KIND_METADATA) { *out = 0.0f; return COSO_OK; }
+    return COSO_ERR_UNIMPLEMENTED; /* the reference's `unreachable!()` arms */
+}
+
+/* traverse_find_nearest on one level of the component.  The caller owns the visited filter (it is shared by the walks of
+ * every filter of a query on that level, vector_store.rs:266-313) */
+static int walk_level_meta(const coso_index *ix, uint32_t level, uint32_t entry_idx, const qdesc *q, uint32_t ef, uint32_t keep, scratch_t *s) {
+    const level_t *L = &ix->mlv[level];
+    const uint32_t M = L->M;
+    const int metric = (int)ix->p.metric;
+    uint32_t slots = M < ix->p.shortlist_size ? M : ix->p.shortlist_size;
+    size_t hn = 0, rn = 0;
+    float d0;
+    int rc = meta_distance(ix, q, L->node_id[entry_idx], &d0);
+    if (rc != COSO_OK) return -rc;
+    s->visited[(L->node_id[entry_idx] >> 6) & (M - 1)] |= 1ull << (L->node_id[entry_idx] & 63);
+    hent e0 = {order_key(metric, d0), L->node_id[entry_idx], entry_idx, d0};
+    heap_push(s, &hn, e0);
+    uint32_t nodes_visited = 0;
+    while (hn > 0) {
+        hent cur = heap_pop(s, &hn);
+        if (nodes_visited >= ef) break;
+        nodes_visited++;
+        if (rn == s->res_cap) { s->res_cap *= 2; s->res = (hent *)realloc(s->res, s->res_cap * sizeof(hent)); }
+        s->res[rn++] = cur;
+        const uint32_t *nb = L->nbr + (size_t)cur.idx * M;
+        for (uint32_t j = 0; j < slots; j++) {
+            uint32_t nidx = nb[j];
+            if (nidx == IDX_NONE) continue;
+            uint32_t nid = L->node_id[nidx];
+            if ((s->visited[(nid >> 6) & (M - 1)] >> (nid & 63)) & 1ull) continue;
+            float d;
+            rc = meta_distance(ix, q, nid, &d);
+            if (rc != COSO_OK) return -rc;
+            s->visited[(nid >> 6) & (M - 1)] |= 1ull << (nid & 63);
+            hent e = {order_key(metric, d), nid, nidx, d};
+            heap_push(s, &hn, e);
+        }
+    }
+    qsort(s->res, rn, sizeof(hent), cmp_hent_desc);
+    if (rn > keep) rn = keep;
+    return (int)rn;
+}
+
+/* ann_search with query_filter_dims (vector_store.rs:273-313): filters [nf][mdim] in {-1,0,1}.  out: concatenated per-level
+ * lists (<= 100 each), top level first. */
+static int ann_search_filtered(const coso_index *ix, const uint8_t *qcode, float qmag, const int32_t *filters, uint32_t nf, scratch_t *s, hent *out,
+                               uint32_t *level_counts) {
+    const uint32_t Ltop = ix->p.num_layers, md = ix->mdim;
+    if (!ix->mlv || ix->mlv[Ltop].root_idx == IDX_NONE) return -COSO_ERR_INVALID;
+    uint32_t entry = ix->mlv[Ltop].root_idx;
+    float *fd = (float *)malloc((size_t)(nf ? nf : 1) * md * 4);
+    qdesc *qd = (qdesc *)malloc((size_t)(nf ? nf : 1) * sizeof(qdesc));
+    for (uint32_t f = 0; f < nf; f++) {
+        for (uint32_t j = 0; j < md; j++) fd[(size_t)f * md + j] = (float)filters[(size_t)f * md + j];
+        qdesc d = {qcode, qmag, filters + (size_t)f * md, fd + (size_t)f * md, coso_seq_norm_f32(fd + (size_t)f * md, (int)md), 0};
+        d.kind = kind_of(d.mmag, 0, 0); /* a query has no id (types.rs:227-236) */
+        qd[f] = d;
+    }
+    hent *cand = (hent *)malloc((size_t)(nf ? nf : 1) * KEEP_SEARCH * sizeof(hent));
+    int total = 0, rc = 0;
+    for (int level = (int)Ltop; level >= 0 && rc == 0; level--) {
+        const level_t *L = &ix->mlv[level];
+        memset(s->visited, 0, (size_t)L->M * 8);
+        s->visited[(COSO_QUERY_ID >> 6) & (L->M - 1)] |= 1ull << (COSO_QUERY_ID & 63);
+        int nc = 0;
+        for (uint32_t f = 0; f < nf; f++) {
+            int cnt = walk_level_meta(ix, (uint32_t)level, entry, &qd[f], ix->p.ef_search, KEEP_SEARCH, s);
+            if (cnt < 0) { rc = cnt; break; }
+            for (int i = 0; i < cnt; i++) {
+                if (ix->p.metric == COSO_METRIC_COSINE && s->res[i].sim == -1.0f) continue; /* strong mismatch: dropped */
+                cand[nc++] = s->res[i];
+            }
+        }
+        if (rc) break;
+        qsort(cand, (size_t)nc, sizeof(hent), cmp_hent_desc);
+        if (nc > KEEP_SEARCH) nc = KEEP_SEARCH;
+        if (nc == 0) { /* vector_store.rs:329-380: the entry node with its strongest match over the filters */
+            int have = 0;
+            hent best = {0, 0, 0, 0.0f};
+            for (uint32_t f = 0; f < nf; f++) {
+                float d;
+                int r = meta_distance(ix, &qd[f], L->node_id[entry], &d);
+                if (r != COSO_OK) { rc = -r; break; }
+                hent e = {order_key((int)ix->p.metric, d), L->node_id[entry], entry, d};
+                if (!have || e.key > best.key) { best = e; have = 1; }
+            }
+            if (rc) break;
+            if (!have) { rc = -COSO_ERR_INVALID; break; }
+            cand[0] = best;
+            nc = 1;
+        }
+        memcpy(out + total, cand, (size_t)nc * sizeof(hent));
+        if (level_counts) level_counts[Ltop - (uint32_t)level] = (uint32_t)nc;
+        total += nc;
+        if (level > 0) entry = L->child[cand[0].idx];
+    }
+    free(cand); free(qd); free(fd);
+    return rc ? rc : total;
+}
+
+/* search_internal with a filter (indexes/hnsw/mod.rs:390-440) for B queries; filters of query b = filter_dims rows
+ * [filter_off[b], filter_off[b+1]) */
+int coso_search_filtered_batch(const coso_index *ix, const float *queries, uint32_t B, const uint32_t *filter_off, const int32_t *filter_dims,
+                               uint32_t top_k, uint32_t *out_ids, float *out_scores, uint32_t *out_counts, int32_t *out_status, int threads) {
+    if (!ix || !ix->raw || !ix->mdim || top_k == 0 || ix->p.visited_mode != COSO_VISITED_REF) return COSO_ERR_INVALID;
+    int first_err = COSO_OK;
+    if (threads < 1) threads = 1;
+    const int d = (int)ix->p.dim;
+#pragma omp parallel num_threads(threads)
+    {
+        scratch_t *s = scratch_new(ix);
+        hent *all = (hent *)malloc((size_t)(ix->p.num_layers + 1) * KEEP_SEARCH * sizeof(hent));
+        fent *f = (fent *)malloc((size_t)(ix->p.num_layers + 1) * KEEP_SEARCH * sizeof(fent));
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            const float *q = queries + (size_t)b * d;
+            float qmag;
+            int rc = coso_quantize(q, d, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo, ix->p.range_hi, s->qcode, &qmag);
+            int total = 0, m = 0;
+            if (rc == COSO_OK) {
+                total = ann_search_filtered(ix, s->qcode, qmag, filter_dims + (size_t)filter_off[b] * ix->mdim, filter_off[b + 1] - filter_off[b], s, all, NULL);
+                if (total < 0) { rc = -total; total = 0; }
+            }
+            if (rc == COSO_OK) {
+                /* remove_duplicates_and_filter: first seen, drop the root and every pseudo node, sort desc, keep 5k */
+                for (int i = 0; i < total; i++) {
+                    int dup = 0;
+                    for (int j = 0; j < m; j++)
+                        if (all[j].id == all[i].id) { dup = 1; break; }
+                    if (dup) continue;
+                    all[m++] = all[i];
+                }
+                int w = 0;
+                for (int i = 0; i < m; i++) {
+                    const int k = meta_index(ix, all[i].id);
+                    const int pseudo = k >= 0 && kind_of(ix->meta_mag[k], 1, all[i].id) == KIND_PSEUDO;
+                    if (all[i].id != COSO_ROOT_ID && !pseudo) all[w++] = all[i];
+                }
+                m = w;
+                qsort(all, (size_t)m, sizeof(hent), cmp_hent_desc);
+                if ((uint32_t)m > 5 * top_k) m = (int)(5 * top_k);
+                float mag_query = coso_seq_norm_f32(q, d);
+                for (int i = 0; i < m; i++) { /* raw embedding of a replica = its base id (collection.rs:368-384) */
+                    const float *rv = ix->raw + (size_t)(all[i].id / ix->replicas) * d;
+                    float dp = coso_dot_f32(q, rv, d);
+                    fent t = {dp / (mag_query * coso_seq_norm_f32(rv, d)), all[i].id};
+                    f[i] = t;
+                }
+                qsort(f, (size_t)m, sizeof(fent), cmp_fent_desc);
+                if ((uint32_t)m > top_k) m = (int)top_k;
+                for (int i = 0; i < m; i++) { out_ids[(size_t)b * top_k + i] = f[i].id; out_scores[(size_t)b * top_k + i] = f[i].cs; }
+            }
+            out_counts[b] = rc == COSO_OK ? (uint32_t)m : 0;
+            if (out_status) out_status[b] = rc;
+            if (rc != COSO_OK) {
+#pragma omp critical
+                if (first_err == COSO_OK) first_err = rc;
+            }
+        }
+        free(all); free(f);
+        scratch_free(s);
+    }
+    return first_err;
+}
+
+/* raw per-level lists of one filtered query (ids, sims, counts top level first) — what the device walk is compared with */
+int coso_ann_search_filtered(const coso_index *ix, const float *query, const int32_t *filter_dims, uint32_t nf, uint32_t *out_ids, float *out_sims,
+                             uint32_t *level_counts) {
+    if (!ix || !ix->mdim) return -COSO_ERR_INVALID;
+    scratch_t *s = scratch_new(ix);
+    float qmag;
+    int rc = coso_quantize(query, (int)ix->p.dim, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo, ix->p.range_hi, s->qcode, &qmag);
+    if (rc != COSO_OK) { scratch_free(s); return -rc; }
+    hent *all = (hent *)malloc((size_t)(ix->p.num_layers + 1) * KEEP_SEARCH * sizeof(hent));
+    int total = ann_search_filtered(ix, s->qcode, qmag, filter_dims, nf, s, all, level_counts);
+    for (int i = 0; i < total; i++) { out_ids[i] = all[i].id; out_sims[i] = all[i].sim; }
+    free(all);
+    scratch_free(s);
+    return total;
+}
+
+/* ---- builder of the component (index side; vector_store.rs:714-1074 with prop_metadata) ---------------------------
+ * Insertion order = ascending position in `order` (node-table indices): the reference inserts the pseudo nodes when the index
+ * is created (api_service.rs:190-210) and the replicas of an embedding as it arrives.  max_levels[i] = the level drawn for
+ * node-table entry i (the host's get_max_insert_level over levels_prob / pseudo_level_probs); the pseudo root is on every level. */
+static uint32_t mlevel_find(const level_t *L, uint32_t id) {
+    for (uint32_t i = 0; i < L->n; i++) if (L->node_id[i] == id) return i;
+    return IDX_NONE;
+}
+
+static void create_node_edges_meta(coso_index *ix, uint32_t level, uint32_t node, const zent *z, int zn) {
+    level_t *L = &ix->mlv[level];
+    const int metric = (int)ix->p.metric;
+    const int kself = meta_index(ix, L->node_id[node]);
+    const int self_kind = kind_of(ix->meta_mag[kself], 1, L->node_id[node]);
+    uint32_t succ = 0;
+    for (int i = 0; i < zn; i++) {
+        if (succ >= L->M) break;
+        const uint32_t nid = L->node_id[z[i].idx];
+        const int kn = meta_index(ix, nid);
+        const int nkind = kind_of(ix->meta_mag[kn], 1, nid);
+        if (metric == COSO_METRIC_COSINE) { /* vector_store.rs:1017-1041 */
+            if (nkind == KIND_PSEUDO && self_kind == KIND_METADATA && z[i].sim != 1.0f) continue;
+            if (nkind == KIND_METADATA && self_kind == KIND_METADATA && z[i].sim == -1.0f) continue;
+        }
+        int r = add_neighbor(L, metric, node, z[i].idx, z[i].sim);
+        if (r >= 0) {
+            int r2 = add_neighbor(L, metric, z[i].idx, node, z[i].sim);
+            if (r2 >= 0) succ++;
+            else if (L->nbr[(size_t)node * L->M + (uint32_t)r] == z[i].idx) L->nbr[(size_t)node * L->M + (uint32_t)r] = IDX_NONE;
+        }
+    }
+}
+
+static int index_embedding_meta(coso_index *ix, uint32_t id, const qdesc *q, uint32_t parent_idx, uint32_t entry_idx, int level, int max_level,
+                                scratch_t *s) {
+    level_t *L = &ix->mlv[level];
+    memset(s->visited, 0, (size_t)L->M * 8);
+    s->visited[(id >> 6) & (L->M - 1)] |= 1ull << (id & 63); /* skipm.insert(new_node_id) :807 */
+    int zn = walk_level_meta(ix, (uint32_t)level, entry_idx, q, ix->p.ef_construction, KEEP_INDEX, s);
+    if (zn < 0) return -zn;
+    zent z[KEEP_INDEX];
+    if (zn == 0) { /* only when ef_construction == 0; the fallback's VectorData has id: None (vector_store.rs:833-838) */
+        float d;
+        qdesc q0 = *q;
+        q0.kind = kind_of(q->mmag, 0, 0);
+        int rc = meta_distance(ix, &q0, L->node_id[entry_idx], &d);
+        if (rc != COSO_OK) return rc;
+        z[0].idx = entry_idx; z[0].sim = d; zn = 1;
+    } else
+        for (int i = 0; i < zn; i++) { z[i].idx = s->res[i].idx; z[i].sim = s->res[i].sim; }
+    uint32_t child = level > 0 ? L->child[z[0].idx] : IDX_NONE;
+    if (level > max_level) {
+        if (level != 0) return index_embedding_meta(ix, id, q, IDX_NONE, child, level - 1, max_level, s);
+        return COSO_OK;
+    }
+    uint32_t me = level_append(L, id, (int)ix->p.metric);
+    if (parent_idx != IDX_NONE) ix->mlv[level + 1].child[parent_idx] = me;
+    if (level != 0) {
+        int rc = index_embedding_meta(ix, id, q, me, child, level - 1, max_level, s);
+        if (rc != COSO_OK) return rc;
+    }
+    create_node_edges_meta(ix, (uint32_t)level, me, z, zn);
+    return COSO_OK;
+}
+
+int coso_meta_build(coso_index *ix, const uint8_t *max_levels /*[n_meta], node-table order*/) {
+    if (!ix || !ix->mdim || !ix->n_meta || !max_levels || ix->p.visited_mode != COSO_VISITED_REF) return COSO_ERR_INVALID;
+    const uint32_t Ltop = ix->p.num_layers, md = ix->mdim;
+    const int kroot = meta_index(ix, PSEUDO_LO);
+    if (kroot < 0) return COSO_ERR_INVALID; /* the node table must hold the pseudo root */
+    for (uint32_t l = 0; l <= Ltop; l++) level_free(&ix->mlv[l]);
+    for (uint32_t l = 0; l <= Ltop; l++) { /* create_pseudo_root_node: one node per level, linked parent/child */
+        uint32_t r = level_append(&ix->mlv[l], PSEUDO_LO, (int)ix->p.metric);
+        ix->mlv[l].root_idx = r;
+        if (l > 0) ix->mlv[l].child[r] = ix->mlv[l - 1].root_idx;
+    }
+    scratch_t *s = scratch_new(ix);
+    int rc = COSO_OK;
+    /* pseudo nodes first (ids after the pseudo root, ascending), then the replicas in id order */
+    for (int pass = 0; pass < 2 && rc == COSO_OK; pass++)
+        for (uint32_t i = 0; i < ix->n_meta && rc == COSO_OK; i++) {
+            const uint32_t id = ix->meta_id[i];
+            const int pseudo = id >= PSEUDO_LO && id <= PSEUDO_HI;
+            if (id == PSEUDO_LO || pseudo != (pass == 0)) continue;
+            const uint32_t row = meta_row_of(ix, id);
+            /* x side of the distance while indexing: VectorData{id: Some(prop_value.id), ..} — the embedding's BASE id, or the
+             * pseudo root's id for pseudo nodes (vector_store.rs:820-832, 621-640) */
+            const uint32_t xid = pseudo ? PSEUDO_LO : id - id % ix->replicas;
+            qdesc q = {ix->codes + (size_t)row * ix->cb, ix->mags[row], ix->meta_mbits + (size_t)i * md, ix->meta_mdims + (size_t)i * md,
+                       ix->meta_mag[i], kind_of(ix->meta_mag[i], 1, xid)};
+            if (q.kind == KIND_BASE) continue; /* base replicas live under the MAIN root (types.rs:196-204): not in this component */
+            rc = index_embedding_meta(ix, id, &q, IDX_NONE, ix->mlv[Ltop].root_idx, (int)Ltop, (int)max_levels[i], s);
+        }
+    scratch_free(s);
+    (void)mlevel_find;
+    return rc;
+}
+
+uint32_t coso_meta_level_count(const coso_index *ix, uint32_t level) { return (ix->mlv && level <= ix->p.num_layers) ? ix->mlv[level].n : 0; }
+
+/* flat export / import of the component (same conventions as coso_index_export_level, the pseudo root is an ordinary id) */
+int coso_meta_export_level(const coso_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids) {
+    if (!ix->mlv || level > ix->p.num_layers) return COSO_ERR_INVALID;
+    const level_t *L = &ix->mlv[level];
+    idpair *ord = (idpair *)malloc((size_t)L->n * sizeof(idpair));
+    for (uint32_t i = 0; i < L->n; i++) { ord[i].id = L->node_id[i]; ord[i].idx = i; }
+    qsort(ord, L->n, sizeof(idpair), cmp_idpair);
+    for (uint32_t k = 0; k < L->n; k++) {
+        node_ids[k] = ord[k].id;
+        for (uint32_t j = 0; j < L->M; j++) {
+            uint32_t t = L->nbr[(size_t)ord[k].idx * L->M + j];
+            nbr_ids[(size_t)k * L->M + j] = t == IDX_NONE ? COSO_SLOT_EMPTY : L->node_id[t];
+        }
+    }
+    free(ord);
+    return COSO_OK;
+}
+
+/* pseudo_level_probs (metadata/mod.rs:182-209): values/levels get num_levels + 1 entries */
+void coso_pseudo_level_probs(int num_levels, int num_pseudo_nodes, double *values, uint8_t *levels) {
+    int ilog10 = 0;
+    for (int v = num_pseudo_nodes; v >= 10; v /= 10) ilog10++;
+    int higher = ilog10 + 1, lower;
+    if (higher > num_levels) { higher = 0; lower = num_levels; } else lower = num_levels - higher;
+    int k = 0;
+    if (higher > 0) {
+        double hv[64];
+        uint8_t hl[64];
+        coso_level_probs(10.0, higher, hv, hl);
+        for (int i = 0; i <= higher; i++) {
+            if (hl[i] == 0) continue;
+            values[k] = hv[i];
+            levels[k] = (uint8_t)(lower + hl[i]);
+            k++;
+        }
+    }
+    for (int i = lower; i >= 0; i--) { values[k] = 0.0; levels[k] = (uint8_t)i; k++; }
 }

@@ -96,6 +96,14 @@ def lib():
         "coso_ann_search": (C.c_int, [vp, vp, vp, vp, vp]),
         "coso_flat_search_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_int]),
         "coso_bruteforce_topk": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
+        "coso_meta_enable": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+        "coso_meta_set_nodes": (C.c_int, [vp, C.c_uint32, vp, vp]),
+        "coso_meta_build": (C.c_int, [vp, vp]),
+        "coso_meta_level_count": (C.c_uint32, [vp, C.c_uint32]),
+        "coso_meta_export_level": (C.c_int, [vp, C.c_uint32, vp, vp]),
+        "coso_search_filtered_batch": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_int]),
+        "coso_ann_search_filtered": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp]),
+        "coso_pseudo_level_probs": (None, [C.c_int, C.c_int, P(C.c_double), u8p]),
         "coso_bm25_idf": (C.c_float, [C.c_uint32, C.c_uint32]),
         "coso_bm25_tf": (C.c_float, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float]),
         "coso_bm25_search": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]),
@@ -409,6 +417,65 @@ class OracleIndex:
             raise ValueError(f"flat search status {rc}")
         return ids, scores, counts
 
+    # ---- metadata-filtered search (f4a) ----
+    def meta_enable(self, mdim, max_replicas):
+        self.mdim, self.replicas = int(mdim), int(max_replicas)
+        rc = lib().coso_meta_enable(self._h, self.mdim, self.replicas)
+        if rc != OK:
+            raise ValueError(f"meta_enable status {rc}")
+        return self
+
+    def meta_set_nodes(self, ids_sorted, mbits):
+        ids, mb = _c(ids_sorted, np.uint32), _c(mbits, np.int32)
+        assert mb.shape == (ids.size, self.mdim)
+        rc = lib().coso_meta_set_nodes(self._h, ids.size, _p(ids), _p(mb))
+        if rc != OK:
+            raise ValueError(f"meta_set_nodes status {rc}")
+        return self
+
+    def meta_build(self, max_levels):
+        ml = _c(max_levels, np.uint8)
+        rc = lib().coso_meta_build(self._h, _p(ml))
+        if rc != OK:
+            raise ValueError(f"meta_build status {rc}")
+        return self
+
+    def meta_export_graph(self):
+        out = []
+        for l in range(self.params.num_layers + 1):
+            n = lib().coso_meta_level_count(self._h, l)
+            ids = np.zeros(n, np.uint32)
+            nbr = np.zeros((n, self.level_M(l)), np.uint32)
+            rc = lib().coso_meta_export_level(self._h, l, _p(ids), _p(nbr))
+            if rc != OK:
+                raise ValueError(f"meta export status {rc}")
+            out.append((ids, nbr))
+        return out
+
+    def search_filtered_batch(self, queries, filter_off, filter_dims, top_k, threads=1, raise_on_error=True):
+        q = _c(queries, np.float32)
+        B = q.shape[0]
+        off, fd = _c(filter_off, np.uint32), _c(filter_dims, np.int32)
+        ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+        scores = np.zeros((B, top_k), np.float32)
+        counts = np.zeros(B, np.uint32)
+        status = np.zeros(B, np.int32)
+        rc = lib().coso_search_filtered_batch(self._h, _p(q), B, _p(off), _p(fd), top_k, _p(ids), _p(scores), _p(counts), _p(status), threads)
+        if rc != OK and raise_on_error:
+            raise ValueError(f"filtered search status {rc}")
+        return (ids, scores, counts) if raise_on_error else (ids, scores, counts, rc, status)
+
+    def ann_search_filtered(self, query, filter_dims):
+        q, fd = _c(query, np.float32), _c(np.atleast_2d(filter_dims), np.int32)
+        cap = (self.params.num_layers + 1) * 100
+        ids = np.zeros(cap, np.uint32)
+        sims = np.zeros(cap, np.float32)
+        lc = np.zeros(self.params.num_layers + 1, np.uint32)
+        n = lib().coso_ann_search_filtered(self._h, _p(q), _p(fd), fd.shape[0], _p(ids), _p(sims), _p(lc))
+        if n < 0:
+            raise ValueError(f"ann_search_filtered status {-n}")
+        return ids[:n], sims[:n], lc
+
     def ann_search(self, query):
         """ann_search output before finalisation: (ids, sims, per-level counts top level first)."""
         q = _c(query, np.float32)
@@ -430,6 +497,23 @@ def bruteforce_topk(raw, queries, k, threads=1):
     if rc != OK:
         raise ValueError(f"bruteforce status {rc}")
     return ids, scores
+
+
+def pseudo_level_probs(num_levels, num_pseudo_nodes):
+    v = (C.c_double * (num_levels + 1))()
+    l = (C.c_uint8 * (num_levels + 1))()
+    lib().coso_pseudo_level_probs(num_levels, num_pseudo_nodes, v, l)
+    return [(v[i], l[i]) for i in range(num_levels + 1)]
+
+
+def schema_level_probs(num_layers, num_pseudo_incl_root, factor=4.0):
+    """levels_prob of an index whose collection has a metadata schema (api_service.rs:113-131): the layers pseudo_level_probs
+    gives to the pseudo nodes get probability 1.0 (x >= 1.0 never holds: no replica lands there), the layers below use
+    generate_level_probs(4.0, lower)"""
+    plp = pseudo_level_probs(num_layers, num_pseudo_incl_root)
+    lower = sum(1 for p, _ in plp if p == 0.0) - 1
+    higher = num_layers - lower
+    return [(1.0, num_layers - i) for i in range(higher)] + level_probs(factor, lower)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,93 @@
+"""Metadata-filtered search on the device vs the oracle on the same collection: per-level lists of the
+filtered ann_search, final results (replica ids + exact scores), error behaviour, and the BASE graph of a metadata collection
+(ids = vector row x max_replicas) for unfiltered search and for the device builder."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import meta_helpers as MH
+from tests.test_gpu_parity import _assert_same_search, _assert_same_walk
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same_filtered(sc, oix, dix, Q, off, rows, top_k):
+    ids, sims, counts = dix.ann_search_filtered(Q, off, rows.astype(np.int8))
+    for b in range(Q.shape[0]):
+        oi, osim, olc = oix.ann_search_filtered(Q[b], rows[off[b]:off[b + 1]])
+        assert np.array_equal(counts[b], olc), f"query {b}: level counts {counts[b]} vs {olc}"
+        o = 0
+        for s, c in enumerate(olc):
+            c = int(c)
+            assert np.array_equal(ids[b, s, :c], oi[o:o + c]), f"query {b} slot {s}: ids differ\n{ids[b, s, :c]}\n{oi[o:o + c]}"
+            assert np.array_equal(sims[b, s, :c].view(np.uint32), osim[o:o + c].view(np.uint32)), f"query {b} slot {s}: sims differ"
+            o += c
+    gi, gs, gc = dix.search_filtered(Q, off, rows.astype(np.int8), top_k)
+    ei, es, ec = oix.search_filtered_batch(Q, off, rows, top_k, threads=4)
+    assert np.array_equal(gc, ec)
+    for b in range(Q.shape[0]):
+        c = int(gc[b])
+        assert np.array_equal(gi[b, :c], ei[b, :c]), f"query {b}: final ids differ"
+        assert np.array_equal(gs[b, :c].view(np.uint32), es[b, :c].view(np.uint32)), f"query {b}: final scores differ"
+    return gi, gc
+
+
+@pytest.mark.parametrize("storage,res,dim", [(O.STORAGE_U8, 0, 64), (O.STORAGE_U8, 0, 1024), (O.STORAGE_SUBBYTE, 2, 128), (O.STORAGE_F32, 0, 96),
+                                             (O.STORAGE_F16, 0, 72)])
+def test_filtered_search_matches_oracle(storage, res, dim):
+    sc = MH.Scenario(n=1500, dim=dim, seed=4, storage=storage, res=res)
+    oix = sc.oracle()
+    dix = sc.device(oix)
+    Q, off, rows, desc = sc.queries(nq=36, seed=7)
+    gi, gc = _assert_same_filtered(sc, oix, dix, Q, off, rows, 10)
+    assert (gc > 0).sum() >= 18                                   # is / and / or filters do find their replicas
+    for ef in (16, 200, 400):
+        oix.set_ef_search(ef)
+        dix.set_ef_search(ef)
+        _assert_same_filtered(sc, oix, dix, Q[:12], off[:13], rows[:off[12]], 5)
+
+
+def test_unfiltered_search_and_builder_on_a_metadata_collection():
+    """the Base replicas: ids are vector row x 4 in the visited filter, the lists and the results"""
+    import cosdata_amd as ca
+    sc = MH.Scenario(n=2500, dim=96, seed=8)
+    oix = sc.oracle()
+    dix = sc.device(oix)
+    Q, *_ = sc.queries(nq=32, seed=2)
+    _assert_same_walk(oix, dix, Q)
+    _assert_same_search(oix, dix, Q, 10)
+    assert (dix.batch_search(Q, 10)[0] % 4 == 0).all()
+    # device builder on the same collection == the oracle's rounds builder (both number the nodes row x 4)
+    p = sc.params
+    o2 = O.OracleIndex(p).set_vectors(sc.X)
+    o2.meta_enable(MH.MDIM, MH.REPLICAS)
+    o2.build_rounds(256, greedy=False)
+    hp = ca.HNSWHyperParams(num_layers=p.num_layers, ef_construction=p.ef_construction, ef_search=p.ef_search,
+                            level_0_neighbors_count=p.level0_neighbors_count, neighbors_count=p.neighbors_count)
+    d2 = ca.HNSWIndex(sc.dim, hp, seed=p.seed)
+    d2.upload_vectors(sc.X).enable_metadata(MH.MDIM, MH.REPLICAS)
+    d2.build(256)
+    for (di, dn), (oi, on) in zip(d2.download_graph(), o2.export_graph()):
+        assert np.array_equal(di, oi) and np.array_equal(dn, on)
+
+
+def test_filtered_search_argument_and_error_contract():
+    import cosdata_amd as ca
+    sc = MH.Scenario(n=600, dim=32, seed=1)
+    oix = sc.oracle()
+    dix = sc.device(oix)
+    Q, off, rows, _ = sc.queries(nq=6, seed=1)
+    with pytest.raises(ca.CosdataError) as ei:                     # a query without a filter belongs to cos_search_batch
+        dix.search_filtered(Q[:2], np.array([0, 1, 1], np.uint32), rows[:1].astype(np.int8), 5)
+    assert ei.value.status == 3
+    Qz = Q.copy()
+    Qz[1] = -1.0                                                   # zero quantized norm: CalculationError once a vector cosine is needed
+    g = dix.search_filtered(Qz, off, rows.astype(np.int8), 5, return_status=True)
+    e = oix.search_filtered_batch(Qz, off, rows, 5, threads=2, raise_on_error=False)
+    assert g[3] == e[3] and np.array_equal(g[4], e[4])
+    plain = ca.HNSWIndex(32, ca.HNSWHyperParams(num_layers=2))
+    plain.upload_vectors(sc.X)
+    with pytest.raises(ca.CosdataError) as ei:
+        plain.mdim = MH.MDIM
+        plain.search_filtered(Q[:1], off[:2], rows[:off[1]].astype(np.int8), 5)
+    assert ei.value.status == 6                                    # NotReady: no metadata component
