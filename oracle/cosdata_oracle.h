@@ -199,6 +199,15 @@ int coso_bm25_search(const uint32_t *term_hashes, const uint64_t *offsets, uint3
 int coso_rrf_fuse(const uint32_t *dense_ids, uint32_t nd, const uint32_t *sparse_ids, uint32_t ns, float k_rrf,
                   uint32_t top_k, uint32_t *out_ids, float *out_scores);
 
+/* ---- learned-sparse inverted index ---- */
+uint8_t coso_sparse_quantize(float value, float values_upper_bound, int bits); /* inverted_index.rs:168-172 */
+/* CSR: dims[T] ascending; ids of (dimension t, key q) = vec_ids[key_off[t*(2^bits+1)+q] .. key_off[t*(2^bits+1)+q+1]) */
+int coso_sparse_search(const uint32_t *dims, uint32_t T, const uint64_t *key_off, const uint32_t *vec_ids, uint32_t n_vectors, int bits,
+                       float values_upper_bound, float early_terminate_threshold, const uint32_t *q_dims, const float *q_vals, uint32_t nq,
+                       uint32_t k_with_reranking, uint32_t *out_ids, uint32_t *out_sims, uint32_t cap);
+int coso_sparse_rerank(const uint64_t *row_off, const uint32_t *raw_dims, const float *raw_vals, const uint32_t *cand_ids, uint32_t m,
+                       const uint32_t *q_dims, const float *q_vals, uint32_t nq, uint32_t top_k, uint32_t *out_ids, float *out_scores);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,9 @@ def lib():
         "coso_search_filtered_batch": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_int]),
         "coso_ann_search_filtered": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp]),
         "coso_pseudo_level_probs": (None, [C.c_int, C.c_int, P(C.c_double), u8p]),
+        "coso_sparse_quantize": (C.c_uint8, [C.c_float, C.c_float, C.c_int]),
+        "coso_sparse_search": (C.c_int, [vp, C.c_uint32, vp, vp, C.c_uint32, C.c_int, C.c_float, C.c_float, vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32]),
+        "coso_sparse_rerank": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, vp, vp]),
         "coso_bm25_idf": (C.c_float, [C.c_uint32, C.c_uint32]),
         "coso_bm25_tf": (C.c_float, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float]),
         "coso_bm25_search": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]),
@@ -541,4 +544,34 @@ def rrf_fuse(dense_ids, sparse_ids, k_rrf, top_k):
     ids = np.zeros(max(top_k, 1), np.uint32)
     sc = np.zeros(max(top_k, 1), np.float32)
     m = lib().coso_rrf_fuse(_p(d), d.size, _p(s), s.size, k_rrf, top_k, _p(ids), _p(sc))
+    return ids[:m], sc[:m]
+
+
+# ------------------------------------------------------------------------------------------------
+# learned-sparse inverted index (f4b)
+# ------------------------------------------------------------------------------------------------
+def sparse_quantize(value, upper, bits):
+    return int(lib().coso_sparse_quantize(float(value), float(upper), int(bits)))
+
+
+def sparse_search(dims, key_off, vec_ids, n_vectors, bits, upper, early_terminate_threshold, q_dims, q_vals, k_with_reranking=0):
+    """sequential_search: (ids, similarities) by similarity descending (larger id first); k_with_reranking = 0 -> all touched"""
+    d, ko, vi = _c(dims, np.uint32), _c(key_off, np.uint64), _c(vec_ids, np.uint32)
+    qd, qv = _c(q_dims, np.uint32), _c(q_vals, np.float32)
+    cap = n_vectors if not k_with_reranking else k_with_reranking
+    ids = np.zeros(max(cap, 1), np.uint32)
+    sims = np.zeros(max(cap, 1), np.uint32)
+    m = lib().coso_sparse_search(_p(d), d.size, _p(ko), _p(vi), n_vectors, bits, upper, early_terminate_threshold, _p(qd), _p(qv), qd.size,
+                                 k_with_reranking, _p(ids), _p(sims), cap)
+    if m < 0:
+        raise ValueError(f"sparse_search status {-m}")
+    return ids[:m], sims[:m]
+
+
+def sparse_rerank(row_off, raw_dims, raw_vals, cand_ids, q_dims, q_vals, top_k=0):
+    ro, rd, rv = _c(row_off, np.uint64), _c(raw_dims, np.uint32), _c(raw_vals, np.float32)
+    ci, qd, qv = _c(cand_ids, np.uint32), _c(q_dims, np.uint32), _c(q_vals, np.float32)
+    ids = np.zeros(max(ci.size, 1), np.uint32)
+    sc = np.zeros(max(ci.size, 1), np.float32)
+    m = lib().coso_sparse_rerank(_p(ro), _p(rd), _p(rv), _p(ci), ci.size, _p(qd), _p(qv), qd.size, top_k, _p(ids), _p(sc))
     return ids[:m], sc[:m]
