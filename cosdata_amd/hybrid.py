@@ -71,3 +71,41 @@ def rrf_fuse_batch(dense_ids, dense_counts, sparse_ids, sparse_counts, fusion_co
     check(_lib.lib().cos_rrf_fuse_batch(_p(d), _p(dc), d.shape[1], _p(s), _p(sc_), s.shape[1], B, fusion_constant_k, top_k,
                                         _p(ids), _p(sc), _p(cnt)))
     return ids, sc, cnt
+
+
+class InvertedIndex:
+    """Device-resident learned-sparse inverted index (src/indexes/inverted/mod.rs, src/models/inverted_index.rs) as CSR:
+    dims ascending, key_offsets [T][2^bits + 1], vec_ids; optional raw sparse vectors (CSR) for the raw-value rerank."""
+
+    def __init__(self, quantization_bits: int, values_upper_bound: float, dims, key_offsets, vec_ids, n_vectors: int,
+                 raw_row_offsets=None, raw_dims=None, raw_vals=None, device: int = 0):
+        d, ko, vi = _c(dims, np.uint32), _c(key_offsets, np.uint64), _c(vec_ids, np.uint32)
+        raw = None
+        if raw_row_offsets is not None:
+            raw = (_c(raw_row_offsets, np.uint64), _c(raw_dims, np.uint32), _c(raw_vals, np.float32))
+        self._h = C.c_void_p()
+        check(_lib.lib().cos_sparse_create(device, quantization_bits, values_upper_bound, _p(d), d.size, _p(ko), _p(vi), n_vectors,
+                                           _p(raw[0]) if raw else None, _p(raw[1]) if raw else None, _p(raw[2]) if raw else None,
+                                           C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().cos_sparse_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_batch(self, q_dims, q_vals, q_offsets, top_k: int, early_terminate_threshold: float = 0.0, reranking_factor: int = 0):
+        """InvertedIndex::search_internal for B queries (CSR pairs): ids [B][k], scores [B][k], counts [B]"""
+        qd, qv, qo = _c(q_dims, np.uint32), _c(q_vals, np.float32), _c(q_offsets, np.uint32)
+        B = qo.size - 1
+        ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+        scores = np.zeros((B, top_k), np.float32)
+        counts = np.zeros(B, np.uint32)
+        check(_lib.lib().cos_sparse_search_batch(self._h, _p(qd), _p(qv), _p(qo), B, top_k, early_terminate_threshold, reranking_factor,
+                                                 _p(ids), _p(scores), _p(counts)))
+        return ids, scores, counts

@@ -266,6 +266,26 @@ int32_t cos_rrf_fuse_batch(const uint32_t *dense_ids, const uint32_t *dense_coun
                            float fusion_constant_k, uint32_t top_k, uint32_t *out_ids, float *out_scores,
                            uint32_t *out_counts);
 
+/* ---- learned-sparse inverted index ----------------------------------------- */
+typedef struct cos_sparse cos_sparse;
+/* InvertedIndexRoot as CSR (models/inverted_index.rs): dims[n_dims] ascending; for dimension t and quantized key q in
+ * [0, 2^bits) the vector ids vec_ids[key_offsets[t*(2^bits+1)+q] .. key_offsets[t*(2^bits+1)+q+1]) (one list per
+ * (dimension, key), as InvertedIndexNode::insert files them, inverted_index.rs:176-200); posting ranges of consecutive
+ * dimensions are contiguous.  Optional raw sparse vectors as CSR (row_offsets[n_vectors+1], dims ascending per row) for
+ * finalize_sparse_ann_results' raw-value rerank; pass NULLs without it. */
+int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits, float values_upper_bound, const uint32_t *dims, uint32_t n_dims,
+                          const uint64_t *key_offsets, const uint32_t *vec_ids, uint32_t n_vectors, const uint64_t *row_offsets,
+                          const uint32_t *raw_dims, const float *raw_vals, cos_sparse **out);
+int32_t cos_sparse_destroy(cos_sparse *s);
+/* InvertedIndex::search_internal (indexes/inverted/mod.rs:278-331) -> SparseAnnQueryBasic::sequential_search
+ * (models/sparse_ann_query.rs:68-147) for B queries given as CSR pairs (q_offsets[B+1] into q_dims / q_vals).
+ * reranking_factor = 0: config.rerank_sparse_with_raw_values = false -> scores are the quantized similarities as f32;
+ * otherwise the best top_k * reranking_factor candidates are re-scored with the raw values and sorted (<= 64 candidates).
+ * Order: score descending, larger id first (the reference leaves the order of equal / unranked entries to its hash map). */
+int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims, const float *q_vals, const uint32_t *q_offsets, uint32_t B,
+                                uint32_t top_k, float early_terminate_threshold, uint32_t reranking_factor, uint32_t *out_ids,
+                                float *out_scores, uint32_t *out_counts);
+
 /* ---- multi-GPU helper ----------------------------------------------------------------------- */
 /* S-way merge of per-shard top-k lists gathered by the caller's RCCL all-gather
  * (SURVEY.md §8e): in [S][B][k] -> out [B][k], total_cmp desc, larger id first on ties.

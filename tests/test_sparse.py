@@ -1,0 +1,125 @@
+"""Learned-sparse inverted index: the C oracle against an independent pure-Python restatement written from
+models/sparse_ann_query.rs:68-147 (dict of dot products, per-(dimension, key) lists), and the device against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def _corpus(n=3000, vocab=400, nnz=24, bits=6, upper=3.0, seed=0):
+    """random sparse vectors -> (per-vector pairs, CSR inverted index by (dimension, quantized key), raw CSR)"""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for v in range(n):
+        d = np.sort(rng.choice(vocab, size=int(rng.integers(4, nnz)), replace=False)).astype(np.uint32)
+        x = rng.gamma(1.2, 0.7, d.size).astype(np.float32)
+        x[rng.random(d.size) < 0.05] *= 5.0            # some values above the upper bound: clamp
+        rows.append((d, x))
+    Q = 1 << bits
+    lists = {}
+    for v, (d, x) in enumerate(rows):                   # InvertedIndexNode::insert: push the id on the list of its quantized value
+        for di, xi in zip(d, x):
+            lists.setdefault(int(di), [[] for _ in range(Q)])[O.sparse_quantize(xi, upper, bits)].append(v)
+    dims = np.array(sorted(lists), np.uint32)
+    key_off, vec_ids = [], []
+    for di in dims:
+        for k in range(Q):
+            key_off.append(len(vec_ids))
+            vec_ids += lists[int(di)][k]
+        key_off.append(len(vec_ids))
+    row_off = np.cumsum([0] + [len(d) for d, _ in rows]).astype(np.uint64)
+    raw_dims = np.concatenate([d for d, _ in rows]).astype(np.uint32)
+    raw_vals = np.concatenate([x for _, x in rows]).astype(np.float32)
+    return rows, dims, np.array(key_off, np.uint64), np.array(vec_ids, np.uint32), row_off, raw_dims, raw_vals
+
+
+def _queries(nq, vocab, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(nq):
+        d = rng.choice(vocab + 20, size=int(rng.integers(2, 12)), replace=False).astype(np.uint32)   # some dimensions are unknown
+        x = rng.gamma(1.5, 0.8, d.size).astype(np.float32)
+        x[rng.random(d.size) < 0.1] = 0.01                                                              # tiny values quantize to 0
+        out.append((d, x))
+    return out
+
+
+def _py_sequential_search(lists_by_dim, bits, upper, thr, q):
+    """straight from sparse_ann_query.rs:68-124"""
+    one_q = (1 << bits) - 1
+    etv = int(min(np.float32(1 << bits) * np.float32(thr), np.float32(255.0)))
+    low = int(np.float32(thr) * np.float32(1 << bits))
+    dots = {}
+    for dim, val in sorted(zip(*q), key=lambda t: -t[1]):
+        node = lists_by_dim.get(int(dim))
+        if node is None:
+            continue
+        qq = O.sparse_quantize(val, upper, bits)
+        keys = range(one_q, -1, -1) if qq > low else range(one_q, etv - 1, -1)
+        for key in keys:
+            for v in node[key]:
+                dots[v] = dots.get(v, 0) + qq * key
+    return dots
+
+
+def test_quantize_rule():
+    """(((value / upper) * max).clamp(0, max) as u8).min(max) — truncation, clamp, NaN -> 0"""
+    assert O.sparse_quantize(0.0, 3.0, 6) == 0 and O.sparse_quantize(3.0, 3.0, 6) == 63 and O.sparse_quantize(100.0, 3.0, 6) == 63
+    assert O.sparse_quantize(-1.0, 3.0, 6) == 0 and O.sparse_quantize(float("nan"), 3.0, 6) == 0
+    assert O.sparse_quantize(1.49, 3.0, 4) == int(np.float32(1.49) / np.float32(3.0) * np.float32(15.0))
+    assert O.sparse_quantize(2.0, 2.0, 8) == 255
+
+
+@pytest.mark.parametrize("bits,thr", [(6, 0.0), (4, 0.5), (5, 0.75), (8, 0.3)])
+def test_oracle_matches_python_restatement(bits, thr):
+    upper = 3.0
+    rows, dims, key_off, vec_ids, row_off, raw_dims, raw_vals = _corpus(n=1200, bits=bits, upper=upper, seed=bits)
+    Qn = 1 << bits
+    lists = {int(d): [list(vec_ids[int(key_off[t * (Qn + 1) + k]):int(key_off[t * (Qn + 1) + k + 1])]) for k in range(Qn)] for t, d in enumerate(dims)}
+    for q in _queries(12, 400, seed=bits + 1):
+        want = _py_sequential_search(lists, bits, upper, thr, q)
+        ids, sims = O.sparse_search(dims, key_off, vec_ids, 1200, bits, upper, thr, q[0], q[1])
+        assert dict(zip(ids.tolist(), sims.tolist())) == want
+        assert all((sims[i], ids[i]) >= (sims[i + 1], ids[i + 1]) for i in range(len(ids) - 1))     # similarity desc, larger id first
+        top, _ = O.sparse_search(dims, key_off, vec_ids, 1200, bits, upper, thr, q[0], q[1], k_with_reranking=25)
+        assert np.array_equal(top, ids[:25])
+        # raw-value rerank (finalize_sparse_ann_results): f32 sum over the query pairs in order
+        rid, rsc = O.sparse_rerank(row_off, raw_dims, raw_vals, top, q[0], q[1], top_k=5)
+        exp = []
+        for v in top:
+            m = dict(zip(rows[v][0].tolist(), rows[v][1].tolist()))
+            dp = np.float32(0.0)
+            for d, x in zip(*q):
+                if int(d) in m:
+                    dp = np.float32(dp + np.float32(np.float32(m[int(d)]) * np.float32(x)))
+            exp.append((float(dp), int(v)))
+        exp.sort(reverse=True)
+        assert [e[1] for e in exp[:5]] == rid.tolist() and np.allclose([e[0] for e in exp[:5]], rsc, rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,thr", [(6, 0.0), (4, 0.5), (8, 0.3)])
+def test_device_matches_oracle(bits, thr):
+    import cosdata_amd as ca
+    upper = 3.0
+    n = 20000
+    rows, dims, key_off, vec_ids, row_off, raw_dims, raw_vals = _corpus(n=n, vocab=600, bits=bits, upper=upper, seed=10 + bits)
+    ix = ca.InvertedIndex(bits, upper, dims, key_off, vec_ids, n, row_off, raw_dims, raw_vals)
+    qs = _queries(70, 600, seed=3)
+    qo = np.cumsum([0] + [len(q[0]) for q in qs]).astype(np.uint32)
+    qd = np.concatenate([q[0] for q in qs]).astype(np.uint32)
+    qv = np.concatenate([q[1] for q in qs]).astype(np.float32)
+    for k, rf in ((10, 0), (10, 5), (1, 0), (64, 0), (12, 5)):
+        ids, sc, cnt = ix.search_batch(qd, qv, qo, k, thr, rf)
+        for b, q in enumerate(qs):
+            cand, sims = O.sparse_search(dims, key_off, vec_ids, n, bits, upper, thr, q[0], q[1], k_with_reranking=k * max(rf, 1))
+            if rf == 0:
+                eid, esc = cand[:k], sims[:k].astype(np.float32)
+            else:
+                eid, esc = O.sparse_rerank(row_off, raw_dims, raw_vals, cand, q[0], q[1], top_k=k)
+            c = int(cnt[b])
+            assert c == len(eid), (b, c, len(eid))
+            assert np.array_equal(ids[b, :c], eid), (b, ids[b, :c], eid)
+            assert np.array_equal(sc[b, :c].view(np.uint32), np.asarray(esc, np.float32).view(np.uint32))
+    with pytest.raises(ca.CosdataError):
+        ix.search_batch(qd, qv, qo, 20, thr, 5)             # 100 candidates > 64
