@@ -109,3 +109,31 @@ class InvertedIndex:
         check(_lib.lib().cos_sparse_search_batch(self._h, _p(qd), _p(qv), _p(qo), B, top_k, early_terminate_threshold, reranking_factor,
                                                  _p(ids), _p(scores), _p(counts)))
         return ids, scores, counts
+
+
+STEM_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_char), C.c_size_t, C.POINTER(C.c_char), C.c_size_t)
+
+
+def process_text(text: str, max_token_len: int = 40, average_document_length: float = 1.0, k1: float = 1.5, b: float = 0.75, stemmer=None):
+    """TFIDFIndex's process_text: text -> (term hashes ascending u32[], stored BM25 term frequencies f32[]).
+    `stemmer`: optional callable str -> str standing in for the reference's snowball stemmer (un-vendored dependency)."""
+    raw = text.encode("utf-8")
+    cap = max(16, len(raw) // 2 + 4)
+    hashes = np.zeros(cap, np.uint32)
+    tfs = np.zeros(cap, np.float32)
+    n = C.c_uint32()
+    cb = None
+    if stemmer is not None:
+        def _shim(_ctx, tok, tok_len, out, out_cap):
+            res = stemmer(C.string_at(tok, tok_len).decode("utf-8")).encode("utf-8")[:out_cap]
+            C.memmove(out, res, len(res))
+            return len(res)
+        cb = STEM_FN(_shim)
+    check(_lib.lib().cos_text_process(raw, len(raw), max_token_len, average_document_length, k1, b, C.cast(cb, C.c_void_p) if cb else None, None,
+                                      _p(hashes), _p(tfs), cap, C.byref(n)))
+    return hashes[:n.value].copy(), tfs[:n.value].copy()
+
+
+def count_tokens(text: str, max_token_len: int = 40) -> int:
+    raw = text.encode("utf-8")
+    return int(_lib.lib().cos_text_count_tokens(raw, len(raw), max_token_len))

@@ -266,6 +266,19 @@ int32_t cos_rrf_fuse_batch(const uint32_t *dense_ids, const uint32_t *dense_coun
                            float fusion_constant_k, uint32_t top_k, uint32_t *out_ids, float *out_scores,
                            uint32_t *out_counts);
 
+/* ---- text -> BM25 terms (host code, no device needed) -------------------------- */
+/* TFIDFIndex's text side: tokenize (indexes/tf_idf/mod.rs:288-308), STOPWORDS (:282-286), process_text (:310-360: tokens longer
+ * than max_token_len bytes skipped, lowercase, stopwords, stem, xxhash32 seed 0, count per hash), compute_bm25_term_frequency
+ * (:362-371), count_tokens (:373-389).  The stemmer is the reference's un-vendored git dependency: `stem` is the host's shim over
+ * it — (ctx, token, token_len, out, out_cap) -> bytes written; NULL hashes the lowercased token unstemmed.  Terms come out by
+ * ascending hash (the reference: FxHashMap order); *out_n = distinct terms (also set when cap is too small -> Invalid). */
+typedef size_t (*cos_stem_fn)(void *ctx, const char *token, size_t token_len, char *out, size_t out_cap);
+int32_t cos_text_process(const char *utf8, size_t len, uint32_t max_token_len, float average_document_length, float k1, float b,
+                         cos_stem_fn stem, void *stem_ctx, uint32_t *out_hashes, float *out_tfs, uint32_t cap, uint32_t *out_n);
+uint32_t cos_text_count_tokens(const char *utf8, size_t len, uint32_t max_token_len);
+float cos_bm25_term_frequency(uint32_t count, uint32_t document_length, float average_document_length, float k1, float b);
+uint32_t cos_xxhash32(const void *data, size_t len, uint32_t seed); /* twox-hash XxHash32 (indexes/tf_idf/mod.rs:343-345) */
+
 /* ---- learned-sparse inverted index ----------------------------------------- */
 typedef struct cos_sparse cos_sparse;
 /* InvertedIndexRoot as CSR (models/inverted_index.rs): dims[n_dims] ascending; for dimension t and quantized key q in
