@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "engine_internal.h"
@@ -174,6 +175,14 @@ struct cos_bm25 {
     std::vector<u64> offsets;
     u32 *d_docs = nullptr;
     float *d_tfs = nullptr;
+    // per-handle workspace of the search (grown on demand, reused across calls: no allocation on the query path)
+    std::mutex mu;
+    QueryTerms *d_qt = nullptr, *h_qt = nullptr; // device / pinned host
+    u64 *d_buckets = nullptr;
+    u32 *d_ids = nullptr, *d_cnt = nullptr;
+    float *d_sc = nullptr;
+    u32 capB = 0, cap_k = 0;
+    hipStream_t stream = nullptr;
 };
 
 extern "C" int32_t cos_bm25_create(int32_t device, const uint32_t *term_hashes, const uint64_t *offsets, uint32_t n_terms, const uint32_t *doc_ids,
@@ -206,22 +215,21 @@ extern "C" int32_t cos_bm25_create(int32_t device, const uint32_t *term_hashes, 
 extern "C" int32_t cos_bm25_destroy(cos_bm25 *b) {
     if (!b) return COS_OK;
     (void)hipSetDevice(b->device);
-    if (b->d_docs) (void)hipFree(b->d_docs);
-    if (b->d_tfs) (void)hipFree(b->d_tfs);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    void *ptrs[] = {b->d_docs, b->d_tfs, b->d_qt, b->d_buckets, b->d_ids, b->d_cnt, b->d_sc};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (b->h_qt) (void)hipHostFree(b->h_qt);
     delete b;
     return COS_OK;
 }
 
-extern "C" int32_t cos_bm25_search_batch(cos_bm25 *b, const uint32_t *q_terms, const uint32_t *q_offsets, uint32_t B, uint32_t top_k,
-                                         uint32_t *out_ids, float *out_scores, uint32_t *out_counts) {
-    if (!b || !q_terms || !q_offsets || !out_ids || !out_scores || !out_counts || B == 0 || top_k == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(b->device));
-    // host: sort each query's terms by hash, look the posting lists up, idf via libm log1pf (sparse_ann_query.rs:298-302)
-    std::vector<QueryTerms> qts(B);
+// host side of a batch: sort each query's terms by hash, look the posting lists up, idf via libm log1pf
+// (sparse_ann_query.rs:298-302) -> QueryTerms in pinned memory
+static int32_t bm25_prepare(cos_bm25 *b, const uint32_t *q_terms, const uint32_t *q_offsets, u32 B) {
     for (u32 q = 0; q < B; q++) {
         std::vector<u32> t(q_terms + q_offsets[q], q_terms + q_offsets[q + 1]);
         std::sort(t.begin(), t.end());
-        QueryTerms &qt = qts[q];
+        QueryTerms &qt = b->h_qt[q];
         qt.n = 0;
         for (u32 h : t) {
             auto it = std::lower_bound(b->term_hashes.begin(), b->term_hashes.end(), h);
@@ -235,35 +243,78 @@ extern "C" int32_t cos_bm25_search_batch(cos_bm25 *b, const uint32_t *q_terms, c
             qt.n++;
         }
     }
-    QueryTerms *d_qt = nullptr;
-    u64 *d_buckets = nullptr;
-    u32 *d_ids = nullptr, *d_cnt = nullptr;
-    float *d_sc = nullptr;
-    hipError_t e = hipMalloc(&d_qt, (size_t)B * sizeof(QueryTerms));
-    if (e == hipSuccess) e = hipMalloc(&d_buckets, (size_t)B * BUCKETS * 8);
-    if (e == hipSuccess) e = hipMalloc(&d_ids, (size_t)B * top_k * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_sc, (size_t)B * top_k * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)B * 4);
-    if (e == hipSuccess) e = hipMemcpy(d_qt, qts.data(), (size_t)B * sizeof(QueryTerms), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(d_buckets, 0, (size_t)B * BUCKETS * 8);
-    if (e == hipSuccess) {
-        const u32 max_doc = b->max_doc; // doc ids are internal ids; the largest one bounds the tile count
-        const u32 span = max_doc + 1;
-        const u32 n_tiles = (span + TILE - 1) / TILE;
-        const u32 splits = std::max(1u, std::min(n_tiles, std::max(1u, 2048u / B)));
-        hipLaunchKernelGGL(bm25_score_kernel, dim3(B, splits), dim3(256), 0, 0, b->d_docs, b->d_tfs, d_qt, span, d_buckets);
-        e = hipGetLastError();
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(bm25_topk_kernel, dim3(B), dim3(64), 0, 0, d_buckets, B, top_k, d_ids, d_sc, d_cnt);
-            e = hipGetLastError();
-        }
+    return COS_OK;
+}
+
+static int32_t bm25_workspace(cos_bm25 *b, u32 B, u32 top_k) {
+    if (!b->stream) HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    if (B > b->capB || top_k > b->cap_k) {
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        const u32 nb = std::max(B, b->capB), nk = std::max(top_k, b->cap_k);
+        void *ptrs[] = {b->d_qt, b->d_buckets, b->d_ids, b->d_cnt, b->d_sc};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+        if (b->h_qt) (void)hipHostFree(b->h_qt);
+        b->d_qt = nullptr; b->h_qt = nullptr; b->d_buckets = nullptr; b->d_ids = nullptr; b->d_cnt = nullptr; b->d_sc = nullptr;
+        b->capB = b->cap_k = 0;
+        HIP_TRY(hipMalloc((void **)&b->d_qt, (size_t)nb * sizeof(QueryTerms)));
+        HIP_TRY(hipHostMalloc((void **)&b->h_qt, (size_t)nb * sizeof(QueryTerms)));
+        HIP_TRY(hipMalloc((void **)&b->d_buckets, (size_t)nb * BUCKETS * 8));
+        HIP_TRY(hipMalloc((void **)&b->d_ids, (size_t)nb * nk * 4));
+        HIP_TRY(hipMalloc((void **)&b->d_sc, (size_t)nb * nk * 4));
+        HIP_TRY(hipMalloc((void **)&b->d_cnt, (size_t)nb * 4));
+        b->capB = nb;
+        b->cap_k = nk;
     }
-    if (e == hipSuccess) e = hipMemcpy(out_ids, d_ids, (size_t)B * top_k * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(out_scores, d_sc, (size_t)B * top_k * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(out_counts, d_cnt, (size_t)B * 4, hipMemcpyDeviceToHost);
-    void *ptrs[] = {d_qt, d_buckets, d_ids, d_sc, d_cnt};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
-    HIP_TRY(e);
+    return COS_OK;
+}
+
+// scoring + bucket top-k enqueued on `st`; outputs are device pointers
+static int32_t bm25_launch(cos_bm25 *b, u32 B, u32 top_k, u32 *d_out_ids, float *d_out_scores, u32 *d_out_counts, hipStream_t st) {
+    HIP_TRY(hipMemcpyAsync(b->d_qt, b->h_qt, (size_t)B * sizeof(QueryTerms), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(b->d_buckets, 0, (size_t)B * BUCKETS * 8, st));
+    const u32 span = b->max_doc + 1; // doc ids are internal ids; the largest one bounds the tile count
+    const u32 n_tiles = (span + TILE - 1) / TILE;
+    const u32 splits = std::max(1u, std::min(n_tiles, std::max(1u, 2048u / B)));
+    hipLaunchKernelGGL(bm25_score_kernel, dim3(B, splits), dim3(256), 0, st, b->d_docs, b->d_tfs, b->d_qt, span, b->d_buckets);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(bm25_topk_kernel, dim3(B), dim3(64), 0, st, b->d_buckets, B, top_k, d_out_ids, d_out_scores, d_out_counts);
+    HIP_TRY(hipGetLastError());
+    return COS_OK;
+}
+
+extern "C" int32_t cos_bm25_search_batch_device(cos_bm25 *b, const uint32_t *q_terms, const uint32_t *q_offsets, uint32_t B, uint32_t top_k,
+                                                uint32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts, void *stream) {
+    if (!b || !q_terms || !q_offsets || !d_out_ids || !d_out_scores || !d_out_counts || B == 0 || top_k == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(b->device));
+    std::lock_guard<std::mutex> g(b->mu);
+    int32_t rc = bm25_workspace(b, B, top_k);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream)); // the pinned term table of the previous batch must have been consumed
+    rc = bm25_prepare(b, q_terms, q_offsets, B);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : b->stream;
+    rc = bm25_launch(b, B, top_k, d_out_ids, d_out_scores, d_out_counts, st);
+    if (rc) return rc;
+    if (st != b->stream) HIP_TRY(hipStreamSynchronize(st)); // caller's stream: the pinned table may be reused as soon as we return
+    return COS_OK;
+}
+
+extern "C" int32_t cos_bm25_search_batch(cos_bm25 *b, const uint32_t *q_terms, const uint32_t *q_offsets, uint32_t B, uint32_t top_k,
+                                         uint32_t *out_ids, float *out_scores, uint32_t *out_counts) {
+    if (!b || !q_terms || !q_offsets || !out_ids || !out_scores || !out_counts || B == 0 || top_k == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(b->device));
+    std::lock_guard<std::mutex> g(b->mu);
+    int32_t rc = bm25_workspace(b, B, top_k);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    rc = bm25_prepare(b, q_terms, q_offsets, B);
+    if (rc) return rc;
+    rc = bm25_launch(b, B, top_k, b->d_ids, b->d_sc, b->d_cnt, b->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_ids, b->d_ids, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(out_scores, b->d_sc, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(out_counts, b->d_cnt, (size_t)B * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
     return COS_OK;
 }
 

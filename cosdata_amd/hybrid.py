@@ -61,6 +61,16 @@ class BM25Index:
         return ids, sc, cnt
 
 
+def _bm25_search_batch_device(self, q_terms, q_offsets, top_k: int, out_ids_ptr: int, out_scores_ptr: int, out_counts_ptr: int, stream: int = 0):
+    """same scoring, results left in device memory ([B][k] ids, [B][k] scores, [B] counts); enqueued on `stream`"""
+    qt, qo = _c(q_terms, np.uint32), _c(q_offsets, np.uint32)
+    check(_lib.lib().cos_bm25_search_batch_device(self._h, _p(qt), _p(qo), qo.size - 1, top_k, C.c_void_p(out_ids_ptr), C.c_void_p(out_scores_ptr),
+                                                  C.c_void_p(out_counts_ptr), C.c_void_p(stream)))
+
+
+BM25Index.search_batch_device = _bm25_search_batch_device
+
+
 def rrf_fuse_batch(dense_ids, dense_counts, sparse_ids, sparse_counts, fusion_constant_k: float, top_k: int):
     d, s = _c(dense_ids, np.uint32), _c(sparse_ids, np.uint32)
     dc, sc_ = _c(dense_counts, np.uint32), _c(sparse_counts, np.uint32)

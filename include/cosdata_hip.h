@@ -260,6 +260,12 @@ int32_t cos_bm25_destroy(cos_bm25 *b);
  * pre-hashed terms (CSR q_offsets[B+1] into q_terms); outputs [B][top_k]. */
 int32_t cos_bm25_search_batch(cos_bm25 *b, const uint32_t *q_terms, const uint32_t *q_offsets, uint32_t B,
                               uint32_t top_k, uint32_t *out_ids, float *out_scores, uint32_t *out_counts);
+/* Same scoring with the results left in DEVICE memory (d_out_* : [B][top_k], [B][top_k], [B]) and the kernels enqueued on
+ * `stream` (NULL = the handle's own stream, asynchronous): the BM25 half of a hybrid batch can run next to the dense half and
+ * feed a fusion stage without a round trip through the host.  q_terms / q_offsets are host arrays (the term lookup and the
+ * idf use host tables, like the reference's radix tree walk). */
+int32_t cos_bm25_search_batch_device(cos_bm25 *b, const uint32_t *q_terms, const uint32_t *q_offsets, uint32_t B, uint32_t top_k,
+                                     uint32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts, void *stream);
 /* RRF fusion of hybrid_search (api/vectordb/search/repo.rs:311-340) for B queries. */
 int32_t cos_rrf_fuse_batch(const uint32_t *dense_ids, const uint32_t *dense_counts, uint32_t dense_stride,
                            const uint32_t *sparse_ids, const uint32_t *sparse_counts, uint32_t sparse_stride, uint32_t B,

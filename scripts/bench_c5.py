@@ -18,7 +18,7 @@ ap.add_argument("--vocab", type=int, default=200_000)
 ap.add_argument("--doc-len", type=float, default=120.0)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--top-k", type=int, default=10)
-ap.add_argument("--check", type=int, default=64)
+ap.add_argument("--check", type=int, default=256)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n, d, V, B, k = a.n, a.dim, a.vocab, a.batch, a.top_k
@@ -86,6 +86,20 @@ el = (time.time() - t) / reps
 t = time.time()
 for _ in range(reps): bm.search_batch(q_terms, q_off, 3 * k)
 el_bm = (time.time() - t) / reps
+# device-output entry point: no allocation / D2H on the query path; kernel time from HIP events on the caller's stream
+o_i = torch.zeros(B, 3 * k, dtype=torch.int32, device=dev); o_s = torch.zeros(B, 3 * k, device=dev); o_c = torch.zeros(B, dtype=torch.int32, device=dev)
+st_bm = torch.cuda.Stream(device=dev)
+bm.search_batch_device(q_terms, q_off, 3 * k, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), st_bm.cuda_stream)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t = time.time()
+with torch.cuda.stream(st_bm):
+    ev0.record(st_bm)
+    for _ in range(reps): bm.search_batch_device(q_terms, q_off, 3 * k, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), st_bm.cuda_stream)
+    ev1.record(st_bm)
+st_bm.synchronize()
+el_bm_dev = (time.time() - t) / reps
+bm_kernel_ms = ev0.elapsed_time(ev1) / reps
+dev_equal_host = bool(np.array_equal(o_i.cpu().numpy().view(np.uint32), bm.search_batch(q_terms, q_off, 3 * k)[0]))
 post_bytes = 0
 pos = {int(h): i for i, h in enumerate(th_h)}
 for h in q_terms: post_bytes += int(off_h[pos[int(h)] + 1] - off_h[pos[int(h)]]) * 8
@@ -106,4 +120,7 @@ print(json.dumps({"config": f"c5: hybrid dense({d}) HNSW + BM25 + RRF, {n} docs,
                   "hybrid_qps_host_api": B / el, "hybrid_ms_per_batch": el * 1e3,
                   "bm25_ms_per_batch_host_api": el_bm * 1e3, "bm25_posting_bytes_per_batch": post_bytes,
                   "bm25_GBps_host_api_incl_setup": post_bytes / el_bm / 1e9,
+                  "bm25_ms_per_batch_device_api": el_bm_dev * 1e3, "bm25_stream_ms_per_batch_hip_events": bm_kernel_ms,
+                  "bm25_GBps_device_api": post_bytes / (bm_kernel_ms * 1e-3) / 1e9, "bm25_frac_of_hbm_8TBps": post_bytes / (bm_kernel_ms * 1e-3) / 8e12,
+                  "bm25_device_api_equals_host_api": dev_equal_host,
                   "parity_vs_oracle": {"queries": m, "mismatching_queries": int(bad)}}))
