@@ -54,19 +54,41 @@ class ShardSet:
 
 
 class ProcessShardSet:
+    """One local shard of a world-size shard set.  Construction is COLLECTIVE: every rank must call it, and every rank gets the
+    same outcome — either all ranks hold a working communicator, or all of them raise (so a caller can fall back together
+    instead of leaving some ranks blocked in a collective the others never enter)."""
+
     def __init__(self, index, rank: int, world: int, local_rank: int, dist=None):
         import torch
-        uid = np.zeros(UNIQUE_ID_BYTES, np.uint8)
-        if world > 1:
-            if rank == 0:
-                check(_lib.lib().cos_shardset_unique_id(uid.ctypes.data_as(C.c_void_p)))
-            t = torch.from_numpy(uid).to(f"cuda:{local_rank}")
-            dist.broadcast(t, 0)
-            uid = t.cpu().numpy()
-        arr = (C.c_void_p * 1)(index._h)
         self._h = C.c_void_p()
-        self._uid = np.ascontiguousarray(uid)
-        check(_lib.lib().cos_shardset_create(arr, 1, rank, world, self._uid.ctypes.data_as(C.c_void_p) if world > 1 else None, C.byref(self._h)))
+        if world <= 1:
+            arr = (C.c_void_p * 1)(index._h)
+            check(_lib.lib().cos_shardset_create(arr, 1, 0, 1, None, C.byref(self._h)))
+            return
+        dev = f"cuda:{local_rank}"
+        # 1. rank 0 obtains the ncclUniqueId; [ok flag | 128 id bytes] goes to everybody
+        msg = np.zeros(1 + UNIQUE_ID_BYTES, np.uint8)
+        err0 = ""
+        if rank == 0:
+            rc = _lib.lib().cos_shardset_unique_id(msg[1:].ctypes.data_as(C.c_void_p))
+            msg[0] = 1 if rc == _lib.OK else 0
+            if rc != _lib.OK:
+                err0 = _lib.lib().cos_last_error_string().decode("utf-8", "replace")
+        t = torch.from_numpy(msg).to(dev)
+        dist.broadcast(t, 0)
+        msg = t.cpu().numpy()
+        if msg[0] != 1:
+            raise CosdataError(_lib.ERR_HIP, "rank 0 could not create an ncclUniqueId" + (": " + err0 if err0 else ""))
+        # 2. every rank joins the communicator; the outcome is agreed with a MIN all-reduce
+        self._uid = np.ascontiguousarray(msg[1:])
+        arr = (C.c_void_p * 1)(index._h)
+        rc = _lib.lib().cos_shardset_create(arr, 1, rank, world, self._uid.ctypes.data_as(C.c_void_p), C.byref(self._h))
+        err = _lib.lib().cos_last_error_string().decode("utf-8", "replace") if rc != _lib.OK else ""
+        ok = torch.tensor([1 if rc == _lib.OK else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            self.close()
+            raise CosdataError(rc if rc != _lib.OK else _lib.ERR_HIP, "shard set creation failed on " + ("this rank: " + err if err else "another rank"))
 
     def exchange_device(self, packed_ptr: int, B: int, k: int, gathered_ptr: int, out_ids_ptr: int, out_scores_ptr: int, out_counts_ptr: int,
                         stream: int = 0):
