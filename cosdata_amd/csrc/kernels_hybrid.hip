@@ -28,11 +28,14 @@ namespace {
 constexpr u32 BUCKETS = 512;  // sparse_ann_query.rs:154
 constexpr u32 TILE = 8192;    // doc ids per LDS accumulator tile (32 KB of f32 + 1 KB of touched bits)
 constexpr u32 MAX_QTERMS = 64;
+constexpr u32 DIR_MIN = 256;  // posting lists longer than this get a tile directory; shorter ones are scanned whole per tile
+constexpr u32 NO_DIR = 0xFFFFFFFFu;
 
 struct QueryTerms { // per query, terms ascending by hash, only those that have a posting list
     u64 begin[MAX_QTERMS];
     u64 end[MAX_QTERMS];
     float idf[MAX_QTERMS];
+    u32 dir[MAX_QTERMS]; // row of the term in the tile directory, NO_DIR for short lists
     u32 n;
 };
 
@@ -45,8 +48,12 @@ __device__ __forceinline__ u64 lower_bound_doc(const u32 *__restrict__ docs, u64
 }
 
 // grid = (B, splits): block (q, s) owns the tiles s, s+splits, s+2*splits, ...
+// Tile directory: for every posting list longer than DIR_MIN, tile_dir[row][t] = offset (relative to the list's begin) of the
+// first posting whose doc id is >= t * TILE, t = 0 .. n_tiles.  It replaces the two ~17-step binary searches every
+// (query, tile, term) step used to make — the kernel was latency-bound on them at 0.16 of the HBM roof.
 __global__ __launch_bounds__(256) void bm25_score_kernel(const u32 *__restrict__ docs, const float *__restrict__ tfs,
-                                                         const QueryTerms *__restrict__ qts, u32 n_docs, u64 *__restrict__ buckets /*[B][512]*/) {
+                                                         const QueryTerms *__restrict__ qts, u32 n_docs, const u32 *__restrict__ tile_dir,
+                                                         u64 *__restrict__ buckets /*[B][512]*/) {
     __shared__ float acc[TILE];
     __shared__ u32 touched[TILE / 32];
     __shared__ u64 lb[BUCKETS];
@@ -61,11 +68,18 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(const u32 *__restrict__
         for (u32 i = threadIdx.x; i < TILE / 32; i += blockDim.x) touched[i] = 0;
         __syncthreads();
         for (u32 t = 0; t < nt; t++) {
-            const u64 b = lower_bound_doc(docs, qt->begin[t], qt->end[t], d0);
-            const u64 e = lower_bound_doc(docs, b, qt->end[t], d1 < d0 ? 0xFFFFFFFFu : d1);
+            const u32 dr = qt->dir[t];
+            u64 b = qt->begin[t], e = qt->end[t];
+            if (dr != NO_DIR) { // this tile's slice of the list, straight from the directory
+                const u32 *row = tile_dir + (u64)dr * (n_tiles + 1);
+                e = b + row[tile + 1];
+                b = b + row[tile];
+            } // else: a short list is scanned whole and filtered by range (no search at all)
             const float idf = qt->idf[t];
             for (u64 i = b + threadIdx.x; i < e; i += blockDim.x) {
-                const u32 slot = docs[i] - d0;
+                const u32 doc_i = docs[i];
+                if (dr == NO_DIR && (doc_i < d0 || doc_i - d0 >= TILE)) continue;
+                const u32 slot = doc_i - d0;
                 const float p = __fmul_rn(tfs[i], idf); // tf * head.idf
                 const u32 w = slot >> 5, m = 1u << (slot & 31);
                 const bool seen = touched[w] & m;        // bits of earlier terms only (barrier below)
@@ -175,6 +189,8 @@ struct cos_bm25 {
     std::vector<u64> offsets;
     u32 *d_docs = nullptr;
     float *d_tfs = nullptr;
+    std::vector<u32> dir_row; // [n_terms] row in the tile directory or NO_DIR
+    u32 *d_tile_dir = nullptr; // [rows][n_tiles + 1]
     // per-handle workspace of the search (grown on demand, reused across calls: no allocation on the query path)
     std::mutex mu;
     QueryTerms *d_qt = nullptr, *h_qt = nullptr; // device / pinned host
@@ -183,6 +199,13 @@ struct cos_bm25 {
     float *d_sc = nullptr;
     u32 capB = 0, cap_k = 0;
     hipStream_t stream = nullptr;
+    // cos_hybrid_search_batch: dense half + fusion (second stream, buffers grown on demand)
+    hipStream_t stream_dense = nullptr;
+    hipEvent_t ev_sparse = nullptr;
+    float *d_hq = nullptr, *d_dsc = nullptr, *d_fsc = nullptr;
+    u32 *d_did = nullptr, *d_dcnt = nullptr, *d_fid = nullptr, *d_fcnt = nullptr;
+    int32_t *d_dst = nullptr;
+    size_t hyb_cap_q = 0, hyb_cap_d = 0, hyb_cap_f = 0, hyb_capB = 0;
 };
 
 extern "C" int32_t cos_bm25_create(int32_t device, const uint32_t *term_hashes, const uint64_t *offsets, uint32_t n_terms, const uint32_t *doc_ids,
@@ -203,10 +226,32 @@ extern "C" int32_t cos_bm25_create(int32_t device, const uint32_t *term_hashes, 
     const u64 nnz = offsets[n_terms];
     for (u32 t = 0; t < n_terms; t++)
         if (offsets[t + 1] > offsets[t]) b->max_doc = std::max(b->max_doc, doc_ids[offsets[t + 1] - 1]); // lists are doc-id ascending
+    // tile directory of the long posting lists (one pass over their postings on the host)
+    const u32 n_tiles = (b->max_doc + 1 + TILE - 1) / TILE;
+    b->dir_row.assign(n_terms, NO_DIR);
+    std::vector<u32> dir;
+    u32 rows = 0;
+    for (u32 t = 0; t < n_terms; t++) {
+        const u64 lo = offsets[t], hi = offsets[t + 1];
+        if (hi - lo <= DIR_MIN) continue;
+        if (hi - lo > 0xFFFFFFFFull) { cos_bm25_destroy(b); return cos_fail(COS_ERR_UNIMPLEMENTED, "posting list of term %u too long", term_hashes[t]); }
+        b->dir_row[t] = rows++;
+        const size_t base = dir.size();
+        dir.resize(base + n_tiles + 1);
+        u64 p = lo;
+        for (u32 tile = 0; tile <= n_tiles; tile++) {
+            const u64 bound = (u64)tile * TILE;
+            while (p < hi && doc_ids[p] < bound) p++;
+            dir[base + tile] = (u32)(p - lo);
+        }
+        dir[base + n_tiles] = (u32)(hi - lo);
+    }
     hipError_t e = hipMalloc(&b->d_docs, std::max<u64>(nnz, 1) * 4);
     if (e == hipSuccess) e = hipMalloc(&b->d_tfs, std::max<u64>(nnz, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&b->d_tile_dir, std::max<size_t>(dir.size(), 1) * 4);
     if (e == hipSuccess) e = hipMemcpy(b->d_docs, doc_ids, nnz * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_tfs, tfs, nnz * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !dir.empty()) e = hipMemcpy(b->d_tile_dir, dir.data(), dir.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) { cos_bm25_destroy(b); HIP_TRY(e); }
     *out = b;
     return COS_OK;
@@ -216,7 +261,10 @@ extern "C" int32_t cos_bm25_destroy(cos_bm25 *b) {
     if (!b) return COS_OK;
     (void)hipSetDevice(b->device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    void *ptrs[] = {b->d_docs, b->d_tfs, b->d_qt, b->d_buckets, b->d_ids, b->d_cnt, b->d_sc};
+    if (b->stream_dense) { (void)hipStreamSynchronize(b->stream_dense); (void)hipStreamDestroy(b->stream_dense); }
+    if (b->ev_sparse) (void)hipEventDestroy(b->ev_sparse);
+    void *ptrs[] = {b->d_docs, b->d_tfs, b->d_qt, b->d_buckets, b->d_ids, b->d_cnt, b->d_sc, b->d_tile_dir,
+                    b->d_hq, b->d_dsc, b->d_fsc, b->d_did, b->d_dcnt, b->d_fid, b->d_fcnt, b->d_dst};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (b->h_qt) (void)hipHostFree(b->h_qt);
     delete b;
@@ -240,6 +288,7 @@ static int32_t bm25_prepare(cos_bm25 *b, const uint32_t *q_terms, const uint32_t
             qt.begin[qt.n] = b->offsets[ti];
             qt.end[qt.n] = b->offsets[ti + 1];
             qt.idf[qt.n] = log1pf(((float)(u32)(b->documents_count - len) + 0.5f) / ((float)len + 0.5f));
+            qt.dir[qt.n] = b->dir_row[ti];
             qt.n++;
         }
     }
@@ -275,7 +324,7 @@ static int32_t bm25_launch(cos_bm25 *b, u32 B, u32 top_k, u32 *d_out_ids, float 
     const u32 span = b->max_doc + 1; // doc ids are internal ids; the largest one bounds the tile count
     const u32 n_tiles = (span + TILE - 1) / TILE;
     const u32 splits = std::max(1u, std::min(n_tiles, std::max(1u, 2048u / B)));
-    hipLaunchKernelGGL(bm25_score_kernel, dim3(B, splits), dim3(256), 0, st, b->d_docs, b->d_tfs, b->d_qt, span, b->d_buckets);
+    hipLaunchKernelGGL(bm25_score_kernel, dim3(B, splits), dim3(256), 0, st, b->d_docs, b->d_tfs, b->d_qt, span, b->d_tile_dir, b->d_buckets);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(bm25_topk_kernel, dim3(B), dim3(64), 0, st, b->d_buckets, B, top_k, d_out_ids, d_out_scores, d_out_counts);
     HIP_TRY(hipGetLastError());
@@ -361,5 +410,82 @@ extern "C" int32_t cos_rrf_fuse_batch(const uint32_t *dense_ids, const uint32_t 
     void *ptrs[] = {d_d, d_s, d_dc, d_sc, d_oi, d_os, d_oc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     HIP_TRY(e);
+    return COS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// repo::hybrid_search (api/vectordb/search/repo.rs:168-341) in one call: the dense index and the BM25 index are each asked
+// for top_k * 3 (:200, :240, :251) — here concurrently, on two streams of the same device — and the two lists are fused with
+// RRF on the device; only the fused top_k crosses PCIe.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static hipError_t grow_buf(T *&p, size_t &cap, size_t need) {
+    if (need <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&p, need * sizeof(T));
+    if (e == hipSuccess) cap = need;
+    return e;
+}
+
+extern "C" int32_t cos_hybrid_search_batch(cos_index *ix, cos_bm25 *b, const float *queries, const uint32_t *q_terms, const uint32_t *q_offsets, uint32_t B,
+                                           uint32_t top_k, float fusion_constant_k, uint32_t *out_ids, float *out_scores, uint32_t *out_counts) {
+    if (!ix || !b || !queries || !q_terms || !q_offsets || !out_ids || !out_scores || !out_counts || B == 0 || top_k == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    if (ix->p.device != b->device) return cos_fail(COS_ERR_INVALID, "the dense index and the BM25 index live on different devices");
+    const u32 k3 = 3 * top_k, maxn = 2 * k3;
+    if (maxn > 1024) return cos_fail(COS_ERR_UNIMPLEMENTED, "top_k above 170: RRF lists longer than 1024 entries");
+    HIP_TRY(hipSetDevice(b->device));
+    std::lock_guard<std::mutex> g(b->mu);
+    int32_t rc = bm25_workspace(b, B, k3);
+    if (rc) return rc;
+    if (!b->stream_dense) HIP_TRY(hipStreamCreateWithFlags(&b->stream_dense, hipStreamNonBlocking));
+    if (!b->ev_sparse) HIP_TRY(hipEventCreateWithFlags(&b->ev_sparse, hipEventDisableTiming));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream_dense));
+    const size_t dim = ix->p.dim;
+    {
+        size_t c1 = b->hyb_cap_q, c2 = b->hyb_cap_d, c3 = b->hyb_cap_d, c4 = b->hyb_capB, c5 = b->hyb_capB, c6 = b->hyb_cap_f, c7 = b->hyb_cap_f, c8 = b->hyb_capB;
+        HIP_TRY(grow_buf(b->d_hq, c1, (size_t)B * dim));
+        HIP_TRY(grow_buf(b->d_did, c2, (size_t)B * k3));
+        HIP_TRY(grow_buf(b->d_dsc, c3, (size_t)B * k3));
+        HIP_TRY(grow_buf(b->d_dcnt, c4, (size_t)B));
+        HIP_TRY(grow_buf(b->d_dst, c5, (size_t)B));
+        HIP_TRY(grow_buf(b->d_fid, c6, (size_t)B * top_k));
+        HIP_TRY(grow_buf(b->d_fsc, c7, (size_t)B * top_k));
+        HIP_TRY(grow_buf(b->d_fcnt, c8, (size_t)B));
+        b->hyb_cap_q = c1; b->hyb_cap_d = std::min(c2, c3); b->hyb_capB = std::min(std::min(c4, c5), c8); b->hyb_cap_f = std::min(c6, c7);
+    }
+    rc = bm25_prepare(b, q_terms, q_offsets, B);
+    if (rc) return rc;
+    // sparse half on its stream
+    rc = bm25_launch(b, B, k3, b->d_ids, b->d_sc, b->d_cnt, b->stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(b->ev_sparse, b->stream));
+    // dense half on the other
+    hipStream_t sd = b->stream_dense;
+    HIP_TRY(hipMemcpyAsync(b->d_hq, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, sd));
+    rc = cos_search_batch_device(ix, b->d_hq, B, k3, b->d_did, b->d_dsc, b->d_dcnt, b->d_dst, sd);
+    if (rc) return rc;
+    // fusion once both lists are there
+    HIP_TRY(hipStreamWaitEvent(sd, b->ev_sparse, 0));
+    const size_t smem = (size_t)maxn * 4;
+#define LAUNCH(R) hipLaunchKernelGGL(rrf_kernel<R>, dim3(B), dim3(64), smem, sd, b->d_did, b->d_dcnt, k3, b->d_ids, b->d_cnt, k3, B, fusion_constant_k, top_k, b->d_fid, b->d_fsc, b->d_fcnt)
+    if (maxn <= 64) LAUNCH(1);
+    else if (maxn <= 128) LAUNCH(2);
+    else if (maxn <= 256) LAUNCH(4);
+    else if (maxn <= 512) LAUNCH(8);
+    else LAUNCH(16);
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> status(B);
+    HIP_TRY(hipMemcpyAsync(out_ids, b->d_fid, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, sd));
+    HIP_TRY(hipMemcpyAsync(out_scores, b->d_fsc, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, sd));
+    HIP_TRY(hipMemcpyAsync(out_counts, b->d_fcnt, (size_t)B * 4, hipMemcpyDeviceToHost, sd));
+    HIP_TRY(hipMemcpyAsync(status.data(), b->d_dst, (size_t)B * 4, hipMemcpyDeviceToHost, sd));
+    HIP_TRY(hipStreamSynchronize(sd));
+    for (u32 q = 0; q < B; q++)
+        if (status[q] != COS_OK) return cos_fail(status[q], "dense half: query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", q, status[q]);
     return COS_OK;
 }

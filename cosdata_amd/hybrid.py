@@ -83,6 +83,18 @@ def rrf_fuse_batch(dense_ids, dense_counts, sparse_ids, sparse_counts, fusion_co
     return ids, sc, cnt
 
 
+def hybrid_search_batch(index, bm25: "BM25Index", queries, q_terms, q_offsets, top_k: int, fusion_constant_k: float = 60.0):
+    """repo::hybrid_search for B queries in one call: dense (top_k*3) + BM25 (top_k*3) concurrently on the device, RRF there"""
+    q = index._queries(queries)
+    qt, qo = _c(q_terms, np.uint32), _c(q_offsets, np.uint32)
+    B = q.shape[0]
+    ids = np.full((B, top_k), 0xFFFFFFFF, np.uint32)
+    sc = np.zeros((B, top_k), np.float32)
+    cnt = np.zeros(B, np.uint32)
+    check(_lib.lib().cos_hybrid_search_batch(index._h, bm25._h, _p(q), _p(qt), _p(qo), B, top_k, fusion_constant_k, _p(ids), _p(sc), _p(cnt)))
+    return ids, sc, cnt
+
+
 class InvertedIndex:
     """Device-resident learned-sparse inverted index (src/indexes/inverted/mod.rs, src/models/inverted_index.rs) as CSR:
     dims ascending, key_offsets [T][2^bits + 1], vec_ids; optional raw sparse vectors (CSR) for the raw-value rerank."""

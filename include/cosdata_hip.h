@@ -272,6 +272,13 @@ int32_t cos_rrf_fuse_batch(const uint32_t *dense_ids, const uint32_t *dense_coun
                            float fusion_constant_k, uint32_t top_k, uint32_t *out_ids, float *out_scores,
                            uint32_t *out_counts);
 
+/* repo::hybrid_search (api/vectordb/search/repo.rs:168-341) in one call: dense top_k*3 (walk + exact rerank) and BM25 top_k*3
+ * run concurrently on two streams of the device both indexes live on, RRF fuses them there (fusion_constant_k: dtos.rs:10-12,
+ * default 60); host buffers in, fused [B][top_k] out.  A failing dense query fails the call like cos_search_batch. */
+int32_t cos_hybrid_search_batch(cos_index *ix, cos_bm25 *b, const float *queries, const uint32_t *q_terms, const uint32_t *q_offsets,
+                                uint32_t B, uint32_t top_k, float fusion_constant_k, uint32_t *out_ids, float *out_scores,
+                                uint32_t *out_counts);
+
 /* ---- text -> BM25 terms (host code, no device needed) -------------------------- */
 /* TFIDFIndex's text side: tokenize (indexes/tf_idf/mod.rs:288-308), STOPWORDS (:282-286), process_text (:310-360: tokens longer
  * than max_token_len bytes skipped, lowercase, stopwords, stem, xxhash32 seed 0, count per hash), compute_bm25_term_frequency

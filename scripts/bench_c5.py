@@ -100,6 +100,12 @@ st_bm.synchronize()
 el_bm_dev = (time.time() - t) / reps
 bm_kernel_ms = ev0.elapsed_time(ev1) / reps
 dev_equal_host = bool(np.array_equal(o_i.cpu().numpy().view(np.uint32), bm.search_batch(q_terms, q_off, 3 * k)[0]))
+# one-call hybrid: dense and BM25 concurrently on the device, RRF there
+ca.hybrid_search_batch(ix, bm, Qh, q_terms, q_off, k, 60.0)
+t = time.time()
+for _ in range(reps): h_ids, h_sc, h_cnt = ca.hybrid_search_batch(ix, bm, Qh, q_terms, q_off, k, 60.0)
+el_h1 = (time.time() - t) / reps
+one_call_equal = bool(np.array_equal(h_ids, fres[0]) and np.array_equal(h_sc.view(np.uint32), fres[1].view(np.uint32)) and np.array_equal(h_cnt, fres[2]))
 post_bytes = 0
 pos = {int(h): i for i, h in enumerate(th_h)}
 for h in q_terms: post_bytes += int(off_h[pos[int(h)] + 1] - off_h[pos[int(h)]]) * 8
@@ -123,4 +129,5 @@ print(json.dumps({"config": f"c5: hybrid dense({d}) HNSW + BM25 + RRF, {n} docs,
                   "bm25_ms_per_batch_device_api": el_bm_dev * 1e3, "bm25_stream_ms_per_batch_hip_events": bm_kernel_ms,
                   "bm25_GBps_device_api": post_bytes / (bm_kernel_ms * 1e-3) / 1e9, "bm25_frac_of_hbm_8TBps": post_bytes / (bm_kernel_ms * 1e-3) / 8e12,
                   "bm25_device_api_equals_host_api": dev_equal_host,
+                  "hybrid_one_call_ms_per_batch": el_h1 * 1e3, "hybrid_one_call_qps": B / el_h1, "hybrid_one_call_equals_three_calls": one_call_equal,
                   "parity_vs_oracle": {"queries": m, "mismatching_queries": int(bad)}}))
