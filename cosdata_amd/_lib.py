@@ -93,6 +93,13 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise CosdataError(ERR_NO_DEVICE, f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                           "(the HIP extension is mandatory; there is no CPU path)")
+    # The PyTorch wheel bundles its own copy of the HIP runtime.  Two runtimes can live in one process only when torch's is
+    # initialised first (the other order leaves torch with "No HIP GPUs are available"), so a Python process that will also use
+    # torch for device buffers / torch.distributed gets torch imported before this library.  C / C++ / Rust hosts are unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     vp, i32, u32, f32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
     sig = {

@@ -303,17 +303,24 @@ constexpr int CM = 256, CN = 128, CK = 64, CLD = 80;
 
 __device__ __forceinline__ u32 spread4(u32 nib) { return (nib * 0x00204081u) & 0x01010101u; }
 
-// 16 digits (dims k0..k0+15 of a 64-dim chunk) -> 16 i8 values
+// 16 digits (dims k0..k0+15 of a 64-dim chunk) -> 16 i8 values, in two halves so the global load of a later k panel can be in
+// flight while the current one is multiplied: load16_raw (16 B as stored) and unpack16 (what the MFMA reads from LDS)
 template <int ENG>
-__device__ __forceinline__ uint4 stage16(const uint8_t *__restrict__ row, u32 k0 /*multiple of 16*/, bool valid) {
+__device__ __forceinline__ uint4 load16_raw(const uint8_t *__restrict__ row, u32 k0 /*multiple of 16*/, bool valid) {
+    if (!valid) return make_uint4(0, 0, 0, 0);
+    if constexpr (ENG == ENG_U8) return *(const uint4 *)(row + k0);
+    else return *(const uint4 *)(row + (u64)(k0 >> 6) * 16); // 16 B per 64 dims: [plane0 8 B | plane1 8 B]
+}
+template <int ENG>
+__device__ __forceinline__ uint4 unpack16(uint4 raw, u32 k0, bool valid) {
     uint4 o = make_uint4(0, 0, 0, 0);
     if constexpr (ENG == ENG_U8) {
-        if (valid) o = *(const uint4 *)(row + k0);
+        o = raw;
         o.x ^= 0x80808080u; o.y ^= 0x80808080u; o.z ^= 0x80808080u; o.w ^= 0x80808080u; // padding (0) becomes -128 too: see epilogue
     } else {
         if (valid) {
-            const u32 chunk = k0 >> 6, sh = k0 & 63; // 16 B per 64 dims: [plane0 8 B | plane1 8 B]
-            const u64 p0 = *(const u64 *)(row + (u64)chunk * 16), p1 = *(const u64 *)(row + (u64)chunk * 16 + 8);
+            const u32 sh = k0 & 63;
+            const u64 p0 = (u64)raw.x | ((u64)raw.y << 32), p1 = (u64)raw.z | ((u64)raw.w << 32);
             const u32 b0 = (u32)(p0 >> sh) & 0xFFFFu, b1 = (u32)(p1 >> sh) & 0xFFFFu;
             o.x = spread4(b0 & 15u) + 2u * spread4(b1 & 15u);
             o.y = spread4((b0 >> 4) & 15u) + 2u * spread4((b1 >> 4) & 15u);
@@ -322,6 +329,10 @@ __device__ __forceinline__ uint4 stage16(const uint8_t *__restrict__ row, u32 k0
         }
     }
     return o;
+}
+template <int ENG>
+__device__ __forceinline__ uint4 stage16(const uint8_t *__restrict__ row, u32 k0 /*multiple of 16*/, bool valid) {
+    return unpack16<ENG>(load16_raw<ENG>(row, k0, valid), k0, valid);
 }
 
 // queries' quaternary planes -> the i8 digits the GEMM multiplies, once per batch ([B][kdims] bytes): the scan kernel then
@@ -348,8 +359,8 @@ struct FusedOut {
     const uint8_t *qdigits; // ENG_Q2: [B][kdims] pre-expanded query digits (expand_q2_digits_kernel)
 };
 
-template <int ENG, bool FUSED>
-__global__ __launch_bounds__(512) void flat_codes_gemm_i8(const uint8_t *__restrict__ qcodes, const float *__restrict__ qmags,
+template <int ENG, bool FUSED, int PF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void flat_codes_gemm_i8(const uint8_t *__restrict__ qcodes, const float *__restrict__ qmags,
                                                           const u32 *__restrict__ qsums, u32 B, const uint8_t *__restrict__ codes,
                                                           const float *__restrict__ mags, const u32 *__restrict__ csums, u64 row_stride,
                                                           u32 n0, u32 n_chunk, u32 kdims /*padded to 64*/, u32 metric,
@@ -367,33 +378,56 @@ __global__ __launch_bounds__(512) void flat_codes_gemm_i8(const uint8_t *__restr
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
     const u32 code_k = ENG == ENG_U8 ? (u32)row_stride : (u32)(row_stride / 16) * 64; // dims covered by stored bytes
-    for (u32 k0 = 0; k0 < kdims; k0 += CK) {
-        { // A: 256 rows x 64 B = 1024 x 16 B pieces, 2 per thread;  B: 128 rows x 64 B = 512 pieces, 1 per thread
+    // Register ring of PF k panels: the 16 B pieces of panels k+1 .. k+PF are in flight (global -> VGPR) while panel k is
+    // unpacked into LDS and multiplied.  With only 2 workgroups per CU the un-prefetched loop exposed the full HBM latency on
+    // every panel (0.21 of the MFMA peak); the ring hides it behind PF panels of MFMA work per workgroup.
+    // A: 256 rows x 64 B = 1024 x 16 B pieces, 2 per thread;  B: 128 rows x 64 B = 512 pieces, 1 per thread
+    const int ar[2] = {(tid * 2) >> 2, (tid * 2 + 1) >> 2}, akq[2] = {((tid * 2) & 3) * 16, ((tid * 2 + 1) & 3) * 16};
+    const int br = tid >> 2, bkq = (tid & 3) * 16;
+    const bool b_in = col0 + br < n_chunk;
+    const uint8_t *b_row = codes + (u64)(n0 + (b_in ? col0 + br : 0)) * row_stride;
+    uint4 ra[PF][2], rb[PF];
+    auto fetch = [&](int s, u32 k0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const u32 qr = row0 + ar[h];
+            if constexpr (FUSED && ENG == ENG_Q2)
+                ra[s][h] = qr < B ? *(const uint4 *)(fo.qdigits + (u64)qr * kdims + k0 + akq[h]) : make_uint4(0, 0, 0, 0);
+            else
+                ra[s][h] = load16_raw<ENG>(qcodes + (u64)(qr < B ? qr : 0) * row_stride, k0 + akq[h], qr < B && k0 + akq[h] < code_k);
+        }
+        rb[s] = load16_raw<ENG>(b_row, k0 + bkq, b_in && k0 + bkq < code_k);
+    };
+#pragma unroll
+    for (int s = 0; s < PF; s++)
+        if ((u32)s * CK < kdims) fetch(s, (u32)s * CK);
+    for (u32 kb = 0; kb < kdims; kb += PF * CK) {
+#pragma unroll
+        for (int s = 0; s < PF; s++) {
+            const u32 k0 = kb + (u32)s * CK;
+            if (k0 >= kdims) break; // uniform
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int piece = tid * 2 + h, r = piece >> 2, kq = (piece & 3) * 16;
-                const u32 qr = row0 + r;
                 if constexpr (FUSED && ENG == ENG_Q2)
-                    *(uint4 *)(As + r * CLD + kq) = qr < B ? *(const uint4 *)(fo.qdigits + (u64)qr * kdims + k0 + kq) : make_uint4(0, 0, 0, 0);
+                    *(uint4 *)(As + ar[h] * CLD + akq[h]) = ra[s][h];
                 else
-                    *(uint4 *)(As + r * CLD + kq) = stage16<ENG>(qcodes + (u64)qr * row_stride, k0 + kq, qr < B && k0 + kq < code_k);
+                    *(uint4 *)(As + ar[h] * CLD + akq[h]) = unpack16<ENG>(ra[s][h], k0 + akq[h], row0 + ar[h] < B && k0 + akq[h] < code_k);
             }
-            const int r = tid >> 2, kq = (tid & 3) * 16;
-            const u32 xr = col0 + r;
-            *(uint4 *)(Bs + r * CLD + kq) = stage16<ENG>(codes + (u64)(n0 + xr) * row_stride, k0 + kq, xr < n_chunk && k0 + kq < code_k);
-        }
-        __syncthreads();
+            *(uint4 *)(Bs + br * CLD + bkq) = unpack16<ENG>(rb[s], k0 + bkq, b_in && k0 + bkq < code_k);
+            if (k0 + PF * CK < kdims) fetch(s, k0 + PF * CK);
+            __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < CK; ks += 32) {
-            const int ko = ks + (lane >> 5) * 16;
-            const i32x4 a0 = *(const i32x4 *)(As + (wr * 64 + (lane & 31)) * CLD + ko), a1 = *(const i32x4 *)(As + (wr * 64 + 32 + (lane & 31)) * CLD + ko);
-            const i32x4 b0 = *(const i32x4 *)(Bs + (wc * 64 + (lane & 31)) * CLD + ko), b1 = *(const i32x4 *)(Bs + (wc * 64 + 32 + (lane & 31)) * CLD + ko);
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+            for (int ks = 0; ks < CK; ks += 32) {
+                const int ko = ks + (lane >> 5) * 16;
+                const i32x4 a0 = *(const i32x4 *)(As + (wr * 64 + (lane & 31)) * CLD + ko), a1 = *(const i32x4 *)(As + (wr * 64 + 32 + (lane & 31)) * CLD + ko);
+                const i32x4 b0 = *(const i32x4 *)(Bs + (wc * 64 + (lane & 31)) * CLD + ko), b1 = *(const i32x4 *)(Bs + (wc * 64 + 32 + (lane & 31)) * CLD + ko);
+                acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if constexpr (FUSED) {
         // per-row filter state in LDS (the operand panels are dead: the k loop ended with a barrier)
@@ -458,6 +492,189 @@ __global__ __launch_bounds__(512) void flat_codes_gemm_i8(const uint8_t *__restr
                 }
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Query-resident scan (quaternary codes, fused epilogue).  Counters on flat_codes_gemm_i8 at 10M x 768 (profiles/
+// r02_c3_i8_scan_sq_lds_counters.txt): VALU 49 % busy, LDS 42 %, MFMA 26 % — every 256 x 128 tile restages the same 196 KB
+// of query digits through LDS, and the per-element epilogue costs ten VALU ops.  Here the query operand never moves:
+//   * a workgroup is 4 waves, one per SIMD; wave w keeps the MFMA A fragments of query rows 64w .. 64w+63 for the WHOLE k
+//     range in registers (K / 32 fragments x 2 row blocks x 4 VGPRs = 192 VGPRs at K = 768) for the life of the kernel;
+//   * candidates stream through LDS in tiles of 64 rows x K digit bytes, double-buffered: while the MFMAs of tile t run,
+//     the same waves expand tile t+1 (planes -> digits, 4 VALU ops per dword thanks to a dim permutation inside each 64-dim
+//     chunk that the query digits share) and the raw loads of tile t+2 are in flight.  One barrier per tile;
+//   * LDS rows are K + 16 bytes, so the 16 lanes of a ds_read_b128 group (distinct rows mod 16) hit 16 distinct 16 B slots,
+//     and the staging stores (lane = candidate) are conflict-free too;
+//   * the epilogue is a per-lane "does any of my 16 rows pass" test (cvt + fma + max3 per element) against thresholds held
+//     in registers; the exact quotient and the append run only for the rare lanes that pass.  Same survivors as the
+//     tile kernel: the estimate only decides who gets the exact test.
+// One workgroup per CU, persistent over the tiles of the launch.
+// ------------------------------------------------------------------------------------------------
+// 16 digit bytes of piece pp (0..3) of a 64-dim chunk, permuted: byte b of dword jj is dim 32*(pp>>1) + 4*(pp&1) + jj + 8*b
+__device__ __forceinline__ uint4 q2_piece_perm(uint4 raw /*[plane0 8 B | plane1 8 B]*/, int pp) {
+    const u32 w0 = pp < 2 ? raw.x : raw.y, w1 = pp < 2 ? raw.z : raw.w;
+    const int j0 = 4 * (pp & 1);
+    u32 o[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        const int sh = j0 + jj;
+        const u32 x0 = w0 >> sh, x1 = sh ? (w1 >> (sh - 1)) : (w1 << 1);
+        o[jj] = (x0 & 0x01010101u) | (x1 & 0x02020202u);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void expand_q2_digits_perm_kernel(const uint8_t *__restrict__ qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *__restrict__ digits) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 chunks = kdims / 64;
+    if (t >= (u64)B * chunks) return;
+    const u32 q = (u32)(t / chunks), j = (u32)(t % chunks);
+    const uint4 raw = (u64)j * 16 < row_stride ? *(const uint4 *)(qcodes + (u64)q * row_stride + (u64)j * 16) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) *(uint4 *)(digits + (u64)q * kdims + (u64)j * 64 + pp * 16) = q2_piece_perm(raw, pp);
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void flat_scan_q2_areg(const uint8_t *__restrict__ qdig /*[B][64 KC] permuted digits*/,
+                                                         const float *__restrict__ qmags, u32 B, const uint8_t *__restrict__ codes,
+                                                         const float *__restrict__ mags, u64 row_stride, u32 n0, u32 n_chunk, u32 metric,
+                                                         const FusedOut fo) {
+    constexpr int K = KC * 64, KS = KC * 2, LDB = K + 16, ITS = (KC + 3) / 4, PIECES = ITS * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const u32 row0 = blockIdx.y * 256 + w * 64;
+    const u32 n_tiles = (n_chunk + 63) / 64, G = gridDim.x;
+    u32 t = blockIdx.x;
+    if (t >= n_tiles) return; // uniform
+    i32x4 a[2][KS];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const u32 row = row0 + 32 * i + l31; // rows past B: clamped loads (no branches in the prologue), zeroed
+            const i32x4 v = *(const i32x4 *)(qdig + (u64)(row < B ? row : B - 1) * K + 32 * s + 16 * half);
+            a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
+        }
+    // thresholds of this lane's 32 accumulator rows, in the units of dot * (1 / |x|): T = thr_lo * |q| (cosine) or thr_lo (dot)
+    float T[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, rc = row < B ? row : B - 1;
+            const u64 k = fo.thr[rc];
+            const float qm = qmags[rc];
+            const float lo = k == 0ull ? -1.0f : simkey_inv((u32)(k >> 32)) * (1.0f - 4e-6f); // scores of quaternary codes are >= 0
+            const float v = metric == 0u ? lo * qm : lo;
+            T[i][r] = row < B ? v : __builtin_inff();
+        }
+    // staging: lane = candidate of the tile, wave w expands chunks w, w+4, w+8, ...  Loads are unconditional (clamped
+    // addresses) so that they stay in flight across the MFMAs; validity is applied when the piece is expanded.
+    uint4 raw[ITS];
+    bool rv[ITS];
+    auto load_raw = [&](u32 tile, int it) {
+        const int j = w + 4 * it;
+        const u32 c = tile * 64 + lane;
+        rv[it] = tile < n_tiles && c < n_chunk && (KC % 4 == 0 || j < KC);
+        const u32 cc = c < n_chunk ? c : n_chunk - 1;
+        raw[it] = *(const uint4 *)(codes + (u64)(n0 + cc) * row_stride + (u64)(KC % 4 == 0 || j < KC ? j : 0) * 16);
+    };
+    auto store_piece = [&](int buf, int it, int pp) {
+        const int j = w + 4 * it;
+        const uint4 r = rv[it] ? raw[it] : make_uint4(0, 0, 0, 0);
+        if (KC % 4 == 0 || j < KC) *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + lane * LDB + j * 64 + pp * 16) = q2_piece_perm(r, pp);
+    };
+#pragma unroll
+    for (int it = 0; it < ITS; it++) load_raw(t, it);
+#pragma unroll
+    for (int it = 0; it < ITS; it++)
+#pragma unroll
+        for (int pp = 0; pp < 4; pp++) store_piece(0, it, pp);
+#pragma unroll
+    for (int it = 0; it < ITS; it++) load_raw(t + G, it);
+    __syncthreads();
+    // candidate norms of a tile (needed only by its epilogue) are fetched half a tile ahead, like the raw codes: every load
+    // the top of the loop may have to wait for is at least half an iteration old
+    float xm[2], xm_next[2] = {1.0f, 1.0f};
+    auto load_norms = [&](u32 tile, float *dst) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const u32 col = tile * 64 + 32 * j + l31;
+            dst[j] = mags[n0 + (col < n_chunk ? col : n_chunk - 1)];
+        }
+    };
+    load_norms(t, xm);
+    int buf = 0;
+    for (; t < n_tiles; t += G, buf ^= 1) {
+        i32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
+        const unsigned char *bt = areg_lds + (size_t)buf * 64 * LDB + l31 * LDB + 16 * half;
+        i32x4 bf[3][2]; // candidate fragments, read two k steps ahead of their MFMAs (one wave per SIMD: nothing else hides LDS latency)
+#pragma unroll
+        for (int s = 0; s < 2 && s < KS; s++) {
+            bf[s][0] = *(const i32x4 *)(bt + 32 * s);
+            bf[s][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * s);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            if (s + 2 < KS) {
+                bf[(s + 2) % 3][0] = *(const i32x4 *)(bt + 32 * (s + 2));
+                bf[(s + 2) % 3][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * (s + 2));
+            }
+            __builtin_amdgcn_sched_barrier(0); // keep the reads two steps ahead (the scheduler would sink them next to their use)
+            const i32x4 b0 = bf[s % 3][0], b1 = bf[s % 3][1];
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][s], b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][s], b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][s], b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][s], b1, acc[1][1], 0, 0, 0);
+            if (s < PIECES) { // expand one piece of tile t + G in the shadow of the MFMAs (PIECES <= KS); reload its chunk for t + 2G
+                const int it = s >> 2, pp = s & 3;
+                store_piece(buf ^ 1, it, pp);
+                if (pp == 3) load_raw(t + 2 * G, it);
+            }
+            if (s == (PIECES < KS ? PIECES : KS - 1)) load_norms(t + G, xm_next);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bool cv[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) cv[j] = t * 64 + 32 * j + l31 < n_chunk;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float rx = metric == 0u ? __builtin_amdgcn_rcpf(xm[j]) : 1.0f;
+            const u32 col = t * 64 + 32 * j + l31;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                float best = -__builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 16; r++) best = fmaxf(best, __builtin_fmaf((float)(u32)acc[i][j][r], rx, -T[i][r]));
+                if (best >= 0.0f && cv[j]) { // rare: some row of this lane may beat its query's threshold
+                    u32 rbase = row0 + 32 * i + 4 * half;
+                    asm volatile("" : "+v"(rbase)); // opaque: keeps the 32 rows' addresses from being hoisted out of the tile loop (192 VGPRs)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const u32 row = rbase + (r & 3) + 8 * (r >> 2);
+                        const float dotf = (float)(u32)acc[i][j][r];
+                        if (row < B && __builtin_fmaf(dotf, rx, -T[i][r]) >= 0.0f) {
+                            const float sc = metric == 0u ? __fdiv_rn(dotf, __fmul_rn(qmags[row], xm[j])) : dotf;
+                            const u64 key = pack_key(simkey(sc), n0 + col);
+                            if (key > fo.thr[row]) {
+                                const u32 pos = atomicAdd(&fo.app_cnt[row], 1u);
+                                if (pos < fo.cap) fo.app[(u64)row * fo.cap + pos] = key;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        xm[0] = xm_next[0];
+        xm[1] = xm_next[1];
+        __syncthreads();
+    }
 }
 
 __global__ void code_sums_kernel(const uint8_t *__restrict__ codes, u64 row_stride, u32 n, u32 *__restrict__ sums) {
@@ -570,6 +787,32 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     return COS_OK;
 }
 
+// query-resident scan launcher: KC = k chunks of 64 dims; false when this K has no instantiation (the tile kernel runs instead)
+static bool areg_supported(u32 kdims) {
+    const u32 kc = kdims / 64;
+    return kdims % 64 == 0 && (kc == 2 || kc == 4 || kc == 6 || kc == 8 || kc == 12 || kc == 16);
+}
+template <int KC>
+static hipError_t launch_areg_kc(dim3 grid, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes, const float *mags,
+                                 u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
+    const size_t lds = (size_t)2 * 64 * (KC * 64 + 16);
+    hipError_t e = hipFuncSetAttribute((const void *)flat_scan_q2_areg<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((flat_scan_q2_areg<KC>), grid, dim3(256), lds, st, qdig, qmags, B, codes, mags, row_stride, n0, nc, metric, fo);
+    return hipGetLastError();
+}
+static hipError_t launch_areg(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes,
+                              const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
+    const u32 n_tiles = (nc + 63) / 64;
+    dim3 grid(std::min(n_tiles, n_cus), (B + 255) / 256);
+#define AREG_CASE(KC) case KC: return launch_areg_kc<KC>(grid, st, qdig, qmags, B, codes, mags, row_stride, n0, nc, metric, fo)
+    switch (kdims / 64) {
+        AREG_CASE(2); AREG_CASE(4); AREG_CASE(6); AREG_CASE(8); AREG_CASE(12); AREG_CASE(16);
+        default: return hipErrorInvalidValue;
+    }
+#undef AREG_CASE
+}
+
 // ------------------------------------------------------------------------------------------------
 // cos_flat_search_batch: exhaustive search over the index's quantized codes (i8 MFMA) + exact rerank of the best 5k
 // ------------------------------------------------------------------------------------------------
@@ -589,12 +832,18 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     // the append capacity.  An adversarially ordered corpus can still overflow it; that is detected on the device and the
     // call is repeated on the unfused path, so the result never depends on the shortcut.  COS_FLAT_UNFUSED=1 forces that path.
     const bool allow_fused = getenv("COS_FLAT_UNFUSED") == nullptr;
+    const char *pf_env = getenv("COS_FLAT_PF"); // k panels prefetched into registers (1..3); tuning knob, results do not depend on it
+    const int pf = pf_env ? atoi(pf_env) : 1;
+    // fused chunks of quaternary codes run on the query-resident kernel when K has an instantiation (COS_FLAT_TILE_KERNEL=1: never)
+    const bool use_areg = ix->eng == ENG_Q2 && areg_supported(kdims) && getenv("COS_FLAT_TILE_KERNEL") == nullptr;
+    int n_cus = 0;
+    if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, ix->p.device) != hipSuccess || n_cus <= 0) n_cus = 256;
     constexpr u32 SEED = 16384, APP_CAP = 4096;
     u32 chunk = (u32)std::min<u64>(1u << 20, ((1ull << 31) / B / 4) / CN * CN); // unfused: the [B][chunk] score buffer stays <= 2 GiB
     chunk = std::min(n, std::max<u32>(chunk, CN));
     hipStream_t st = ix->own_stream;
     float *d_q = nullptr, *d_qm = nullptr, *d_qrm = nullptr, *d_scores = nullptr, *d_os = nullptr;
-    uint8_t *d_qc = nullptr, *d_qd = nullptr;
+    uint8_t *d_qc = nullptr, *d_qd = nullptr, *d_qdp = nullptr;
     u32 *d_qs = nullptr, *d_cs = nullptr, *d_oi = nullptr, *d_oc = nullptr, *d_zero = nullptr, *d_appcnt = nullptr;
     u64 *d_pool = nullptr, *d_part = nullptr, *d_thr = nullptr, *d_app = nullptr;
     std::vector<hipEvent_t> evs; // (start, stop) of every GEMM launch, read after the last one
@@ -616,6 +865,7 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
             if (e == hipSuccess) e = hipMalloc(&d_qrm, (size_t)B * 4);
             if (e == hipSuccess) e = hipMalloc(&d_qc, (size_t)B * ix->row_stride);
             if (e == hipSuccess) e = hipMalloc(&d_qd, (size_t)B * kdims);
+            if (e == hipSuccess && use_areg) e = hipMalloc(&d_qdp, (size_t)B * kdims);
             if (e == hipSuccess) e = hipMalloc(&d_qs, (size_t)B * 4);
             if (e == hipSuccess) e = hipMalloc(&d_cs, ((size_t)n + 1) * 4);
             if (e == hipSuccess) e = hipMalloc(&d_pool, (size_t)B * SEL * 8);
@@ -635,6 +885,9 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
             if (e == hipSuccess && ix->eng == ENG_Q2) {
                 const u64 pieces = (u64)B * (kdims / 16);
                 hipLaunchKernelGGL(expand_q2_digits_kernel, dim3((u32)((pieces + 255) / 256)), dim3(256), 0, st, d_qc, ix->row_stride, B, kdims, d_qd);
+                if (use_areg)
+                    hipLaunchKernelGGL(expand_q2_digits_perm_kernel, dim3((u32)(((u64)B * (kdims / 64) + 255) / 256)), dim3(256), 0, st, d_qc, ix->row_stride, B,
+                                       kdims, d_qdp);
                 e = hipGetLastError();
             }
             // zero-norm screening (cosine): the reference aborts a search on the first zero denominator it meets; an
@@ -672,13 +925,18 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
             if (e == hipSuccess) { evs.push_back(ev1); e = hipEventRecord(ev0, st); }
             if (e != hipSuccess) break;
 #define FLAT_ARGS d_qc, d_qm, d_qs, B, ix->d_codes, ix->d_mags, d_cs, ix->row_stride, n0, nc, kdims, ix->p.metric, d_scores, s_stride, fo
-            if (ix->eng == ENG_U8) {
-                if (use_fused) hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, true>), grid, dim3(512), 0, st, FLAT_ARGS);
-                else hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, false>), grid, dim3(512), 0, st, FLAT_ARGS);
+#define FLAT_LAUNCH(E, F, P) hipLaunchKernelGGL((flat_codes_gemm_i8<E, F, P>), grid, dim3(512), 0, st, FLAT_ARGS)
+#define FLAT_LAUNCH_PF(E, F) do { if (pf == 2) FLAT_LAUNCH(E, F, 2); else if (pf == 3) FLAT_LAUNCH(E, F, 3); else FLAT_LAUNCH(E, F, 1); } while (0)
+            if (use_fused && use_areg) {
+                e = launch_areg(kdims, (u32)n_cus, st, d_qdp, d_qm, B, ix->d_codes, ix->d_mags, ix->row_stride, n0, nc, ix->p.metric, fo);
+                if (e != hipSuccess) break;
+            } else if (ix->eng == ENG_U8) {
+                if (use_fused) FLAT_LAUNCH_PF(ENG_U8, true); else FLAT_LAUNCH_PF(ENG_U8, false);
             } else {
-                if (use_fused) hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_Q2, true>), grid, dim3(512), 0, st, FLAT_ARGS);
-                else hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_Q2, false>), grid, dim3(512), 0, st, FLAT_ARGS);
+                if (use_fused) FLAT_LAUNCH_PF(ENG_Q2, true); else FLAT_LAUNCH_PF(ENG_Q2, false);
             }
+#undef FLAT_LAUNCH_PF
+#undef FLAT_LAUNCH
 #undef FLAT_ARGS
             e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(ev1, st);
@@ -719,7 +977,7 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
         stats->int8_ops = 2.0 * (double)B * (double)n * (double)kdims;
         stats->code_bytes = streamed;
     }
-    void *ptrs[] = {d_q, d_qm, d_qrm, d_qc, d_qd, d_qs, d_cs, d_scores, d_pool, d_part, d_zero, d_oi, d_os, d_oc, d_thr, d_app, d_appcnt};
+    void *ptrs[] = {d_q, d_qm, d_qrm, d_qc, d_qd, d_qdp, d_qs, d_cs, d_scores, d_pool, d_part, d_zero, d_oi, d_os, d_oc, d_thr, d_app, d_appcnt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
     HIP_TRY(e);

@@ -76,15 +76,27 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(const u32 *__restrict__
                 b = b + row[tile];
             } // else: a short list is scanned whole and filtered by range (no search at all)
             const float idf = qt->idf[t];
-            for (u64 i = b + threadIdx.x; i < e; i += blockDim.x) {
-                const u32 doc_i = docs[i];
-                if (dr == NO_DIR && (doc_i < d0 || doc_i - d0 >= TILE)) continue;
-                const u32 slot = doc_i - d0;
-                const float p = __fmul_rn(tfs[i], idf); // tf * head.idf
-                const u32 w = slot >> 5, m = 1u << (slot & 31);
-                const bool seen = touched[w] & m;        // bits of earlier terms only (barrier below)
-                acc[slot] = seen ? __fadd_rn(acc[slot], p) : p;
-                if (!seen) atomicOr(&touched[w], m);
+            // 4 postings per thread in flight before the (dependent) LDS read-modify-writes: the loop is load-latency-bound otherwise
+            for (u64 i0 = b + threadIdx.x; i0 < e; i0 += 4ull * 256) {
+                u32 dv[4];
+                float tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const u64 i = i0 + (u64)u * 256;
+                    const bool in = i < e;
+                    dv[u] = in ? docs[i] : 0xFFFFFFFFu;
+                    tv[u] = in ? tfs[i] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const u32 slot = dv[u] - d0;                  // out of range (other tile of a short list, or padding) wraps >= TILE
+                    if (dv[u] < d0 || slot >= TILE) continue;
+                    const float p = __fmul_rn(tv[u], idf);        // tf * head.idf
+                    const u32 w = slot >> 5, m = 1u << (slot & 31);
+                    const bool seen = touched[w] & m;             // bits of earlier terms only (barrier below)
+                    acc[slot] = seen ? __fadd_rn(acc[slot], p) : p;
+                    if (!seen) atomicOr(&touched[w], m);
+                }
             }
             __syncthreads();
         }

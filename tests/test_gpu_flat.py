@@ -71,7 +71,8 @@ def test_flat_code_scan_zero_norm_is_calculation_error():
 
 
 @pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2)])
-@pytest.mark.parametrize("n,dim,B,k", [(70000, 96, 70, 10), (40000, 768, 260, 12)])
+@pytest.mark.parametrize("n,dim,B,k", [(70000, 96, 70, 10), (40000, 768, 260, 12), (30001, 384, 70, 10), (20003, 1024, 40, 10),
+                                       (25000, 200, 300, 5), (21000, 960, 9, 10)])
 def test_flat_code_scan_fused_epilogue_matches_oracle(storage, res, n, dim, B, k):
     """n above the 16384-candidate seed chunk: the remaining chunks run the threshold-filtered (fused) epilogue — survivors are
     appended per query instead of a [B][chunk] score matrix — and the answer must still be the oracle's, bit for bit."""
@@ -87,7 +88,8 @@ def test_flat_code_scan_fused_epilogue_matches_oracle(storage, res, n, dim, B, k
     assert st.gemm_launches >= 2
 
 
-def test_flat_code_scan_fused_overflow_falls_back_exactly():
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2)])
+def test_flat_code_scan_fused_overflow_falls_back_exactly(storage, res):
     """adversarial order: every later vector is closer to the query than all earlier ones, so everything beats the running
     threshold and the per-query append buffer overflows — the scan must notice and repeat on the unfused path (same answer)"""
     import cosdata_amd as ca
@@ -102,9 +104,27 @@ def test_flat_code_scan_fused_overflow_falls_back_exactly():
     X /= np.linalg.norm(X, axis=1, keepdims=True)
     X *= 0.9
     Q = np.stack([q * 0.9, -q * 0.9, X[100], X[59000]]).astype(np.float32)
-    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType.UnsignedByte())
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType(ca.StorageKind(storage), res))
     ix.upload_vectors(X)
     ids, sc, cnt = ix.flat_search(Q, 10)
-    oix = O.OracleIndex(O.HNSWParams(dim=dim, num_layers=3)).set_vectors(X)
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, storage=storage, resolution=res, num_layers=3)).set_vectors(X)
     oids, osc, ocnt = oix.flat_search_batch(Q, 10, threads=8)
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+
+
+def test_flat_code_scan_query_resident_kernel_equals_tile_kernel(monkeypatch):
+    """quaternary fused chunks run on the query-resident kernel (A fragments in registers, candidates streamed through LDS);
+    COS_FLAT_TILE_KERNEL=1 forces the 256 x 128 tile kernel, COS_FLAT_UNFUSED=1 the score-matrix path: three implementations,
+    one answer"""
+    import cosdata_amd as ca
+    n, dim, B, k = 50000, 768, 64, 10
+    X = H.clustered_corpus(n, dim, n_centers=30, sigma=0.25, seed=31)
+    Q = H.queries_from(X, B, noise=0.05, seed=9)
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType(ca.StorageKind(O.STORAGE_SUBBYTE), 2))
+    ix.upload_vectors(X)
+    ref = ix.flat_search(Q, k)
+    for env in ("COS_FLAT_TILE_KERNEL", "COS_FLAT_UNFUSED"):
+        monkeypatch.setenv(env, "1")
+        got = ix.flat_search(Q, k)
+        monkeypatch.delenv(env)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), env

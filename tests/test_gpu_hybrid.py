@@ -16,6 +16,7 @@ def _postings(n_docs, vocab, seed):
     # document frequencies: a few very long lists, a long tail of short ones, some exactly at the directory threshold
     df = np.clip((n_docs / (1.0 + np.arange(vocab)) ** 1.05).astype(np.int64), 1, n_docs)
     df[10:14] = [256, 257, 255, 8192]
+    df = np.minimum(df, n_docs)
     rng.shuffle(df)
     docs, tfs, offsets = [], [], [0]
     for t in range(vocab):
