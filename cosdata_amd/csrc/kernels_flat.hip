@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "dot_engines.h"
@@ -511,17 +512,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // One workgroup per CU, persistent over the tiles of the launch.
 // ------------------------------------------------------------------------------------------------
 // 16 digit bytes of piece pp (0..3) of a 64-dim chunk, permuted: byte b of dword jj is dim 32*(pp>>1) + 4*(pp&1) + jj + 8*b
-__device__ __forceinline__ uint4 q2_piece_perm(uint4 raw /*[plane0 8 B | plane1 8 B]*/, int pp) {
+__device__ __forceinline__ u32 q2_dword_perm(uint4 raw /*[plane0 8 B | plane1 8 B]*/, int pp, int jj) {
     const u32 w0 = pp < 2 ? raw.x : raw.y, w1 = pp < 2 ? raw.z : raw.w;
-    const int j0 = 4 * (pp & 1);
-    u32 o[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) {
-        const int sh = j0 + jj;
-        const u32 x0 = w0 >> sh, x1 = sh ? (w1 >> (sh - 1)) : (w1 << 1);
-        o[jj] = (x0 & 0x01010101u) | (x1 & 0x02020202u);
-    }
-    return make_uint4(o[0], o[1], o[2], o[3]);
+    const int sh = 4 * (pp & 1) + jj;
+    const u32 x0 = w0 >> sh, x1 = sh ? (w1 >> (sh - 1)) : (w1 << 1);
+    return (x0 & 0x01010101u) | (x1 & 0x02020202u);
+}
+__device__ __forceinline__ uint4 q2_piece_perm(uint4 raw, int pp) {
+    return make_uint4(q2_dword_perm(raw, pp, 0), q2_dword_perm(raw, pp, 1), q2_dword_perm(raw, pp, 2), q2_dword_perm(raw, pp, 3));
 }
 
 __global__ void expand_q2_digits_perm_kernel(const uint8_t *__restrict__ qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *__restrict__ digits) {
@@ -534,27 +532,64 @@ __global__ void expand_q2_digits_perm_kernel(const uint8_t *__restrict__ qcodes,
     for (int pp = 0; pp < 4; pp++) *(uint4 *)(digits + (u64)q * kdims + (u64)j * 64 + pp * 16) = q2_piece_perm(raw, pp);
 }
 
+// The MFMA of the query-resident kernel with its register classes spelled out: query fragment in AccVGPRs (192 of them at
+// K = 768, resident for the whole kernel), candidate fragment and accumulators in VGPRs.  Left to the register allocator the
+// fragments were parked in AccVGPRs and copied back (v_accvgpr_read x 4) before every use, ~280 extra VALU issues per tile, and
+// the accumulators needed 64 more copies before the epilogue could read them.  Hazards: the 4 accumulators rotate (an MFMA never
+// depends on one of the 3 before it), VALU code reads an accumulator set a whole tile after its last MFMA, candidate fragments
+// are rewritten (ds_read) two k steps after their last use.
+template <bool FIRST>
+__device__ __forceinline__ void areg_mfma(i32x16 &acc, const i32x4 &afrag, const i32x4 &bfrag) {
+    if constexpr (FIRST) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag));
+    else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag));
+}
+
+constexpr int AREG_STAGE = 1024; // survivors a workgroup can park in LDS per launch (expected: a few hundred)
+
+// exact score of one survivor of the estimate, compared with the query's threshold key, appended if it beats it
+__device__ __forceinline__ void areg_append(const FusedOut &fo, const float *__restrict__ qmags, const float *__restrict__ mags, u32 metric, u32 n0,
+                                            u32 col, u32 row, u32 dot) {
+    const float dotf = (float)dot;
+    const float sc = metric == 0u ? __fdiv_rn(dotf, __fmul_rn(qmags[row], mags[n0 + col])) : dotf;
+    const u64 key = pack_key(simkey(sc), n0 + col);
+    if (key > fo.thr[row]) {
+        const u32 pos = atomicAdd(&fo.app_cnt[row], 1u);
+        if (pos < fo.cap) fo.app[(u64)row * fo.cap + pos] = key;
+    }
+}
+
+// compile-time loop: the body sees its index as an integral_constant, so register arrays stay statically indexed whatever
+// the unroller's size thresholds say (a `#pragma unroll` over the 24 k steps of the query-resident kernel is refused)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <int KC>
 __global__ __launch_bounds__(256) void flat_scan_q2_areg(const uint8_t *__restrict__ qdig /*[B][64 KC] permuted digits*/,
                                                          const float *__restrict__ qmags, u32 B, const uint8_t *__restrict__ codes,
                                                          const float *__restrict__ mags, u64 row_stride, u32 n0, u32 n_chunk, u32 metric,
                                                          const FusedOut fo) {
     constexpr int K = KC * 64, KS = KC * 2, LDB = K + 16, ITS = (KC + 3) / 4, PIECES = ITS * 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB]
+    extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB] | survivors [AREG_STAGE][3] u32 | count
+    u32 *stage = (u32 *)(areg_lds + (size_t)2 * 64 * LDB), *stage_cnt = stage + 3 * AREG_STAGE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const u32 row0 = blockIdx.y * 256 + w * 64;
     const u32 n_tiles = (n_chunk + 63) / 64, G = gridDim.x;
     u32 t = blockIdx.x;
     if (t >= n_tiles) return; // uniform
+    if (tid == 0) *stage_cnt = 0; // published by the barrier after the first tile's expansion
     i32x4 a[2][KS];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
-            const u32 row = row0 + 32 * i + l31; // rows past B: clamped loads (no branches in the prologue), zeroed
-            const i32x4 v = *(const i32x4 *)(qdig + (u64)(row < B ? row : B - 1) * K + 32 * s + 16 * half);
-            a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
-        }
+    static_for<0, 2 * KS>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(Ic)::value / KS, s = decltype(Ic)::value % KS;
+        const u32 row = row0 + 32 * i + l31; // rows past B: clamped loads (no branches in the prologue), zeroed
+        const i32x4 v = *(const i32x4 *)(qdig + (u64)(row < B ? row : B - 1) * K + 32 * s + 16 * half);
+        a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
+        asm volatile("" : "+a"(a[i][s])); // the value now IS an AccVGPR tuple: its MFMA uses need no copies
+    });
     // thresholds of this lane's 32 accumulator rows, in the units of dot * (1 / |x|): T = thr_lo * |q| (cosine) or thr_lo (dot)
     float T[2][16];
 #pragma unroll
@@ -568,113 +603,173 @@ __global__ __launch_bounds__(256) void flat_scan_q2_areg(const uint8_t *__restri
             const float v = metric == 0u ? lo * qm : lo;
             T[i][r] = row < B ? v : __builtin_inff();
         }
-    // staging: lane = candidate of the tile, wave w expands chunks w, w+4, w+8, ...  Loads are unconditional (clamped
-    // addresses) so that they stay in flight across the MFMAs; validity is applied when the piece is expanded.
-    uint4 raw[ITS];
-    bool rv[ITS];
-    auto load_raw = [&](u32 tile, int it) {
+    // Staging: lane = candidate of the tile, wave w expands chunks w, w+4, w+8, ...  Two raw sets: while tile t is multiplied,
+    // set (PAR^1) (tile t+G) is expanded into the other LDS buffer and reloaded with tile t+3G; set PAR (tile t+2G) is in
+    // flight.  Loads are unconditional (addresses clamped to the last row of the chunk: a duplicated row is never appended,
+    // its columns fail the `col < n_chunk` test), so they stay in flight across the MFMAs.
+    uint4 raw[2][ITS];
+    auto load_raw = [&](u32 tile, uint4 *dst, int it) __attribute__((always_inline)) {
         const int j = w + 4 * it;
-        const u32 c = tile * 64 + lane;
-        rv[it] = tile < n_tiles && c < n_chunk && (KC % 4 == 0 || j < KC);
-        const u32 cc = c < n_chunk ? c : n_chunk - 1;
-        raw[it] = *(const uint4 *)(codes + (u64)(n0 + cc) * row_stride + (u64)(KC % 4 == 0 || j < KC ? j : 0) * 16);
+        const u32 c = tile * 64 + lane, cc = c < n_chunk ? c : n_chunk - 1;
+        dst[it] = *(const uint4 *)(codes + (u64)(n0 + cc) * row_stride + (u64)(KC % 4 == 0 || j < KC ? j : 0) * 16);
     };
-    auto store_piece = [&](int buf, int it, int pp) {
+    auto store_piece = [&](int buf, const uint4 *src, int it, int pp) __attribute__((always_inline)) {
         const int j = w + 4 * it;
-        const uint4 r = rv[it] ? raw[it] : make_uint4(0, 0, 0, 0);
-        if (KC % 4 == 0 || j < KC) *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + lane * LDB + j * 64 + pp * 16) = q2_piece_perm(r, pp);
+        if (KC % 4 == 0 || j < KC) *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + lane * LDB + j * 64 + pp * 16) = q2_piece_perm(src[it], pp);
     };
-#pragma unroll
-    for (int it = 0; it < ITS; it++) load_raw(t, it);
-#pragma unroll
-    for (int it = 0; it < ITS; it++)
-#pragma unroll
-        for (int pp = 0; pp < 4; pp++) store_piece(0, it, pp);
-#pragma unroll
-    for (int it = 0; it < ITS; it++) load_raw(t + G, it);
-    __syncthreads();
-    // candidate norms of a tile (needed only by its epilogue) are fetched half a tile ahead, like the raw codes: every load
-    // the top of the loop may have to wait for is at least half an iteration old
-    float xm[2], xm_next[2] = {1.0f, 1.0f};
-    auto load_norms = [&](u32 tile, float *dst) {
+    float xm[2][2]; // candidate norms of the tile in accumulator set 0 / 1 (consumed by the deferred epilogue)
+    auto load_norms = [&](u32 tile, float *dst) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const u32 col = tile * 64 + 32 * j + l31;
             dst[j] = mags[n0 + (col < n_chunk ? col : n_chunk - 1)];
         }
     };
-    load_norms(t, xm);
-    int buf = 0;
-    for (; t < n_tiles; t += G, buf ^= 1) {
-        i32x16 acc[2][2];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+    for (int it = 0; it < ITS; it++) load_raw(t, raw[0], it);
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+    for (int it = 0; it < ITS; it++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
-        const unsigned char *bt = areg_lds + (size_t)buf * 64 * LDB + l31 * LDB + 16 * half;
-        i32x4 bf[3][2]; // candidate fragments, read two k steps ahead of their MFMAs (one wave per SIMD: nothing else hides LDS latency)
+        for (int pp = 0; pp < 4; pp++) store_piece(0, raw[0], it, pp);
+#pragma unroll
+    for (int it = 0; it < ITS; it++) {
+        load_raw(t + G, raw[1], it);
+        load_raw(t + 2 * G, raw[0], it);
+    }
+    xm[1][0] = xm[1][1] = 1.0f;
+    __syncthreads();
+    i32x16 acc[2][2][2]; // [set][row block][column block]
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[1][i][j][r] = 0;
+
+    // deferred epilogue of accumulator set P (tile tp), in 8 slices of 8 rows so that each slice fits in the shadow of one k step
+    // of the next tile: slice e -> column block j = e >> 2, row block i = (e >> 1) & 1, rows r = 8 (e & 1) .. +7
+    float best = 0.0f;
+    // rows h8 + r0, h8 + r0 + 1 of slice e: two (cvt, fma, max) triples — what fits beside one MFMA
+    auto epi_rows = [&](auto Pc, int e, int r0) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        const int j = e >> 2, i = (e >> 1) & 1, h8 = (e & 1) * 8;
+        const float rx = metric == 0u ? __builtin_amdgcn_rcpf(xm[P][j]) : 1.0f;
+        if (h8 == 0 && r0 == 0) best = -__builtin_inff();
+#pragma unroll
+        for (int r = r0; r < r0 + 2; r++) best = fmaxf(best, __builtin_fmaf((float)(u32)acc[P][i][j][h8 + r], rx, -T[i][h8 + r]));
+    };
+    // after the 16th row of a (row block, column block): the rare lanes with a row that may beat its query's threshold park
+    // the survivors in LDS for the end of the kernel — the exact quotient, the key compare and the global append counter are
+    // round trips to memory that a lone wave per SIMD cannot hide
+    auto epi_finish = [&](auto Pc, int e, u32 tp, bool tp_valid) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        const int j = e >> 2, i = (e >> 1) & 1;
+        if ((e & 1) == 0) return;
+        const u32 col = tp * 64 + 32 * j + l31;
+        if (best >= 0.0f && tp_valid && col < n_chunk) {
+            const float rx = metric == 0u ? __builtin_amdgcn_rcpf(xm[P][j]) : 1.0f;
+            u32 rbase = row0 + 32 * i + 4 * half;
+            asm volatile("" : "+v"(rbase)); // opaque: keeps the 32 rows' addresses from being hoisted out of the tile loop
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32 row = rbase + (r & 3) + 8 * (r >> 2);
+                const float dotf = (float)(u32)acc[P][i][j][r];
+                if (row < B && __builtin_fmaf(dotf, rx, -T[i][r]) >= 0.0f) {
+                    const u32 sp = atomicAdd(stage_cnt, 1u);
+                    if (sp < AREG_STAGE) {
+                        stage[3 * sp] = col;
+                        stage[3 * sp + 1] = row;
+                        stage[3 * sp + 2] = (u32)acc[P][i][j][r];
+                    } else
+                        areg_append(fo, qmags, mags, metric, n0, col, row, (u32)acc[P][i][j][r]); // staging full: append from here
+                }
+            }
+        }
+    };
+    auto epi_slice = [&](auto Pc, int e, u32 tp, bool tp_valid) __attribute__((always_inline)) {
+        epi_rows(Pc, e, 0); epi_rows(Pc, e, 2); epi_rows(Pc, e, 4); epi_rows(Pc, e, 6);
+        epi_finish(Pc, e, tp, tp_valid);
+    };
+    // One tile: MFMAs of tile tt into set P from LDS buffer P.  A lone wave per SIMD issues in order, so whatever is to run in
+    // the shadow of an MFMA has to sit right behind it in the instruction stream: every k step is four (MFMA, <= 6 VALU) pairs —
+    // one dword of the expansion of tile tt+G during the first PIECES steps, two rows of the epilogue of tile tt-G (set P^1)
+    // during the next 8 — pinned by sched_barriers.
+    constexpr int EPI0 = PIECES + 8 <= KS ? PIECES : (KS >= 8 ? KS - 8 : 0); // first step that carries an epilogue slice
+    auto tile_body = [&](auto Pc, u32 tt, bool prev_valid) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        const unsigned char *bt = areg_lds + (size_t)P * 64 * LDB + l31 * LDB + 16 * half;
+        i32x4 bf[3][2]; // candidate fragments, read two k steps ahead of their MFMAs
 #pragma unroll
         for (int s = 0; s < 2 && s < KS; s++) {
             bf[s][0] = *(const i32x4 *)(bt + 32 * s);
             bf[s][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * s);
         }
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
+        load_norms(tt, xm[P]);
+        static_for<0, KS>([&](auto Sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(Sc)::value;
+            constexpr bool expand = s < PIECES, epi = s >= EPI0 && s < EPI0 + 8;
+            constexpr int it = (s < PIECES ? s : 0) >> 2, pp = s & 3, j = 0;
             if (s + 2 < KS) {
                 bf[(s + 2) % 3][0] = *(const i32x4 *)(bt + 32 * (s + 2));
                 bf[(s + 2) % 3][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * (s + 2));
             }
-            __builtin_amdgcn_sched_barrier(0); // keep the reads two steps ahead (the scheduler would sink them next to their use)
-            const i32x4 b0 = bf[s % 3][0], b1 = bf[s % 3][1];
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][s], b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][s], b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][s], b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][s], b1, acc[1][1], 0, 0, 0);
-            if (s < PIECES) { // expand one piece of tile t + G in the shadow of the MFMAs (PIECES <= KS); reload its chunk for t + 2G
-                const int it = s >> 2, pp = s & 3;
-                store_piece(buf ^ 1, it, pp);
-                if (pp == 3) load_raw(t + 2 * G, it);
-            }
-            if (s == (PIECES < KS ? PIECES : KS - 1)) load_norms(t + G, xm_next);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        bool cv[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) cv[j] = t * 64 + 32 * j + l31 < n_chunk;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const float rx = metric == 0u ? __builtin_amdgcn_rcpf(xm[j]) : 1.0f;
-            const u32 col = t * 64 + 32 * j + l31;
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                float best = -__builtin_inff();
-#pragma unroll
-                for (int r = 0; r < 16; r++) best = fmaxf(best, __builtin_fmaf((float)(u32)acc[i][j][r], rx, -T[i][r]));
-                if (best >= 0.0f && cv[j]) { // rare: some row of this lane may beat its query's threshold
-                    u32 rbase = row0 + 32 * i + 4 * half;
-                    asm volatile("" : "+v"(rbase)); // opaque: keeps the 32 rows' addresses from being hoisted out of the tile loop (192 VGPRs)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const u32 row = rbase + (r & 3) + 8 * (r >> 2);
-                        const float dotf = (float)(u32)acc[i][j][r];
-                        if (row < B && __builtin_fmaf(dotf, rx, -T[i][r]) >= 0.0f) {
-                            const float sc = metric == 0u ? __fdiv_rn(dotf, __fmul_rn(qmags[row], xm[j])) : dotf;
-                            const u64 key = pack_key(simkey(sc), n0 + col);
-                            if (key > fo.thr[row]) {
-                                const u32 pos = atomicAdd(&fo.app_cnt[row], 1u);
-                                if (pos < fo.cap) fo.app[(u64)row * fo.cap + pos] = key;
-                            }
-                        }
-                    }
-                }
+            const i32x4 b0 = bf[s % 3][0], b1 = bf[s % 3][1];
+            const bool lane_stores = KC % 4 == 0 || w + 4 * it < KC;
+            u32 o[4] = {0, 0, 0, 0};
+            areg_mfma<s == 0>(acc[P][0][0], a[0][s], b0);
+            if (expand) { o[0] = q2_dword_perm(raw[P ^ 1][it], pp, 0); asm volatile("" : "+v"(o[0])); } // pinned behind its MFMA
+            if (epi) epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            areg_mfma<s == 0>(acc[P][0][1], a[0][s], b1);
+            if (expand) { o[1] = q2_dword_perm(raw[P ^ 1][it], pp, 1); asm volatile("" : "+v"(o[1])); } // pinned behind its MFMA
+            if (epi) epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            areg_mfma<s == 0>(acc[P][1][0], a[1][s], b0);
+            if (expand) { o[2] = q2_dword_perm(raw[P ^ 1][it], pp, 2); asm volatile("" : "+v"(o[2])); } // pinned behind its MFMA
+            if (epi) epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            areg_mfma<s == 0>(acc[P][1][1], a[1][s], b1);
+            if (expand) {
+                o[3] = q2_dword_perm(raw[P ^ 1][it], pp, 3);
+                asm volatile("" : "+v"(o[3]));
+                if (lane_stores)
+                    *(uint4 *)(areg_lds + (size_t)(P ^ 1) * 64 * LDB + lane * LDB + (w + 4 * it) * 64 + pp * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+                if (pp == 3) load_raw(tt + 3 * G, raw[P ^ 1], it); // the chunk's registers are free: reload them for tile tt + 3G
             }
+            if (epi) {
+                epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 6);
+                epi_finish(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, tt - G, prev_valid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (EPI0 + 8 > KS) { // short K: the slices that did not fit in the k loop
+            static_for<KS - EPI0, 8>([&](auto Ec) __attribute__((always_inline)) { epi_slice(std::integral_constant<int, (P ^ 1)>{}, decltype(Ec)::value, tt - G, prev_valid); });
         }
-        xm[0] = xm_next[0];
-        xm[1] = xm_next[1];
         __syncthreads();
+    };
+    bool prev_valid = false;
+    int last = 1;
+    while (true) {
+        tile_body(std::integral_constant<int, 0>{}, t, prev_valid);
+        prev_valid = true;
+        last = 0;
+        t += G;
+        if (t >= n_tiles) break;
+        tile_body(std::integral_constant<int, 1>{}, t, true);
+        last = 1;
+        t += G;
+        if (t >= n_tiles) break;
     }
+    // drain: epilogue of the last tile (t was advanced once past it)
+    if (last == 0) {
+        static_for<0, 8>([&](auto Ec) __attribute__((always_inline)) { epi_slice(std::integral_constant<int, 0>{}, decltype(Ec)::value, t - G, true); });
+    } else {
+        static_for<0, 8>([&](auto Ec) __attribute__((always_inline)) { epi_slice(std::integral_constant<int, 1>{}, decltype(Ec)::value, t - G, true); });
+    }
+    __syncthreads();
+    const u32 staged = min(*stage_cnt, (u32)AREG_STAGE);
+    for (u32 e = tid; e < staged; e += 256) areg_append(fo, qmags, mags, metric, n0, stage[3 * e], stage[3 * e + 1], stage[3 * e + 2]);
 }
 
 __global__ void code_sums_kernel(const uint8_t *__restrict__ codes, u64 row_stride, u32 n, u32 *__restrict__ sums) {
@@ -795,7 +890,7 @@ static bool areg_supported(u32 kdims) {
 template <int KC>
 static hipError_t launch_areg_kc(dim3 grid, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes, const float *mags,
                                  u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
-    const size_t lds = (size_t)2 * 64 * (KC * 64 + 16);
+    const size_t lds = (size_t)2 * 64 * (KC * 64 + 16) + (size_t)AREG_STAGE * 12 + 16;
     hipError_t e = hipFuncSetAttribute((const void *)flat_scan_q2_areg<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((flat_scan_q2_areg<KC>), grid, dim3(256), lds, st, qdig, qmags, B, codes, mags, row_stride, n0, nc, metric, fo);
