@@ -1,0 +1,30 @@
+// Shared between kernels_flat.hip (host flow, tile kernel) and kernels_scan.hip (query-resident quaternary scan kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "engine_types.h"
+
+namespace cosdev {
+
+// Threshold-filtered epilogue (FUSED): instead of writing the [B][chunk] score matrix to HBM for a second kernel to select from
+// (10 GB written + 10 GB re-read per 256 x 10M scan against 1.9 GB of codes), every score is compared with its query's current
+// SEL-th best key and only the rare survivors are appended to app[B][cap] through a per-query counter.  A reciprocal-based
+// estimate (4 VALU ops) screens the elements; the exact IEEE quotient — the value that is ranked — is formed only for those
+// within 4e-6 of the threshold or above it, so results are identical to the unfused path.
+struct FusedOut {
+    const u64 *thr;   // [B] SEL-th best (key) so far; 0 = pool not full yet, everything passes
+    u64 *app;         // [B][cap]
+    u32 *app_cnt;     // [B]
+    u32 cap;
+    const uint8_t *qdigits; // ENG_Q2: [B][kdims] pre-expanded query digits (expand_q2_digits_kernel)
+};
+
+
+// query-resident quaternary scan (kernels_scan.hip)
+bool flat_scan_supported(u32 kdims);
+// queries' planes -> permuted digit bytes [B][kdims] (the layout the scan kernel multiplies)
+hipError_t launch_flat_scan_expand_queries(const uint8_t *qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *digits, hipStream_t st);
+hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes,
+                            const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo);
+
+} // namespace cosdev

@@ -19,6 +19,7 @@
 
 #include "dot_engines.h"
 #include "engine_internal.h"
+#include "flat_scan.h"
 
 using namespace cosdev;
 
@@ -347,19 +348,6 @@ __global__ void expand_q2_digits_kernel(const uint8_t *__restrict__ qcodes, u64 
     *(uint4 *)(digits + (u64)q * kdims + k0) = stage16<ENG_Q2>(qcodes + (u64)q * row_stride, k0, k0 < code_k);
 }
 
-// Threshold-filtered epilogue (FUSED): instead of writing the [B][chunk] score matrix to HBM for a second kernel to select from
-// (10 GB written + 10 GB re-read per 256 x 10M scan against 1.9 GB of codes), every score is compared with its query's current
-// SEL-th best key and only the rare survivors are appended to app[B][cap] through a per-query counter.  A reciprocal-based
-// estimate (4 VALU ops) screens the elements; the exact IEEE quotient — the value that is ranked — is formed only for those
-// within 4e-6 of the threshold or above it, so results are identical to the unfused path.
-struct FusedOut {
-    const u64 *thr;   // [B] SEL-th best (key) so far; 0 = pool not full yet, everything passes
-    u64 *app;         // [B][cap]
-    u32 *app_cnt;     // [B]
-    u32 cap;
-    const uint8_t *qdigits; // ENG_Q2: [B][kdims] pre-expanded query digits (expand_q2_digits_kernel)
-};
-
 template <int ENG, bool FUSED, int PF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void flat_codes_gemm_i8(const uint8_t *__restrict__ qcodes, const float *__restrict__ qmags,
                                                           const u32 *__restrict__ qsums, u32 B, const uint8_t *__restrict__ codes,
@@ -495,283 +483,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Query-resident scan (quaternary codes, fused epilogue).  Counters on flat_codes_gemm_i8 at 10M x 768 (profiles/
-// r02_c3_i8_scan_sq_lds_counters.txt): VALU 49 % busy, LDS 42 %, MFMA 26 % — every 256 x 128 tile restages the same 196 KB
-// of query digits through LDS, and the per-element epilogue costs ten VALU ops.  Here the query operand never moves:
-//   * a workgroup is 4 waves, one per SIMD; wave w keeps the MFMA A fragments of query rows 64w .. 64w+63 for the WHOLE k
-//     range in registers (K / 32 fragments x 2 row blocks x 4 VGPRs = 192 VGPRs at K = 768) for the life of the kernel;
-//   * candidates stream through LDS in tiles of 64 rows x K digit bytes, double-buffered: while the MFMAs of tile t run,
-//     the same waves expand tile t+1 (planes -> digits, 4 VALU ops per dword thanks to a dim permutation inside each 64-dim
-//     chunk that the query digits share) and the raw loads of tile t+2 are in flight.  One barrier per tile;
-//   * LDS rows are K + 16 bytes, so the 16 lanes of a ds_read_b128 group (distinct rows mod 16) hit 16 distinct 16 B slots,
-//     and the staging stores (lane = candidate) are conflict-free too;
-//   * the epilogue is a per-lane "does any of my 16 rows pass" test (cvt + fma + max3 per element) against thresholds held
-//     in registers; the exact quotient and the append run only for the rare lanes that pass.  Same survivors as the
-//     tile kernel: the estimate only decides who gets the exact test.
-// One workgroup per CU, persistent over the tiles of the launch.
-// ------------------------------------------------------------------------------------------------
-// 16 digit bytes of piece pp (0..3) of a 64-dim chunk, permuted: byte b of dword jj is dim 32*(pp>>1) + 4*(pp&1) + jj + 8*b
-__device__ __forceinline__ u32 q2_dword_perm(uint4 raw /*[plane0 8 B | plane1 8 B]*/, int pp, int jj) {
-    const u32 w0 = pp < 2 ? raw.x : raw.y, w1 = pp < 2 ? raw.z : raw.w;
-    const int sh = 4 * (pp & 1) + jj;
-    const u32 x0 = w0 >> sh, x1 = sh ? (w1 >> (sh - 1)) : (w1 << 1);
-    return (x0 & 0x01010101u) | (x1 & 0x02020202u);
-}
-__device__ __forceinline__ uint4 q2_piece_perm(uint4 raw, int pp) {
-    return make_uint4(q2_dword_perm(raw, pp, 0), q2_dword_perm(raw, pp, 1), q2_dword_perm(raw, pp, 2), q2_dword_perm(raw, pp, 3));
-}
-
-__global__ void expand_q2_digits_perm_kernel(const uint8_t *__restrict__ qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *__restrict__ digits) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 chunks = kdims / 64;
-    if (t >= (u64)B * chunks) return;
-    const u32 q = (u32)(t / chunks), j = (u32)(t % chunks);
-    const uint4 raw = (u64)j * 16 < row_stride ? *(const uint4 *)(qcodes + (u64)q * row_stride + (u64)j * 16) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int pp = 0; pp < 4; pp++) *(uint4 *)(digits + (u64)q * kdims + (u64)j * 64 + pp * 16) = q2_piece_perm(raw, pp);
-}
-
-// The MFMA of the query-resident kernel with its register classes spelled out: query fragment in AccVGPRs (192 of them at
-// K = 768, resident for the whole kernel), candidate fragment and accumulators in VGPRs.  Left to the register allocator the
-// fragments were parked in AccVGPRs and copied back (v_accvgpr_read x 4) before every use, ~280 extra VALU issues per tile, and
-// the accumulators needed 64 more copies before the epilogue could read them.  Hazards: the 4 accumulators rotate (an MFMA never
-// depends on one of the 3 before it), VALU code reads an accumulator set a whole tile after its last MFMA, candidate fragments
-// are rewritten (ds_read) two k steps after their last use.
-template <bool FIRST>
-__device__ __forceinline__ void areg_mfma(i32x16 &acc, const i32x4 &afrag, const i32x4 &bfrag) {
-    if constexpr (FIRST) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag));
-    else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag));
-}
-
-constexpr int AREG_STAGE = 1024; // survivors a workgroup can park in LDS per launch (expected: a few hundred)
-
-// exact score of one survivor of the estimate, compared with the query's threshold key, appended if it beats it
-__device__ __forceinline__ void areg_append(const FusedOut &fo, const float *__restrict__ qmags, const float *__restrict__ mags, u32 metric, u32 n0,
-                                            u32 col, u32 row, u32 dot) {
-    const float dotf = (float)dot;
-    const float sc = metric == 0u ? __fdiv_rn(dotf, __fmul_rn(qmags[row], mags[n0 + col])) : dotf;
-    const u64 key = pack_key(simkey(sc), n0 + col);
-    if (key > fo.thr[row]) {
-        const u32 pos = atomicAdd(&fo.app_cnt[row], 1u);
-        if (pos < fo.cap) fo.app[(u64)row * fo.cap + pos] = key;
-    }
-}
-
-// compile-time loop: the body sees its index as an integral_constant, so register arrays stay statically indexed whatever
-// the unroller's size thresholds say (a `#pragma unroll` over the 24 k steps of the query-resident kernel is refused)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-template <int KC>
-__global__ __launch_bounds__(256) void flat_scan_q2_areg(const uint8_t *__restrict__ qdig /*[B][64 KC] permuted digits*/,
-                                                         const float *__restrict__ qmags, u32 B, const uint8_t *__restrict__ codes,
-                                                         const float *__restrict__ mags, u64 row_stride, u32 n0, u32 n_chunk, u32 metric,
-                                                         const FusedOut fo) {
-    constexpr int K = KC * 64, KS = KC * 2, LDB = K + 16, ITS = (KC + 3) / 4, PIECES = ITS * 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB] | survivors [AREG_STAGE][3] u32 | count
-    u32 *stage = (u32 *)(areg_lds + (size_t)2 * 64 * LDB), *stage_cnt = stage + 3 * AREG_STAGE;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const u32 row0 = blockIdx.y * 256 + w * 64;
-    const u32 n_tiles = (n_chunk + 63) / 64, G = gridDim.x;
-    u32 t = blockIdx.x;
-    if (t >= n_tiles) return; // uniform
-    if (tid == 0) *stage_cnt = 0; // published by the barrier after the first tile's expansion
-    i32x4 a[2][KS];
-    static_for<0, 2 * KS>([&](auto Ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(Ic)::value / KS, s = decltype(Ic)::value % KS;
-        const u32 row = row0 + 32 * i + l31; // rows past B: clamped loads (no branches in the prologue), zeroed
-        const i32x4 v = *(const i32x4 *)(qdig + (u64)(row < B ? row : B - 1) * K + 32 * s + 16 * half);
-        a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
-        asm volatile("" : "+a"(a[i][s])); // the value now IS an AccVGPR tuple: its MFMA uses need no copies
-    });
-    // thresholds of this lane's 32 accumulator rows, in the units of dot * (1 / |x|): T = thr_lo * |q| (cosine) or thr_lo (dot)
-    float T[2][16];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const u32 row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, rc = row < B ? row : B - 1;
-            const u64 k = fo.thr[rc];
-            const float qm = qmags[rc];
-            const float lo = k == 0ull ? -1.0f : simkey_inv((u32)(k >> 32)) * (1.0f - 4e-6f); // scores of quaternary codes are >= 0
-            const float v = metric == 0u ? lo * qm : lo;
-            T[i][r] = row < B ? v : __builtin_inff();
-        }
-    // Staging: lane = candidate of the tile, wave w expands chunks w, w+4, w+8, ...  Two raw sets: while tile t is multiplied,
-    // set (PAR^1) (tile t+G) is expanded into the other LDS buffer and reloaded with tile t+3G; set PAR (tile t+2G) is in
-    // flight.  Loads are unconditional (addresses clamped to the last row of the chunk: a duplicated row is never appended,
-    // its columns fail the `col < n_chunk` test), so they stay in flight across the MFMAs.
-    uint4 raw[2][ITS];
-    auto load_raw = [&](u32 tile, uint4 *dst, int it) __attribute__((always_inline)) {
-        const int j = w + 4 * it;
-        const u32 c = tile * 64 + lane, cc = c < n_chunk ? c : n_chunk - 1;
-        dst[it] = *(const uint4 *)(codes + (u64)(n0 + cc) * row_stride + (u64)(KC % 4 == 0 || j < KC ? j : 0) * 16);
-    };
-    auto store_piece = [&](int buf, const uint4 *src, int it, int pp) __attribute__((always_inline)) {
-        const int j = w + 4 * it;
-        if (KC % 4 == 0 || j < KC) *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + lane * LDB + j * 64 + pp * 16) = q2_piece_perm(src[it], pp);
-    };
-    float xm[2][2]; // candidate norms of the tile in accumulator set 0 / 1 (consumed by the deferred epilogue)
-    auto load_norms = [&](u32 tile, float *dst) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const u32 col = tile * 64 + 32 * j + l31;
-            dst[j] = mags[n0 + (col < n_chunk ? col : n_chunk - 1)];
-        }
-    };
-#pragma unroll
-    for (int it = 0; it < ITS; it++) load_raw(t, raw[0], it);
-#pragma unroll
-    for (int it = 0; it < ITS; it++)
-#pragma unroll
-        for (int pp = 0; pp < 4; pp++) store_piece(0, raw[0], it, pp);
-#pragma unroll
-    for (int it = 0; it < ITS; it++) {
-        load_raw(t + G, raw[1], it);
-        load_raw(t + 2 * G, raw[0], it);
-    }
-    xm[1][0] = xm[1][1] = 1.0f;
-    __syncthreads();
-    i32x16 acc[2][2][2]; // [set][row block][column block]
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[1][i][j][r] = 0;
-
-    // deferred epilogue of accumulator set P (tile tp), in 8 slices of 8 rows so that each slice fits in the shadow of one k step
-    // of the next tile: slice e -> column block j = e >> 2, row block i = (e >> 1) & 1, rows r = 8 (e & 1) .. +7
-    float best = 0.0f;
-    // rows h8 + r0, h8 + r0 + 1 of slice e: two (cvt, fma, max) triples — what fits beside one MFMA
-    auto epi_rows = [&](auto Pc, int e, int r0) __attribute__((always_inline)) {
-        constexpr int P = decltype(Pc)::value;
-        const int j = e >> 2, i = (e >> 1) & 1, h8 = (e & 1) * 8;
-        const float rx = metric == 0u ? __builtin_amdgcn_rcpf(xm[P][j]) : 1.0f;
-        if (h8 == 0 && r0 == 0) best = -__builtin_inff();
-#pragma unroll
-        for (int r = r0; r < r0 + 2; r++) best = fmaxf(best, __builtin_fmaf((float)(u32)acc[P][i][j][h8 + r], rx, -T[i][h8 + r]));
-    };
-    // after the 16th row of a (row block, column block): the rare lanes with a row that may beat its query's threshold park
-    // the survivors in LDS for the end of the kernel — the exact quotient, the key compare and the global append counter are
-    // round trips to memory that a lone wave per SIMD cannot hide
-    auto epi_finish = [&](auto Pc, int e, u32 tp, bool tp_valid) __attribute__((always_inline)) {
-        constexpr int P = decltype(Pc)::value;
-        const int j = e >> 2, i = (e >> 1) & 1;
-        if ((e & 1) == 0) return;
-        const u32 col = tp * 64 + 32 * j + l31;
-        if (best >= 0.0f && tp_valid && col < n_chunk) {
-            const float rx = metric == 0u ? __builtin_amdgcn_rcpf(xm[P][j]) : 1.0f;
-            u32 rbase = row0 + 32 * i + 4 * half;
-            asm volatile("" : "+v"(rbase)); // opaque: keeps the 32 rows' addresses from being hoisted out of the tile loop
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const u32 row = rbase + (r & 3) + 8 * (r >> 2);
-                const float dotf = (float)(u32)acc[P][i][j][r];
-                if (row < B && __builtin_fmaf(dotf, rx, -T[i][r]) >= 0.0f) {
-                    const u32 sp = atomicAdd(stage_cnt, 1u);
-                    if (sp < AREG_STAGE) {
-                        stage[3 * sp] = col;
-                        stage[3 * sp + 1] = row;
-                        stage[3 * sp + 2] = (u32)acc[P][i][j][r];
-                    } else
-                        areg_append(fo, qmags, mags, metric, n0, col, row, (u32)acc[P][i][j][r]); // staging full: append from here
-                }
-            }
-        }
-    };
-    auto epi_slice = [&](auto Pc, int e, u32 tp, bool tp_valid) __attribute__((always_inline)) {
-        epi_rows(Pc, e, 0); epi_rows(Pc, e, 2); epi_rows(Pc, e, 4); epi_rows(Pc, e, 6);
-        epi_finish(Pc, e, tp, tp_valid);
-    };
-    // One tile: MFMAs of tile tt into set P from LDS buffer P.  A lone wave per SIMD issues in order, so whatever is to run in
-    // the shadow of an MFMA has to sit right behind it in the instruction stream: every k step is four (MFMA, <= 6 VALU) pairs —
-    // one dword of the expansion of tile tt+G during the first PIECES steps, two rows of the epilogue of tile tt-G (set P^1)
-    // during the next 8 — pinned by sched_barriers.
-    constexpr int EPI0 = PIECES + 8 <= KS ? PIECES : (KS >= 8 ? KS - 8 : 0); // first step that carries an epilogue slice
-    auto tile_body = [&](auto Pc, u32 tt, bool prev_valid) __attribute__((always_inline)) {
-        constexpr int P = decltype(Pc)::value;
-        const unsigned char *bt = areg_lds + (size_t)P * 64 * LDB + l31 * LDB + 16 * half;
-        i32x4 bf[3][2]; // candidate fragments, read two k steps ahead of their MFMAs
-#pragma unroll
-        for (int s = 0; s < 2 && s < KS; s++) {
-            bf[s][0] = *(const i32x4 *)(bt + 32 * s);
-            bf[s][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * s);
-        }
-        load_norms(tt, xm[P]);
-        static_for<0, KS>([&](auto Sc) __attribute__((always_inline)) {
-            constexpr int s = decltype(Sc)::value;
-            constexpr bool expand = s < PIECES, epi = s >= EPI0 && s < EPI0 + 8;
-            constexpr int it = (s < PIECES ? s : 0) >> 2, pp = s & 3, j = 0;
-            if (s + 2 < KS) {
-                bf[(s + 2) % 3][0] = *(const i32x4 *)(bt + 32 * (s + 2));
-                bf[(s + 2) % 3][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * (s + 2));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const i32x4 b0 = bf[s % 3][0], b1 = bf[s % 3][1];
-            const bool lane_stores = KC % 4 == 0 || w + 4 * it < KC;
-            u32 o[4] = {0, 0, 0, 0};
-            areg_mfma<s == 0>(acc[P][0][0], a[0][s], b0);
-            if (expand) { o[0] = q2_dword_perm(raw[P ^ 1][it], pp, 0); asm volatile("" : "+v"(o[0])); } // pinned behind its MFMA
-            if (epi) epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            areg_mfma<s == 0>(acc[P][0][1], a[0][s], b1);
-            if (expand) { o[1] = q2_dword_perm(raw[P ^ 1][it], pp, 1); asm volatile("" : "+v"(o[1])); } // pinned behind its MFMA
-            if (epi) epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            areg_mfma<s == 0>(acc[P][1][0], a[1][s], b0);
-            if (expand) { o[2] = q2_dword_perm(raw[P ^ 1][it], pp, 2); asm volatile("" : "+v"(o[2])); } // pinned behind its MFMA
-            if (epi) epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 4);
-            __builtin_amdgcn_sched_barrier(0);
-            areg_mfma<s == 0>(acc[P][1][1], a[1][s], b1);
-            if (expand) {
-                o[3] = q2_dword_perm(raw[P ^ 1][it], pp, 3);
-                asm volatile("" : "+v"(o[3]));
-                if (lane_stores)
-                    *(uint4 *)(areg_lds + (size_t)(P ^ 1) * 64 * LDB + lane * LDB + (w + 4 * it) * 64 + pp * 16) = make_uint4(o[0], o[1], o[2], o[3]);
-                if (pp == 3) load_raw(tt + 3 * G, raw[P ^ 1], it); // the chunk's registers are free: reload them for tile tt + 3G
-            }
-            if (epi) {
-                epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 6);
-                epi_finish(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, tt - G, prev_valid);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if constexpr (EPI0 + 8 > KS) { // short K: the slices that did not fit in the k loop
-            static_for<KS - EPI0, 8>([&](auto Ec) __attribute__((always_inline)) { epi_slice(std::integral_constant<int, (P ^ 1)>{}, decltype(Ec)::value, tt - G, prev_valid); });
-        }
-        __syncthreads();
-    };
-    bool prev_valid = false;
-    int last = 1;
-    while (true) {
-        tile_body(std::integral_constant<int, 0>{}, t, prev_valid);
-        prev_valid = true;
-        last = 0;
-        t += G;
-        if (t >= n_tiles) break;
-        tile_body(std::integral_constant<int, 1>{}, t, true);
-        last = 1;
-        t += G;
-        if (t >= n_tiles) break;
-    }
-    // drain: epilogue of the last tile (t was advanced once past it)
-    if (last == 0) {
-        static_for<0, 8>([&](auto Ec) __attribute__((always_inline)) { epi_slice(std::integral_constant<int, 0>{}, decltype(Ec)::value, t - G, true); });
-    } else {
-        static_for<0, 8>([&](auto Ec) __attribute__((always_inline)) { epi_slice(std::integral_constant<int, 1>{}, decltype(Ec)::value, t - G, true); });
-    }
-    __syncthreads();
-    const u32 staged = min(*stage_cnt, (u32)AREG_STAGE);
-    for (u32 e = tid; e < staged; e += 256) areg_append(fo, qmags, mags, metric, n0, stage[3 * e], stage[3 * e + 1], stage[3 * e + 2]);
-}
-
 __global__ void code_sums_kernel(const uint8_t *__restrict__ codes, u64 row_stride, u32 n, u32 *__restrict__ sums) {
     const int lane = threadIdx.x & 63;
     const u32 row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -882,32 +593,6 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     return COS_OK;
 }
 
-// query-resident scan launcher: KC = k chunks of 64 dims; false when this K has no instantiation (the tile kernel runs instead)
-static bool areg_supported(u32 kdims) {
-    const u32 kc = kdims / 64;
-    return kdims % 64 == 0 && (kc == 2 || kc == 4 || kc == 6 || kc == 8 || kc == 12 || kc == 16);
-}
-template <int KC>
-static hipError_t launch_areg_kc(dim3 grid, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes, const float *mags,
-                                 u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
-    const size_t lds = (size_t)2 * 64 * (KC * 64 + 16) + (size_t)AREG_STAGE * 12 + 16;
-    hipError_t e = hipFuncSetAttribute((const void *)flat_scan_q2_areg<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((flat_scan_q2_areg<KC>), grid, dim3(256), lds, st, qdig, qmags, B, codes, mags, row_stride, n0, nc, metric, fo);
-    return hipGetLastError();
-}
-static hipError_t launch_areg(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes,
-                              const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
-    const u32 n_tiles = (nc + 63) / 64;
-    dim3 grid(std::min(n_tiles, n_cus), (B + 255) / 256);
-#define AREG_CASE(KC) case KC: return launch_areg_kc<KC>(grid, st, qdig, qmags, B, codes, mags, row_stride, n0, nc, metric, fo)
-    switch (kdims / 64) {
-        AREG_CASE(2); AREG_CASE(4); AREG_CASE(6); AREG_CASE(8); AREG_CASE(12); AREG_CASE(16);
-        default: return hipErrorInvalidValue;
-    }
-#undef AREG_CASE
-}
-
 // ------------------------------------------------------------------------------------------------
 // cos_flat_search_batch: exhaustive search over the index's quantized codes (i8 MFMA) + exact rerank of the best 5k
 // ------------------------------------------------------------------------------------------------
@@ -930,7 +615,7 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     const char *pf_env = getenv("COS_FLAT_PF"); // k panels prefetched into registers (1..3); tuning knob, results do not depend on it
     const int pf = pf_env ? atoi(pf_env) : 1;
     // fused chunks of quaternary codes run on the query-resident kernel when K has an instantiation (COS_FLAT_TILE_KERNEL=1: never)
-    const bool use_areg = ix->eng == ENG_Q2 && areg_supported(kdims) && getenv("COS_FLAT_TILE_KERNEL") == nullptr;
+    const bool use_areg = ix->eng == ENG_Q2 && flat_scan_supported(kdims) && getenv("COS_FLAT_TILE_KERNEL") == nullptr;
     int n_cus = 0;
     if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, ix->p.device) != hipSuccess || n_cus <= 0) n_cus = 256;
     constexpr u32 SEED = 16384, APP_CAP = 4096;
@@ -980,10 +665,8 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
             if (e == hipSuccess && ix->eng == ENG_Q2) {
                 const u64 pieces = (u64)B * (kdims / 16);
                 hipLaunchKernelGGL(expand_q2_digits_kernel, dim3((u32)((pieces + 255) / 256)), dim3(256), 0, st, d_qc, ix->row_stride, B, kdims, d_qd);
-                if (use_areg)
-                    hipLaunchKernelGGL(expand_q2_digits_perm_kernel, dim3((u32)(((u64)B * (kdims / 64) + 255) / 256)), dim3(256), 0, st, d_qc, ix->row_stride, B,
-                                       kdims, d_qdp);
                 e = hipGetLastError();
+                if (e == hipSuccess && use_areg) e = launch_flat_scan_expand_queries(d_qc, ix->row_stride, B, kdims, d_qdp, st);
             }
             // zero-norm screening (cosine): the reference aborts a search on the first zero denominator it meets; an
             // exhaustive scan meets every vector, so any zero |q| or zero |v| is a CalculationError for the call.
@@ -1023,7 +706,7 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
 #define FLAT_LAUNCH(E, F, P) hipLaunchKernelGGL((flat_codes_gemm_i8<E, F, P>), grid, dim3(512), 0, st, FLAT_ARGS)
 #define FLAT_LAUNCH_PF(E, F) do { if (pf == 2) FLAT_LAUNCH(E, F, 2); else if (pf == 3) FLAT_LAUNCH(E, F, 3); else FLAT_LAUNCH(E, F, 1); } while (0)
             if (use_fused && use_areg) {
-                e = launch_areg(kdims, (u32)n_cus, st, d_qdp, d_qm, B, ix->d_codes, ix->d_mags, ix->row_stride, n0, nc, ix->p.metric, fo);
+                e = launch_flat_scan(kdims, (u32)n_cus, st, d_qdp, d_qm, B, ix->d_codes, ix->d_mags, ix->row_stride, n0, nc, ix->p.metric, fo);
                 if (e != hipSuccess) break;
             } else if (ix->eng == ENG_U8) {
                 if (use_fused) FLAT_LAUNCH_PF(ENG_U8, true); else FLAT_LAUNCH_PF(ENG_U8, false);
