@@ -203,6 +203,7 @@ extern "C" int32_t cos_index_destroy(cos_index *ix) {
     (void)hipSetDevice(ix->p.device);
     (void)hipDeviceSynchronize();
     for (auto &kv : ix->ws) free_ws(kv.second);
+    cos_flat_ws_release(ix);
     for (auto &kv : ix->thread_streams) if (kv.second) (void)hipStreamDestroy(kv.second);
     for (auto &l : ix->lv) free_level(l);
     for (auto &l : ix->meta.lv) free_level(l);
@@ -231,6 +232,7 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     if (ix->d_mags) (void)hipFree(ix->d_mags);
     ix->d_raw = nullptr; ix->d_raw_mags = nullptr; ix->d_codes = nullptr; ix->d_mags = nullptr;
     ix->have_vectors = false;
+    cos_flat_ws_release(ix); // cached sums of the stored codes, scan buffers sized for the old corpus
     ix->have_root = false;
     for (auto &l : ix->lv) free_level(l); // a graph refers to vector rows: new vectors invalidate it
     for (auto &l : ix->meta.lv) free_level(l);

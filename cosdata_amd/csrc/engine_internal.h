@@ -145,9 +145,12 @@ struct cos_index {
     std::mutex chain_mu;
     hipEvent_t chain_ev = nullptr; // walk_done of the most recent chained walk
     u32 chain_min_B = 16384;
+    struct FlatWs *flat_ws = nullptr; // cos_flat_search_batch's buffers (kernels_flat.hip), created on first use under `mu`
 };
 
 
+struct FlatWs;
+void cos_flat_ws_release(cos_index *ix);
 cosdev::IndexDev cos_make_index_dev(const cos_index *ix);
 cosdev::IndexDev cos_make_meta_dev(const cos_index *ix);
 int32_t cos_set_device(const cos_index *ix);

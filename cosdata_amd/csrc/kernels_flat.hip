@@ -593,6 +593,46 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     return COS_OK;
 }
 
+// Per-index workspace of cos_flat_search_batch: every buffer is grow-only and lives until the index is destroyed (or its
+// vectors are replaced), so a scan makes no allocation and creates no event on the query path — 17 hipMalloc / hipFree pairs
+// and a dozen event create / destroy calls used to cost about as much wall time as the scan kernel itself.
+struct FlatWs {
+    std::mutex mu; // the scan runs on the index's own stream: one call at a time
+    struct Buf { void *p = nullptr; size_t cap = 0; };
+    Buf q, zero, qm, qrm, qc, qd, qdp, qs, cs, pool, thr, app, appcnt, oi, os, oc, scores, part;
+    bool cs_valid = false; // code sums of the stored vectors (u8 engine) computed for the current upload
+    u32 cs_n = 0;
+    std::vector<hipEvent_t> evs;
+    hipError_t need(Buf &b, size_t bytes) {
+        if (bytes <= b.cap && b.p) return hipSuccess;
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+        hipError_t e = hipMalloc(&b.p, bytes ? bytes : 1);
+        if (e == hipSuccess) b.cap = bytes ? bytes : 1;
+        return e;
+    }
+    hipError_t event(size_t i, hipEvent_t *out) {
+        while (evs.size() <= i) {
+            hipEvent_t ev = nullptr;
+            hipError_t e = hipEventCreate(&ev);
+            if (e != hipSuccess) return e;
+            evs.push_back(ev);
+        }
+        *out = evs[i];
+        return hipSuccess;
+    }
+    ~FlatWs() {
+        for (Buf *b : {&q, &zero, &qm, &qrm, &qc, &qd, &qdp, &qs, &cs, &pool, &thr, &app, &appcnt, &oi, &os, &oc, &scores, &part})
+            if (b->p) (void)hipFree(b->p);
+        for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+    }
+};
+
+void cos_flat_ws_release(cos_index *ix) { // cos_index_destroy, and every upload that replaces the stored vectors
+    delete ix->flat_ws;
+    ix->flat_ws = nullptr;
+}
+
 // ------------------------------------------------------------------------------------------------
 // cos_flat_search_batch: exhaustive search over the index's quantized codes (i8 MFMA) + exact rerank of the best 5k
 // ------------------------------------------------------------------------------------------------
@@ -622,11 +662,17 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     u32 chunk = (u32)std::min<u64>(1u << 20, ((1ull << 31) / B / 4) / CN * CN); // unfused: the [B][chunk] score buffer stays <= 2 GiB
     chunk = std::min(n, std::max<u32>(chunk, CN));
     hipStream_t st = ix->own_stream;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        if (!ix->flat_ws) ix->flat_ws = new FlatWs();
+    }
+    FlatWs *W = ix->flat_ws;
+    std::lock_guard<std::mutex> wg(W->mu);
     float *d_q = nullptr, *d_qm = nullptr, *d_qrm = nullptr, *d_scores = nullptr, *d_os = nullptr;
     uint8_t *d_qc = nullptr, *d_qd = nullptr, *d_qdp = nullptr;
     u32 *d_qs = nullptr, *d_cs = nullptr, *d_oi = nullptr, *d_oc = nullptr, *d_zero = nullptr, *d_appcnt = nullptr;
     u64 *d_pool = nullptr, *d_part = nullptr, *d_thr = nullptr, *d_app = nullptr;
-    std::vector<hipEvent_t> evs; // (start, stop) of every GEMM launch, read after the last one
+    size_t n_ev = 0; // (start, stop) events of the GEMM launches, read after the last one
     float gemm_ms = 0.f;
     u32 launches = 0;
     double streamed = 0.0;
@@ -638,28 +684,33 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
         const u64 s_stride = ((u64)std::min(first, n) + 63) & ~63ull;
         const u32 S = select_segments(B, std::min(first, n));
         if (attempt == 0) {
-            e = hipMalloc(&d_q, (size_t)B * dim * 4);
-            if (e == hipSuccess) e = hipMalloc(&d_zero, 8);
+#define WS_NEED(buf, ptr, bytes) if (e == hipSuccess) { e = W->need(W->buf, (bytes)); ptr = (decltype(ptr))W->buf.p; }
+            WS_NEED(q, d_q, (size_t)B * dim * 4)
+            WS_NEED(zero, d_zero, 8)
             if (e == hipSuccess) e = hipMemsetAsync(d_zero, 0, 8, st);
-            if (e == hipSuccess) e = hipMalloc(&d_qm, (size_t)B * 4);
-            if (e == hipSuccess) e = hipMalloc(&d_qrm, (size_t)B * 4);
-            if (e == hipSuccess) e = hipMalloc(&d_qc, (size_t)B * ix->row_stride);
-            if (e == hipSuccess) e = hipMalloc(&d_qd, (size_t)B * kdims);
-            if (e == hipSuccess && use_areg) e = hipMalloc(&d_qdp, (size_t)B * kdims);
-            if (e == hipSuccess) e = hipMalloc(&d_qs, (size_t)B * 4);
-            if (e == hipSuccess) e = hipMalloc(&d_cs, ((size_t)n + 1) * 4);
-            if (e == hipSuccess) e = hipMalloc(&d_pool, (size_t)B * SEL * 8);
-            if (e == hipSuccess) e = hipMalloc(&d_thr, (size_t)B * 8);
-            if (e == hipSuccess) e = hipMalloc(&d_app, (size_t)B * APP_CAP * 8);
-            if (e == hipSuccess) e = hipMalloc(&d_appcnt, (size_t)B * 4);
-            if (e == hipSuccess) e = hipMalloc(&d_oi, (size_t)B * top_k * 4);
-            if (e == hipSuccess) e = hipMalloc(&d_os, (size_t)B * top_k * 4);
-            if (e == hipSuccess) e = hipMalloc(&d_oc, (size_t)B * 4);
+            WS_NEED(qm, d_qm, (size_t)B * 4)
+            WS_NEED(qrm, d_qrm, (size_t)B * 4)
+            WS_NEED(qc, d_qc, (size_t)B * ix->row_stride)
+            WS_NEED(qd, d_qd, (size_t)B * kdims)
+            if (use_areg) WS_NEED(qdp, d_qdp, (size_t)B * kdims)
+            WS_NEED(qs, d_qs, (size_t)B * 4)
+            WS_NEED(cs, d_cs, ((size_t)n + 1) * 4)
+            WS_NEED(pool, d_pool, (size_t)B * SEL * 8)
+            WS_NEED(thr, d_thr, (size_t)B * 8)
+            WS_NEED(app, d_app, (size_t)B * APP_CAP * 8)
+            WS_NEED(appcnt, d_appcnt, (size_t)B * 4)
+            WS_NEED(oi, d_oi, (size_t)B * top_k * 4)
+            WS_NEED(os, d_os, (size_t)B * top_k * 4)
+            WS_NEED(oc, d_oc, (size_t)B * 4)
             if (e == hipSuccess) e = hipMemcpyAsync(d_q, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = launch_quantize_rows(ix->eng, d_q, dim, B, dim, ix->p.range_lo, ix->p.range_hi, d_qc, ix->row_stride, d_qm, d_qrm, st);
             if (e == hipSuccess && ix->eng == ENG_U8) {
                 hipLaunchKernelGGL(code_sums_kernel, dim3((B + 3) / 4), dim3(256), 0, st, d_qc, ix->row_stride, B, d_qs);
-                hipLaunchKernelGGL(code_sums_kernel, dim3((n + 3) / 4), dim3(256), 0, st, ix->d_codes, ix->row_stride, n, d_cs);
+                if (!W->cs_valid || W->cs_n != n) { // the stored vectors' sums: once per upload
+                    hipLaunchKernelGGL(code_sums_kernel, dim3((n + 3) / 4), dim3(256), 0, st, ix->d_codes, ix->row_stride, n, d_cs);
+                    W->cs_valid = true;
+                    W->cs_n = n;
+                }
                 e = hipGetLastError();
             }
             if (e == hipSuccess && ix->eng == ENG_Q2) {
@@ -681,11 +732,9 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
             zero = hzero != 0;
             if (zero) break;
         }
-        if (d_scores) (void)hipFree(d_scores);
-        if (d_part) (void)hipFree(d_part);
-        d_scores = nullptr; d_part = nullptr;
-        if (e == hipSuccess) e = hipMalloc(&d_scores, (size_t)B * s_stride * 4);
-        if (e == hipSuccess) e = hipMalloc(&d_part, (size_t)B * S * SEL * 8);
+        WS_NEED(scores, d_scores, (size_t)B * s_stride * 4)
+        WS_NEED(part, d_part, (size_t)B * S * SEL * 8)
+#undef WS_NEED
         if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(d_thr, 0, (size_t)B * 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(d_appcnt, 0, (size_t)B * 4, st);
@@ -698,9 +747,9 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
             nc = std::min(nc, n - n0);
             dim3 grid((nc + CN - 1) / CN, (B + CM - 1) / CM);
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
-            e = hipEventCreate(&ev0);
-            if (e == hipSuccess) { evs.push_back(ev0); e = hipEventCreate(&ev1); }
-            if (e == hipSuccess) { evs.push_back(ev1); e = hipEventRecord(ev0, st); }
+            e = W->event(n_ev, &ev0);
+            if (e == hipSuccess) e = W->event(n_ev + 1, &ev1);
+            if (e == hipSuccess) { n_ev += 2; e = hipEventRecord(ev0, st); }
             if (e != hipSuccess) break;
 #define FLAT_ARGS d_qc, d_qm, d_qs, B, ix->d_codes, ix->d_mags, d_cs, ix->row_stride, n0, nc, kdims, ix->p.metric, d_scores, s_stride, fo
 #define FLAT_LAUNCH(E, F, P) hipLaunchKernelGGL((flat_codes_gemm_i8<E, F, P>), grid, dim3(512), 0, st, FLAT_ARGS)
@@ -743,9 +792,9 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
         if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_os, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_oc, (size_t)B * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        for (size_t i = 0; i + 1 < evs.size() && e == hipSuccess; i += 2) {
+        for (size_t i = 0; i + 1 < n_ev && e == hipSuccess; i += 2) {
             float ms = 0.f;
-            e = hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
+            e = hipEventElapsedTime(&ms, W->evs[i], W->evs[i + 1]);
             gemm_ms += ms;
         }
     }
@@ -755,9 +804,6 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
         stats->int8_ops = 2.0 * (double)B * (double)n * (double)kdims;
         stats->code_bytes = streamed;
     }
-    void *ptrs[] = {d_q, d_qm, d_qrm, d_qc, d_qd, d_qdp, d_qs, d_cs, d_scores, d_pool, d_part, d_zero, d_oi, d_os, d_oc, d_thr, d_app, d_appcnt};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
     HIP_TRY(e);
     if (zero) return cos_fail(COS_ERR_CALCULATION, "zero-norm query or stored vector: DistanceError::CalculationError (cosine.rs:228-232)");
     return COS_OK;
