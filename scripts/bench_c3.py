@@ -45,11 +45,21 @@ for _ in range(a.reps):
     if best is None or st.gemm_ms < best[0]:
         best = (st.gemm_ms, wall, st)
 gemm_ms, wall, st = best
+# full-size parity property: three implementations of the scan (query-resident kernel, 256x128 tile kernel with the fused
+# epilogue, unfused score-matrix path) must return the same ids / score bits / counts; the oracle checks each of them at the
+# sizes it can finish (tests/test_gpu_flat.py)
+same = {}
+for env in ("COS_FLAT_TILE_KERNEL", "COS_FLAT_UNFUSED"):
+    os.environ[env] = "1"
+    i2, s2, c2 = ix.flat_search(Qh, 10)
+    del os.environ[env]
+    same[env] = bool(np.array_equal(i2, ids) and np.array_equal(s2.view(np.uint32), sc.view(np.uint32)) and np.array_equal(c2, cnt))
 rec_flat = float(np.mean([len(set(ids[i].tolist()) & set(gt[i].tolist())) / 10 for i in range(B)]))
 out = {"config": f"c3: {n} x {d} quaternary (SubByte 2), flat scan of the codes, query batch {B}",
        "flat": {"gemm_ms": gemm_ms, "gemm_launches": st.gemm_launches, "int8_tops": st.int8_ops / gemm_ms / 1e9,
                 "int8_peak_tops_dense": 5000.0, "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall,
-                "qps_end_to_end": B / wall, "recall_at_10_vs_f32_bruteforce": rec_flat, "upload_quantize_s": t_up}}
+                "qps_end_to_end": B / wall, "recall_at_10_vs_f32_bruteforce": rec_flat, "upload_quantize_s": t_up,
+                "same_answer_as_tile_kernel": same["COS_FLAT_TILE_KERNEL"], "same_answer_as_unfused_path": same["COS_FLAT_UNFUSED"]}}
 del ix
 if a.walk_n <= 0:   # flat scan only
     print(json.dumps(out))
