@@ -743,7 +743,9 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
         u32 n0 = 0, seen = 0;
         while (n0 < n && e == hipSuccess) {
             const bool use_fused = fused && n0 > 0;
-            u32 nc = use_fused ? std::min<u64>((u64)seen * 8, 1ull << 22) : first;
+            // chunk cap: the tile kernel's grid (and its event granularity) like 4 M; the query-resident kernel is persistent and
+            // pays ~35 us of prologue per launch, so it takes everything that is left once the 8x rule allows it
+            u32 nc = use_fused ? (u32)std::min<u64>((u64)seen * 8, use_areg ? (1ull << 31) : (1ull << 22)) : first;
             nc = std::min(nc, n - n0);
             dim3 grid((nc + CN - 1) / CN, (B + CM - 1) / CM);
             hipEvent_t ev0 = nullptr, ev1 = nullptr;

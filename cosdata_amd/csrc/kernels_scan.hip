@@ -71,7 +71,7 @@ __device__ __forceinline__ void areg_mfma(i32x16 &acc, const i32x4 &afrag, const
     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag, bfrag, FIRST ? z : acc, 0, 0, 0);
 }
 
-constexpr int AREG_STAGE = 1024; // survivors a workgroup can park in LDS per launch (expected: a few hundred)
+constexpr int AREG_STAGE = 2048; // survivors a workgroup can park in LDS per launch (expected: a few hundred)
 
 // exact score of one survivor of the estimate, compared with the query's threshold key, appended if it beats it
 __device__ __forceinline__ void areg_append(const FusedOut &fo, const float *__restrict__ qmags, const float *__restrict__ mags, u32 metric, u32 n0,

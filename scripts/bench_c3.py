@@ -37,14 +37,13 @@ ix = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, st_q2, (-1.
 t = time.time(); ix.upload_vectors_device(X.data_ptr(), n, keepalive=X); t_up = time.time() - t
 Qh = Q.cpu().numpy()
 gt, _ = ix.bruteforce_topk(Qh, 10)
-best = None
+ix.flat_search(Qh, 10)                       # first call sizes the per-index workspace: not timed
+runs = []
 for _ in range(a.reps):
     t = time.time()
     ids, sc, cnt, st = ix.flat_search(Qh, 10, with_stats=True)
-    wall = time.time() - t
-    if best is None or st.gemm_ms < best[0]:
-        best = (st.gemm_ms, wall, st)
-gemm_ms, wall, st = best
+    runs.append((st.gemm_ms, time.time() - t, st))
+gemm_ms = float(np.median([r[0] for r in runs])); wall = float(np.median([r[1] for r in runs])); st = runs[-1][2]
 # full-size parity property: three implementations of the scan (query-resident kernel, 256x128 tile kernel with the fused
 # epilogue, unfused score-matrix path) must return the same ids / score bits / counts; the oracle checks each of them at the
 # sizes it can finish (tests/test_gpu_flat.py)
@@ -57,7 +56,7 @@ for env in ("COS_FLAT_TILE_KERNEL", "COS_FLAT_UNFUSED"):
 rec_flat = float(np.mean([len(set(ids[i].tolist()) & set(gt[i].tolist())) / 10 for i in range(B)]))
 out = {"config": f"c3: {n} x {d} quaternary (SubByte 2), flat scan of the codes, query batch {B}",
        "flat": {"gemm_ms": gemm_ms, "gemm_launches": st.gemm_launches, "int8_tops": st.int8_ops / gemm_ms / 1e9,
-                "int8_peak_tops_dense": 5000.0, "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall,
+                "int8_peak_tops_dense": 5000.0, "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall, "timing": f"median of {a.reps} calls after one untimed call",
                 "qps_end_to_end": B / wall, "recall_at_10_vs_f32_bruteforce": rec_flat, "upload_quantize_s": t_up,
                 "same_answer_as_tile_kernel": same["COS_FLAT_TILE_KERNEL"], "same_answer_as_unfused_path": same["COS_FLAT_UNFUSED"]}}
 del ix
