@@ -128,3 +128,20 @@ def test_flat_code_scan_query_resident_kernel_equals_tile_kernel(monkeypatch):
         got = ix.flat_search(Q, k)
         monkeypatch.delenv(env)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), env
+
+
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2)])
+def test_flat_code_scan_dot_product_metric_fused(storage, res):
+    """DotProduct metric through the fused chunks (scores are the raw integer dots: no norms, no reciprocal estimate) — the
+    quaternary case runs the query-resident kernel's `metric != cosine` arm"""
+    import cosdata_amd as ca
+    n, dim, B, k = 45000, 384, 70, 10
+    X = H.clustered_corpus(n, dim, n_centers=25, sigma=0.25, seed=37) * 0.8
+    Q = H.queries_from(X, B, noise=0.05, seed=5)
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), distance_metric=ca.DistanceMetric.DotProduct,
+                      storage_type=ca.StorageType(ca.StorageKind(storage), res))
+    ix.upload_vectors(X)
+    ids, sc, cnt = ix.flat_search(Q, k)
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, metric=O.METRIC_DOT, storage=storage, resolution=res, num_layers=3)).set_vectors(X)
+    oids, osc, ocnt = oix.flat_search_batch(Q, k, threads=8)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
