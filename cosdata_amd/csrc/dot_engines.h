@@ -127,6 +127,41 @@ __device__ __forceinline__ float f32_pair_dot(const float *__restrict__ row, con
 
 
 
+// The same reference-order f32 dot by EIGHT lanes, lane c owning accumulator (chain) c: element 8s + c of the row at step s.
+// A walk expansion discovers ~7 new neighbours: with a lane PAIR per row 25 of the 32 pairs of a wave idle while each busy lane
+// streams 1.5 KB with 8 loads in flight — the bytes in flight per CU, not the HBM, bounded the f32-storage walk at 0.44 of the
+// roof.  With 8 lanes per row a pass evaluates 8 rows, every lane streams 1/8 of a row with 32 dword loads in flight, and the
+// per-lane FMA count drops 4x.  Same chains, same order inside each chain, same pairwise tree — ((s0+s1)+(s2+s3)) +
+// ((s4+s5)+(s6+s7)), IEEE addition being commutative — so the result is the pair version's bit for bit.  Returns the full dot
+// in all 8 lanes of the group (lanes 8g .. 8g+7).
+__device__ __forceinline__ float f32_oct_dot(const float *__restrict__ row, const float *__restrict__ q_lds, u32 dim, int c) {
+    float a = 0.f;
+    const u32 chunks = dim >> 3;
+    const float *rp = row + c;
+    const float *qp = q_lds + c;
+    u32 s = 0;
+    for (; s + 32 <= chunks; s += 32) {
+        float y[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) y[u] = rp[8 * (s + u)];
+#pragma unroll
+        for (int u = 0; u < 32; u++) a = __fmaf_rn(qp[8 * (s + u)], y[u], a);
+    }
+    for (; s + 8 <= chunks; s += 8) {
+        float y[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) y[u] = rp[8 * (s + u)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a = __fmaf_rn(qp[8 * (s + u)], y[u], a);
+    }
+    for (; s < chunks; s++) a = __fmaf_rn(qp[8 * s], rp[8 * s], a);
+    float t = __fadd_rn(a, __shfl_xor(a, 1, 64)); // s0+s1 | s2+s3 | s4+s5 | s6+s7
+    t = __fadd_rn(t, __shfl_xor(t, 2, 64));       // (s0+s1)+(s2+s3) | (s4+s5)+(s6+s7)
+    float r = __fadd_rn(t, __shfl_xor(t, 4, 64)); // low half + high half
+    for (u32 i = chunks * 8; i < dim; i++) r = __fadd_rn(r, __fmul_rn(q_lds[i], row[i])); // scalar tail, non-fused
+    return r;
+}
+
 // dot_product_f16 (dot_product.rs:13-19): sequential sum of f32(a) * f32(b), no SIMD in the reference.  ONE lane
 // walks one stored row; the query's f16 code is held as f32 in LDS (f32::from(b) is exact).
 __device__ __forceinline__ float f16_lane_dot(const uint8_t *__restrict__ row, const float *__restrict__ q_lds, u32 dim) {

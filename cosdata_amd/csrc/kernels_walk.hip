@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
 
     // ---- engine set-up -------------------------------------------------------------------------
     constexpr bool FLOAT_ENG = ENG == ENG_F32 || ENG == ENG_F16; // ordered f32 chains instead of integer chunk dots
-    const int G = (ENG == ENG_F32) ? 2 : (ENG == ENG_F16 ? 1 : (int)ix.G);
+    const int G = (ENG == ENG_F32) ? 8 : (ENG == ENG_F16 ? 1 : (int)ix.G); // f32: eight lanes per row, one per accumulator chain
     const int lig = lane & (G - 1);  // lane in group
     const int grp = lane / G;        // group index
     const int RP = 64 / G;           // rows per pass
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
             float d = f16_lane_dot(ix.codes + (u64)row * ix.row_stride, sm.qf, ix.dim);
             dotf = __uint_as_float(readlane_u32(__float_as_uint(d), 0));
         } else {
-            float d = f32_pair_dot((const float *)(ix.codes + (u64)row * ix.row_stride), sm.qf, ix.dim, lane & 1);
+            float d = f32_oct_dot((const float *)(ix.codes + (u64)row * ix.row_stride), sm.qf, ix.dim, lane & 7);
             dotf = __uint_as_float(readlane_u32(__float_as_uint(d), 0));
         }
         if (metric == 0u) { // cosine_similarity_from_dot_product (cosine.rs:223-235)
@@ -443,12 +443,12 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                         }
                     }
                     if constexpr (FLOAT_ENG) {
-                        // every lane (pair) runs the uniform-trip-count dot; lanes without a winner read row 0 and are ignored
+                        // every lane group runs the uniform-trip-count dot; groups without a winner read row 0 and are ignored
 #pragma unroll
                         for (int p = 0; p < PB; p++) {
                             if (base + p * RP >= W) break;
                             if constexpr (ENG == ENG_F32)
-                                fdot[p] = f32_pair_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 1);
+                                fdot[p] = f32_oct_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 7);
                             else
                                 fdot[p] = f16_lane_dot(ix.codes + (u64)prow[p] * ix.row_stride, sm.qf, ix.dim);
                         }
