@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
     const u32 f0 = wa.f_off[qi], f1 = wa.f_off[qi + 1];
 
     constexpr bool FLOAT_ENG = ENG == ENG_F32 || ENG == ENG_F16;
-    const int G = (ENG == ENG_F32) ? 2 : (ENG == ENG_F16 ? 1 : (int)ix.G);
+    const int G = (ENG == ENG_F32) ? 8 : (ENG == ENG_F16 ? 1 : (int)ix.G); // f32: eight lanes per row (f32_oct_dot)
     const int lig = lane & (G - 1), grp = lane / G, RP = 64 / G;
     uint4 qreg[CH];
     if constexpr (!FLOAT_ENG) {
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
         } else if constexpr (ENG == ENG_F16) {
             dotf = __uint_as_float(readlane_u32(__float_as_uint(f16_lane_dot(ix.codes + (u64)row * ix.row_stride, sm.qf, ix.dim)), 0));
         } else {
-            dotf = __uint_as_float(readlane_u32(__float_as_uint(f32_pair_dot((const float *)(ix.codes + (u64)row * ix.row_stride), sm.qf, ix.dim, lane & 1)), 0));
+            dotf = __uint_as_float(readlane_u32(__float_as_uint(f32_oct_dot((const float *)(ix.codes + (u64)row * ix.row_stride), sm.qf, ix.dim, lane & 7)), 0));
         }
         if (metric == 0u) {
             const float den = __fmul_rn(qmag, ix.mags[row]);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                                 if (v && chunk < ix.nchunks) buf[p][c] = *(const uint4 *)(ix.codes + (u64)prow[p] * ix.row_stride + (u64)chunk * 16);
                             }
                         } else if constexpr (ENG == ENG_F32)
-                            fdot[p] = f32_pair_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 1);
+                            fdot[p] = f32_oct_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 7);
                         else
                             fdot[p] = f16_lane_dot(ix.codes + (u64)prow[p] * ix.row_stride, sm.qf, ix.dim);
                     }
