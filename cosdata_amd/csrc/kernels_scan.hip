@@ -321,7 +321,6 @@ static hipError_t launch_areg_kc(dim3 grid, hipStream_t st, const uint8_t *qdig,
 hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes,
                               const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
     const u32 n_tiles = (nc + 63) / 64;
-    if (const char *g = getenv("COS_AREG_GRID")) n_cus = (u32)atoi(g); // debugging knob: persistent workgroups per launch
     dim3 grid(std::min(n_tiles, n_cus), (B + 255) / 256);
 #define AREG_CASE(KC) case KC: return launch_areg_kc<KC>(grid, st, qdig, qmags, B, codes, mags, row_stride, n0, nc, metric, fo)
     switch (kdims / 64) {
