@@ -317,7 +317,10 @@ __global__ __launch_bounds__(256) void quantize_ref_kernel(const float *__restri
     if (row >= n) return;
     const float *xr = x + (u64)row * dim;
     uint8_t *cr = codes + (u64)row * cb;
-    if (lane == 0) mags[row] = seq_norm(xr, dim); // norm of the ORIGINAL vector for both kinds
+    {
+        const float rn = seq_norm_wave(xr, dim, lane); // norm of the ORIGINAL vector for both kinds
+        if (lane == 0) mags[row] = rn;
+    }
     if (storage == COS_STORAGE_F16) {
         __half *h = (__half *)cr;
         for (u32 i = lane; i < dim; i += 64) h[i] = __float2half_rn(xr[i]); // half::f16::from_f32 (RNE)

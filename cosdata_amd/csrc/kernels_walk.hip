@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
     uint8_t *cr = codes + (u64)row * row_stride;
     float rn = 0.0f;
     const bool need_seq = (raw_mags != nullptr) || (ENG != ENG_U8);
-    if (need_seq && lane == 0) rn = seq_norm(xr, dim);
+    if (need_seq) rn = seq_norm_wave(xr, dim, lane); // wave-uniform branch; every lane gets the value
     if (raw_mags && lane == 0) raw_mags[row] = rn;
     if constexpr (ENG == ENG_U8) {
         u32 ss = 0;
