@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""One un-coalesced 256-query batch at a time on a c2-like index (200k x 768 u8): run under `rocprofv3 --kernel-trace --stats` to
+see how the 1.5 ms of a single batch split over quantize / walk / finalize."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cosdata_amd as ca
+from bench import mixture
+dev = torch.device("cuda:0")
+n, d, B, k = 1_000_000, 768, 256, 10
+g = torch.Generator(device=dev); g.manual_seed(41)
+c = torch.randn(1000, d, generator=g, device=dev); c = c / c.norm(dim=1, keepdim=True)
+X = mixture(n, d, 42, dev, c); Q = mixture(B, d, 43, dev, c)
+vr = ca.sample_values_range(X[:1000].cpu().numpy(), 1.0)
+ix = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), vr, 64, device=0, seed=42)
+ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
+ix.build(4096)
+ix.set_ef_search(64)
+s = torch.cuda.Stream(device=dev)
+o_i = torch.zeros(B, k, dtype=torch.int32, device=dev); o_s = torch.zeros(B, k, device=dev)
+o_c = torch.zeros(B, dtype=torch.int32, device=dev); o_t = torch.zeros(B, dtype=torch.int32, device=dev)
+for _ in range(3):
+    ix.batch_search_device(Q.data_ptr(), B, k, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), o_t.data_ptr(), s.cuda_stream)
+s.synchronize()
+t = time.perf_counter()
+for _ in range(40):
+    ix.batch_search_device(Q.data_ptr(), B, k, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), o_t.data_ptr(), s.cuda_stream)
+s.synchronize()
+print("single batch ms", (time.perf_counter() - t) / 40 * 1e3)
