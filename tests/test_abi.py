@@ -70,3 +70,11 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 code = "\n".join(l for l in src.splitlines() if not l.strip().startswith(("//", "#", "*", "/*")))
                 assert "import oracle" not in code and "from oracle" not in code and "libcosdata_oracle" not in code, f
+
+
+def test_scan_kernel_is_built_in_vgpr_form():
+    """kernels_scan.hip relies on -mllvm -amdgpu-mfma-vgpr-form=1 (accumulators in VGPRs, query fragments read straight from
+    AccVGPRs): without it the kernel is still correct but ~2x slower, so losing the flag in a Makefile edit must fail loudly."""
+    mk = open(os.path.join(ROOT, "cosdata_amd", "csrc", "Makefile")).read()
+    assert "kernels_scan.o: CXXFLAGS += -mllvm -amdgpu-mfma-vgpr-form=1" in mk
+    assert "kernels_scan.hip" in mk
