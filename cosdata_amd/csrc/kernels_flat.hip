@@ -35,10 +35,11 @@ constexpr size_t GEMM_SMEM = 2ull * (BM + BN) * LDT * sizeof(float); // double-b
 // of 32 double-buffered in LDS: panel p+1 travels HBM -> registers while panel p is multiplied, then registers -> LDS, one
 // barrier per panel.  A lane's MFMA operand for k-step s of an 8-wide k block is element s of ONE ds_read_b128
 // (k = 4*(lane>>5) + s): the k permutation is the same for both operands, so the sum is unchanged.
-template <bool VEC>
+template <bool VEC, bool FUSED>
 __global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q, u64 q_stride, const float *__restrict__ qmags, u32 B,
                                                      const float *__restrict__ X, u64 x_stride, const float *__restrict__ xmags, u32 n0,
-                                                     u32 n_chunk, u32 dim, float *__restrict__ scores /*[B][n_chunk_padded]*/, u64 s_stride) {
+                                                     u32 n_chunk, u32 dim, float *__restrict__ scores /*[B][n_chunk_padded]*/, u64 s_stride,
+                                                     const FusedOut fo /*FUSED: thresholds in, survivors out (see flat_codes_gemm_i8)*/) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -134,7 +135,18 @@ __global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const u32 row = row0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < B && col < n_chunk) scores[(u64)row * s_stride + col] = x86_div(acc[i][j][r], qmags[row] * xm);
+                if (row < B && col < n_chunk) {
+                    const float sc = x86_div(acc[i][j][r], qmags[row] * xm);
+                    if constexpr (FUSED) { // the score matrix never reaches HBM: only what beats the query's 64th best so far is kept
+                        const u64 key = pack_key(simkey(sc), n0 + col);
+                        if (key > fo.thr[row]) {
+                            const u32 pos = atomicAdd(&fo.app_cnt[row], 1u);
+                            if (pos < fo.cap) fo.app[(u64)row * fo.cap + pos] = key;
+                        }
+                    } else {
+                        scores[(u64)row * s_stride + col] = sc;
+                    }
+                }
             }
         }
 }
@@ -547,10 +559,15 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     // candidates per pass: the [B][chunk] score buffer stays <= 1 GiB
     u32 chunk = (u32)std::min<u64>(1u << 18, ((1ull << 30) / B / 4) / BN * BN);
     chunk = std::min(n, std::max<u32>(chunk, BN));
+    // Same schedule as cos_flat_search_batch: the first SEED candidates go through the score matrix + segmented selection and
+    // seed every query's threshold; later chunks grow 8x and the GEMM epilogue appends only what beats the threshold.  An
+    // append-buffer overflow repeats the call on the unfused path (COS_FLAT_UNFUSED=1 forces it).
+    constexpr u32 SEED = 16384, APP_CAP = 4096;
+    const bool allow_fused = getenv("COS_FLAT_UNFUSED") == nullptr && n > SEED;
     const u64 s_stride = ((u64)chunk + 63) & ~63ull;
     float *d_q = nullptr, *d_qm = nullptr, *d_scores = nullptr, *d_os = nullptr, *d_dummy = nullptr;
-    u64 *d_pool = nullptr, *d_part = nullptr;
-    u32 *d_oi = nullptr;
+    u64 *d_pool = nullptr, *d_part = nullptr, *d_thr = nullptr, *d_app = nullptr;
+    u32 *d_oi = nullptr, *d_appcnt = nullptr, *d_over = nullptr;
     uint8_t *d_codes = nullptr;
     hipStream_t st = ix->own_stream;
     const u32 S = select_segments(B, chunk);
@@ -561,23 +578,55 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     if (e == hipSuccess) e = hipMalloc(&d_codes, (size_t)B * (((size_t)dim * 4 + 15) & ~(size_t)15));
     if (e == hipSuccess) e = hipMalloc(&d_scores, (size_t)B * s_stride * 4);
     if (e == hipSuccess) e = hipMalloc(&d_pool, (size_t)B * SEL * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_thr, (size_t)B * 8);
+    if (e == hipSuccess && allow_fused) e = hipMalloc(&d_app, (size_t)B * APP_CAP * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_appcnt, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_over, 4);
     if (e == hipSuccess) e = hipMalloc(&d_oi, (size_t)B * k * 4);
     if (e == hipSuccess) e = hipMalloc(&d_os, (size_t)B * k * 4);
     if (e == hipSuccess) e = hipMemcpyAsync(d_q, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
     // |q| in the reference's sequential order (vector_store.rs:414): reuse the F32 quantize kernel's raw_mags output
     if (e == hipSuccess) e = launch_quantize_rows(ENG_F32, d_q, dim, B, dim, 0.f, 0.f, d_codes, ((u64)dim * 4 + 15) & ~15ull, d_dummy, d_qm, st);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)flat_gemm_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)flat_gemm_f32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
-    for (u32 n0 = 0; n0 < n && e == hipSuccess; n0 += chunk) {
-        const u32 nc = std::min(chunk, n - n0);
-        dim3 grid((nc + BN - 1) / BN, (B + BM - 1) / BM);
-        // float4 staging needs 16 B aligned rows: dim % 4 == 0 (hipMalloc'd bases are 256 B aligned; a borrowed raw pointer is checked)
-        const bool vec = dim % 4 == 0 && ((uintptr_t)ix->d_raw & 15) == 0;
-        if (vec) hipLaunchKernelGGL(flat_gemm_f32<true>, grid, dim3(256), GEMM_SMEM, st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim, ix->d_raw_mags, n0, nc, dim, d_scores, s_stride);
-        else hipLaunchKernelGGL(flat_gemm_f32<false>, grid, dim3(256), GEMM_SMEM, st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim, ix->d_raw_mags, n0, nc, dim, d_scores, s_stride);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = launch_select(d_scores, s_stride, B, n0, nc, d_part, S, d_pool, st);
+    for (const void *f : {(const void *)flat_gemm_f32<true, false>, (const void *)flat_gemm_f32<false, false>, (const void *)flat_gemm_f32<true, true>,
+                          (const void *)flat_gemm_f32<false, true>})
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
+    // float4 staging needs 16 B aligned rows: dim % 4 == 0 (hipMalloc'd bases are 256 B aligned; a borrowed raw pointer is checked)
+    const bool vec = dim % 4 == 0 && ((uintptr_t)ix->d_raw & 15) == 0;
+    for (int attempt = 0; attempt < 2 && e == hipSuccess; attempt++) {
+        const bool fused = allow_fused && attempt == 0;
+        if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_thr, 0, (size_t)B * 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_appcnt, 0, (size_t)B * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_over, 0, 4, st);
+        const FusedOut fo{d_thr, d_app, d_appcnt, APP_CAP, nullptr};
+        u32 n0 = 0;
+        while (n0 < n && e == hipSuccess) {
+            const bool use_fused = fused && n0 > 0;
+            u32 nc = use_fused ? (u32)std::min<u64>((u64)n0 * 8, 1ull << 22) : (fused ? std::min(SEED, chunk) : chunk);
+            nc = std::min(nc, n - n0);
+            dim3 grid((nc + BN - 1) / BN, (B + BM - 1) / BM);
+#define GEMM_ARGS d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim, ix->d_raw_mags, n0, nc, dim, d_scores, s_stride, fo
+            if (use_fused) {
+                if (vec) hipLaunchKernelGGL((flat_gemm_f32<true, true>), grid, dim3(256), GEMM_SMEM, st, GEMM_ARGS);
+                else hipLaunchKernelGGL((flat_gemm_f32<false, true>), grid, dim3(256), GEMM_SMEM, st, GEMM_ARGS);
+                e = hipGetLastError();
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(flat_select_append, dim3(B), dim3(64), 0, st, (const u64 *)d_app, d_appcnt, APP_CAP, B, d_pool, d_thr, d_over);
+                    e = hipGetLastError();
+                }
+            } else {
+                if (vec) hipLaunchKernelGGL((flat_gemm_f32<true, false>), grid, dim3(256), GEMM_SMEM, st, GEMM_ARGS);
+                else hipLaunchKernelGGL((flat_gemm_f32<false, false>), grid, dim3(256), GEMM_SMEM, st, GEMM_ARGS);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = launch_select(d_scores, s_stride, B, n0, nc, d_part, select_segments(B, nc), d_pool, st, d_thr);
+            }
+#undef GEMM_ARGS
+            n0 += nc;
+        }
+        u32 hover = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&hover, d_over, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess || !fused || hover == 0) break; // done; otherwise the append buffer overflowed: repeat unfused
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(flat_rescore, dim3(B), dim3(64), (((size_t)dim * 4 + 15) & ~(size_t)15), st, d_q, (u64)dim, d_qm, B, ix->d_raw, (u64)dim,
@@ -587,7 +636,7 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_oi, (size_t)B * k * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_os, (size_t)B * k * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    void *ptrs[] = {d_q, d_qm, d_dummy, d_codes, d_scores, d_pool, d_part, d_oi, d_os};
+    void *ptrs[] = {d_q, d_qm, d_dummy, d_codes, d_scores, d_pool, d_part, d_thr, d_app, d_appcnt, d_over, d_oi, d_os};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     HIP_TRY(e);
     return COS_OK;

@@ -9,7 +9,8 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,dim,B,k", [(3000, 96, 37, 10), (20000, 768, 130, 10), (5001, 100, 5, 32), (700, 20, 300, 1)])
+@pytest.mark.parametrize("n,dim,B,k", [(3000, 96, 37, 10), (20000, 768, 130, 10), (5001, 100, 5, 32), (700, 20, 300, 1), (70000, 96, 37, 10),
+                                       (150001, 128, 300, 32)])
 def test_bruteforce_matches_oracle(n, dim, B, k):
     import cosdata_amd as ca
     X = H.clustered_corpus(n, dim, n_centers=20, seed=3)
