@@ -509,6 +509,12 @@ extern "C" int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode) {
     ix->p.visited_mode = mode;
     return COS_OK;
 }
+extern "C" int32_t cos_index_set_latency_mode(cos_index *ix, uint32_t max_queries) {
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->lat_max_B = max_queries;
+    return COS_OK;
+}
 extern "C" int32_t cos_index_enable_timing(cos_index *ix, int32_t on) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null");
     std::lock_guard<std::mutex> g(ix->mu);
@@ -608,11 +614,12 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
                           u32 *d_out_counts, int32_t *d_out_status, bool do_finalize, hipStream_t st) {
     IndexDev dev = cos_make_index_dev(ix);
     bool timed;
-    u32 ef;
+    u32 ef, lat_max_B;
     { // one consistent snapshot of the knobs cos_index_set_* may change from another thread
         std::lock_guard<std::mutex> g(ix->mu);
         timed = ix->timing;
         ef = ix->p.ef_search;
+        lat_max_B = ix->lat_max_B;
         dev.visited_mode = ix->p.visited_mode;
     }
     WalkArgs wa;
@@ -640,11 +647,11 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
         std::lock_guard<std::mutex> g(ix->chain_mu);
         if (ix->chain_ev && ix->chain_ev != w->walk_done) HIP_TRY(hipStreamWaitEvent(st, ix->chain_ev, 0));
         if (timed) HIP_TRY(hipEventRecord(ev[1], st)); // the kernel's own duration: after the wait
-        HIP_TRY(launch_walk(ix->eng, dev, wa, st));
+        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, st));
         HIP_TRY(hipEventRecord(w->walk_done, st));
         ix->chain_ev = w->walk_done;
     } else
-        HIP_TRY(launch_walk(ix->eng, dev, wa, st));
+        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, st));
     if (timed) HIP_TRY(hipEventRecord(ev[2], st));
     if (do_finalize) {
         HIP_TRY(launch_finalize(dev, d_queries, ix->p.dim, w->q_raw_mags, w->walk_ids, w->walk_sims, w->walk_counts, w->walk_status, B, top_k,

@@ -19,7 +19,7 @@ hipError_t launch_link_round(const LinkArgs &a, u32 maxM, const u32 *pend, const
                              u32 count_ub, u32 round, hipStream_t st);
 hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
                                 u64 row_stride, float *mags, float *raw_mags, hipStream_t st);
-hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
+hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, hipStream_t st);
 hipError_t launch_walk_meta(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
@@ -145,6 +145,8 @@ struct cos_index {
     std::mutex chain_mu;
     hipEvent_t chain_ev = nullptr; // walk_done of the most recent chained walk
     u32 chain_min_B = 16384;
+    // launches of at most this many queries run the latency variant of the walk (kernels_walk_lat.hip) where it applies; 0 = never
+    u32 lat_max_B = COS_LATENCY_MODE_DEFAULT_MAX_B;
     struct FlatWs *flat_ws = nullptr; // cos_flat_search_batch's buffers (kernels_flat.hip), created on first use under `mu`
 };
 

@@ -236,6 +236,10 @@ class HNSWIndex:
     def set_visited_mode(self, mode: int):
         check(_lib.lib().cos_index_set_visited_mode(self._h, mode))
 
+    def set_latency_mode(self, max_queries: int):
+        """Launches of at most `max_queries` queries take the latency variant of the walk (0 = never); same results."""
+        check(_lib.lib().cos_index_set_latency_mode(self._h, max_queries))
+
     def batch_search(self, queries, top_k: int, return_status: bool = False):
         """IndexOps::batch_search: [B][dim] raw f32 -> (ids [B][k], scores [B][k], counts [B]).
         Raises CosdataError (status 2 = CalculationError) if any query fails, like the

@@ -173,6 +173,13 @@ int32_t cos_ann_search_batch(cos_index *ix, const float *queries, uint32_t B, ui
 int32_t cos_index_set_coalescing(cos_index *ix, uint32_t max_queries, uint32_t window_us);
 int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef_search);
 int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode);
+/* Latency mode.  A launch of at most max_queries queries (default COS_LATENCY_MODE_DEFAULT_MAX_B; 0 = never) runs the latency
+ * variant of the walk where it applies (u8 / quaternary storage, ef <= 256, reference visited filter): the code rows of every
+ * entry of the lookahead window are fetched speculatively in one go and committed in pop order.  Same results bit for bit;
+ * it trades bandwidth (idle on a small launch) for dependent round trips.  The reference's caller submits one 256-query batch
+ * at a time per worker (indexes/mod.rs:260-272); bigger launches (coalesced batches) keep the throughput kernel. */
+#define COS_LATENCY_MODE_DEFAULT_MAX_B 2048u
+int32_t cos_index_set_latency_mode(cos_index *ix, uint32_t max_queries);
 /* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
 int32_t cos_index_enable_timing(cos_index *ix, int32_t on);
 int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out);

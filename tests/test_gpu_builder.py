@@ -17,6 +17,8 @@ def _device_index(X, storage, res, metric=0, shortlist_size=64, **kw):
     dix = ca.HNSWIndex(X.shape[1], hp, ca.DistanceMetric(metric), ca.StorageType(ca.StorageKind(storage), res), shortlist_size=shortlist_size,
                        seed=kw.get("seed", 42))
     dix.upload_vectors(X)
+    if "latency" in kw:
+        dix.set_latency_mode(kw["latency"])
     return dix
 
 
@@ -30,11 +32,15 @@ def _assert_same_graph(dix, oix):
 
 
 @pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2), (O.STORAGE_F32, 0), (O.STORAGE_F16, 0), (O.STORAGE_SUBBYTE, 1), (O.STORAGE_SUBBYTE, 3)])
-@pytest.mark.parametrize("n,dim,bs", [(1500, 96, 64), (4000, 128, 512)])
-def test_device_build_equals_oracle_rounds(storage, res, n, dim, bs):
+@pytest.mark.parametrize("n,dim,bs,latency", [(1500, 96, 64, 0), (4000, 128, 512, 0), (4000, 128, 512, 2048)])
+def test_device_build_equals_oracle_rounds(storage, res, n, dim, bs, latency):
+    """latency = cos_index_set_latency_mode: the builder's walks run on walk_kernel (0) or, for u8 / quaternary codes, on
+    walk_lat_kernel (batches of <= 2048 new vectors) — same graph either way"""
+    if latency and storage not in (O.STORAGE_U8,) and not (storage == O.STORAGE_SUBBYTE and res == 2):
+        pytest.skip("the latency kernel covers u8 and quaternary codes")
     X = H.clustered_corpus(n, dim, n_centers=16, seed=9)
     kw = dict(num_layers=5, ef_construction=64, ef_search=64, seed=77)
-    dix = _device_index(X, storage, res, **kw).build(bs)
+    dix = _device_index(X, storage, res, latency=latency, **kw).build(bs)
     oix = O.OracleIndex(O.HNSWParams(dim=dim, storage=storage, resolution=res, **kw)).set_vectors(X).build_rounds(bs, greedy=False)[0]
     _assert_same_graph(dix, oix)
     # and the freshly built device graph answers exactly like the oracle on it
@@ -54,9 +60,10 @@ def test_device_link_graph_shapes(M, M0, shortlist, bs):
     batches as large as a quarter of the graph (many conflicting claims -> many rounds)"""
     X = H.clustered_corpus(3000, 64, n_centers=6, seed=M + M0)
     kw = dict(num_layers=4, ef_construction=48, ef_search=48, seed=5, neighbors_count=M, level0_neighbors_count=M0)
-    dix = _device_index(X, O.STORAGE_U8, 0, shortlist_size=shortlist, **kw).build(bs)
     oix = O.OracleIndex(O.HNSWParams(dim=64, shortlist_size=shortlist, **kw)).set_vectors(X).build_rounds(bs, greedy=False)[0]
-    _assert_same_graph(dix, oix)
+    for latency in (0, 0xFFFFFFFF):
+        dix = _device_index(X, O.STORAGE_U8, 0, shortlist_size=shortlist, latency=latency, **kw).build(bs)
+        _assert_same_graph(dix, oix)
 
 
 def test_device_link_dot_metric_and_duplicates():

@@ -44,27 +44,42 @@ def test_resident_codes_match_oracle(name, storage, res, dim):
     assert np.array_equal(np.asarray(mags).view(np.uint32), omags.view(np.uint32))
 
 
+WALK_VARIANTS = [("throughput kernel", 0), ("latency kernel where it applies", 0xFFFFFFFF)]
+
+
 def _assert_same_search(oix, dix, Q, top_k):
-    ids, sc, cnt = dix.batch_search(Q, top_k)
+    """both variants of the walk (cos_index_set_latency_mode: walk_kernel / walk_lat_kernel) must give the oracle's answer"""
     oids, osc, ocnt = oix.search_batch(Q, top_k, threads=4)[:3]
-    assert np.array_equal(cnt, ocnt)
-    for b in range(Q.shape[0]):
-        c = int(cnt[b])
-        assert np.array_equal(ids[b, :c], oids[b, :c]), f"query {b}: ids differ\n{ids[b,:c]}\n{oids[b,:c]}"
-        assert np.array_equal(sc[b, :c].view(np.uint32), osc[b, :c].view(np.uint32)), f"query {b}: scores differ"
+    for vname, max_b in WALK_VARIANTS:
+        dix.set_latency_mode(max_b)
+        ids, sc, cnt = dix.batch_search(Q, top_k)
+        assert np.array_equal(cnt, ocnt), vname
+        for b in range(Q.shape[0]):
+            c = int(cnt[b])
+            assert np.array_equal(ids[b, :c], oids[b, :c]), f"{vname}: query {b}: ids differ\n{ids[b,:c]}\n{oids[b,:c]}"
+            assert np.array_equal(sc[b, :c].view(np.uint32), osc[b, :c].view(np.uint32)), f"{vname}: query {b}: scores differ"
+    dix.set_latency_mode(ca_default_latency())
+
+
+def ca_default_latency():
+    return 2048  # COS_LATENCY_MODE_DEFAULT_MAX_B (include/cosdata_hip.h)
 
 
 def _assert_same_walk(oix, dix, Q):
-    ids, sims, counts = dix.ann_search_batch(Q)
-    for b in range(Q.shape[0]):
-        oi, osim, olc = oix.ann_search(Q[b])
-        assert np.array_equal(counts[b], olc), f"query {b}: level counts {counts[b]} vs {olc}"
-        off = 0
-        for s, c in enumerate(olc):
-            c = int(c)
-            assert np.array_equal(ids[b, s, :c], oi[off:off + c]), f"query {b} slot {s}: walk ids differ"
-            assert np.array_equal(sims[b, s, :c].view(np.uint32), osim[off:off + c].view(np.uint32)), f"query {b} slot {s}: sims differ"
-            off += c
+    ow = [oix.ann_search(Q[b]) for b in range(Q.shape[0])]
+    for vname, max_b in WALK_VARIANTS:
+        dix.set_latency_mode(max_b)
+        ids, sims, counts = dix.ann_search_batch(Q)
+        for b in range(Q.shape[0]):
+            oi, osim, olc = ow[b]
+            assert np.array_equal(counts[b], olc), f"{vname}: query {b}: level counts {counts[b]} vs {olc}"
+            off = 0
+            for s, c in enumerate(olc):
+                c = int(c)
+                assert np.array_equal(ids[b, s, :c], oi[off:off + c]), f"{vname}: query {b} slot {s}: walk ids differ"
+                assert np.array_equal(sims[b, s, :c].view(np.uint32), osim[off:off + c].view(np.uint32)), f"{vname}: query {b} slot {s}: sims differ"
+                off += c
+    dix.set_latency_mode(ca_default_latency())
 
 
 @pytest.mark.parametrize("name,storage,res", STORAGES)
@@ -96,13 +111,15 @@ def test_zero_norm_query_is_calculation_error():
     dix = H.device_index_from_oracle(oix, X)
     Q = H.queries_from(X, 4)
     Q[2, :] = -1.0  # quantizes to all-zero bytes -> |q| = 0 -> DistanceError::CalculationError (cosine.rs:228-232)
-    with pytest.raises(ca.CosdataError) as ei:
-        dix.batch_search(Q, 5)
-    assert ei.value.status == 2
-    ids, sc, cnt, rc, status = dix.batch_search(Q, 5, return_status=True)
     o = oix.search_batch(Q, 5, raise_on_error=False)
-    assert rc == 2 and o[3] == 2
-    assert np.array_equal(status, o[4])
+    for _, max_b in WALK_VARIANTS:
+        dix.set_latency_mode(max_b)
+        with pytest.raises(ca.CosdataError) as ei:
+            dix.batch_search(Q, 5)
+        assert ei.value.status == 2
+        ids, sc, cnt, rc, status = dix.batch_search(Q, 5, return_status=True)
+        assert rc == 2 and o[3] == 2
+        assert np.array_equal(status, o[4])
 
 
 @pytest.mark.parametrize("name,storage,res", STORAGES[:2])
