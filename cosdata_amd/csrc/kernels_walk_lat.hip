@@ -367,9 +367,12 @@ bool walk_lat_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 ma
 }
 
 hipError_t launch_walk_lat(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
-    const char *la_s = getenv("COS_WALK_LAT_LA"); // experiments: window size 1..8, read per launch
+    // window size: 4 measured best (profiles/r02_latency_walk_sweep.jsonl: an 8-entry window needs 24 % fewer rounds but only 3.9
+    // of its 8 entries are consumed before it goes stale, and the wasted evaluations cost more issue time than the rounds save);
+    // COS_WALK_LAT_LA=1..8 overrides it per launch (experiments)
+    const char *la_s = getenv("COS_WALK_LAT_LA");
     const u32 la_env = la_s ? (u32)atoi(la_s) : 0u;
-    u32 la = la_env ? la_env : (u32)LAL;
+    u32 la = la_env ? la_env : 4u;
     if (la > (u32)LAL) la = LAL;
     const u32 ch = (ix.nchunks + GL - 1) / GL;
     if (eng == ENG_U8) return launch_lat_ch<ENG_U8>(ix, wa, ch, la, st);
