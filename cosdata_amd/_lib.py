@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_coalescing", "cos_index_set_ef_search",
     "cos_index_set_visited_mode", "cos_index_set_latency_mode", "cos_index_enable_timing", "cos_index_last_stats", "cos_index_timing_summary", "cos_quantize_batch",
     "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
-    "cos_bm25_search_batch", "cos_bm25_search_batch_device", "cos_rrf_fuse_batch", "cos_hybrid_search_batch", "cos_text_process", "cos_text_count_tokens", "cos_bm25_term_frequency", "cos_xxhash32", "cos_sparse_create", "cos_sparse_destroy", "cos_sparse_search_batch", "cos_merge_topk_device", "cos_merge_topk_packed_device", "cos_hbm_probe",
+    "cos_bm25_search_batch", "cos_bm25_search_batch_device", "cos_rrf_fuse_batch", "cos_hybrid_search_batch", "cos_text_process", "cos_text_count_tokens", "cos_bm25_term_frequency", "cos_xxhash32", "cos_stem_english", "cos_sparse_create", "cos_sparse_destroy", "cos_sparse_search_batch", "cos_merge_topk_device", "cos_merge_topk_packed_device", "cos_hbm_probe",
     "cos_shardset_unique_id", "cos_shardset_create", "cos_shardset_destroy", "cos_shardset_search_batch", "cos_shardset_exchange_device",
 ]
 
@@ -161,6 +161,8 @@ def lib():
         fn.argtypes = args
     L.cos_last_error_string.restype = C.c_char_p
     L.cos_last_error_string.argtypes = []
+    L.cos_stem_english.restype = C.c_size_t
+    L.cos_stem_english.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     L.cos_text_process.restype = i32
     L.cos_text_process.argtypes = [C.c_char_p, C.c_size_t, u32, f32, f32, f32, vp, vp, vp, vp, u32, C.POINTER(u32)]
     L.cos_text_count_tokens.restype = u32

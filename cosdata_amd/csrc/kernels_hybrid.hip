@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -47,70 +48,134 @@ __device__ __forceinline__ u64 lower_bound_doc(const u32 *__restrict__ docs, u64
     return lo;
 }
 
-// grid = (B, splits): block (q, s) owns the tiles s, s+splits, s+2*splits, ...
+// grid = B * splits blocks: block (q, s) owns the tiles s, s+splits, s+2*splits, ...
 // Tile directory: for every posting list longer than DIR_MIN, tile_dir[row][t] = offset (relative to the list's begin) of the
 // first posting whose doc id is >= t * TILE, t = 0 .. n_tiles.  It replaces the two ~17-step binary searches every
 // (query, tile, term) step used to make — the kernel was latency-bound on them at 0.16 of the HBM roof.
+//
+// Software pipeline.  A block walks a flat sequence of CHUNKS — (tile, term, PU * 256 consecutive postings of the term's slice
+// of the tile) — and always has the NEXT chunk's postings in flight (registers) while it applies the current one to the LDS
+// accumulators, across term barriers and tile flushes alike.  Before, a thread's 4 loads were issued, waited for and applied, so
+// a CU had ~16 KB in flight half of the time: 2.5 TB/s is what Little's law gives for that at ~1.5 us of loaded HBM latency
+// (profiles/r02_c5_hybrid_1M_tile_directory.json).  Now 2 x 16 KB per block, 4 blocks per CU.
+constexpr int PU = 8; // postings per thread per chunk
+
+struct Bm25Cursor { // block-uniform
+    u32 tile, t;
+    u64 base, e; // postings [base, min(base + PU * 256, e)) of term t's slice of the tile
+    bool valid;
+};
+
 __global__ __launch_bounds__(256) void bm25_score_kernel(const u32 *__restrict__ docs, const float *__restrict__ tfs,
                                                          const QueryTerms *__restrict__ qts, u32 n_docs, const u32 *__restrict__ tile_dir,
-                                                         u64 *__restrict__ buckets /*[B][512]*/) {
+                                                         u64 *__restrict__ buckets /*[B][512]*/, const u32 *__restrict__ order, u32 splits) {
     __shared__ float acc[TILE];
     __shared__ u32 touched[TILE / 32];
     __shared__ u64 lb[BUCKETS];
-    const u32 q = blockIdx.x;
+    // 1-D grid, heaviest queries first: block id -> (rank in the host's descending-postings order, split).  Query sizes are
+    // heavy-tailed (a few Zipf-head terms decide everything), so the blocks of the heaviest queries must not be the last to start.
+    const u32 q = order[blockIdx.x / splits];
+    const u32 split = blockIdx.x % splits;
     const QueryTerms *qt = &qts[q];
     const u32 nt = qt->n;
     if (nt == 0) return;
-    for (u32 i = threadIdx.x; i < BUCKETS; i += blockDim.x) lb[i] = 0ull;
     const u32 n_tiles = (n_docs + TILE - 1) / TILE;
-    for (u32 tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
-        const u32 d0 = tile * TILE, d1 = d0 + TILE; // [d0, d1)
-        for (u32 i = threadIdx.x; i < TILE / 32; i += blockDim.x) touched[i] = 0;
-        __syncthreads();
-        for (u32 t = 0; t < nt; t++) {
-            const u32 dr = qt->dir[t];
-            u64 b = qt->begin[t], e = qt->end[t];
-            if (dr != NO_DIR) { // this tile's slice of the list, straight from the directory
-                const u32 *row = tile_dir + (u64)dr * (n_tiles + 1);
-                e = b + row[tile + 1];
-                b = b + row[tile];
-            } // else: a short list is scanned whole and filtered by range (no search at all)
-            const float idf = qt->idf[t];
-            // 4 postings per thread in flight before the (dependent) LDS read-modify-writes: the loop is load-latency-bound otherwise
-            for (u64 i0 = b + threadIdx.x; i0 < e; i0 += 4ull * 256) {
-                u32 dv[4];
-                float tv[4];
+    if (split >= n_tiles) return;
+    for (u32 i = threadIdx.x; i < BUCKETS; i += blockDim.x) lb[i] = 0ull;
+    for (u32 i = threadIdx.x; i < TILE / 32; i += blockDim.x) touched[i] = 0;
+
+    auto slice = [&](u32 tile, u32 t, u64 &b, u64 &e) { // term t's postings inside the tile
+        const u32 dr = qt->dir[t];
+        b = qt->begin[t];
+        e = qt->end[t];
+        if (dr != NO_DIR) { // straight from the directory
+            const u32 *row = tile_dir + (u64)dr * (n_tiles + 1);
+            e = b + row[tile + 1];
+            b = b + row[tile];
+        } // else: a short list is scanned whole and filtered by range (no search at all)
+    };
+    auto advance = [&](const Bm25Cursor &c) -> Bm25Cursor {
+        Bm25Cursor n = c;
+        if (c.base + (u64)PU * 256 < c.e) { n.base = c.base + (u64)PU * 256; return n; }
+        if (c.t + 1 < nt) n.t = c.t + 1;
+        else { n.t = 0; n.tile = c.tile + splits; }
+        n.valid = n.tile < n_tiles;
+        if (n.valid) slice(n.tile, n.t, n.base, n.e);
+        return n;
+    };
+    // Every load is issued unconditionally (masked lanes read posting 0 and drop it): a fixed number of loads per chunk lets the
+    // compiler wait for exactly the older chunk (s_waitcnt vmcnt(2 * PU)) while the newer one stays in flight; with predicated
+    // loads it had to drain the queue (vmcnt(0)) before touching the current chunk.
+    // The loaded registers are not touched here (the lane mask travels separately): any use would wait for the data.
+    auto fetch = [&](const Bm25Cursor &c, u32 (&dv)[PU], float (&tv)[PU]) -> u32 {
+        u32 mask = 0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const u64 i = i0 + (u64)u * 256;
-                    const bool in = i < e;
-                    dv[u] = in ? docs[i] : 0xFFFFFFFFu;
-                    tv[u] = in ? tfs[i] : 0.0f;
-                }
+        for (int u = 0; u < PU; u++) {
+            const u64 i = c.base + threadIdx.x + (u64)u * 256;
+            const bool in = c.valid && i < c.e;
+            const u64 ii = in ? i : 0ull;
+            dv[u] = docs[ii];
+            tv[u] = tfs[ii];
+            mask |= (in ? 1u : 0u) << u;
+        }
+        return mask;
+    };
+    // apply chunk c (registers dv/tv); nx = the chunk after it (already in flight)
+    auto apply = [&](const Bm25Cursor &c, const Bm25Cursor &nx, const u32 (&dv)[PU], const float (&tv)[PU], const u32 mask) {
+        const u32 d0 = c.tile * TILE;
+        const float idf = qt->idf[c.t];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const u32 slot = dv[u] - d0;                  // out of range (other tile of a short list, or padding) wraps >= TILE
-                    if (dv[u] < d0 || slot >= TILE) continue;
-                    const float p = __fmul_rn(tv[u], idf);        // tf * head.idf
-                    const u32 w = slot >> 5, m = 1u << (slot & 31);
-                    const bool seen = touched[w] & m;             // bits of earlier terms only (barrier below)
-                    acc[slot] = seen ? __fadd_rn(acc[slot], p) : p;
-                    if (!seen) atomicOr(&touched[w], m);
+        for (int u = 0; u < PU; u++) {
+            const u32 slot = dv[u] - d0;                  // out of range (other tile of a short list) wraps >= TILE
+            if (!((mask >> u) & 1u) || dv[u] < d0 || slot >= TILE) continue;
+            const float p = __fmul_rn(tv[u], idf);        // tf * head.idf
+            const u32 w = slot >> 5, m = 1u << (slot & 31);
+            const bool seen = touched[w] & m;             // bits of earlier terms only (barrier below)
+            acc[slot] = seen ? __fadd_rn(acc[slot], p) : p;
+            if (!seen) atomicOr(&touched[w], m);
+        }
+        const bool term_done = !nx.valid || nx.tile != c.tile || nx.t != c.t;
+        const bool tile_done = !nx.valid || nx.tile != c.tile;
+        if (term_done) __syncthreads(); // a document's score is p0, then + p1, then + p2 ... in term order
+        if (tile_done) {
+            for (u32 slot = threadIdx.x; slot < TILE; slot += blockDim.x) {
+                if (touched[slot >> 5] & (1u << (slot & 31))) {
+                    const u32 doc = d0 + slot;
+                    const u64 key = pack_key(simkey(acc[slot]), ~doc); // larger score, then smaller doc id
+                    atomicMax((unsigned long long *)&lb[doc % BUCKETS], (unsigned long long)key);
                 }
             }
             __syncthreads();
+            for (u32 i = threadIdx.x; i < TILE / 32; i += blockDim.x) touched[i] = 0;
+            __syncthreads();
         }
-        for (u32 slot = threadIdx.x; slot < TILE; slot += blockDim.x) {
-            if (touched[slot >> 5] & (1u << (slot & 31))) {
-                const u32 doc = d0 + slot;
-                const u64 key = pack_key(simkey(acc[slot]), ~doc); // larger score, then smaller doc id
-                atomicMax((unsigned long long *)&lb[doc % BUCKETS], (unsigned long long)key);
-            }
-        }
-        __syncthreads();
+    };
+
+    Bm25Cursor cur;
+    cur.tile = split; cur.t = 0; cur.valid = true;
+    slice(cur.tile, 0, cur.base, cur.e);
+    u32 da[PU], db[PU];
+    float ta[PU], tb[PU];
+    u32 ma = fetch(cur, da, ta), mb;
+    __syncthreads();
+    for (;;) { // ping-pong between the two register sets: no copies, so nothing waits on the chunk in flight
+        const Bm25Cursor n1 = advance(cur);
+        mb = fetch(n1, db, tb);
+        apply(cur, n1, da, ta, ma);
+        if (!n1.valid) break;
+        const Bm25Cursor n2 = advance(n1);
+        ma = fetch(n2, da, ta);
+        apply(n1, n2, db, tb, mb);
+        if (!n2.valid) break;
+        cur = n2;
     }
-    for (u32 i = threadIdx.x; i < BUCKETS; i += blockDim.x)
-        if (lb[i]) atomicMax((unsigned long long *)&buckets[(u64)q * BUCKETS + i], (unsigned long long)lb[i]);
+    // a query's ~100 blocks all fold into the same 512 global buckets: look before the atomic (a stale read only costs a
+    // redundant atomicMax, never a lost one) — a bucket's running maximum is raised ~ln(blocks) times, not `blocks` times
+    for (u32 i = threadIdx.x; i < BUCKETS; i += blockDim.x) {
+        const u64 v = lb[i];
+        if (v && v > __hip_atomic_load(&buckets[(u64)q * BUCKETS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax((unsigned long long *)&buckets[(u64)q * BUCKETS + i], (unsigned long long)v);
+    }
 }
 
 // one wave per query: 512 buckets -> sort by (score desc, larger id first) -> top k
@@ -205,7 +270,7 @@ struct cos_bm25 {
     u32 *d_tile_dir = nullptr; // [rows][n_tiles + 1]
     // per-handle workspace of the search (grown on demand, reused across calls: no allocation on the query path)
     std::mutex mu;
-    QueryTerms *d_qt = nullptr, *h_qt = nullptr; // device / pinned host
+    QueryTerms *d_qt = nullptr, *h_qt = nullptr; // device / pinned host; followed by the launch order u32[capB] in the same allocation
     u64 *d_buckets = nullptr;
     u32 *d_ids = nullptr, *d_cnt = nullptr;
     float *d_sc = nullptr;
@@ -304,6 +369,16 @@ static int32_t bm25_prepare(cos_bm25 *b, const uint32_t *q_terms, const uint32_t
             qt.n++;
         }
     }
+    // launch order: heaviest query (most postings) first; ties by index
+    std::vector<std::pair<u64, u32>> w(B);
+    for (u32 q = 0; q < B; q++) {
+        u64 tot = 0;
+        for (u32 t = 0; t < b->h_qt[q].n; t++) tot += b->h_qt[q].end[t] - b->h_qt[q].begin[t];
+        w[q] = {~tot, q};
+    }
+    std::sort(w.begin(), w.end());
+    u32 *order = (u32 *)(b->h_qt + b->capB);
+    for (u32 q = 0; q < B; q++) order[q] = w[q].second;
     return COS_OK;
 }
 
@@ -317,8 +392,8 @@ static int32_t bm25_workspace(cos_bm25 *b, u32 B, u32 top_k) {
         if (b->h_qt) (void)hipHostFree(b->h_qt);
         b->d_qt = nullptr; b->h_qt = nullptr; b->d_buckets = nullptr; b->d_ids = nullptr; b->d_cnt = nullptr; b->d_sc = nullptr;
         b->capB = b->cap_k = 0;
-        HIP_TRY(hipMalloc((void **)&b->d_qt, (size_t)nb * sizeof(QueryTerms)));
-        HIP_TRY(hipHostMalloc((void **)&b->h_qt, (size_t)nb * sizeof(QueryTerms)));
+        HIP_TRY(hipMalloc((void **)&b->d_qt, (size_t)nb * (sizeof(QueryTerms) + 4)));
+        HIP_TRY(hipHostMalloc((void **)&b->h_qt, (size_t)nb * (sizeof(QueryTerms) + 4)));
         HIP_TRY(hipMalloc((void **)&b->d_buckets, (size_t)nb * BUCKETS * 8));
         HIP_TRY(hipMalloc((void **)&b->d_ids, (size_t)nb * nk * 4));
         HIP_TRY(hipMalloc((void **)&b->d_sc, (size_t)nb * nk * 4));
@@ -332,11 +407,16 @@ static int32_t bm25_workspace(cos_bm25 *b, u32 B, u32 top_k) {
 // scoring + bucket top-k enqueued on `st`; outputs are device pointers
 static int32_t bm25_launch(cos_bm25 *b, u32 B, u32 top_k, u32 *d_out_ids, float *d_out_scores, u32 *d_out_counts, hipStream_t st) {
     HIP_TRY(hipMemcpyAsync(b->d_qt, b->h_qt, (size_t)B * sizeof(QueryTerms), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_qt + b->capB, b->h_qt + b->capB, (size_t)B * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(b->d_buckets, 0, (size_t)B * BUCKETS * 8, st));
     const u32 span = b->max_doc + 1; // doc ids are internal ids; the largest one bounds the tile count
     const u32 n_tiles = (span + TILE - 1) / TILE;
-    const u32 splits = std::max(1u, std::min(n_tiles, std::max(1u, 2048u / B)));
-    hipLaunchKernelGGL(bm25_score_kernel, dim3(B, splits), dim3(256), 0, st, b->d_docs, b->d_tfs, b->d_qt, span, b->d_tile_dir, b->d_buckets);
+    // blocks per query: enough of them that the heaviest query's share is small against the whole launch (COS_BM25_BLOCKS = target
+    // block count of a launch, experiments; c5, 256 queries: 2048 blocks 1.29 ms, 8192 1.18 ms, 32768 1.16 ms — profiles/r02_c5_*)
+    static const u32 target_blocks = [] { const char *e = getenv("COS_BM25_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? (u32)v : 32768u; }();
+    const u32 splits = std::max(1u, std::min(n_tiles, std::max(1u, target_blocks / B)));
+    hipLaunchKernelGGL(bm25_score_kernel, dim3(B * splits), dim3(256), 0, st, b->d_docs, b->d_tfs, b->d_qt, span, b->d_tile_dir, b->d_buckets,
+                       (const u32 *)(b->d_qt + b->capB), splits);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(bm25_topk_kernel, dim3(B), dim3(64), 0, st, b->d_buckets, B, top_k, d_out_ids, d_out_scores, d_out_counts);
     HIP_TRY(hipGetLastError());

@@ -6,8 +6,9 @@
 //   compute_bm25_term_frequency      indexes/tf_idf/mod.rs:362-371
 //   count_tokens                     indexes/tf_idf/mod.rs:373-389
 // The stemmer is the reference's un-vendored git dependency (snowball-stemmer 0.1.0, Cargo.lock:2571-2573): its source is not
-// available here, so stemming is a CALLBACK the host supplies (the Rust host passes a shim over its own Stemmer); with NULL the
-// lowercased token is hashed unstemmed.  Parity of everything else is pinned: xxhash32 against the `xxhash` package, the
+// available here.  Stemming is a CALLBACK: cos_stem_english (stem_english.hip — the published English Snowball algorithm that
+// crate ports, pinned by the algorithm's sample vocabulary) or a shim over the host's own Stemmer; with NULL the lowercased token
+// is hashed unstemmed.  Parity of everything else is pinned: xxhash32 against the `xxhash` package, the
 // tokenizer / stopwords / tf arithmetic against a Python restatement (tests/test_text_terms.py).  Non-ASCII classification and
 // lowercasing use the C library's Unicode tables (C.UTF-8), which agree with Rust's for letters and decimal digits; Rust also
 // treats the Nl / No number classes (e.g. superscripts, fractions) as alphanumeric and has a few multi-character lowercase

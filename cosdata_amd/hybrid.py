@@ -136,22 +136,33 @@ class InvertedIndex:
 STEM_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_char), C.c_size_t, C.POINTER(C.c_char), C.c_size_t)
 
 
-def process_text(text: str, max_token_len: int = 40, average_document_length: float = 1.0, k1: float = 1.5, b: float = 0.75, stemmer=None):
+def stem_english(word: str) -> str:
+    """the library's English Snowball stemmer (cos_stem_english) on one lowercased token"""
+    raw = word.encode("utf-8")
+    out = C.create_string_buffer(len(raw) + 8)
+    n = _lib.lib().cos_stem_english(None, raw, len(raw), out, len(raw) + 8)
+    return out.raw[:n].decode("utf-8")
+
+
+def process_text(text: str, max_token_len: int = 40, average_document_length: float = 1.0, k1: float = 1.5, b: float = 0.75, stemmer="english"):
     """TFIDFIndex's process_text: text -> (term hashes ascending u32[], stored BM25 term frequencies f32[]).
-    `stemmer`: optional callable str -> str standing in for the reference's snowball stemmer (un-vendored dependency)."""
+    `stemmer`: "english" (default) = the library's English Snowball stemmer, like the reference's `Stemmer::create()`; None =
+    hash the lowercased token unstemmed; or a callable str -> str (e.g. a shim over the host's own stemmer)."""
     raw = text.encode("utf-8")
     cap = max(16, len(raw) // 2 + 4)
     hashes = np.zeros(cap, np.uint32)
     tfs = np.zeros(cap, np.float32)
     n = C.c_uint32()
     cb = None
-    if stemmer is not None:
+    if stemmer == "english":
+        cb = C.cast(_lib.lib().cos_stem_english, C.c_void_p)
+    elif stemmer is not None:
         def _shim(_ctx, tok, tok_len, out, out_cap):
             res = stemmer(C.string_at(tok, tok_len).decode("utf-8")).encode("utf-8")[:out_cap]
             C.memmove(out, res, len(res))
             return len(res)
         cb = STEM_FN(_shim)
-    check(_lib.lib().cos_text_process(raw, len(raw), max_token_len, average_document_length, k1, b, C.cast(cb, C.c_void_p) if cb else None, None,
+    check(_lib.lib().cos_text_process(raw, len(raw), max_token_len, average_document_length, k1, b, C.cast(cb, C.c_void_p) if cb is not None else None, None,
                                       _p(hashes), _p(tfs), cap, C.byref(n)))
     return hashes[:n.value].copy(), tfs[:n.value].copy()
 

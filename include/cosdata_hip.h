@@ -298,6 +298,12 @@ int32_t cos_text_process(const char *utf8, size_t len, uint32_t max_token_len, f
 uint32_t cos_text_count_tokens(const char *utf8, size_t len, uint32_t max_token_len);
 float cos_bm25_term_frequency(uint32_t count, uint32_t document_length, float average_document_length, float k1, float b);
 uint32_t cos_xxhash32(const void *data, size_t len, uint32_t seed); /* twox-hash XxHash32 (indexes/tf_idf/mod.rs:343-345) */
+/* The English Snowball stemmer ("Porter2") as a cos_stem_fn: pass it as `stem` to cos_text_process to get process_text's
+ * `Stemmer::create()` + `stemmer.stem(&lower)` (indexes/tf_idf/mod.rs:317-340) without a host-side shim.  Restated from the
+ * published algorithm the reference's git dependency (snowball-stemmer 0.1.0 @ dcbd7da, Cargo.lock:2571-2573) ports; pinned by
+ * the algorithm's sample vocabulary, not by that crate (its source is not available).  ctx is ignored; returns the byte length
+ * of the stem and writes at most out_cap bytes. */
+size_t cos_stem_english(void *ctx, const char *token, size_t token_len, char *out, size_t out_cap);
 
 /* ---- learned-sparse inverted index ----------------------------------------- */
 typedef struct cos_sparse cos_sparse;

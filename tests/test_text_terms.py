@@ -1,6 +1,6 @@
 """text -> BM25 terms, host code of libcosdata_hip: XXH32 against the `xxhash` package, and tokenizer /
 stopwords / max-token-length / counting / stored-tf arithmetic against a Python restatement of indexes/tf_idf/mod.rs:282-389.
-The stemmer (an un-vendored git dependency of the reference) is a callback: parity of stemmed output stays unpinned."""
+The stemmer is a callback (cos_stem_english or the host's own): tests/test_stem_english.py covers the built-in one."""
 import numpy as np
 import pytest
 
@@ -66,7 +66,7 @@ def test_process_text_matches_python_restatement(text):
     for max_len, avg, k1, b in ((40, 1.0, 1.5, 0.75), (5, 17.5, 1.2, 0.5), (40, 120.0, 2.0, 0.0)):
         n_tokens, want = _py_process(text, max_len, avg, k1, b)
         assert ca.count_tokens(text, max_len) == n_tokens
-        hashes, tfs = ca.process_text(text, max_len, avg, k1, b)
+        hashes, tfs = ca.process_text(text, max_len, avg, k1, b, stemmer=None)
         assert hashes.tolist() == sorted(want)                                   # ascending hash
         assert all(np.float32(tfs[i]).tobytes() == np.float32(want[int(h)]).tobytes() for i, h in enumerate(hashes))
 
