@@ -27,10 +27,11 @@ using namespace cosdev;
 namespace {
 
 constexpr u32 BUCKETS = 512;  // sparse_ann_query.rs:154
-constexpr u32 TILE = 8192;    // doc ids per LDS accumulator tile (32 KB of f32 + 1 KB of touched bits)
+constexpr u32 TILE = 8192;    // doc ids per LDS accumulator tile (32 KB of f32)
 constexpr u32 MAX_QTERMS = 64;
 constexpr u32 DIR_MIN = 256;  // posting lists longer than this get a tile directory; shorter ones are scanned whole per tile
 constexpr u32 NO_DIR = 0xFFFFFFFFu;
+constexpr int PU = 8;       // postings per thread per chunk
 
 struct QueryTerms { // per query, terms ascending by hash, only those that have a posting list
     u64 begin[MAX_QTERMS];
@@ -48,6 +49,36 @@ __device__ __forceinline__ u64 lower_bound_doc(const u32 *__restrict__ docs, u64
     return lo;
 }
 
+// UNTOUCHED marks a document no term has reached yet: a NaN bit pattern that tf * idf and the sums of such products cannot take
+// (cos_bm25_create rejects non-finite stored term frequencies; idf is finite), so the accumulator itself says whether the first
+// posting assigns (p0) or a later one adds (+ p1 ...).  It replaces a separate bitmap whose bits were set with LDS atomics: the
+// postings of a dense term are consecutive documents, so up to 32 lanes of a wave hit the SAME bitmap word per instruction and the
+// hardware serialises same-address atomics — that, not HBM or the barriers, held the kernel at ~1.2 ms per batch on c5 (a
+// barrier-free variant with wave-owned 2048-document tiles measured the same 1.3 ms with the bitmap and 0.75 ms without it,
+// against 0.66 ms for this one: dropped).
+constexpr u32 UNTOUCHED = 0xFFFFFFFFu;
+
+// apply one chunk (PU postings per lane, all of ONE term: distinct documents, so the PU read-modify-writes of a lane and those of
+// the other lanes never touch the same slot and the reads can all be issued before the first write)
+template <u32 N>
+__device__ __forceinline__ void bm25_apply_chunk(float *acc, u32 d0, float idf, const u32 (&dv)[PU], const float (&tv)[PU], u32 mask) {
+    float old[PU];
+    bool ok[PU];
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const u32 slot = dv[u] - d0; // out of range (another tile of a short list) wraps to >= N
+        ok[u] = ((mask >> u) & 1u) && dv[u] >= d0 && slot < N;
+        old[u] = acc[slot & (N - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        if (ok[u]) {
+            const float p = __fmul_rn(tv[u], idf); // tf * head.idf
+            acc[(dv[u] - d0) & (N - 1)] = __float_as_uint(old[u]) != UNTOUCHED ? __fadd_rn(old[u], p) : p;
+        }
+    }
+}
+
 // grid = B * splits blocks: block (q, s) owns the tiles s, s+splits, s+2*splits, ...
 // Tile directory: for every posting list longer than DIR_MIN, tile_dir[row][t] = offset (relative to the list's begin) of the
 // first posting whose doc id is >= t * TILE, t = 0 .. n_tiles.  It replaces the two ~17-step binary searches every
@@ -58,7 +89,6 @@ __device__ __forceinline__ u64 lower_bound_doc(const u32 *__restrict__ docs, u64
 // accumulators, across term barriers and tile flushes alike.  Before, a thread's 4 loads were issued, waited for and applied, so
 // a CU had ~16 KB in flight half of the time: 2.5 TB/s is what Little's law gives for that at ~1.5 us of loaded HBM latency
 // (profiles/r02_c5_hybrid_1M_tile_directory.json).  Now 2 x 16 KB per block, 4 blocks per CU.
-constexpr int PU = 8; // postings per thread per chunk
 
 struct Bm25Cursor { // block-uniform
     u32 tile, t;
@@ -69,8 +99,7 @@ struct Bm25Cursor { // block-uniform
 __global__ __launch_bounds__(256) void bm25_score_kernel(const u32 *__restrict__ docs, const float *__restrict__ tfs,
                                                          const QueryTerms *__restrict__ qts, u32 n_docs, const u32 *__restrict__ tile_dir,
                                                          u64 *__restrict__ buckets /*[B][512]*/, const u32 *__restrict__ order, u32 splits) {
-    __shared__ float acc[TILE];
-    __shared__ u32 touched[TILE / 32];
+    __shared__ float acc[TILE]; // UNTOUCHED (a NaN pattern no score can take) until a term reaches the document
     __shared__ u64 lb[BUCKETS];
     // 1-D grid, heaviest queries first: block id -> (rank in the host's descending-postings order, split).  Query sizes are
     // heavy-tailed (a few Zipf-head terms decide everything), so the blocks of the heaviest queries must not be the last to start.
@@ -82,7 +111,7 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(const u32 *__restrict__
     const u32 n_tiles = (n_docs + TILE - 1) / TILE;
     if (split >= n_tiles) return;
     for (u32 i = threadIdx.x; i < BUCKETS; i += blockDim.x) lb[i] = 0ull;
-    for (u32 i = threadIdx.x; i < TILE / 32; i += blockDim.x) touched[i] = 0;
+    for (u32 i = threadIdx.x; i < TILE; i += blockDim.x) acc[i] = __uint_as_float(UNTOUCHED);
 
     auto slice = [&](u32 tile, u32 t, u64 &b, u64 &e) { // term t's postings inside the tile
         const u32 dr = qt->dir[t];
@@ -124,29 +153,20 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(const u32 *__restrict__
     auto apply = [&](const Bm25Cursor &c, const Bm25Cursor &nx, const u32 (&dv)[PU], const float (&tv)[PU], const u32 mask) {
         const u32 d0 = c.tile * TILE;
         const float idf = qt->idf[c.t];
-#pragma unroll
-        for (int u = 0; u < PU; u++) {
-            const u32 slot = dv[u] - d0;                  // out of range (other tile of a short list) wraps >= TILE
-            if (!((mask >> u) & 1u) || dv[u] < d0 || slot >= TILE) continue;
-            const float p = __fmul_rn(tv[u], idf);        // tf * head.idf
-            const u32 w = slot >> 5, m = 1u << (slot & 31);
-            const bool seen = touched[w] & m;             // bits of earlier terms only (barrier below)
-            acc[slot] = seen ? __fadd_rn(acc[slot], p) : p;
-            if (!seen) atomicOr(&touched[w], m);
-        }
+        bm25_apply_chunk<TILE>(acc, d0, idf, dv, tv, mask);
         const bool term_done = !nx.valid || nx.tile != c.tile || nx.t != c.t;
         const bool tile_done = !nx.valid || nx.tile != c.tile;
         if (term_done) __syncthreads(); // a document's score is p0, then + p1, then + p2 ... in term order
         if (tile_done) {
             for (u32 slot = threadIdx.x; slot < TILE; slot += blockDim.x) {
-                if (touched[slot >> 5] & (1u << (slot & 31))) {
+                const float v = acc[slot];
+                if (__float_as_uint(v) != UNTOUCHED) {
                     const u32 doc = d0 + slot;
-                    const u64 key = pack_key(simkey(acc[slot]), ~doc); // larger score, then smaller doc id
+                    const u64 key = pack_key(simkey(v), ~doc); // larger score, then smaller doc id
                     atomicMax((unsigned long long *)&lb[doc % BUCKETS], (unsigned long long)key);
+                    acc[slot] = __uint_as_float(UNTOUCHED);
                 }
             }
-            __syncthreads();
-            for (u32 i = threadIdx.x; i < TILE / 32; i += blockDim.x) touched[i] = 0;
             __syncthreads();
         }
     };
@@ -291,6 +311,8 @@ extern "C" int32_t cos_bm25_create(int32_t device, const uint32_t *term_hashes, 
     *out = nullptr;
     for (u32 t = 1; t < n_terms; t++)
         if (term_hashes[t] <= term_hashes[t - 1]) return cos_fail(COS_ERR_INVALID, "term hashes must be strictly ascending");
+    for (u64 i = 0; i < offsets[n_terms]; i++) // compute_bm25_term_frequency (indexes/tf_idf/mod.rs:362-371) of a count is always finite
+        if (!std::isfinite(tfs[i])) return cos_fail(COS_ERR_INVALID, "stored term frequency %llu is not finite", (unsigned long long)i);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
     HIP_TRY(hipSetDevice(device));
@@ -410,10 +432,11 @@ static int32_t bm25_launch(cos_bm25 *b, u32 B, u32 top_k, u32 *d_out_ids, float 
     HIP_TRY(hipMemcpyAsync(b->d_qt + b->capB, b->h_qt + b->capB, (size_t)B * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(b->d_buckets, 0, (size_t)B * BUCKETS * 8, st));
     const u32 span = b->max_doc + 1; // doc ids are internal ids; the largest one bounds the tile count
+    // launch shape: enough blocks that the heaviest query's share is small against the whole launch, few enough that a block's fixed
+    // cost (512 buckets, 8192 accumulators to reset and fold per tile) stays small against its postings.  c5, 256 queries
+    // (profiles/r02_c5_bm25_*): 2048 blocks 0.72 ms, 4096 0.67, 8192 0.66, 16384 0.69, 32768 0.89.  COS_BM25_BLOCKS overrides (experiments).
+    static const u32 target_blocks = [] { const char *e = getenv("COS_BM25_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? (u32)v : 8192u; }();
     const u32 n_tiles = (span + TILE - 1) / TILE;
-    // blocks per query: enough of them that the heaviest query's share is small against the whole launch (COS_BM25_BLOCKS = target
-    // block count of a launch, experiments; c5, 256 queries: 2048 blocks 1.29 ms, 8192 1.18 ms, 32768 1.16 ms — profiles/r02_c5_*)
-    static const u32 target_blocks = [] { const char *e = getenv("COS_BM25_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? (u32)v : 32768u; }();
     const u32 splits = std::max(1u, std::min(n_tiles, std::max(1u, target_blocks / B)));
     hipLaunchKernelGGL(bm25_score_kernel, dim3(B * splits), dim3(256), 0, st, b->d_docs, b->d_tfs, b->d_qt, span, b->d_tile_dir, b->d_buckets,
                        (const u32 *)(b->d_qt + b->capB), splits);

@@ -90,3 +90,38 @@ def test_hybrid_search_one_call_matches_oracle_composition():
         c = int(cnt[i])
         assert c == fi.size and np.array_equal(ids[i, :c], fi), (i, ids[i, :c], fi)
         assert np.array_equal(sc[i, :c].view(np.uint32), fs.view(np.uint32)), i
+
+
+def test_bm25_many_queries_several_tiles_per_block():
+    """a launch with more queries than blocks-per-launch / tiles: a block walks several tiles (reset of the accumulators between
+    tiles, the chunk pipeline across a tile boundary), heaviest-first launch order with many ties"""
+    import cosdata_amd as ca
+    n_docs, vocab, B, k = 40000, 400, 2100, 10
+    terms, offsets, docs, tfs = _postings(n_docs, vocab, 13)
+    bm = ca.BM25Index(terms, offsets, docs, tfs, n_docs)
+    q_terms, q_off = _queries(terms, B, 14)
+    ids, sc, cnt = bm.search_batch(q_terms, q_off, k)
+    for i in list(range(0, B, 17)) + [B - 1]:
+        oi, osc = O.bm25_search(terms, offsets, docs, tfs, n_docs, q_terms[q_off[i]:q_off[i + 1]], k)
+        c = int(cnt[i])
+        assert c == oi.size and np.array_equal(ids[i, :c], oi), i
+        assert np.array_equal(sc[i, :c].view(np.uint32), osc.view(np.uint32)), i
+    # the same queries one small batch at a time (one tile per block) give the same answers
+    for s0 in (0, 700, 2000):
+        i2, s2, c2 = bm.search_batch(q_terms[q_off[s0]:q_off[s0 + 64]], q_off[s0:s0 + 65] - q_off[s0], k)
+        assert np.array_equal(c2, cnt[s0:s0 + 64])
+        for j in range(64):
+            c = int(c2[j])
+            assert np.array_equal(i2[j, :c], ids[s0 + j, :c]) and np.array_equal(s2[j, :c].view(np.uint32), sc[s0 + j, :c].view(np.uint32))
+
+
+def test_bm25_rejects_non_finite_term_frequencies():
+    """the accumulators mark 'no term reached this document yet' with a NaN pattern, so stored tfs must be finite — which
+    compute_bm25_term_frequency (indexes/tf_idf/mod.rs:362-371) of a count always is"""
+    import cosdata_amd as ca
+    terms, offsets, docs, tfs = _postings(5000, 50, 2)
+    bad = tfs.copy()
+    bad[7] = np.nan
+    with pytest.raises(ca.CosdataError) as ei:
+        ca.BM25Index(terms, offsets, docs, bad, 5000)
+    assert ei.value.status == 3  # COS_ERR_INVALID
