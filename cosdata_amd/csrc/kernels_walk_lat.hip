@@ -180,33 +180,44 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
             __builtin_amdgcn_wave_barrier();
 
             // ---- 3. similarities of every candidate: 4 rows per pass, PBL passes in flight ---------------------------------
+            // No lane is ever masked off: a lane group without a candidate re-reads the block's first row and a lane past the
+            // row's last chunk re-reads that chunk against a zero query chunk (both dropped / worth 0) — every predicated load
+            // was three scalar instructions of exec bookkeeping, 40 % of this kernel's instructions were scalar
+            // (profiles/r02_single_batch_latency_walk_sq_counters.txt).
             for (u32 b0 = 0; b0 < T; b0 += RPL * PBL) {
                 uint4 buf[PBL][CH];
                 float pmag[PBL];
-                u32 ppos[PBL];
+                u32 ppos[PBL], prow[PBL];
 #pragma unroll
-                for (int p = 0; p < PBL; p++) {
+                for (int p = 0; p < PBL; p++) { // the candidates' rows first: one LDS round trip for the whole block
                     if (b0 + (u32)(p * RPL) >= T) break; // wave-uniform
                     const u32 my = b0 + (u32)(p * RPL + grp);
                     const bool v = my < T;
-                    const u64 e = v ? s_cl[my] : 0ull;
-                    const u32 row = (u32)e;
+                    const u64 e = s_cl[v ? my : b0];
+                    prow[p] = (u32)e;
                     ppos[p] = v ? (u32)(e >> 32) : 0xFFFFFFFFu;
-                    pmag[p] = 1.0f;
-                    if (v) pmag[p] = ix.mags[row];
+                }
+#pragma unroll
+                for (int p = 0; p < PBL; p++) {
+                    if (b0 + (u32)(p * RPL) >= T) break; // wave-uniform
+                    pmag[p] = ix.mags[prow[p]];
+                    const uint8_t *rp = ix.codes + (u64)prow[p] * ix.row_stride;
 #pragma unroll
                     for (int c = 0; c < CH; c++) {
-                        const u32 chunk = (u32)lig + (u32)c * (u32)GL;
-                        buf[p][c] = make_uint4(0, 0, 0, 0);
-                        if (v && chunk < ix.nchunks) buf[p][c] = *(const uint4 *)(ix.codes + (u64)row * ix.row_stride + (u64)chunk * 16);
+                        u32 chunk = (u32)lig + (u32)c * (u32)GL;
+                        if (c == CH - 1) chunk = chunk < ix.nchunks ? chunk : ix.nchunks - 1u; // only the last round of chunks can overshoot
+                        buf[p][c] = *(const uint4 *)(rp + (u64)chunk * 16);
                     }
                 }
 #pragma unroll
                 for (int p = 0; p < PBL; p++) {
                     if (b0 + (u32)(p * RPL) >= T) break; // wave-uniform
-                    u32 acc = 0;
+                    u32 part[CH]; // one chain per chunk: independent dot4 chains interleave instead of waiting on each other
 #pragma unroll
-                    for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
+                    for (int c = 0; c < CH; c++) part[c] = chunk_dot<ENG>(qreg[c], buf[p][c], 0u);
+                    u32 acc = part[0];
+#pragma unroll
+                    for (int c = 1; c < CH; c++) acc += part[c];
                     acc = group_reduce_add_u32(acc, GL);
                     const float dotf = (float)acc; // integer dot `as f32` (RNE)
                     float sim = dotf;
@@ -367,7 +378,7 @@ bool walk_lat_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 ma
 }
 
 hipError_t launch_walk_lat(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
-    // window size: 4 measured best (profiles/r02_latency_walk_sweep.jsonl: an 8-entry window needs 24 % fewer rounds but only 3.9
+    // window size: 4 measured best (profiles/r02_latency_walk_sweep_first_version_window4_vs_8.jsonl: an 8-entry window needs 24 % fewer rounds but only 3.9
     // of its 8 entries are consumed before it goes stale, and the wasted evaluations cost more issue time than the rounds save);
     // COS_WALK_LAT_LA=1..8 overrides it per launch (experiments)
     const char *la_s = getenv("COS_WALK_LAT_LA");

@@ -40,13 +40,13 @@ def run(B, reps):
 
 for ef in (64, 256):
     ix.set_ef_search(ef)
-    for B in (64, 256, 1024, 2048, 4096, 8192, 16384):
+    for B in [int(x) for x in os.environ.get("SWEEP_BS", "64,256,1024,2048,4096,8192,16384").split(",")]:
         reps = max(3, min(40, 16384 // B))
         ix.set_latency_mode(0)
         ms0, ref, st0 = run(B, reps)
         print(json.dumps({"ef": ef, "B": B, "variant": "throughput", "ms": ms0, "qps": B / ms0 * 1e3, "evals_per_q": st0.evals / B,
                           "pops_per_q": st0.expansions / B, "rounds_per_q": st0.reserved / B}), flush=True)
-        for la in (4, 8):
+        for la in [int(x) for x in os.environ.get("SWEEP_LA", "4,8").split(",")]:
             os.environ["COS_WALK_LAT_LA"] = str(la)
             ix.set_latency_mode(0xFFFFFFFF)
             ms1, out, st1 = run(B, reps)

@@ -5,7 +5,7 @@ import sys
 
 
 def short(name):
-    for key in ("walk_kernel", "finalize_kernel", "quantize_rows_kernel", "scatter_rows_kernel", "merge_topk_kernel", "flat_", "bm25_"):
+    for key in ("walk_lat_kernel", "walk_kernel", "finalize_kernel", "quantize_rows_kernel", "scatter_rows_kernel", "merge_topk_kernel", "flat_", "bm25_"):
         if key in name:
             i = name.index(key)
             j = name.find("(", i)
