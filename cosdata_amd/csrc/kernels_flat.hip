@@ -126,6 +126,53 @@ __global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q
         __syncthreads();
     }
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if constexpr (FUSED) {
+        // The score matrix never reaches HBM: only what beats the query's 64th best so far is kept.  Per-row filter state lives in LDS
+        // (the operand panels are dead: the k loop ended with a barrier) and a reciprocal-based estimate screens the 64 elements a
+        // lane holds — the exact quotient, the key and the compare are formed only for estimates within 4e-6 (relative) of the
+        // row's threshold or above.  The first version of this epilogue loaded |q| and the threshold from global memory per
+        // ELEMENT and waited for each pair: 64 dependent L2 round trips per lane per tile, as long as the tile's MFMAs.
+        u64 *thr_key = (u64 *)gsm;                 // [BM]
+        float *thr_lo = (float *)(thr_key + BM);   // [BM] estimate a candidate must reach to be worth the exact quotient
+        float *rq = thr_lo + BM;                   // [BM] ~1 / |q|
+        float *qm = rq + BM;                       // [BM] |q|
+        for (int idx = tid; idx < BM; idx += 256) {
+            const u32 row = row0 + idx;
+            const u64 k = row < B ? fo.thr[row] : ~0ull;
+            const float tsc = simkey_inv((u32)(k >> 32));
+            const float qv = row < B ? qmags[row] : 1.0f;
+            thr_key[idx] = k;
+            thr_lo[idx] = k == 0ull ? -__builtin_inff() : tsc - 4e-6f * __builtin_fabsf(tsc); // 0 = pool not full: everything passes
+            qm[idx] = qv;
+            rq[idx] = __builtin_amdgcn_rcpf(qv);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const u32 col = col0 + wc * 64 + j * 32 + (lane & 31);
+                const bool cv = col < n_chunk;
+                const float xm = cv ? xmags[n0 + col] : 1.0f;
+                const float rx = __builtin_amdgcn_rcpf(xm);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int rl = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float est = acc[i][j][r] * rx * rq[rl];
+                    // NaN-safe: an estimate that is not provably below the bar (incl. 0 * inf of a zero-norm operand) takes the exact path
+                    if (row0 + (u32)rl < B && cv && !(est < thr_lo[rl])) {
+                        const float sc = x86_div(acc[i][j][r], qm[rl] * xm);
+                        const u64 key = pack_key(simkey(sc), n0 + col);
+                        if (key > thr_key[rl]) {
+                            const u32 row = row0 + (u32)rl;
+                            const u32 pos = atomicAdd(&fo.app_cnt[row], 1u);
+                            if (pos < fo.cap) fo.app[(u64)row * fo.cap + pos] = key;
+                        }
+                    }
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -135,18 +182,7 @@ __global__ __launch_bounds__(256) void flat_gemm_f32(const float *__restrict__ Q
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const u32 row = row0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < B && col < n_chunk) {
-                    const float sc = x86_div(acc[i][j][r], qmags[row] * xm);
-                    if constexpr (FUSED) { // the score matrix never reaches HBM: only what beats the query's 64th best so far is kept
-                        const u64 key = pack_key(simkey(sc), n0 + col);
-                        if (key > fo.thr[row]) {
-                            const u32 pos = atomicAdd(&fo.app_cnt[row], 1u);
-                            if (pos < fo.cap) fo.app[(u64)row * fo.cap + pos] = key;
-                        }
-                    } else {
-                        scores[(u64)row * s_stride + col] = sc;
-                    }
-                }
+                if (row < B && col < n_chunk) scores[(u64)row * s_stride + col] = x86_div(acc[i][j][r], qmags[row] * xm);
             }
         }
 }
