@@ -394,14 +394,26 @@ def main():
     aggregate_gbps = avg_bytes * n_launch / elapsed / 1e9         # all launches / wall time (launches on different streams overlap)
     overlap = max(1.0, min(float(S), avg_ms * 1e-3 * n_launch / elapsed))
 
-    # single-stream (one un-coalesced client batch at a time) rate
+    # single-stream (one un-coalesced client batch at a time) rate: launches this small take the latency variant of the walk
+    # (cos_index_set_latency_mode); the throughput kernel is timed on the same batch and must return the same bits
+    def serial_rate():
+        for _ in range(2):
+            ix.batch_search_device(Q[:Bc].data_ptr(), Bc, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(), o_st[0].data_ptr(),
+                                   streams[0].cuda_stream)
+        streams[0].synchronize()
+        t1 = time.perf_counter()
+        for _ in range(8):
+            ix.batch_search_device(Q[:Bc].data_ptr(), Bc, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(), o_st[0].data_ptr(),
+                                   streams[0].cuda_stream)
+        streams[0].synchronize()
+        rate = 8 * Bc / (time.perf_counter() - t1)
+        return rate, (o_ids[0][:Bc].clone(), o_sc[0][:Bc].clone().view(torch.int32), o_cnt[0][:Bc].clone(), o_st[0][:Bc].clone())
     torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for i in range(8):
-        ix.batch_search_device(Q[:Bc].data_ptr(), Bc, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(), o_st[0].data_ptr(),
-                               streams[0].cuda_stream)
-    streams[0].synchronize()
-    serial_qps = 8 * Bc / (time.perf_counter() - t1)
+    serial_qps, serial_out = serial_rate()
+    ix.set_latency_mode(0)
+    serial_qps_throughput_kernel, serial_out_tk = serial_rate()
+    ix.set_latency_mode(2048)  # COS_LATENCY_MODE_DEFAULT_MAX_B
+    serial_identical = all(bool(torch.equal(a, b_)) for a, b_ in zip(serial_out, serial_out_tk))
 
     # ---- optional ef_search sweep (same index, same launch shape): QPS and hold-out recall per setting ----------------------
     sweep = []
@@ -531,7 +543,9 @@ def main():
             "value_note": ("n_gpus == 1: value = queries/s over the whole corpus" if world == 1 else
                            "value = merged answers/s over the GLOBAL corpus (n_gpus x vectors_per_gpu; every query is searched on every "
                            "shard, then all-gathered and merged); shard_searches_per_s = value x n_gpus is the shard-level work"),
-            "single_batch_qps": serial_qps, "ef_selection": ef_table, "ef_sweep": sweep, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
+            "single_batch_qps": serial_qps, "single_batch_qps_throughput_kernel": serial_qps_throughput_kernel,
+            "single_batch_latency_walk_identical_to_throughput_walk": serial_identical,
+            "ef_selection": ef_table, "ef_sweep": sweep, "build_seconds": build_s, "setup_seconds": time.time() - t_setup,
             "roofline": {"bound": "hbm", "achieved": kernel_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": kernel_gbps / HBM_PEAK_GBPS,
                          "traffic": traffic, "empirical": empirical,
                          "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64, %s>" % (1 if ef <= 64 else (4 if ef <= 256 else 8), args.visited),

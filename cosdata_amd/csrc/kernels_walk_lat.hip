@@ -5,7 +5,7 @@
 // 42 % of its cycles issuing (77 instructions per distance evaluation with one code row per wave pass) and 58 % parked on a
 // chain of dependent HBM round trips — adjacency row, then the code rows of every window entry one entry after the other.
 // Here, still one wave per query:
-//   * SPECULATION across the lookahead window.  The adjacency rows of the next `la` (<= 8) pool entries arrive together; every
+//   * SPECULATION across the lookahead window.  The adjacency rows of the next `la` (<= 4) pool entries arrive together; every
 //     neighbour that is unvisited *under the filter as it stands at the start of the round* is a candidate, the code rows of ALL
 //     candidates of ALL window entries are fetched together (up to 32 rows in flight) and their similarities parked in LDS.  The
 //     entries are then COMMITTED in pop order exactly like the throughput kernel: visited claims, inserts, the "still provably
@@ -33,7 +33,7 @@ using namespace cosdev;
 
 namespace {
 
-constexpr int LAL = 8;  // window capacity (adjacency rows prefetched per round); the launch picks la <= LAL
+constexpr int LAL = 4;  // window capacity (adjacency rows prefetched per round); the launch picks la <= LAL.  8 measured slower (see launch_walk_lat)
 constexpr int GL = 16;  // lanes per code row
 constexpr int RPL = 64 / GL; // rows per wave pass
 constexpr int PBL = 8;  // passes in flight before the dots are consumed (32 rows)
@@ -46,16 +46,13 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
     if (qi >= wa.B) return;
 
     const u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
-    u64 *s_spec, *s_cl, *s_res, *s_win_key;
-    u32 *s_vis, *s_win_vec, *s_win_node;
+    u64 *s_spec, *s_cl, *s_res;
+    u32 *s_vis;
     {
         unsigned char *p = smem_raw;
         s_spec = (u64 *)p;     p += (size_t)LAL * 64 * 8; // per (window entry, slot): similarity key | zero-denominator flag << 32
         s_cl = (u64 *)p;       p += (size_t)LAL * 64 * 8; // compacted candidates: vector row | (entry * 64 + slot) << 32
-        s_win_key = (u64 *)p;  p += (size_t)LAL * 8;
         s_res = (u64 *)p;      p += (size_t)wa.ef * 8;    // popped (key, node) list
-        s_win_vec = (u32 *)p;  p += (size_t)LAL * 64 * 4;
-        s_win_node = (u32 *)p; p += (size_t)LAL * 64 * 4;
         s_vis = (u32 *)p;      // visited filter words, Mmax * 2
     }
 
@@ -146,36 +143,34 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
 
             // ---- 1. adjacency rows of the window entries: independent loads, one latency -----------------------------------
             u32 av[LAL], an[LAL];
+            u64 wkey[LAL]; // wave-uniform: the window entries' (key, node); entries past kwin are never looked at
             static_for<0, LAL>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
+                wkey[i] = pool.template peek<i>();
                 av[i] = ROW_EMPTY;
                 an[i] = ROW_EMPTY;
-                if ((u32)i < kwin) { // wave-uniform
-                    const u64 wk = pool.template peek<i>();
-                    if ((u32)lane < slots) {
-                        const u32 nd = (u32)wk;
-                        av[i] = lv.adj_vec[(u64)nd * M + lane];
-                        an[i] = level == 0 ? av[i] : lv.adj_node[(u64)nd * M + lane];
-                    }
-                    if (lane == 0) s_win_key[i] = wk;
+                if ((u32)i < kwin && (u32)lane < slots) {
+                    const u32 nd = (u32)wkey[i];
+                    av[i] = lv.adj_vec[(u64)nd * M + lane];
+                    an[i] = level == 0 ? av[i] : lv.adj_node[(u64)nd * M + lane];
                 }
             });
 
             // ---- 2. candidates: unvisited under the filter as it stands now (read only), compacted entry by entry ----------
             u32 T = 0;
+            u32 vword[LAL]; // the filter words first (one LDS round trip for the window), then the ballots
             static_for<0, LAL>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                if ((u32)i < kwin) {
-                    s_win_vec[i * 64 + lane] = av[i];
-                    s_win_node[i * 64 + lane] = an[i];
-                    const bool valid = av[i] != ROW_EMPTY;
-                    const u32 id = av[i] == N ? COS_ROOT_ID : av[i] * ix.id_stride;
-                    const u32 bit = id & bitmask;
-                    const bool c = valid && !(s_vis[bit >> 5] & (1u << (bit & 31)));
-                    const u64 cm = __ballot(c);
-                    if (c) s_cl[T + (u32)__popcll(cm & lt_mask)] = (u64)av[i] | ((u64)(u32)(i * 64 + lane) << 32);
-                    T += (u32)__popcll(cm);
-                }
+                const u32 id = av[i] == N ? COS_ROOT_ID : av[i] * ix.id_stride; // an empty slot maps somewhere inside the filter too
+                vword[i] = s_vis[(id & bitmask) >> 5];
+            });
+            static_for<0, LAL>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const u32 id = av[i] == N ? COS_ROOT_ID : av[i] * ix.id_stride;
+                const bool c = av[i] != ROW_EMPTY && !(vword[i] & (1u << (id & bitmask & 31u))); // entries past kwin hold only empty slots
+                const u64 cm = __ballot(c);
+                if (c) s_cl[T + (u32)__popcll(cm & lt_mask)] = (u64)av[i] | ((u64)(u32)(i * 64 + lane) << 32);
+                T += (u32)__popcll(cm);
             });
             __builtin_amdgcn_wave_barrier();
 
@@ -233,59 +228,65 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
             __builtin_amdgcn_wave_barrier();
 
             // ---- 4. commit in pop order: walk_kernel's consume loop with the similarities read from LDS --------------------
-            for (u32 wi = 0; wi < kwin; wi++) {
-                const u64 cur = s_win_key[wi];
-                pool.pop_head(lane);
-                npool--;
-                if (lane == 0) s_res[npop] = cur;
-                npop++;
-                n_exp++;
-                adj_bytes += (u64)M * 4;
-                const int limit = (int)wa.ef - (int)npop; // future pops still allowed
-                const int ahead = (int)kwin - 1 - (int)wi; // window entries still waiting at pool positions 0..ahead-1
-                bool window_ok = true;
+            // Unrolled over the window so that an entry's adjacency row and key stay in the registers step 1 loaded them into
+            // (the runtime loop read them back from LDS: three more dependent LDS round trips per pop for a lone wave).
+            bool window_ok = true;
+            static_for<0, LAL>([&](auto ic) {
+                constexpr int wi = decltype(ic)::value;
+                if ((u32)wi < kwin && window_ok && !failed) { // wave-uniform
+                    const u64 sp_all = s_spec[wi * 64 + lane]; // issued with the filter word below: one LDS wait for both
+                    pool.pop_head(lane);
+                    npool--;
+                    if (lane == 0) s_res[npop] = wkey[wi];
+                    npop++;
+                    n_exp++;
+                    adj_bytes += (u64)M * 4;
+                    const int limit = (int)wa.ef - (int)npop;     // future pops still allowed
+                    const int ahead = (int)kwin - 1 - wi;         // window entries still waiting at pool positions 0..ahead-1
 
-                const u32 nb_vec = s_win_vec[wi * 64 + lane], nb_node = s_win_node[wi * 64 + lane];
-                const bool valid = nb_vec != ROW_EMPTY;
-                // PerformantFixedSet: bucket=(id>>6)&(M-1), bit=id&63  <=> linear bit id & (64M-1)
-                const u32 id = nb_vec == N ? COS_ROOT_ID : nb_vec * ix.id_stride;
-                const u32 bit = id & bitmask;
-                const u32 word = bit >> 5, msk = 1u << (bit & 31);
-                const bool pre = valid && (s_vis[word] & msk);
-                const bool cand = valid && !pre;
-                if (!__any(cand)) continue; // nothing new: the next window entry is certainly the next pop
-                u32 old = 0;
-                if (cand) old = atomicOr(&s_vis[word], msk);
-                const bool lost = cand && (old & msk);
-                bool win = cand && !lost;
-                u64 lostmask = __ballot(lost);
-                // two slots of this expansion alias the same residue: the LOWER slot wins (sequential scan order)
-                while (lostmask) {
-                    const int l = __ffsll((long long)lostmask) - 1;
-                    const u32 b = readlane_u32(bit, l);
-                    const u64 g = __ballot(cand && bit == b);
-                    const int w = __ffsll((long long)g) - 1;
-                    if (cand && bit == b) win = (lane == w);
-                    lostmask &= ~g;
-                }
-                u64 m = __ballot(win);
-                n_evals += (u64)__popcll(m);
-                const u64 sp = win ? s_spec[wi * 64 + lane] : 0ull;
-                if (__any(win && (sp >> 32) != 0ull)) { failed = true; break; } // zero denominator -> CalculationError
-                const u32 keyv = (u32)sp;
-                while (m) { // winners in slot order (vector_store.rs:1161-1171)
-                    const int l = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const u64 kk = pack_key(readlane_u32(keyv, l), readlane_u32(nb_node, l));
-                    const int pos = pool.rank_of(kk);
-                    if (pos < limit) {
-                        pool.insert_at(kk, pos, lane);
-                        if (npool < (u32)(64 * R)) npool++;
-                        if (pos < ahead) window_ok = false; // landed ahead of a prefetched entry: the window is stale
+                    const u32 nb_vec = av[wi], nb_node = an[wi];
+                    const bool valid = nb_vec != ROW_EMPTY;
+                    // PerformantFixedSet: bucket=(id>>6)&(M-1), bit=id&63  <=> linear bit id & (64M-1)
+                    const u32 id = nb_vec == N ? COS_ROOT_ID : nb_vec * ix.id_stride;
+                    const u32 bit = id & bitmask;
+                    const u32 word = bit >> 5, msk = 1u << (bit & 31);
+                    const bool pre = valid && (s_vis[word] & msk);
+                    const bool cand = valid && !pre;
+                    if (__any(cand)) { // else nothing new: the next window entry is certainly the next pop
+                        u32 old = 0;
+                        if (cand) old = atomicOr(&s_vis[word], msk);
+                        const bool lost = cand && (old & msk);
+                        bool win = cand && !lost;
+                        u64 lostmask = __ballot(lost);
+                        // two slots of this expansion alias the same residue: the LOWER slot wins (sequential scan order)
+                        while (lostmask) {
+                            const int l = __ffsll((long long)lostmask) - 1;
+                            const u32 b = readlane_u32(bit, l);
+                            const u64 g = __ballot(cand && bit == b);
+                            const int w = __ffsll((long long)g) - 1;
+                            if (cand && bit == b) win = (lane == w);
+                            lostmask &= ~g;
+                        }
+                        u64 m = __ballot(win);
+                        n_evals += (u64)__popcll(m);
+                        if (__any(win && (sp_all >> 32) != 0ull)) failed = true; // zero denominator -> CalculationError
+                        else {
+                            const u32 keyv = (u32)sp_all;
+                            while (m) { // winners in slot order (vector_store.rs:1161-1171)
+                                const int l = __ffsll((long long)m) - 1;
+                                m &= m - 1;
+                                const u64 kk = pack_key(readlane_u32(keyv, l), readlane_u32(nb_node, l));
+                                const int pos = pool.rank_of(kk);
+                                if (pos < limit) {
+                                    pool.insert_at(kk, pos, lane);
+                                    if (npool < (u32)(64 * R)) npool++;
+                                    if (pos < ahead) window_ok = false; // landed ahead of a prefetched entry: the window is stale
+                                }
+                            }
+                        }
                     }
                 }
-                if (!window_ok) break;
-            }
+            });
             if (failed) break;
             __builtin_amdgcn_wave_barrier();
         }
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
 
 size_t walk_lat_smem_bytes(const IndexDev &ix, u32 ef) {
     const u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
-    return (size_t)LAL * 64 * 8 * 2 + (size_t)LAL * 8 + (size_t)ef * 8 + (size_t)LAL * 64 * 4 * 2 + (size_t)Mmax * 8 + 16;
+    return (size_t)LAL * 64 * 8 * 2 + (size_t)ef * 8 + (size_t)Mmax * 8 + 16;
 }
 
 template <int ENG, int CH>
@@ -378,9 +379,9 @@ bool walk_lat_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 ma
 }
 
 hipError_t launch_walk_lat(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
-    // window size: 4 measured best (profiles/r02_latency_walk_sweep_first_version_window4_vs_8.jsonl: an 8-entry window needs 24 % fewer rounds but only 3.9
-    // of its 8 entries are consumed before it goes stale, and the wasted evaluations cost more issue time than the rounds save);
-    // COS_WALK_LAT_LA=1..8 overrides it per launch (experiments)
+    // window size: 4 (profiles/r02_latency_walk_sweep_first_version_window4_vs_8.jsonl: an 8-entry window needs 24 % fewer rounds but only 3.9
+    // of its 8 entries are consumed before it goes stale, and the wasted evaluations cost more issue time than the rounds save; the
+    // kernel has been unrolled for at most LAL = 4 since); COS_WALK_LAT_LA=1..4 narrows it per launch (experiments)
     const char *la_s = getenv("COS_WALK_LAT_LA");
     const u32 la_env = la_s ? (u32)atoi(la_s) : 0u;
     u32 la = la_env ? la_env : 4u;

@@ -46,7 +46,7 @@ for ef in (64, 256):
         ms0, ref, st0 = run(B, reps)
         print(json.dumps({"ef": ef, "B": B, "variant": "throughput", "ms": ms0, "qps": B / ms0 * 1e3, "evals_per_q": st0.evals / B,
                           "pops_per_q": st0.expansions / B, "rounds_per_q": st0.reserved / B}), flush=True)
-        for la in [int(x) for x in os.environ.get("SWEEP_LA", "4,8").split(",")]:
+        for la in [int(x) for x in os.environ.get("SWEEP_LA", "4").split(",")]:
             os.environ["COS_WALK_LAT_LA"] = str(la)
             ix.set_latency_mode(0xFFFFFFFF)
             ms1, out, st1 = run(B, reps)
