@@ -395,16 +395,21 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                         }
                         if (__any(bad)) { failed = true; break; }
                         const u32 keyv = metric_key(metric, sim);
-#pragma unroll
-                        for (int p = 0; p < PB64; p++) {
-                            if (p < cnt) {
-                                const u64 kk = pack_key(readlane_u32(keyv, p), readlane_u32(nodev, p));
-                                const int pos = pool.rank_of(kk);
-                                if (pos < limit) {
-                                    pool.insert_at(kk, pos, lane);
-                                    if (npool < (u32)(64 * R)) npool++;
-                                    if (pos < ahead) window_ok = false;
-                                }
+                        // One vector compare screens the block's winners against the entry that closes the poppable part of the
+                        // pool (position limit - 1): a key below it has at least `limit` entries above it, the loop would rank it
+                        // only to reject it.  The bar can only rise while winners go in, so the screen is conservative and the
+                        // loop's own test stays.  Winners are visited in lane = slot order as before.
+                        const u64 bar = limit > 0 ? pool.peek_dyn((u32)(limit - 1)) : ~0ull;
+                        u64 pm = __ballot(lane < cnt && pack_key(keyv, nodev) > bar);
+                        while (pm) {
+                            const int p = __ffsll((long long)pm) - 1;
+                            pm &= pm - 1;
+                            const u64 kk = pack_key(readlane_u32(keyv, p), readlane_u32(nodev, p));
+                            const int pos = pool.rank_of(kk);
+                            if (pos < limit) {
+                                pool.insert_at(kk, pos, lane);
+                                if (npool < (u32)(64 * R)) npool++;
+                                if (pos < ahead) window_ok = false;
                             }
                         }
                     }
@@ -478,12 +483,16 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                         }
                         if (__any(bad)) { failed = true; break; }
                         const u32 key = metric_key(metric, sim);
-                        // insert this pass's rows in winner order
-                        for (int g = 0; g < RP; g++) {
-                            const int my = base + p * RP + g;
-                            if (my >= W) break;
-                            const u32 k = readlane_u32(key, g * G);
-                            const u64 kk = pack_key(k, sm.wl_node[my]);
+                        // insert this pass's rows in winner order; the same conservative screen as on the G = 64 path: the first lane
+                        // of every group holds its row's key, rows below the entry at pool position limit - 1 are not visited
+                        const int mine = base + p * RP + grp;
+                        const u32 mynode = (lig == 0 && mine < W) ? sm.wl_node[mine] : 0u;
+                        const u64 bar = limit > 0 ? pool.peek_dyn((u32)(limit - 1)) : ~0ull;
+                        u64 pm = __ballot(lig == 0 && mine < W && pack_key(key, mynode) > bar);
+                        while (pm) {
+                            const int l = __ffsll((long long)pm) - 1; // first lane of the row's group: ascending lane = winner order
+                            pm &= pm - 1;
+                            const u64 kk = pack_key(readlane_u32(key, l), readlane_u32(mynode, l));
                             const int pos = pool.rank_of(kk);
                             if (pos < limit) {
                                 pool.insert_at(kk, pos, lane);

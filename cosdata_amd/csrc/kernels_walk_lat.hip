@@ -272,6 +272,11 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
                         if (__any(win && (sp_all >> 32) != 0ull)) failed = true; // zero denominator -> CalculationError
                         else {
                             const u32 keyv = (u32)sp_all;
+                            // one vector compare screens every winner against the entry that closes the poppable part of the pool
+                            // (position limit - 1): below it a key has at least `limit` entries above it and the loop would only
+                            // rank it to reject it.  The bar only rises while winners go in, so the screen is conservative.
+                            const u64 bar = limit > 0 ? pool.peek_dyn((u32)(limit - 1)) : ~0ull;
+                            m = __ballot(win && pack_key(keyv, nb_node) > bar);
                             while (m) { // winners in slot order (vector_store.rs:1161-1171)
                                 const int l = __ffsll((long long)m) - 1;
                                 m &= m - 1;
