@@ -14,7 +14,10 @@
 //     value changes nothing; candidates that lose (claimed by an earlier entry of the round, or the window went stale) are
 //     wasted bandwidth — on a chip that a small launch leaves idle.  A round is two dependent HBM round trips whatever the
 //     window holds.
-//   * 16 lanes per code row (4 rows per wave pass, 48-64 B per lane at 768-1024 u8 dims): ~10 instructions per evaluation.
+//   * 16 lanes per code row (4 rows per wave pass, 48-64 B per lane at 768-1024 u8 dims), no predicated load, one v_dot4 chain per
+//     chunk; the commit is unrolled over the window (rows and keys stay in registers) and screens an expansion's winners with one
+//     vector compare before the insertion loop.  A lone wave pays ~4 clocks for EVERY instruction, scalar ones included, so the
+//     kernel is written for instruction count (DESIGN.md 4.1 has the step-by-step measurements).
 // Integer engines ENG_U8 / ENG_Q2 with <= 64 chunks per row, ef <= 256, reference visited filter; everything else stays on
 // walk_kernel (launch_walk decides; cos_index_set_latency_mode).
 #include <hip/hip_runtime.h>
