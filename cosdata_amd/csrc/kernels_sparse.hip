@@ -48,7 +48,7 @@ __device__ __forceinline__ u32 sparse_quantize(float value, float upper, u32 bit
 // grid (B, terms_max): block (b, i) streams the posting range of query b's i-th term
 __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const SparseDev ix, const u32 *__restrict__ q_dims, const float *__restrict__ q_vals,
                                                                 const u32 *__restrict__ q_off, float early_terminate_threshold, u32 *__restrict__ acc /*[B][n]*/,
-                                                                u32 *__restrict__ touched /*[B][ceil(n/32)]*/) {
+                                                                uint8_t *__restrict__ touched /*[B][n]: reached with weight 0*/) {
     const u32 b = blockIdx.x, i = blockIdx.y;
     const u32 t0 = q_off[b], nt = q_off[b + 1] - t0;
     if (i >= nt) return;
@@ -65,23 +65,37 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const SparseDev 
     if (k0 >= ix.Q) return;
     const u64 *ko = ix.key_off + (u64)lo * (ix.Q + 1);
     const u64 beg = ko[k0], end = ko[ix.Q];
-    const u64 words = ((u64)ix.n + 31) / 32;
-    u32 *ab = acc + (u64)b * ix.n, *tb = touched + (u64)b * words;
+    u32 *ab = acc + (u64)b * ix.n;
+    uint8_t *tb = touched + (u64)b * ix.n;
+    // key of posting p = the last key whose list starts at or before p.  A thread's postings ascend, so after one binary search the
+    // key pointer only moves forward (the first version searched the 2^bits + 1 offsets again for every posting).
+    // A vector is a result as soon as any visited list holds it, also with similarity 0 (key 0, or a query value that quantizes
+    // to 0): weight-0 postings set a BYTE flag with a plain store — idempotent, no read-modify-write — and everything else is one
+    // atomic add; the first version OR-ed a bit into a bitmap for every posting, and the ids of a list ascend: up to 32 lanes of a
+    // wave hit the same word, which same-address atomics serialise (the BM25 kernel's lesson, kernels_hybrid.hip).
+    u32 l2 = k0;
+    bool first = true;
     for (u64 p = beg + threadIdx.x; p < end; p += blockDim.x) {
-        u32 l2 = k0, h2 = ix.Q; // key of posting p: the last key whose list starts at or before p
-        while (l2 + 1 < h2) { const u32 mid = (l2 + h2) / 2; if (ko[mid] <= p) l2 = mid; else h2 = mid; }
+        if (first) {
+            u32 h2 = ix.Q;
+            while (l2 + 1 < h2) { const u32 mid = (l2 + h2) / 2; if (ko[mid] <= p) l2 = mid; else h2 = mid; }
+            first = false;
+        } else {
+            while (l2 + 1 < ix.Q && ko[l2 + 1] <= p) l2++;
+        }
         const u32 v = ix.vec_ids[p];
-        atomicAdd(&ab[v], qq * l2);
-        atomicOr(&tb[v >> 5], 1u << (v & 31));
+        const u32 w = qq * l2;
+        if (w) atomicAdd(&ab[v], w);
+        else tb[v] = 1;
     }
 }
 
-// one wave per (query, segment): top-SEL of the touched vectors by (similarity, id); key = (sim + 1) << 32 | id (0 = empty)
-__global__ __launch_bounds__(64) void sparse_select_segments(const u32 *__restrict__ acc, const u32 *__restrict__ touched, u32 n, u32 seg_len,
+// one wave per (query, segment): top-SEL of the reached vectors (non-zero sum, or the weight-0 flag) by (similarity, id);
+// key = (sim + 1) << 32 | id (0 = empty)
+__global__ __launch_bounds__(64) void sparse_select_segments(const u32 *__restrict__ acc, const uint8_t *__restrict__ touched, u32 n, u32 seg_len,
                                                              u64 *__restrict__ part /*[B][S][64]*/) {
     const int lane = threadIdx.x;
     const u32 q = blockIdx.x, seg = blockIdx.y, S = gridDim.y;
-    const u64 words = ((u64)n + 31) / 32;
     Pool<1> pool;
     pool.clear();
     u64 thr = 0ull;
@@ -89,7 +103,10 @@ __global__ __launch_bounds__(64) void sparse_select_segments(const u32 *__restri
     for (u32 c = c0; c < c1; c += 64) {
         const u32 v = c + lane;
         u64 key = 0ull;
-        if (v < c1 && ((touched[(u64)q * words + (v >> 5)] >> (v & 31)) & 1u)) key = ((u64)(acc[(u64)q * n + v]) + 1ull) << 32 | v;
+        if (v < c1) {
+            const u32 a = acc[(u64)q * n + v];
+            if (a != 0u || touched[(u64)q * n + v]) key = ((u64)a + 1ull) << 32 | v;
+        }
         u64 m = __ballot(key > thr);
         while (m) {
             const int l = __ffsll((long long)m) - 1;
@@ -239,7 +256,6 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     }
     const u32 nq = q_offsets[B];
     SparseDev dev{s->d_dims, s->d_key_off, s->d_vec_ids, s->d_row_off, s->d_raw_dims, s->d_raw_vals, s->T, 1u << s->bits, s->n, s->bits, s->upper};
-    const u64 words = ((u64)s->n + 31) / 32;
     // queries are processed in chunks so that the per-query accumulators stay below 2 GiB
     const u32 chunkB = (u32)std::max<u64>(1, std::min<u64>(B, (2ull << 30) / ((u64)s->n * 4)));
     u32 Sg = std::max<u32>(1u, std::min<u32>(64u, std::min<u32>((s->n + 4095) / 4096, (4096 + chunkB - 1) / chunkB)));
@@ -249,7 +265,7 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     HIP_TRY(d_qv.alloc((size_t)std::max(nq, 1u) * 4));
     HIP_TRY(d_qo.alloc(((size_t)B + 1) * 4));
     HIP_TRY(d_acc.alloc((size_t)chunkB * s->n * 4));
-    HIP_TRY(d_touched.alloc((size_t)chunkB * words * 4));
+    HIP_TRY(d_touched.alloc((size_t)chunkB * s->n));
     HIP_TRY(d_part.alloc((size_t)chunkB * Sg * SEL * 8));
     HIP_TRY(d_oi.alloc((size_t)B * top_k * 4));
     HIP_TRY(d_os.alloc((size_t)B * top_k * 4));
@@ -260,13 +276,13 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     for (u32 b0 = 0; b0 < B; b0 += chunkB) {
         const u32 nb = std::min(chunkB, B - b0);
         HIP_TRY(hipMemsetAsync(d_acc.p, 0, (size_t)nb * s->n * 4, 0));
-        HIP_TRY(hipMemsetAsync(d_touched.p, 0, (size_t)nb * words * 4, 0));
+        HIP_TRY(hipMemsetAsync(d_touched.p, 0, (size_t)nb * s->n, 0));
         if (max_terms) {
             hipLaunchKernelGGL(sparse_accumulate_kernel, dim3(nb, max_terms), dim3(256), 0, 0, dev, d_qd.as<u32>(), d_qv.as<float>(), d_qo.as<u32>() + b0,
-                               early_terminate_threshold, d_acc.as<u32>(), d_touched.as<u32>());
+                               early_terminate_threshold, d_acc.as<u32>(), d_touched.as<uint8_t>());
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(sparse_select_segments, dim3(nb, Sg), dim3(64), 0, 0, d_acc.as<u32>(), d_touched.as<u32>(), s->n, seg_len, d_part.as<u64>());
+        hipLaunchKernelGGL(sparse_select_segments, dim3(nb, Sg), dim3(64), 0, 0, d_acc.as<u32>(), d_touched.as<uint8_t>(), s->n, seg_len, d_part.as<u64>());
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(sparse_finish_kernel, dim3(nb), dim3(64), 0, 0, dev, d_part.as<u64>(), Sg, d_qd.as<u32>(), d_qv.as<float>(), d_qo.as<u32>() + b0, top_k, kwr,
                            rerank ? 1 : 0, d_oi.as<u32>() + (size_t)b0 * top_k, d_os.as<float>() + (size_t)b0 * top_k, d_oc.as<u32>() + b0);
