@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "engine_internal.h"
@@ -188,12 +189,28 @@ struct cos_sparse {
     u32 *d_dims = nullptr, *d_vec_ids = nullptr, *d_raw_dims = nullptr;
     u64 *d_key_off = nullptr, *d_row_off = nullptr;
     float *d_raw_vals = nullptr;
+    // grow-only workspace of cos_sparse_search_batch (no allocation on the query path once warm); `mu` serialises callers
+    std::mutex mu;
+    struct Buf { void *p = nullptr; size_t cap = 0; } w_qd, w_qv, w_qo, w_acc, w_touched, w_part, w_oi, w_os, w_oc;
 };
+
+struct SparseView { void *p; template <typename T> T *as() const { return (T *)p; } };
+
+static hipError_t sparse_grow(cos_sparse::Buf &b, size_t need) {
+    if (need <= b.cap) return hipSuccess;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    hipError_t e = hipMalloc(&b.p, need);
+    if (e == hipSuccess) b.cap = need;
+    return e;
+}
 
 extern "C" int32_t cos_sparse_destroy(cos_sparse *s) {
     if (!s) return COS_OK;
     (void)hipSetDevice(s->device);
-    void *ptrs[] = {s->d_dims, s->d_vec_ids, s->d_raw_dims, s->d_key_off, s->d_row_off, s->d_raw_vals};
+    void *ptrs[] = {s->d_dims, s->d_vec_ids, s->d_raw_dims, s->d_key_off, s->d_row_off, s->d_raw_vals, s->w_qd.p, s->w_qv.p, s->w_qo.p,
+                    s->w_acc.p, s->w_touched.p, s->w_part.p, s->w_oi.p, s->w_os.p, s->w_oc.p};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete s;
     return COS_OK;
@@ -260,16 +277,18 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     const u32 chunkB = (u32)std::max<u64>(1, std::min<u64>(B, (2ull << 30) / ((u64)s->n * 4)));
     u32 Sg = std::max<u32>(1u, std::min<u32>(64u, std::min<u32>((s->n + 4095) / 4096, (4096 + chunkB - 1) / chunkB)));
     const u32 seg_len = ((s->n + Sg - 1) / Sg + 63) / 64 * 64;
-    DevBuf d_qd, d_qv, d_qo, d_acc, d_touched, d_part, d_oi, d_os, d_oc;
-    HIP_TRY(d_qd.alloc((size_t)std::max(nq, 1u) * 4));
-    HIP_TRY(d_qv.alloc((size_t)std::max(nq, 1u) * 4));
-    HIP_TRY(d_qo.alloc(((size_t)B + 1) * 4));
-    HIP_TRY(d_acc.alloc((size_t)chunkB * s->n * 4));
-    HIP_TRY(d_touched.alloc((size_t)chunkB * s->n));
-    HIP_TRY(d_part.alloc((size_t)chunkB * Sg * SEL * 8));
-    HIP_TRY(d_oi.alloc((size_t)B * top_k * 4));
-    HIP_TRY(d_os.alloc((size_t)B * top_k * 4));
-    HIP_TRY(d_oc.alloc((size_t)B * 4));
+    std::lock_guard<std::mutex> guard(s->mu);
+    HIP_TRY(sparse_grow(s->w_qd, (size_t)std::max(nq, 1u) * 4));
+    HIP_TRY(sparse_grow(s->w_qv, (size_t)std::max(nq, 1u) * 4));
+    HIP_TRY(sparse_grow(s->w_qo, ((size_t)B + 1) * 4));
+    HIP_TRY(sparse_grow(s->w_acc, (size_t)chunkB * s->n * 4));
+    HIP_TRY(sparse_grow(s->w_touched, (size_t)chunkB * s->n));
+    HIP_TRY(sparse_grow(s->w_part, (size_t)chunkB * Sg * SEL * 8));
+    HIP_TRY(sparse_grow(s->w_oi, (size_t)B * top_k * 4));
+    HIP_TRY(sparse_grow(s->w_os, (size_t)B * top_k * 4));
+    HIP_TRY(sparse_grow(s->w_oc, (size_t)B * 4));
+    const SparseView d_qd{s->w_qd.p}, d_qv{s->w_qv.p}, d_qo{s->w_qo.p}, d_acc{s->w_acc.p}, d_touched{s->w_touched.p}, d_part{s->w_part.p}, d_oi{s->w_oi.p},
+        d_os{s->w_os.p}, d_oc{s->w_oc.p};
     HIP_TRY(hipMemcpy(d_qd.p, q_dims, (size_t)nq * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_qv.p, q_vals, (size_t)nq * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_qo.p, q_offsets, ((size_t)B + 1) * 4, hipMemcpyHostToDevice));
