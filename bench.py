@@ -431,6 +431,22 @@ def main():
     ix.set_ef_search(ef)
     ix.set_visited_mode(main_mode)
 
+    # ---- the boundary as the Rust host would call it: host buffers in, host buffers out (cos_search_batch: H2D of the queries, the
+    # same kernels, D2H of ids / scores / counts, one synchronisation per call).  PCIe-inclusive, reported next to `value`, never it.
+    host_api = None
+    if rank == 0 and world == 1:
+        qh = Q[:B].cpu().numpy()
+        ix.batch_search(qh, k)                                  # warm-up: the calling thread's stream + workspace
+        t1 = time.perf_counter()
+        reps_h = 4
+        for _ in range(reps_h):
+            h_ids, h_sc, h_cnt = ix.batch_search(qh, k)
+        el_h = (time.perf_counter() - t1) / reps_h
+        host_api = {"queries_per_call": B, "ms_per_call": el_h * 1e3, "qps": B / el_h,
+                    "h2d_bytes_per_call": int(B) * d * 4, "d2h_bytes_per_call": int(B) * (k * 8 + 4),
+                    "note": "cos_search_batch on pageable host memory, one call at a time (no overlap of copies with the previous call's kernels)"}
+        del qh
+
     # ---- CPU baseline + parity: the oracle (C restatement of the Rust path) on this box's host cores, same graph ----------
     cpu = None
     parity = None
@@ -558,6 +574,7 @@ def main():
                          "note": "achieved = algorithmic bytes of one walk launch (evals x (dim+4) + expansions x M x 4, counted by the kernel) / "
                                  "that launch's average HIP-event duration on its own stream over the timed region"},
             "flat_scan_ground_truth": flat, "result_properties": props, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+            "host_api_pcie_inclusive": host_api,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if shardset is not None:
