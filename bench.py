@@ -412,7 +412,7 @@ def main():
     serial_qps, serial_out = serial_rate()
     ix.set_latency_mode(0)
     serial_qps_throughput_kernel, serial_out_tk = serial_rate()
-    ix.set_latency_mode(2048)  # COS_LATENCY_MODE_DEFAULT_MAX_B
+    ix.set_latency_mode(ca.HNSWIndex.LATENCY_MODE_DEFAULT_MAX_B)
     serial_identical = all(bool(torch.equal(a, b_)) for a, b_ in zip(serial_out, serial_out_tk))
 
     # ---- optional ef_search sweep (same index, same launch shape): QPS and hold-out recall per setting ----------------------

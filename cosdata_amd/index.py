@@ -236,6 +236,8 @@ class HNSWIndex:
     def set_visited_mode(self, mode: int):
         check(_lib.lib().cos_index_set_visited_mode(self._h, mode))
 
+    LATENCY_MODE_DEFAULT_MAX_B = 2048  # COS_LATENCY_MODE_DEFAULT_MAX_B (include/cosdata_hip.h)
+
     def set_latency_mode(self, max_queries: int):
         """Launches of at most `max_queries` queries take the latency variant of the walk (0 = never); same results."""
         check(_lib.lib().cos_index_set_latency_mode(self._h, max_queries))

@@ -78,3 +78,11 @@ def test_scan_kernel_is_built_in_vgpr_form():
     mk = open(os.path.join(ROOT, "cosdata_amd", "csrc", "Makefile")).read()
     assert "kernels_scan.o: CXXFLAGS += -mllvm -amdgpu-mfma-vgpr-form=1" in mk
     assert "kernels_scan.hip" in mk
+
+
+def test_python_mirror_of_header_constants():
+    """constants the Python side repeats must equal the header's"""
+    import cosdata_amd as ca
+    hdr = open(os.path.join(ROOT, "include", "cosdata_hip.h")).read()
+    m = re.search(r"#define\s+COS_LATENCY_MODE_DEFAULT_MAX_B\s+(\d+)u", hdr)
+    assert m and int(m.group(1)) == ca.HNSWIndex.LATENCY_MODE_DEFAULT_MAX_B

@@ -62,7 +62,8 @@ def _assert_same_search(oix, dix, Q, top_k):
 
 
 def ca_default_latency():
-    return 2048  # COS_LATENCY_MODE_DEFAULT_MAX_B (include/cosdata_hip.h)
+    import cosdata_amd as ca
+    return ca.HNSWIndex.LATENCY_MODE_DEFAULT_MAX_B
 
 
 def _assert_same_walk(oix, dix, Q):
