@@ -180,6 +180,8 @@ int coso_meta_enable(coso_index *ix, uint32_t mdim, uint32_t max_replicas);
 int coso_meta_set_nodes(coso_index *ix, uint32_t n_nodes, const uint32_t *ids_sorted, const int32_t *mbits);
 /* builds the component with the reference's index-side rules; max_levels[n_nodes] = the level drawn per node (table order) */
 int coso_meta_build(coso_index *ix, const uint8_t *max_levels);
+/* the same component in the batch-synchronous schedule of a device-side builder; batch_size = 1 is coso_meta_build; stats[3] optional */
+int coso_meta_build_rounds(coso_index *ix, const uint8_t *max_levels, uint32_t batch_size, uint64_t *stats);
 uint32_t coso_meta_level_count(const coso_index *ix, uint32_t level);
 int coso_meta_export_level(const coso_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids);
 /* search_internal with a filter: filters of query b = rows [filter_off[b], filter_off[b+1]) of filter_dims[][mdim] (-1/0/1) */

@@ -1463,6 +1463,151 @@ int coso_meta_build(coso_index *ix, const uint8_t *max_levels /*[n_meta], node-t
     return rc;
 }
 
+/* The same component built BATCH-SYNCHRONOUSLY — the schedule a device-side builder would run (cf. coso_index_build_rounds for the
+ * base graph): the nodes of a batch (size min(batch_size, max(1, inserted / 4)), pseudo nodes first, then the replicas in id
+ * order) walk the snapshot that precedes the batch on every level, then their nodes are appended and the levels are linked in
+ * rounds with ordered claims ({self} + candidates; the first claimer of a row in batch order owns it, blocked nodes wait), the
+ * edge-refusal rules of vector_store.rs:1017-1041 applied exactly where create_node_edges_meta applies them, evictions outside
+ * the own claim applied at the end of the round.  batch_size = 1 is coso_meta_build.  stats (optional): rounds, level-batches,
+ * node-levels linked. */
+int coso_meta_build_rounds(coso_index *ix, const uint8_t *max_levels, uint32_t batch_size, uint64_t *stats) {
+    if (!ix || !ix->mdim || !ix->n_meta || !max_levels || ix->p.visited_mode != COSO_VISITED_REF) return COSO_ERR_INVALID;
+    const uint32_t Ltop = ix->p.num_layers, L1 = Ltop + 1, md = ix->mdim;
+    const uint32_t Bmax = batch_size ? batch_size : 4096u;
+    const int metric = (int)ix->p.metric;
+    if (meta_index(ix, PSEUDO_LO) < 0) return COSO_ERR_INVALID;
+    uint64_t st[3] = {0, 0, 0};
+    for (uint32_t l = 0; l <= Ltop; l++) level_free(&ix->mlv[l]);
+    for (uint32_t l = 0; l <= Ltop; l++) { /* create_pseudo_root_node */
+        uint32_t r = level_append(&ix->mlv[l], PSEUDO_LO, metric);
+        ix->mlv[l].root_idx = r;
+        if (l > 0) ix->mlv[l].child[r] = ix->mlv[l - 1].root_idx;
+    }
+    /* insertion order: pseudo nodes (ascending id), then the Metadata replicas (ascending id); Base replicas are not in this component */
+    uint32_t *ord = (uint32_t *)malloc((size_t)ix->n_meta * 4), total = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (uint32_t i = 0; i < ix->n_meta; i++) {
+            const uint32_t id = ix->meta_id[i];
+            const int pseudo = id >= PSEUDO_LO && id <= PSEUDO_HI;
+            if (id == PSEUDO_LO || pseudo != (pass == 0)) continue;
+            const uint32_t xid = pseudo ? PSEUDO_LO : id - id % ix->replicas;
+            if (kind_of(ix->meta_mag[i], 1, xid) == KIND_BASE) continue;
+            ord[total++] = i;
+        }
+    scratch_t *s = scratch_new(ix);
+    zent *z = (zent *)malloc((size_t)Bmax * L1 * KEEP_INDEX * sizeof(zent));
+    uint32_t *zn = (uint32_t *)malloc((size_t)Bmax * L1 * 4), *me = (uint32_t *)malloc((size_t)Bmax * L1 * 4);
+    uint32_t *claim_round = (uint32_t *)calloc((size_t)ix->n_meta + 2, 4), *claim_owner = (uint32_t *)calloc((size_t)ix->n_meta + 2, 4);
+    uint32_t *pending = (uint32_t *)malloc((size_t)Bmax * 4), *next = (uint32_t *)malloc((size_t)Bmax * 4);
+    evict_t *q = (evict_t *)malloc((size_t)Bmax * 2 * KEEP_INDEX * sizeof(evict_t));
+    uint32_t round_id = 0, inserted = 0;
+    int rc = COSO_OK;
+    while (inserted < total && rc == COSO_OK) {
+        uint32_t bs = inserted / 4u;
+        if (bs < 1) bs = 1;
+        if (bs > Bmax) bs = Bmax;
+        if (bs > total - inserted) bs = total - inserted;
+        for (uint32_t b = 0; b < bs && rc == COSO_OK; b++) { /* 1. walks on the snapshot, every level, like index_embedding_meta */
+            const uint32_t i = ord[inserted + b], id = ix->meta_id[i], row = meta_row_of(ix, id);
+            const int pseudo = id >= PSEUDO_LO && id <= PSEUDO_HI;
+            const uint32_t xid = pseudo ? PSEUDO_LO : id - id % ix->replicas;
+            qdesc qd = {ix->codes + (size_t)row * ix->cb, ix->mags[row], ix->meta_mbits + (size_t)i * md, ix->meta_mdims + (size_t)i * md,
+                        ix->meta_mag[i], kind_of(ix->meta_mag[i], 1, xid)};
+            uint32_t entry = ix->mlv[Ltop].root_idx;
+            for (int level = (int)Ltop; level >= 0; level--) {
+                level_t *L = &ix->mlv[level];
+                zent *zz = z + ((size_t)b * L1 + (uint32_t)level) * KEEP_INDEX;
+                memset(s->visited, 0, (size_t)L->M * 8);
+                s->visited[(id >> 6) & (L->M - 1)] |= 1ull << (id & 63);
+                int cnt = walk_level_meta(ix, (uint32_t)level, entry, &qd, ix->p.ef_construction, KEEP_INDEX, s);
+                if (cnt < 0) { rc = -cnt; break; }
+                if (cnt == 0) {
+                    float d;
+                    qdesc q0 = qd;
+                    q0.kind = kind_of(qd.mmag, 0, 0);
+                    rc = meta_distance(ix, &q0, L->node_id[entry], &d);
+                    if (rc != COSO_OK) break;
+                    zz[0].idx = entry; zz[0].sim = d; cnt = 1;
+                } else
+                    for (int k = 0; k < cnt; k++) { zz[k].idx = s->res[k].idx; zz[k].sim = s->res[k].sim; }
+                zn[(size_t)b * L1 + (uint32_t)level] = (uint32_t)cnt;
+                if (level > 0) entry = L->child[zz[0].idx];
+            }
+        }
+        if (rc != COSO_OK) break;
+        for (uint32_t b = 0; b < bs; b++) { /* 2. nodes of the batch */
+            const uint32_t i = ord[inserted + b], id = ix->meta_id[i];
+            uint32_t parent = IDX_NONE;
+            for (int level = (int)max_levels[i]; level >= 0; level--) {
+                uint32_t m = level_append(&ix->mlv[level], id, metric);
+                me[(size_t)b * L1 + (uint32_t)level] = m;
+                if (parent != IDX_NONE) ix->mlv[level + 1].child[parent] = m;
+                parent = m;
+            }
+        }
+        for (uint32_t l = 0; l <= Ltop; l++) { /* 3. rounds */
+            level_t *L = &ix->mlv[l];
+            uint32_t np = 0;
+            for (uint32_t b = 0; b < bs; b++) if (max_levels[ord[inserted + b]] >= l) pending[np++] = b;
+            if (np == 0) continue;
+            st[1]++;
+            st[2] += np;
+            while (np > 0) {
+                round_id++;
+                st[0]++;
+                uint32_t nn = 0, qn = 0;
+                for (uint32_t k = 0; k < np; k++) {
+                    const uint32_t b = pending[k], node = me[(size_t)b * L1 + l];
+                    const zent *zz = z + ((size_t)b * L1 + l) * KEEP_INDEX;
+                    const int cnt = (int)zn[(size_t)b * L1 + l];
+                    int runnable = 1;
+                    for (int c = -1; c < cnt; c++) { /* ordered claims */
+                        const uint32_t r = c < 0 ? node : zz[c].idx;
+                        if (claim_round[r] == round_id) { if (claim_owner[r] != b) runnable = 0; }
+                        else { claim_round[r] = round_id; claim_owner[r] = b; }
+                    }
+                    if (!runnable) { next[nn++] = b; continue; }
+                    const int kself = meta_index(ix, L->node_id[node]);
+                    const int self_kind = kind_of(ix->meta_mag[kself], 1, L->node_id[node]);
+                    uint32_t succ = 0;
+                    for (int c = 0; c < cnt; c++) { /* create_node_edges_meta with deferred evictions */
+                        if (succ >= L->M) break;
+                        const uint32_t nid = L->node_id[zz[c].idx];
+                        const int nkind = kind_of(ix->meta_mag[meta_index(ix, nid)], 1, nid);
+                        if (metric == COSO_METRIC_COSINE) { /* vector_store.rs:1017-1041 */
+                            if (nkind == KIND_PSEUDO && self_kind == KIND_METADATA && zz[c].sim != 1.0f) continue;
+                            if (nkind == KIND_METADATA && self_kind == KIND_METADATA && zz[c].sim == -1.0f) continue;
+                        }
+                        uint32_t ev;
+                        int r = add_neighbor_deferred(L, metric, node, zz[c].idx, zz[c].sim, &ev);
+                        if (ev != IDX_NONE) {
+                            if (claim_round[ev] == round_id && claim_owner[ev] == b) remove_neighbor_by_idx(L, ev, node);
+                            else { q[qn].old_idx = ev; q[qn].target = node; qn++; }
+                        }
+                        if (r >= 0) {
+                            int r2 = add_neighbor_deferred(L, metric, zz[c].idx, node, zz[c].sim, &ev);
+                            if (ev != IDX_NONE) {
+                                if (claim_round[ev] == round_id && claim_owner[ev] == b) remove_neighbor_by_idx(L, ev, zz[c].idx);
+                                else { q[qn].old_idx = ev; q[qn].target = zz[c].idx; qn++; }
+                            }
+                            if (r2 >= 0) succ++;
+                            else if (L->nbr[(size_t)node * L->M + (uint32_t)r] == zz[c].idx) L->nbr[(size_t)node * L->M + (uint32_t)r] = IDX_NONE;
+                        }
+                    }
+                }
+                for (uint32_t e = 0; e < qn; e++) remove_neighbor_by_idx(L, q[e].old_idx, q[e].target); /* end of round */
+                uint32_t *t = pending; pending = next; next = t;
+                np = nn;
+            }
+        }
+        inserted += bs;
+    }
+    if (stats) memcpy(stats, st, sizeof(st));
+    free(ord); free(z); free(zn); free(me); free(claim_round); free(claim_owner); free(pending); free(next); free(q);
+    scratch_free(s);
+    return rc;
+}
+
 uint32_t coso_meta_level_count(const coso_index *ix, uint32_t level) { return (ix->mlv && level <= ix->p.num_layers) ? ix->mlv[level].n : 0; }
 
 /* flat export / import of the component (same conventions as coso_index_export_level, the pseudo root is an ordinary id) */

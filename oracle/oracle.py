@@ -99,6 +99,7 @@ def lib():
         "coso_meta_enable": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "coso_meta_set_nodes": (C.c_int, [vp, C.c_uint32, vp, vp]),
         "coso_meta_build": (C.c_int, [vp, vp]),
+        "coso_meta_build_rounds": (C.c_int, [vp, vp, C.c_uint32, vp]),
         "coso_meta_level_count": (C.c_uint32, [vp, C.c_uint32]),
         "coso_meta_export_level": (C.c_int, [vp, C.c_uint32, vp, vp]),
         "coso_search_filtered_batch": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_int]),
@@ -442,6 +443,16 @@ class OracleIndex:
         if rc != OK:
             raise ValueError(f"meta_build status {rc}")
         return self
+
+    def meta_build_rounds(self, max_levels, batch_size):
+        """the pseudo-root component in the batch-synchronous schedule of a device-side builder (batch_size = 1 == meta_build);
+        returns (self, {rounds, level_batches, node_levels})"""
+        ml = _c(max_levels, np.uint8)
+        st = np.zeros(3, np.uint64)
+        rc = lib().coso_meta_build_rounds(self._h, _p(ml), batch_size, _p(st))
+        if rc != OK:
+            raise ValueError(f"meta_build_rounds status {rc}")
+        return self, {"rounds": int(st[0]), "level_batches": int(st[1]), "node_levels": int(st[2])}
 
     def meta_export_graph(self):
         out = []

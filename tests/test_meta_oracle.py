@@ -77,3 +77,66 @@ def test_base_graph_of_a_metadata_collection_uses_base_ids(world):
     assert (counts == 10).all() and (ids % 4 == 0).all() and (ids // 4 < sc.n).all()
     for lid, _ in oix.export_graph():
         assert ((lid[:-1] % 4) == 0).all() and lid[-1] == 0xFFFFFFFF
+
+
+def _same_component(a, b):
+    ga, gb = a.meta_export_graph(), b.meta_export_graph()
+    assert len(ga) == len(gb)
+    for l, ((ia, na), (ib, nb)) in enumerate(zip(ga, gb)):
+        assert np.array_equal(ia, ib), f"level {l}: node sets differ"
+        assert np.array_equal(na, nb), f"level {l}: adjacency differs in {np.count_nonzero((na != nb).any(axis=1))} rows"
+
+
+def test_batch_synchronous_component_builder_with_batches_of_one_is_the_sequential_builder():
+    """coso_meta_build_rounds is the schedule a device-side builder of the pseudo-root component would run; with batch_size = 1 every
+    node walks the graph all its predecessors are linked into and is alone in its rounds, so it must reproduce
+    index_embedding / create_node_edges of the sequential builder (vector_store.rs:714-1074) slot for slot — including the
+    edge-refusal rules and the deferred back-edge removals"""
+    for seed, kw in ((2, {}), (5, dict(neighbors_count=8, level0_neighbors_count=16)), (7, dict(num_layers=3, ef_construction=16))):
+        sc = MH.Scenario(n=500, dim=32, seed=seed, **kw)
+        a = sc.oracle()
+        b = O.OracleIndex(sc.params).set_vectors(sc.X)
+        b.meta_enable(MH.MDIM, MH.REPLICAS)
+        b.build()
+        b.meta_set_nodes(sc.node_ids, sc.mbits)
+        _, st = b.meta_build_rounds(sc.max_levels, 1)
+        _same_component(a, b)
+        assert st["rounds"] == st["node_levels"]  # one node per round
+
+
+def test_batch_synchronous_component_builder_is_deterministic_and_serves_filters():
+    """bigger batches give a different (batch-synchronous) graph: deterministic, same node sets per level as the sequential one,
+    and filtered search on it still returns only matching replicas with full lists for the broad filters"""
+    sc = MH.Scenario(n=1500, dim=48, seed=4)
+    seq = sc.oracle()
+    graphs = []
+    for _ in range(2):
+        b = O.OracleIndex(sc.params).set_vectors(sc.X)
+        b.meta_enable(MH.MDIM, MH.REPLICAS)
+        b.build()
+        b.meta_set_nodes(sc.node_ids, sc.mbits)
+        _, st = b.meta_build_rounds(sc.max_levels, 256)
+        graphs.append(b)
+    _same_component(graphs[0], graphs[1])
+    assert st["rounds"] < st["node_levels"]  # nodes do share rounds
+    for (ia, _), (ib, _) in zip(seq.meta_export_graph(), graphs[0].meta_export_graph()):
+        assert np.array_equal(ia, ib)          # who lives on which level does not depend on the schedule
+    Q, off, rows, desc = sc.queries(nq=30, seed=6)
+    ids, scores, counts = graphs[0].search_filtered_batch(Q, off, rows, 10, threads=4)
+    ids_s, _, counts_s = seq.search_filtered_batch(Q, off, rows, 10, threads=4)
+    overlap = []
+    for b, (kind, c, s) in enumerate(desc):
+        for j in range(int(counts[b])):
+            rid = int(ids[b, j])
+            r, rep = rid // 4, rid % 4
+            assert rid < MH.PSEUDO_ROOT
+            if kind == "is_color":
+                assert rep == 1 and sc.color[r] == c
+            elif kind == "is_size":
+                assert rep == 2 and sc.size[r] == s
+            elif kind == "and":
+                assert rep == 3 and sc.color[r] == c and sc.size[r] == s
+        if kind in ("is_color", "is_size", "or"):
+            assert counts[b] == 10
+            overlap.append(len(set(ids[b, :10].tolist()) & set(ids_s[b, :10].tolist())) / 10)
+    assert np.mean(overlap) >= 0.7, np.mean(overlap)  # both graphs find mostly the same nearest matching replicas
