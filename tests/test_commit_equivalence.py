@@ -3,6 +3,8 @@
 (a) the bounded sorted pool with the `rank < limit` insertion rule pops exactly what the reference's unbounded BinaryHeap pops
     (vector_store.rs:1125-1192) — the kernels' basic premise;
 (b) the winner pre-screen (one compare against the pool entry at position limit - 1) never drops a key the loop would insert;
+(b') the latency kernel's speculation: every winner of a window entry at commit time was unvisited under the filter at the start
+    of the round, so its similarity has been computed;
 (c) the data-parallel formulation of a window commit that DESIGN.md §10 proposes for a several-waves-per-query kernel — first
     occurrence per filter bit in (entry, slot) order, commit horizon = first entry whose best winner beats the last waiting window
     entry, pool := top-C of (pool minus the popped heads) ∪ (winners of the committed entries) — leaves the walk in a state that is
@@ -73,6 +75,10 @@ class Walk:
     def round_sequential(self):
         kwin = min(len(self.pool), self.la, self.ef - len(self.pops))
         window = self.pool[:kwin]
+        # the latency kernel's speculation: similarities are computed up front for every neighbour that is unvisited under the
+        # filter as it stands at the START of the round; whoever wins at commit time must be among them
+        speculated = {(wi, nb) for wi, (_, node) in enumerate(window) for nb in self.adj[node]
+                      if nb is not EMPTY and (nb & self.mask) not in self.vis}
         for wi, (_, node) in enumerate(window):
             assert self.pool[0][1] == node
             self.pool.pop(0)
@@ -81,6 +87,7 @@ class Walk:
             ahead = kwin - 1 - wi
             stale = False
             win = self._winners(node, self.vis)
+            assert all((wi, nb) in speculated for _, nb in win)
             if self.prescreen and limit > 0:
                 bar = self.pool[limit - 1][0] if limit - 1 < len(self.pool) else 0
                 dropped = [w for w in win if not w[0] > bar]
