@@ -257,6 +257,80 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
     return COS_OK;
 }
 
+// InvertedIndexNode::quantize on the host (the same f32 operations as sparse_quantize above; this file is built with -ffp-contract=off)
+static inline uint32_t host_sparse_quantize(float value, float upper, uint32_t bits) {
+    const uint32_t quantization = (1u << bits) - 1u;
+    const float max_val = (float)quantization;
+    float t = (value / upper) * max_val;
+    t = t < 0.0f ? 0.0f : (t > max_val ? max_val : t); // f32::clamp keeps NaN
+    const uint32_t q = !(t == t) || t <= 0.0f ? 0u : (t >= 255.0f ? 255u : (uint32_t)(int)t); // `as u8`
+    return q < quantization ? q : quantization;
+}
+
+// InvertedIndex::insert for a whole collection (indexes/inverted/mod.rs + models/inverted_index.rs:176-200): the vectors are taken in
+// id order and every (dimension, value) pair pushes the id to the END of the list of (dimension, quantize(value)) — so the CSR this
+// produces is what the host's tree holds after inserting ids 0 .. n-1.  Host code, no device.
+extern "C" int32_t cos_sparse_build_csr(uint32_t quantization_bits, float values_upper_bound, uint32_t n_vectors, const uint64_t *row_offsets,
+                                        const uint32_t *raw_dims, const float *raw_vals, uint32_t *out_dims, uint64_t *out_key_offsets,
+                                        uint32_t *out_vec_ids, uint32_t *n_dims) {
+    if (!row_offsets || !raw_dims || !raw_vals || !n_dims || n_vectors == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    if (quantization_bits < 1 || quantization_bits > 8) return cos_fail(COS_ERR_INVALID, "quantization_bits must be in [1, 8] (keys are u8)");
+    const u32 Q = 1u << quantization_bits;
+    const u64 nnz = row_offsets[n_vectors];
+    for (u32 v = 0; v < n_vectors; v++)
+        if (row_offsets[v + 1] < row_offsets[v]) return cos_fail(COS_ERR_INVALID, "row offsets decrease at vector %u", v);
+    std::vector<u32> dims(raw_dims, raw_dims + nnz);
+    std::sort(dims.begin(), dims.end());
+    dims.erase(std::unique(dims.begin(), dims.end()), dims.end());
+    const u32 T = (u32)dims.size();
+    const bool sizes_only = !out_dims && !out_key_offsets && !out_vec_ids;
+    if (sizes_only) { *n_dims = T; return COS_OK; }
+    if (!out_dims || !out_key_offsets || !out_vec_ids) return cos_fail(COS_ERR_INVALID, "all three output arrays or none");
+    if (*n_dims < T) { *n_dims = T; return cos_fail(COS_ERR_INVALID, "%u distinct dimensions, room for fewer", T); }
+    *n_dims = T;
+    std::vector<u64> count((size_t)T * Q, 0);
+    std::vector<u32> slot(nnz);
+    for (u64 p = 0; p < nnz; p++) {
+        const u32 t = (u32)(std::lower_bound(dims.begin(), dims.end(), raw_dims[p]) - dims.begin());
+        slot[p] = t * Q + host_sparse_quantize(raw_vals[p], values_upper_bound, quantization_bits);
+        count[slot[p]]++;
+    }
+    std::vector<u64> cursor((size_t)T * Q);
+    u64 run = 0;
+    for (u32 t = 0; t < T; t++) {
+        for (u32 k = 0; k < Q; k++) {
+            out_key_offsets[(size_t)t * (Q + 1) + k] = run;
+            cursor[(size_t)t * Q + k] = run;
+            run += count[(size_t)t * Q + k];
+        }
+        out_key_offsets[(size_t)t * (Q + 1) + Q] = run;
+        out_dims[t] = dims[t];
+    }
+    for (u32 v = 0; v < n_vectors; v++) // id order = push order
+        for (u64 p = row_offsets[v]; p < row_offsets[v + 1]; p++) out_vec_ids[cursor[slot[p]]++] = v;
+    return COS_OK;
+}
+
+// cos_sparse_build_csr + cos_sparse_create in one call; keep_raw != 0 also uploads the raw vectors for the raw-value rerank
+// (their dims must then ascend within a row, finalize_sparse_ann_results' lookup is a binary search)
+extern "C" int32_t cos_sparse_create_from_vectors(int32_t device, uint32_t quantization_bits, float values_upper_bound, uint32_t n_vectors,
+                                                  const uint64_t *row_offsets, const uint32_t *raw_dims, const float *raw_vals, int32_t keep_raw,
+                                                  cos_sparse **out) {
+    if (!out) return cos_fail(COS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    u32 T = 0;
+    int32_t rc = cos_sparse_build_csr(quantization_bits, values_upper_bound, n_vectors, row_offsets, raw_dims, raw_vals, nullptr, nullptr, nullptr, &T);
+    if (rc) return rc;
+    const u32 Q = 1u << quantization_bits;
+    std::vector<u32> dims(std::max(T, 1u)), ids((size_t)std::max<u64>(row_offsets[n_vectors], 1));
+    std::vector<uint64_t> ko((size_t)std::max(T, 1u) * (Q + 1));
+    rc = cos_sparse_build_csr(quantization_bits, values_upper_bound, n_vectors, row_offsets, raw_dims, raw_vals, dims.data(), ko.data(), ids.data(), &T);
+    if (rc) return rc;
+    if (T == 0) return cos_fail(COS_ERR_INVALID, "no postings");
+    return cos_sparse_create(device, quantization_bits, values_upper_bound, dims.data(), T, ko.data(), ids.data(), n_vectors,
+                             keep_raw ? row_offsets : nullptr, keep_raw ? raw_dims : nullptr, keep_raw ? raw_vals : nullptr, out);
+}
+
 extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims, const float *q_vals, const uint32_t *q_offsets, uint32_t B, uint32_t top_k,
                                            float early_terminate_threshold, uint32_t reranking_factor, uint32_t *out_ids, float *out_scores,
                                            uint32_t *out_counts) {

@@ -110,6 +110,17 @@ class InvertedIndex:
                                            _p(raw[0]) if raw else None, _p(raw[1]) if raw else None, _p(raw[2]) if raw else None,
                                            C.byref(self._h)))
 
+    @classmethod
+    def from_vectors(cls, quantization_bits: int, values_upper_bound: float, row_offsets, raw_dims, raw_vals, keep_raw: bool = True,
+                     device: int = 0):
+        """InvertedIndex::insert for ids 0 .. n-1 (cos_sparse_create_from_vectors): the CSR is built by the library on the host"""
+        ro, rd, rv = _c(row_offsets, np.uint64), _c(raw_dims, np.uint32), _c(raw_vals, np.float32)
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        check(_lib.lib().cos_sparse_create_from_vectors(device, quantization_bits, values_upper_bound, ro.size - 1, _p(ro), _p(rd), _p(rv),
+                                                        1 if keep_raw else 0, C.byref(self._h)))
+        return self
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             _lib.lib().cos_sparse_destroy(self._h)
@@ -131,6 +142,19 @@ class InvertedIndex:
         check(_lib.lib().cos_sparse_search_batch(self._h, _p(qd), _p(qv), _p(qo), B, top_k, early_terminate_threshold, reranking_factor,
                                                  _p(ids), _p(scores), _p(counts)))
         return ids, scores, counts
+
+
+def sparse_build_csr(quantization_bits: int, values_upper_bound: float, row_offsets, raw_dims, raw_vals):
+    """cos_sparse_build_csr (host code, no device): raw sparse vectors in id order -> (dims, key_offsets, vec_ids)"""
+    ro, rd, rv = _c(row_offsets, np.uint64), _c(raw_dims, np.uint32), _c(raw_vals, np.float32)
+    n, nd = ro.size - 1, C.c_uint32(0)
+    L = _lib.lib()
+    check(L.cos_sparse_build_csr(quantization_bits, values_upper_bound, n, _p(ro), _p(rd), _p(rv), None, None, None, C.byref(nd)))
+    dims = np.zeros(max(nd.value, 1), np.uint32)
+    ko = np.zeros(max(nd.value, 1) * ((1 << quantization_bits) + 1), np.uint64)
+    ids = np.zeros(max(int(ro[-1]), 1), np.uint32)
+    check(L.cos_sparse_build_csr(quantization_bits, values_upper_bound, n, _p(ro), _p(rd), _p(rv), _p(dims), _p(ko), _p(ids), C.byref(nd)))
+    return dims[:nd.value], ko[:nd.value * ((1 << quantization_bits) + 1)], ids[:int(ro[-1])]
 
 
 STEM_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_char), C.c_size_t, C.POINTER(C.c_char), C.c_size_t)

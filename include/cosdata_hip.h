@@ -315,6 +315,17 @@ typedef struct cos_sparse cos_sparse;
 int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits, float values_upper_bound, const uint32_t *dims, uint32_t n_dims,
                           const uint64_t *key_offsets, const uint32_t *vec_ids, uint32_t n_vectors, const uint64_t *row_offsets,
                           const uint32_t *raw_dims, const float *raw_vals, cos_sparse **out);
+/* InvertedIndex::insert for a whole collection (models/inverted_index.rs:168-200): vectors in id order, every (dimension, value) pair
+ * pushes the id to the end of the list of (dimension, quantize(value)).  Host code, no device.  Call once with the three output arrays
+ * NULL to get *n_dims (the posting count is row_offsets[n_vectors]), then with out_dims[*n_dims], out_key_offsets[*n_dims * (2^bits + 1)],
+ * out_vec_ids[nnz]. */
+int32_t cos_sparse_build_csr(uint32_t quantization_bits, float values_upper_bound, uint32_t n_vectors, const uint64_t *row_offsets,
+                             const uint32_t *raw_dims, const float *raw_vals, uint32_t *out_dims, uint64_t *out_key_offsets,
+                             uint32_t *out_vec_ids, uint32_t *n_dims);
+/* cos_sparse_build_csr + cos_sparse_create; keep_raw != 0 keeps the raw vectors on the device for the raw-value rerank. */
+int32_t cos_sparse_create_from_vectors(int32_t device, uint32_t quantization_bits, float values_upper_bound, uint32_t n_vectors,
+                                       const uint64_t *row_offsets, const uint32_t *raw_dims, const float *raw_vals, int32_t keep_raw,
+                                       cos_sparse **out);
 int32_t cos_sparse_destroy(cos_sparse *s);
 /* InvertedIndex::search_internal (indexes/inverted/mod.rs:278-331) -> SparseAnnQueryBasic::sequential_search
  * (models/sparse_ann_query.rs:68-147) for B queries given as CSR pairs (q_offsets[B+1] into q_dims / q_vals).

@@ -123,3 +123,44 @@ def test_device_matches_oracle(bits, thr):
             assert np.array_equal(sc[b, :c].view(np.uint32), np.asarray(esc, np.float32).view(np.uint32))
     with pytest.raises(ca.CosdataError):
         ix.search_batch(qd, qv, qo, 20, thr, 5)             # 100 candidates > 64
+
+
+@pytest.mark.parametrize("bits", [1, 4, 6, 8])
+def test_library_builds_the_csr_insert_would_build(bits):
+    """cos_sparse_build_csr (host code): InvertedIndexNode::insert for ids 0 .. n-1 — quantize, push the id to the end of the
+    (dimension, key) list — against the dict-of-lists construction of _corpus (which uses the oracle's quantizer)"""
+    import cosdata_amd as ca
+    rows, dims, key_off, vec_ids, row_off, raw_dims, raw_vals = _corpus(n=1500, vocab=300, bits=bits, upper=2.5, seed=bits)
+    raw_vals = raw_vals.copy()
+    raw_vals[:7] = [0.0, -1.0, 2.5, 2.4999, 1e30, np.nan, 1e-30]   # edge values of quantize: zero, negative, the bound, huge, NaN
+    rows2 = [(raw_dims[int(row_off[v]):int(row_off[v + 1])], raw_vals[int(row_off[v]):int(row_off[v + 1])]) for v in range(len(rows))]
+    Q = 1 << bits
+    lists = {}
+    for v, (d, x) in enumerate(rows2):
+        for di, xi in zip(d, x):
+            lists.setdefault(int(di), [[] for _ in range(Q)])[O.sparse_quantize(xi, 2.5, bits)].append(v)
+    want_dims = np.array(sorted(lists), np.uint32)
+    want_off, want_ids = [], []
+    for di in want_dims:
+        for k in range(Q):
+            want_off.append(len(want_ids))
+            want_ids += lists[int(di)][k]
+        want_off.append(len(want_ids))
+    d, ko, ids = ca.sparse_build_csr(bits, 2.5, row_off, raw_dims, raw_vals)
+    assert np.array_equal(d, want_dims) and np.array_equal(ko, np.array(want_off, np.uint64)) and np.array_equal(ids, np.array(want_ids, np.uint32))
+
+
+@pytest.mark.gpu
+def test_index_created_from_vectors_answers_like_the_index_created_from_the_csr():
+    import cosdata_amd as ca
+    n, bits, upper = 8000, 6, 3.0
+    rows, dims, key_off, vec_ids, row_off, raw_dims, raw_vals = _corpus(n=n, vocab=500, bits=bits, upper=upper, seed=21)
+    a = ca.InvertedIndex(bits, upper, dims, key_off, vec_ids, n, row_off, raw_dims, raw_vals)
+    b = ca.InvertedIndex.from_vectors(bits, upper, row_off, raw_dims, raw_vals)
+    qs = _queries(40, 500, seed=8)
+    qo = np.cumsum([0] + [len(q[0]) for q in qs]).astype(np.uint32)
+    qd = np.concatenate([q[0] for q in qs]).astype(np.uint32)
+    qv = np.concatenate([q[1] for q in qs]).astype(np.float32)
+    for k, rf in ((10, 0), (8, 4)):
+        ra, rb = a.search_batch(qd, qv, qo, k, 0.2, rf), b.search_batch(qd, qv, qo, k, 0.2, rf)
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
