@@ -24,6 +24,33 @@ int main() {
     if (cos_shardset_create(nullptr, 0, 0, 0, nullptr, &ss) != COS_ERR_INVALID || ss != nullptr) { printf("FAIL shardset null list\n"); return 1; }
     if (cos_shardset_search_batch(nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr) != COS_ERR_INVALID) { printf("FAIL shardset search args\n"); return 1; }
     if (cos_shardset_destroy(nullptr) != COS_OK) { printf("FAIL shardset destroy(null)\n"); return 1; }
+    // host-side entry points (no GPU needed): text -> BM25 terms with the built-in English stemmer, sparse index construction
+    {
+        char st[32];
+        const size_t n = cos_stem_english(nullptr, "consolidating", 13, st, sizeof(st));
+        if (n != 8 || memcmp(st, "consolid", 8) != 0) { printf("FAIL stem\n"); return 1; }
+        const char *text = "The knights were knitting; a knight's consolation.";
+        uint32_t hashes[16], nterms = 0;
+        float tfs[16];
+        if (cos_text_process(text, strlen(text), 40, 6.0f, 1.5f, 0.75f, cos_stem_english, nullptr, hashes, tfs, 16, &nterms) != COS_OK) { printf("FAIL text_process\n"); return 1; }
+        // kept tokens: knights were knitting knight consolation ("the", "a", "s" are stop words) -> stems knight x2, were, knit, consol
+        if (cos_text_count_tokens(text, strlen(text), 40) != 5 || nterms != 4) { printf("FAIL text terms %u\n", nterms); return 1; }
+        bool found = false;
+        for (uint32_t i = 0; i < nterms; i++) found |= hashes[i] == cos_xxhash32("knight", 6, 0) && tfs[i] == cos_bm25_term_frequency(2, 5, 6.0f, 1.5f, 0.75f);
+        if (!found) { printf("FAIL stemmed term\n"); return 1; }
+        // two vectors, dims {3, 7} / {7}: dimension 7 holds both ids, filed under their quantized values
+        const uint64_t row_off[3] = {0, 2, 3};
+        const uint32_t rdims[3] = {3, 7, 7};
+        const float rvals[3] = {1.5f, 0.1f, 2.9f};
+        uint32_t nd = 0;
+        if (cos_sparse_build_csr(2, 3.0f, 2, row_off, rdims, rvals, nullptr, nullptr, nullptr, &nd) != COS_OK || nd != 2) { printf("FAIL csr sizes\n"); return 1; }
+        uint32_t dims[2], ids[3];
+        uint64_t ko[2 * 5];
+        if (cos_sparse_build_csr(2, 3.0f, 2, row_off, rdims, rvals, dims, ko, ids, &nd) != COS_OK) { printf("FAIL csr\n"); return 1; }
+        // quantize(v) = min(3, trunc(v / 3 * 3)): 1.5 -> 1, 0.1 -> 0, 2.9 -> 2
+        if (dims[0] != 3 || dims[1] != 7 || ko[0] != 0 || ko[1] != 0 || ko[2] != 1 || ko[4] != 1 || ko[5] != 1 || ko[6] != 2 || ko[7] != 2 || ko[8] != 3 ||
+            ko[9] != 3 || ids[0] != 0 || ids[1] != 0 || ids[2] != 1) { printf("FAIL csr content\n"); return 1; }
+    }
     int ndev = -1;
     int rcd = cos_device_count(&ndev);
     rc = cos_index_create(&p, &ix);
