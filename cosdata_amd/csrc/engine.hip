@@ -198,13 +198,36 @@ static void free_ws(Workspace *w) {
     delete w;
 }
 
+// the whole pseudo-root component: levels, node table, metadata dimensions, and the id stride it imposed on the base graph.
+// After this the handle is a collection without a metadata schema again (cos_index_enable_metadata re-creates row n + 1).
+static void reset_meta(cos_index *ix) {
+    for (auto &l : ix->meta.lv) free_level(l);
+    if (ix->meta.d_mbits) (void)hipFree(ix->meta.d_mbits);
+    if (ix->meta.d_mmags) (void)hipFree(ix->meta.d_mmags);
+    ix->meta.d_mbits = nullptr;
+    ix->meta.d_mmags = nullptr;
+    ix->meta.node_ids.clear();
+    ix->meta.mdim = 0;
+    ix->id_stride = 1;
+}
+
+static void free_pipe(HostPipe *hp) {
+    void *ptrs[] = {hp->d_q, hp->d_ids, hp->d_counts, hp->d_scores, hp->d_status};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : hp->ev_in) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : hp->ev_walk) if (e) (void)hipEventDestroy(e);
+    hipStream_t sts[] = {hp->s[0], hp->s[1], hp->sc, hp->sf};
+    for (hipStream_t st : sts) if (st) (void)hipStreamDestroy(st);
+    delete hp;
+}
+
 extern "C" int32_t cos_index_destroy(cos_index *ix) {
     if (!ix) return COS_OK;
     (void)hipSetDevice(ix->p.device);
     (void)hipDeviceSynchronize();
     for (auto &kv : ix->ws) free_ws(kv.second);
     cos_flat_ws_release(ix);
-    for (auto &kv : ix->thread_streams) if (kv.second) (void)hipStreamDestroy(kv.second);
+    for (HostPipe *hp : ix->pipes_all) free_pipe(hp);
     for (auto &l : ix->lv) free_level(l);
     for (auto &l : ix->meta.lv) free_level(l);
     if (ix->meta.d_mbits) (void)hipFree(ix->meta.d_mbits);
@@ -235,7 +258,7 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     cos_flat_ws_release(ix); // cached sums of the stored codes, scan buffers sized for the old corpus
     ix->have_root = false;
     for (auto &l : ix->lv) free_level(l); // a graph refers to vector rows: new vectors invalidate it
-    for (auto &l : ix->meta.lv) free_level(l);
+    reset_meta(ix);                       // ... and so do the pseudo-root component, its node table and the id stride
     const u64 dim = ix->p.dim;
     struct Rollback { // a failed upload leaves the handle empty instead of half-populated
         cos_index *ix;
@@ -572,14 +595,16 @@ int32_t vis_tab_prepare(VisTab &vt, const cos_index *ix, u32 B, u32 ef, hipStrea
     return COS_OK;
 }
 
-static int32_t get_workspace(cos_index *ix, void *stream_key, u32 B, u32 top_k, bool host_api, Workspace **out) {
+// the workspace registered under `key` (a caller's stream, or a HostPipe slot), grown to B queries; `st` is the stream the
+// workspace's previous launches ran on (drained before a buffer is replaced)
+static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u32 top_k, bool host_api, Workspace **out) {
     std::lock_guard<std::mutex> g(ix->mu);
-    Workspace *&w = ix->ws[stream_key];
+    Workspace *&w = ix->ws[key];
     if (!w) w = new Workspace();
     const u32 L1 = ix->p.num_layers + 1;
     if (B > w->capB) {
         u32 cap = std::max(B, 64u);
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream_key));
+        HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(regrow(w->q_codes, (size_t)cap * ix->row_stride));
         HIP_TRY(regrow(w->q_mags, cap));
         HIP_TRY(regrow(w->q_raw_mags, cap));
@@ -609,9 +634,12 @@ static int32_t get_workspace(cos_index *ix, void *stream_key, u32 B, u32 top_k, 
     return COS_OK;
 }
 
-// quantize -> walk -> (finalize) on `st`; all buffers device memory
+// quantize -> walk on `st`, then (finalize) on `st_fin` (the same stream unless the caller pipelines chunks: then `st_fin` waits
+// for the walk through an event); all buffers device memory.  `chain` = take part in the walk chain (big launches of
+// different streams one after the other); the chunks of one pipelined host call co-run instead.
 static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u32 B, u32 top_k, u32 *d_out_ids, float *d_out_scores,
-                          u32 *d_out_counts, int32_t *d_out_status, bool do_finalize, hipStream_t st) {
+                          u32 *d_out_counts, int32_t *d_out_status, bool do_finalize, hipStream_t st, hipStream_t st_fin = nullptr,
+                          hipEvent_t walk_ev = nullptr, bool chain = true) {
     IndexDev dev = cos_make_index_dev(ix);
     bool timed;
     u32 ef, lat_max_B;
@@ -643,7 +671,7 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     wa.out_counts = w->walk_counts;
     wa.out_status = w->walk_status;
     wa.out_stats = w->stats;
-    if (B >= ix->chain_min_B) { // walk chain (engine_internal.h): wait for the previous big walk, whichever stream it ran on
+    if (chain && B >= ix->chain_min_B) { // walk chain (engine_internal.h): wait for the previous big walk, whichever stream it ran on
         std::lock_guard<std::mutex> g(ix->chain_mu);
         if (ix->chain_ev && ix->chain_ev != w->walk_done) HIP_TRY(hipStreamWaitEvent(st, ix->chain_ev, 0));
         if (timed) HIP_TRY(hipEventRecord(ev[1], st)); // the kernel's own duration: after the wait
@@ -653,11 +681,17 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     } else
         HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, st));
     if (timed) HIP_TRY(hipEventRecord(ev[2], st));
+    hipStream_t sf = st;
+    if (st_fin && st_fin != st) { // finalize on its own stream, ordered after this walk
+        HIP_TRY(hipEventRecord(walk_ev, st));
+        HIP_TRY(hipStreamWaitEvent(st_fin, walk_ev, 0));
+        sf = st_fin;
+    }
     if (do_finalize) {
         HIP_TRY(launch_finalize(dev, d_queries, ix->p.dim, w->q_raw_mags, w->walk_ids, w->walk_sims, w->walk_counts, w->walk_status, B, top_k,
-                                d_out_ids, d_out_scores, d_out_counts, d_out_status, w->rerank_rows, st));
+                                d_out_ids, d_out_scores, d_out_counts, d_out_status, w->rerank_rows, sf));
     }
-    if (timed) { HIP_TRY(hipEventRecord(ev[3], st)); w->ev_count++; }
+    if (timed) { HIP_TRY(hipEventRecord(ev[3], sf)); w->ev_count++; }
     w->lastB = B;
     w->timed = timed;
     { std::lock_guard<std::mutex> g(ix->mu); ix->last_ws = w; }
@@ -678,45 +712,156 @@ extern "C" int32_t cos_search_batch_device(cos_index *ix, const float *d_queries
     if (rc) return rc;
     if (!d_out_ids || !d_out_scores || !d_out_counts || !d_out_status) return cos_fail(COS_ERR_INVALID, "null output");
     Workspace *w;
-    rc = get_workspace(ix, stream, B, top_k, false, &w);
+    rc = get_workspace(ix, stream, (hipStream_t)stream, B, top_k, false, &w);
     if (rc) return rc;
     return run_search(ix, w, d_queries, B, top_k, d_out_ids, d_out_scores, d_out_counts, d_out_status, true, (hipStream_t)stream);
 }
 
-// host API: a private stream (and, through it, a private workspace) per calling thread, so concurrent callers (rayon
-// workers, indexes/mod.rs:268-271) neither serialise nor share staging buffers.  The streams belong to the handle and
-// die with it (cos_index_destroy).
-static int32_t thread_stream(cos_index *ix, hipStream_t *out) {
-    std::lock_guard<std::mutex> g(ix->mu);
-    hipStream_t &st = ix->thread_streams[std::this_thread::get_id()];
-    if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    *out = st;
-    return COS_OK;
+// host API: every call leases a HostPipe (private streams, staging and, through it, private workspaces) from the handle's
+// bounded pool, so concurrent callers (rayon workers, indexes/mod.rs:268-271) neither serialise nor share staging buffers, and
+// a host that churns threads (pool restarts, per-request threads) re-uses the same few pipes instead of growing device memory.
+// The pipes belong to the handle and die with it (cos_index_destroy).
+struct PipeLease {
+    cos_index *ix;
+    HostPipe *hp = nullptr;
+    explicit PipeLease(cos_index *ix_) : ix(ix_) {}
+    PipeLease(const PipeLease &) = delete;
+    PipeLease &operator=(const PipeLease &) = delete;
+    int32_t acquire() {
+        std::unique_lock<std::mutex> lk(ix->pipe_mu);
+        for (;;) {
+            if (!ix->pipes_free.empty()) { hp = ix->pipes_free.back(); ix->pipes_free.pop_back(); break; }
+            if (ix->pipes_all.size() < COS_MAX_HOST_PIPES) {
+                HostPipe *n = new HostPipe();
+                hipError_t e = hipStreamCreateWithFlags(&n->s[0], hipStreamNonBlocking);
+                if (e != hipSuccess) { delete n; return cos_fail(COS_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(e)); }
+                ix->pipes_all.push_back(n);
+                hp = n;
+                break;
+            }
+            ix->pipe_cv.wait(lk); // COS_MAX_HOST_PIPES calls are in flight: wait for one to finish
+        }
+        ix->host_calls_active.fetch_add(1);
+        return COS_OK;
+    }
+    ~PipeLease() {
+        if (!hp) return;
+        ix->host_calls_active.fetch_sub(1);
+        { std::lock_guard<std::mutex> g(ix->pipe_mu); ix->pipes_free.push_back(hp); }
+        ix->pipe_cv.notify_one();
+    }
+};
+
+template <typename T>
+static hipError_t grow_elems(T *&p, size_t &cap, size_t need) { // one capacity per buffer; a failed allocation leaves (null, 0)
+    if (need <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&p, need * sizeof(T));
+    if (e == hipSuccess) cap = need;
+    return e;
 }
 
-// one launch for a contiguous host batch, on the calling thread's private stream
-static int32_t search_host_once(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,
-                                uint32_t *out_counts, int32_t *out_status) {
-    int32_t rc;
-    hipStream_t st;
-    rc = thread_stream(ix, &st);
-    if (rc) return rc;
-    Workspace *w;
-    rc = get_workspace(ix, (void *)st, B, top_k, true, &w);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(w->d_queries, queries, (size_t)B * ix->p.dim * 4, hipMemcpyHostToDevice, st));
-    rc = run_search(ix, w, w->d_queries, B, top_k, w->d_out_ids, w->d_out_scores, w->d_out_counts, w->d_out_status, true, st);
-    if (rc) return rc;
-    std::vector<int32_t> status(B);
-    HIP_TRY(hipMemcpyAsync(out_ids, w->d_out_ids, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out_scores, w->d_out_scores, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out_counts, w->d_out_counts, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(status.data(), w->d_out_status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
+static int32_t report_status(const int32_t *status, u32 B) {
     for (u32 b = 0; b < B; b++)
         if (status[b] != COS_OK) return cos_fail(status[b], "query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", b, status[b]);
     return COS_OK;
+}
+
+// one launch for a contiguous host batch, on the leased pipe's stream
+static int32_t search_host_simple(cos_index *ix, HostPipe *hp, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,
+                                  uint32_t *out_counts, int32_t *out_status) {
+    hipStream_t st = hp->s[0];
+    Workspace *w;
+    int32_t rc = get_workspace(ix, (void *)st, st, B, top_k, true, &w);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(w->d_queries, queries, (size_t)B * ix->p.dim * 4, hipMemcpyHostToDevice, st));
+    rc = run_search(ix, w, w->d_queries, B, top_k, w->d_out_ids, w->d_out_scores, w->d_out_counts, w->d_out_status, true, st);
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    std::vector<int32_t> status(B);
+    hipError_t e = hipMemcpyAsync(out_ids, w->d_out_ids, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, w->d_out_scores, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_counts, w->d_out_counts, (size_t)B * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(status.data(), w->d_out_status, (size_t)B * 4, hipMemcpyDeviceToHost, st);
+    const hipError_t es = hipStreamSynchronize(st); // always drained before the host buffers go out of scope
+    HIP_TRY(e);
+    HIP_TRY(es);
+    if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
+    return report_status(status.data(), B);
+}
+
+// A big host batch with nobody else on the device: the call's own copies would sit in front of and behind its one walk
+// (H2D of 100 MB ahead of a 32 768 x 768 launch, finalize + D2H after it).  So the batch runs as <= 4 chunks:
+//   sc        H2D chunk 0 | H2D chunk 1 | H2D chunk 2 | H2D chunk 3              (straight from the caller's buffer)
+//   s[0]                   quantize+walk 0             | quantize+walk 2
+//   s[1]                                 quantize+walk 1             | quantize+walk 3
+//   sf                                                   finalize 0 | finalize 1 | finalize 2 | finalize 3 | D2H
+// chunk i+1 travels while chunk i is walked, chunk i is reranked while chunk i+1 is walked, and neighbouring walks co-run (the
+// next one fills the wave slots the previous one drains; they are not put in the walk chain).  Results are those of one
+// launch: queries are independent.  When other host calls are in flight the same overlap already happens ACROSS calls (their
+// copies hide under this call's chained walk), and whole-batch launches are the better shape — then the simple path is used.
+static int32_t search_host_pipelined(cos_index *ix, HostPipe *hp, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                                     float *out_scores, uint32_t *out_counts, int32_t *out_status) {
+    const size_t dim = ix->p.dim;
+    const u32 chunk = (((B + HostPipe::MAX_CHUNKS - 1) / HostPipe::MAX_CHUNKS) + 255u) & ~255u;
+    const u32 nch = (B + chunk - 1) / chunk;
+    if (!hp->s[1]) HIP_TRY(hipStreamCreateWithFlags(&hp->s[1], hipStreamNonBlocking));
+    if (!hp->sc) HIP_TRY(hipStreamCreateWithFlags(&hp->sc, hipStreamNonBlocking));
+    if (!hp->sf) HIP_TRY(hipStreamCreateWithFlags(&hp->sf, hipStreamNonBlocking));
+    for (u32 i = 0; i < HostPipe::MAX_CHUNKS; i++) {
+        if (!hp->ev_in[i]) HIP_TRY(hipEventCreateWithFlags(&hp->ev_in[i], hipEventDisableTiming));
+        if (!hp->ev_walk[i]) HIP_TRY(hipEventCreateWithFlags(&hp->ev_walk[i], hipEventDisableTiming));
+    }
+    HIP_TRY(grow_elems(hp->d_q, hp->cap_q, (size_t)B * dim));
+    HIP_TRY(grow_elems(hp->d_ids, hp->cap_ids, (size_t)B * top_k));
+    HIP_TRY(grow_elems(hp->d_scores, hp->cap_scores, (size_t)B * top_k));
+    HIP_TRY(grow_elems(hp->d_counts, hp->cap_counts, (size_t)B));
+    HIP_TRY(grow_elems(hp->d_status, hp->cap_status, (size_t)B));
+    struct Drain { // whatever happens, nothing of this call is still running when its buffers are handed back
+        HostPipe *hp;
+        ~Drain() { hipStream_t sts[] = {hp->sc, hp->s[0], hp->s[1], hp->sf}; for (hipStream_t st : sts) if (st) (void)hipStreamSynchronize(st); }
+    } drain{hp};
+    for (u32 i = 0; i < nch; i++) {
+        const u32 c0 = i * chunk, cb = std::min(chunk, B - c0);
+        hipStream_t st = hp->s[i & 1];
+        Workspace *w;
+        int32_t rc = get_workspace(ix, (void *)&hp->wkey[i], st, cb, top_k, false, &w);
+        if (rc) return rc;
+        float *dq = hp->d_q + (size_t)c0 * dim;
+        HIP_TRY(hipMemcpyAsync(dq, queries + (size_t)c0 * dim, (size_t)cb * dim * 4, hipMemcpyHostToDevice, hp->sc));
+        HIP_TRY(hipEventRecord(hp->ev_in[i], hp->sc));
+        HIP_TRY(hipStreamWaitEvent(st, hp->ev_in[i], 0));
+        rc = run_search(ix, w, dq, cb, top_k, hp->d_ids + (size_t)c0 * top_k, hp->d_scores + (size_t)c0 * top_k, hp->d_counts + c0, hp->d_status + c0,
+                        true, st, hp->sf, hp->ev_walk[i], false);
+        if (rc) return rc;
+    }
+    std::vector<int32_t> status(B);
+    hipError_t e = hipMemcpyAsync(out_ids, hp->d_ids, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, hp->sf);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, hp->d_scores, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, hp->sf);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_counts, hp->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, hp->sf);
+    if (e == hipSuccess) e = hipMemcpyAsync(status.data(), hp->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, hp->sf);
+    const hipError_t es = hipStreamSynchronize(hp->sf);
+    HIP_TRY(e);
+    HIP_TRY(es);
+    if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
+    return report_status(status.data(), B);
+}
+
+static u32 host_pipeline_min_B() { // COS_HOST_PIPELINE_MIN_B: experiments (0 = never chunk)
+    static const u32 v = [] { const char *e = getenv("COS_HOST_PIPELINE_MIN_B"); return e ? (u32)strtoul(e, nullptr, 10) : 8192u; }();
+    return v;
+}
+
+static int32_t search_host_once(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,
+                                uint32_t *out_counts, int32_t *out_status) {
+    PipeLease lease(ix);
+    int32_t rc = lease.acquire();
+    if (rc) return rc;
+    const u32 min_B = host_pipeline_min_B();
+    if (min_B && B >= min_B && ix->host_calls_active.load() == 1)
+        return search_host_pipelined(ix, lease.hp, queries, B, top_k, out_ids, out_scores, out_counts, out_status);
+    return search_host_simple(ix, lease.hp, queries, B, top_k, out_ids, out_scores, out_counts, out_status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -838,11 +983,12 @@ extern "C" int32_t cos_ann_search_batch(cos_index *ix, const float *queries, uin
     int32_t rc = check_search_args(ix, queries, B, 1);
     if (rc) return rc;
     if (!out_ids || !out_sims || !out_counts) return cos_fail(COS_ERR_INVALID, "null output");
-    hipStream_t st;
-    rc = thread_stream(ix, &st); // same per-thread stream + workspace as cos_search_batch: thread-safe on a shared handle
+    PipeLease lease(ix); // a leased pipe like cos_search_batch: thread-safe on a shared handle
+    rc = lease.acquire();
     if (rc) return rc;
+    hipStream_t st = lease.hp->s[0];
     Workspace *w;
-    rc = get_workspace(ix, (void *)st, B, 1, true, &w);
+    rc = get_workspace(ix, (void *)st, st, B, 1, true, &w);
     if (rc) return rc;
     const u32 L1 = ix->p.num_layers + 1;
     HIP_TRY(hipMemcpyAsync(w->d_queries, queries, (size_t)B * ix->p.dim * 4, hipMemcpyHostToDevice, st));
@@ -959,7 +1105,7 @@ extern "C" int32_t cos_index_enable_metadata(cos_index *ix, uint32_t mdim, uint3
 
 extern "C" int32_t cos_index_upload_meta_nodes(cos_index *ix, uint32_t n_nodes, const uint32_t *node_ids, const int32_t *mbits) {
     if (!ix || !node_ids || !mbits || n_nodes == 0) return cos_fail(COS_ERR_INVALID, "null/empty node table");
-    if (!ix->meta.mdim) return cos_fail(COS_ERR_NOT_READY, "cos_index_enable_metadata first");
+    if (!ix->meta.mdim || !ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "cos_index_enable_metadata first");
     int32_t rc = cos_set_device(ix);
     if (rc) return rc;
     const u32 md = ix->meta.mdim;
@@ -988,7 +1134,7 @@ extern "C" int32_t cos_index_upload_meta_nodes(cos_index *ix, uint32_t n_nodes, 
 
 extern "C" int32_t cos_index_upload_meta_graph_level(cos_index *ix, uint32_t level, uint32_t n_nodes, const uint32_t *node_ids, const uint32_t *nbr_ids) {
     if (!ix || !node_ids || !nbr_ids || n_nodes == 0) return cos_fail(COS_ERR_INVALID, "null/empty level");
-    if (ix->meta.node_ids.empty()) return cos_fail(COS_ERR_NOT_READY, "cos_index_upload_meta_nodes first");
+    if (!ix->meta.mdim || !ix->have_vectors || ix->meta.node_ids.empty()) return cos_fail(COS_ERR_NOT_READY, "cos_index_enable_metadata + cos_index_upload_meta_nodes first");
     if (level > ix->p.num_layers) return cos_fail(COS_ERR_INVALID, "bad level");
     int32_t rc = cos_set_device(ix);
     if (rc) return rc;
@@ -1003,7 +1149,9 @@ extern "C" int32_t cos_index_upload_meta_graph_level(cos_index *ix, uint32_t lev
         auto it = std::lower_bound(tab.begin(), tab.end(), node_ids[i]);
         if (it == tab.end() || *it != node_ids[i]) return cos_fail(COS_ERR_INVALID, "level %u: node %u is not in the node table", level, node_ids[i]);
         node_meta[i] = (u32)(it - tab.begin());
-        node_vec[i] = (node_ids[i] >= PSEUDO_LO && node_ids[i] <= PSEUDO_HI) ? n + 1 : node_ids[i] / ix->id_stride;
+        const bool pseudo = node_ids[i] >= PSEUDO_LO && node_ids[i] <= PSEUDO_HI;
+        if (!pseudo && node_ids[i] / ix->id_stride >= n) return cos_fail(COS_ERR_INVALID, "level %u: replica id %u has no resident vector", level, node_ids[i]);
+        node_vec[i] = pseudo ? n + 1 : node_ids[i] / ix->id_stride;
         if (node_ids[i] == PSEUDO_LO) root_idx = i;
     }
     for (u32 i = 0; i < n_nodes; i++)
@@ -1075,13 +1223,15 @@ static int32_t search_filtered_host(cos_index *ix, const float *queries, u32 B, 
         for (u32 j = 0; j < md; j++) { const int32_t v = f_dims[(size_t)f * md + j]; fd[(size_t)f * md + j] = v; const float x = (float)v; acc = acc + x * x; }
         fm[f] = sqrtf(acc);
     }
-    hipStream_t st;
-    rc = thread_stream(ix, &st);
+    DevBuf d_fd, d_fm, d_fo; // declared before the lease: the stream is drained (below, on every path) before they are freed
+    PipeLease lease(ix);
+    rc = lease.acquire();
     if (rc) return rc;
+    hipStream_t st = lease.hp->s[0];
+    struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drain{st};
     Workspace *w;
-    rc = get_workspace(ix, (void *)st, B, top_k ? top_k : 1, true, &w);
+    rc = get_workspace(ix, (void *)st, st, B, top_k ? top_k : 1, true, &w);
     if (rc) return rc;
-    DevBuf d_fd, d_fm, d_fo;
     HIP_TRY(d_fd.alloc(fd.size() * 4));
     HIP_TRY(d_fm.alloc(fm.size() * 4));
     HIP_TRY(d_fo.alloc(((size_t)B + 1) * 4));

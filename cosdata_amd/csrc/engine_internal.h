@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -111,6 +112,22 @@ struct MetaGraph {
     std::vector<LevelHost> lv;    // [num_layers + 1]
 };
 
+// Device-side resources of ONE host-API call in flight (cos_search_batch, cos_ann_search_batch, cos_search_filtered_batch):
+// s[0] is the call's stream on the simple path; big batches run as a chunk pipeline (engine.hip, search_host_pipelined):
+// H2D of chunk i+1 on `sc` under the walk of chunk i on s[i & 1], finalize of chunk i on `sf` under the walk of chunk i+1.
+struct HostPipe {
+    static constexpr u32 MAX_CHUNKS = 4;
+    hipStream_t s[2] = {nullptr, nullptr}, sc = nullptr, sf = nullptr;
+    hipEvent_t ev_in[MAX_CHUNKS] = {}, ev_walk[MAX_CHUNKS] = {};
+    char wkey[MAX_CHUNKS] = {}; // &wkey[i] = key of chunk i's Workspace in cos_index::ws
+    float *d_q = nullptr;       // [B][dim] the call's queries
+    u32 *d_ids = nullptr, *d_counts = nullptr;
+    float *d_scores = nullptr;
+    int32_t *d_status = nullptr;
+    size_t cap_q = 0, cap_ids = 0, cap_scores = 0, cap_counts = 0, cap_status = 0; // elements, one capacity per buffer
+};
+static constexpr u32 COS_MAX_HOST_PIPES = 32; // concurrent host-API calls served at once; further callers wait for a pipe
+
 struct cos_index {
     cos_params p;
     int eng = -1;
@@ -129,7 +146,12 @@ struct cos_index {
     hipStream_t own_stream = nullptr; // uploads / builder stream (exclusive entry points)
     std::mutex mu;                    // guards the workspace + thread-stream maps, the timing flag, ef_search and visited_mode
     std::map<void *, Workspace *> ws;
-    std::map<std::thread::id, hipStream_t> thread_streams; // host-API searches: one private stream per calling thread, owned here
+    // host-API searches: a call leases one HostPipe (private streams + staging) for its duration from a bounded pool, so
+    // concurrent callers neither serialise nor share buffers and a host that churns threads cannot grow device memory
+    std::mutex pipe_mu;
+    std::condition_variable pipe_cv;
+    std::vector<struct HostPipe *> pipes_all, pipes_free;
+    std::atomic<int> host_calls_active{0};
     Workspace *last_ws = nullptr; // most recent batch (cos_index_last_stats with stream == NULL)
     // host-API request coalescing (cos_index_set_coalescing)
     std::mutex co_mu;

@@ -302,7 +302,9 @@ struct cos_bm25 {
     float *d_hq = nullptr, *d_dsc = nullptr, *d_fsc = nullptr;
     u32 *d_did = nullptr, *d_dcnt = nullptr, *d_fid = nullptr, *d_fcnt = nullptr;
     int32_t *d_dst = nullptr;
-    size_t hyb_cap_q = 0, hyb_cap_d = 0, hyb_cap_f = 0, hyb_capB = 0;
+    // one capacity per buffer, written back by grow_buf itself: a failed hipMalloc leaves that buffer null WITH capacity 0,
+    // so a later, smaller batch grows it again instead of launching on a null pointer
+    size_t cap_hq = 0, cap_did = 0, cap_dsc = 0, cap_dcnt = 0, cap_dst = 0, cap_fid = 0, cap_fsc = 0, cap_fcnt = 0;
 };
 
 extern "C" int32_t cos_bm25_create(int32_t device, const uint32_t *term_hashes, const uint64_t *offsets, uint32_t n_terms, const uint32_t *doc_ids,
@@ -560,18 +562,14 @@ extern "C" int32_t cos_hybrid_search_batch(cos_index *ix, cos_bm25 *b, const flo
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream_dense));
     const size_t dim = ix->p.dim;
-    {
-        size_t c1 = b->hyb_cap_q, c2 = b->hyb_cap_d, c3 = b->hyb_cap_d, c4 = b->hyb_capB, c5 = b->hyb_capB, c6 = b->hyb_cap_f, c7 = b->hyb_cap_f, c8 = b->hyb_capB;
-        HIP_TRY(grow_buf(b->d_hq, c1, (size_t)B * dim));
-        HIP_TRY(grow_buf(b->d_did, c2, (size_t)B * k3));
-        HIP_TRY(grow_buf(b->d_dsc, c3, (size_t)B * k3));
-        HIP_TRY(grow_buf(b->d_dcnt, c4, (size_t)B));
-        HIP_TRY(grow_buf(b->d_dst, c5, (size_t)B));
-        HIP_TRY(grow_buf(b->d_fid, c6, (size_t)B * top_k));
-        HIP_TRY(grow_buf(b->d_fsc, c7, (size_t)B * top_k));
-        HIP_TRY(grow_buf(b->d_fcnt, c8, (size_t)B));
-        b->hyb_cap_q = c1; b->hyb_cap_d = std::min(c2, c3); b->hyb_capB = std::min(std::min(c4, c5), c8); b->hyb_cap_f = std::min(c6, c7);
-    }
+    HIP_TRY(grow_buf(b->d_hq, b->cap_hq, (size_t)B * dim));
+    HIP_TRY(grow_buf(b->d_did, b->cap_did, (size_t)B * k3));
+    HIP_TRY(grow_buf(b->d_dsc, b->cap_dsc, (size_t)B * k3));
+    HIP_TRY(grow_buf(b->d_dcnt, b->cap_dcnt, (size_t)B));
+    HIP_TRY(grow_buf(b->d_dst, b->cap_dst, (size_t)B));
+    HIP_TRY(grow_buf(b->d_fid, b->cap_fid, (size_t)B * top_k));
+    HIP_TRY(grow_buf(b->d_fsc, b->cap_fsc, (size_t)B * top_k));
+    HIP_TRY(grow_buf(b->d_fcnt, b->cap_fcnt, (size_t)B));
     rc = bm25_prepare(b, q_terms, q_offsets, B);
     if (rc) return rc;
     // sparse half on its stream

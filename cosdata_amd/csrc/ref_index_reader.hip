@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -68,16 +69,21 @@ struct Cbor {
         else return ok = false;
         return true;
     }
-    bool skip() {
+    // every element of an array / map takes at least one byte, so a declared length beyond the bytes that are left is a
+    // corrupt or truncated record: refuse it BEFORE any allocation or loop sized by it
+    bool fits(uint64_t elements) const { return elements <= (uint64_t)(end - p); }
+    static constexpr int MAX_DEPTH = 32; // the prop records nest 4 deep; bounded so a crafted file cannot overflow the stack
+    bool skip(int depth = 0) {
         int mj, info;
         uint64_t a;
+        if (depth > MAX_DEPTH) return ok = false;
         if (!head(mj, a, info)) return false;
         switch (mj) {
         case 0: case 1: return true;
         case 2: case 3: if ((uint64_t)(end - p) < a) return ok = false; p += a; return true;
-        case 4: for (uint64_t i = 0; i < a; i++) if (!skip()) return false; return true;
-        case 5: for (uint64_t i = 0; i < 2 * a; i++) if (!skip()) return false; return true;
-        case 6: return skip();
+        case 4: if (!fits(a)) return ok = false; for (uint64_t i = 0; i < a; i++) if (!skip(depth + 1)) return false; return true;
+        case 5: if (a > (1ull << 62) || !fits(2 * a)) return ok = false; for (uint64_t i = 0; i < 2 * a; i++) if (!skip(depth + 1)) return false; return true;
+        case 6: return skip(depth + 1);
         default: return true; // simple / float: the argument bytes were consumed by head()
         }
     }
@@ -90,8 +96,8 @@ struct Cbor {
         p += a;
         return true;
     }
-    bool map(uint64_t &n) { int mj, info; return head(mj, n, info) && (mj == 5 || (ok = false)); }
-    bool array(uint64_t &n) { int mj, info; return head(mj, n, info) && (mj == 4 || (ok = false)); }
+    bool map(uint64_t &n) { int mj, info; return head(mj, n, info) && ((mj == 5 && n <= (1ull << 62) && fits(2 * n)) || (ok = false)); }
+    bool array(uint64_t &n) { int mj, info; return head(mj, n, info) && ((mj == 4 && fits(n)) || (ok = false)); }
     // f16 / f32 / f64 (serde_cbor writes the shortest lossless form) or an integer
     bool number(double &v) {
         int mj, info;
@@ -121,7 +127,8 @@ struct PropValue {
 };
 
 // {"id": u32, "value": {<variant>: {...}}}
-bool parse_prop(const uint8_t *p, size_t len, bool want_code, PropValue &out) {
+// max_code = the largest code this index could have stored (cos_code_bytes of f32 storage): anything longer is not a vector of it
+bool parse_prop(const uint8_t *p, size_t len, bool want_code, size_t max_code, PropValue &out) {
     Cbor c{p, p + len};
     uint64_t n;
     if (!c.map(n)) return false;
@@ -150,14 +157,15 @@ bool parse_prop(const uint8_t *p, size_t len, bool want_code, PropValue &out) {
                 else if (fk == "resolution") { uint64_t r; if (!c.uint(r)) return false; out.resolution = (u32)r; }
                 else if (fk == "quant_vec" || fk == "vec") {
                     uint64_t m;
-                    if (!c.array(m)) return false;
+                    if (!c.array(m)) return false;       // m <= bytes left in the record (Cbor::fits)
+                    if (m * (out.storage == COS_STORAGE_F32 ? 4 : out.storage == COS_STORAGE_F16 ? 2 : 1) > max_code) return false;
                     if (out.storage == COS_STORAGE_U8) {
                         out.code.resize(m);
                         for (uint64_t j = 0; j < m; j++) { uint64_t b; if (!c.uint(b)) return false; out.code[j] = (uint8_t)b; }
                     } else if (out.storage == COS_STORAGE_SUBBYTE) { // planes, plane-major
                         for (uint64_t pl = 0; pl < m; pl++) {
                             uint64_t pb;
-                            if (!c.array(pb)) return false;
+                            if (!c.array(pb) || out.code.size() + pb > max_code) return false;
                             for (uint64_t j = 0; j < pb; j++) { uint64_t b; if (!c.uint(b)) return false; out.code.push_back((uint8_t)b); }
                         }
                     } else if (out.storage == COS_STORAGE_F16) { // half::f16 serialises as its u16 bits
@@ -187,7 +195,7 @@ struct ParsedDir {
 };
 
 // Parses the directory.  M_of(level) = neighbour slots per node; n_vectors = 0 skips the id range check.
-int32_t parse_dir(const char *dir, u32 Ltop, u32 M, u32 M0, u32 n_vectors, bool have_root_ptr, u32 root_ptr_offset, bool want_codes, ParsedDir &out) {
+static int32_t parse_dir_impl(const char *dir, u32 Ltop, u32 M, u32 M0, u32 n_vectors, bool have_root_ptr, u32 root_ptr_offset, bool want_codes, size_t max_code, ParsedDir &out) {
     const std::string root(dir);
     std::vector<uint8_t> ptrs, props;
     if (!read_file(root + "/nodes.ptr", ptrs)) return cos_fail(COS_ERR_INVALID, "cannot read %s/nodes.ptr", dir);
@@ -224,7 +232,7 @@ int32_t parse_dir(const char *dir, u32 Ltop, u32 M, u32 M0, u32 n_vectors, bool 
         PropValue pv;
         const bool is_root_entry = have_root_ptr && (u32)(e * 8) == root_ptr_offset;
         const bool code_wanted = is_root_entry || (want_codes && level == 0);
-        if (!parse_prop(&props[prop_off], prop_len, code_wanted, pv)) return cos_fail(COS_ERR_INVALID, "entry %zu: malformed CBOR prop record", e);
+        if (!parse_prop(&props[prop_off], prop_len, code_wanted, max_code, pv)) return cos_fail(COS_ERR_INVALID, "entry %zu: malformed CBOR prop record", e);
         if (n_vectors && pv.id != COS_ROOT_ID && pv.id >= n_vectors) return cos_fail(COS_ERR_INVALID, "entry %zu: internal id %u but only %u vectors are resident", e, pv.id, n_vectors);
         if (is_root_entry) {
             if (pv.id != COS_ROOT_ID) return cos_fail(COS_ERR_INVALID, "root ptr offset %u names node %u, not the root (u32::MAX)", root_ptr_offset, pv.id);
@@ -259,24 +267,36 @@ int32_t parse_dir(const char *dir, u32 Ltop, u32 M, u32 M0, u32 n_vectors, bool 
     return COS_OK;
 }
 
+// nothing may unwind through the extern "C" entry points (a Rust host aborts, or worse): allocation failures and anything else
+// the standard containers throw on a damaged directory become COS_ERR_INVALID
+int32_t parse_dir(const char *dir, u32 Ltop, u32 M, u32 M0, u32 n_vectors, bool have_root_ptr, u32 root_ptr_offset, bool want_codes, size_t max_code, ParsedDir &out) {
+    try {
+        return parse_dir_impl(dir, Ltop, M, M0, n_vectors, have_root_ptr, root_ptr_offset, want_codes, max_code, out);
+    } catch (const std::exception &e) {
+        return cos_fail(COS_ERR_INVALID, "reading %s failed: %s", dir, e.what());
+    } catch (...) {
+        return cos_fail(COS_ERR_INVALID, "reading %s failed", dir);
+    }
+}
+
 } // namespace
 
 // ---- host-only inspection (no device needed): what a maintainer's exporter / a test uses to look at a directory -------------
-extern "C" int32_t cos_reference_dir_level_counts(const char *dir, uint32_t num_layers, uint32_t neighbors_count, uint32_t level0_neighbors_count,
+static int32_t cos_reference_dir_level_counts_impl(const char *dir, uint32_t num_layers, uint32_t neighbors_count, uint32_t level0_neighbors_count,
                                                   uint32_t *level_counts) {
     if (!dir || !level_counts || num_layers + 1 > (u32)MAX_LEVELS) return cos_fail(COS_ERR_INVALID, "bad argument");
     ParsedDir pd;
-    int32_t rc = parse_dir(dir, num_layers, neighbors_count, level0_neighbors_count, 0, false, 0, false, pd);
+    int32_t rc = parse_dir(dir, num_layers, neighbors_count, level0_neighbors_count, 0, false, 0, false, 0, pd);
     if (rc) return rc;
     for (u32 l = 0; l <= num_layers; l++) level_counts[l] = (u32)pd.levels[l].size();
     return COS_OK;
 }
 
-extern "C" int32_t cos_reference_dir_read_level(const char *dir, uint32_t num_layers, uint32_t neighbors_count, uint32_t level0_neighbors_count,
+static int32_t cos_reference_dir_read_level_impl(const char *dir, uint32_t num_layers, uint32_t neighbors_count, uint32_t level0_neighbors_count,
                                                 uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids) {
     if (!dir || !node_ids || !nbr_ids || num_layers + 1 > (u32)MAX_LEVELS || level > num_layers) return cos_fail(COS_ERR_INVALID, "bad argument");
     ParsedDir pd;
-    int32_t rc = parse_dir(dir, num_layers, neighbors_count, level0_neighbors_count, 0, false, 0, false, pd);
+    int32_t rc = parse_dir(dir, num_layers, neighbors_count, level0_neighbors_count, 0, false, 0, false, 0, pd);
     if (rc) return rc;
     const u32 Ml = level == 0 ? level0_neighbors_count : neighbors_count;
     const std::vector<NodeRec> &L = pd.levels[level];
@@ -287,14 +307,14 @@ extern "C" int32_t cos_reference_dir_read_level(const char *dir, uint32_t num_la
     return COS_OK;
 }
 
-extern "C" int32_t cos_index_load_reference_dir(cos_index *ix, const char *dir, uint32_t root_ptr_offset, uint32_t flags) {
+static int32_t cos_index_load_reference_dir_impl(cos_index *ix, const char *dir, uint32_t root_ptr_offset, uint32_t flags) {
     if (!ix || !dir) return cos_fail(COS_ERR_INVALID, "null argument");
     if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload the raw vectors (cos_index_upload_vectors) before loading the graph");
     const u32 Ltop = ix->p.num_layers, n = ix->n;
     const bool verify = flags & COS_LOAD_VERIFY_CODES;
     const size_t cb = cos_code_bytes(ix->p.storage, ix->p.resolution, ix->p.dim);
     ParsedDir pd;
-    int32_t rc = parse_dir(dir, Ltop, ix->p.neighbors_count, ix->p.level0_neighbors_count, n, true, root_ptr_offset, verify, pd);
+    int32_t rc = parse_dir(dir, Ltop, ix->p.neighbors_count, ix->p.level0_neighbors_count, n, true, root_ptr_offset, verify, (size_t)ix->p.dim * 4, pd);
     if (rc) return rc;
     auto storage_ok = [&](const PropValue &pv) {
         return pv.storage == (int)ix->p.storage && pv.code.size() == cb && (pv.storage != COS_STORAGE_SUBBYTE || pv.resolution == ix->p.resolution);
@@ -328,4 +348,34 @@ extern "C" int32_t cos_index_load_reference_dir(cos_index *ix, const char *dir, 
         if (rc) return rc;
     }
     return COS_OK;
+}
+
+extern "C" int32_t cos_reference_dir_level_counts(const char *dir, uint32_t num_layers, uint32_t neighbors_count, uint32_t level0_neighbors_count, uint32_t *level_counts) {
+    try {
+        return cos_reference_dir_level_counts_impl(dir, num_layers, neighbors_count, level0_neighbors_count, level_counts);
+    } catch (const std::exception &e) {
+        return cos_fail(COS_ERR_INVALID, "cos_reference_dir_level_counts: %s", e.what());
+    } catch (...) {
+        return cos_fail(COS_ERR_INVALID, "cos_reference_dir_level_counts failed");
+    }
+}
+
+extern "C" int32_t cos_reference_dir_read_level(const char *dir, uint32_t num_layers, uint32_t neighbors_count, uint32_t level0_neighbors_count, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids) {
+    try {
+        return cos_reference_dir_read_level_impl(dir, num_layers, neighbors_count, level0_neighbors_count, level, node_ids, nbr_ids);
+    } catch (const std::exception &e) {
+        return cos_fail(COS_ERR_INVALID, "cos_reference_dir_read_level: %s", e.what());
+    } catch (...) {
+        return cos_fail(COS_ERR_INVALID, "cos_reference_dir_read_level failed");
+    }
+}
+
+extern "C" int32_t cos_index_load_reference_dir(cos_index *ix, const char *dir, uint32_t root_ptr_offset, uint32_t flags) {
+    try {
+        return cos_index_load_reference_dir_impl(ix, dir, root_ptr_offset, flags);
+    } catch (const std::exception &e) {
+        return cos_fail(COS_ERR_INVALID, "cos_index_load_reference_dir: %s", e.what());
+    } catch (...) {
+        return cos_fail(COS_ERR_INVALID, "cos_index_load_reference_dir failed");
+    }
 }

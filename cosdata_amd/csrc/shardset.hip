@@ -203,7 +203,10 @@ static int32_t exchange_local(cos_shardset *ss, size_t words) {
     for (u32 s = 0; s < S; s++) {
         LocalShard &src = ss->sh[s];
         if (s) HIP_TRY(hipStreamWaitEvent(root.stream, src.done, 0));
-        HIP_TRY(hipMemcpyAsync(root.d_gathered + (size_t)s * words, src.d_packed, words * 4, hipMemcpyDeviceToDevice, root.stream));
+        if (src.device == root.device)
+            HIP_TRY(hipMemcpyAsync(root.d_gathered + (size_t)s * words, src.d_packed, words * 4, hipMemcpyDeviceToDevice, root.stream));
+        else // a mixed set (e.g. 3 shards on 2 GPUs): explicit peer copy, valid with or without peer access between the two devices
+            HIP_TRY(hipMemcpyPeerAsync(root.d_gathered + (size_t)s * words, root.device, src.d_packed, src.device, words * 4, root.stream));
     }
     return COS_OK;
 }
@@ -226,6 +229,13 @@ extern "C" int32_t cos_shardset_search_batch(cos_shardset *ss, const float *quer
     std::lock_guard<std::mutex> g(ss->mu);
     const u32 S = ss->world, dim = ss->sh[0].ix->p.dim;
     const size_t words = (size_t)B * (2 * (size_t)top_k + 1);
+    struct DrainAll { // every return path — a later shard's error, a failed grow, a failed exchange — leaves no walk or collective
+        cos_shardset *ss; // of this batch queued on any shard's stream: the next call (or destroy) starts from idle streams
+        ~DrainAll() {
+            for (LocalShard &s : ss->sh) { (void)hipSetDevice(s.device); (void)hipStreamSynchronize(s.stream); }
+            (void)hipSetDevice(ss->sh[0].device);
+        }
+    } drain_all{ss};
     // 1. every shard: queries up, walk + exact rerank into its packed record (all shards run concurrently on their devices)
     for (LocalShard &s : ss->sh) {
         HIP_TRY(hipSetDevice(s.device));

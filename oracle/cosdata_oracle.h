@@ -143,6 +143,7 @@ const void *coso_index_codes(const coso_index *ix);     /* [n+1][code_bytes], ro
 const float *coso_index_mags(const coso_index *ix);     /* [n+1] */
 void coso_index_set_ef_search(coso_index *ix, uint32_t ef);
 void coso_index_set_visited_mode(coso_index *ix, uint32_t mode);
+void coso_index_clear_graph(coso_index *ix); /* drop all levels, keep the vectors */
 
 /* per-query device-comparable counters */
 typedef struct {
@@ -165,6 +166,9 @@ int coso_candidates_batch(const coso_index *ix, const float *queries, uint32_t B
  * out_ids/out_sims: [ (num_layers+1) * 100 ]; returns count or negative status. */
 int coso_ann_search(const coso_index *ix, const float *query, uint32_t *out_ids, float *out_sims,
                     uint32_t *level_counts /*[num_layers+1], top level first*/);
+/* ids [B][5*top_k] of the flat search's rerank candidates (streamed corpora: fetch those raw rows, set_raw_subset, search) */
+int coso_flat_candidates_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                               uint32_t *out_counts, int threads);
 /* exhaustive search over the quantized codes + exact rerank of the best 5k (device "flat" mode) */
 int coso_flat_search_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
                            float *out_scores, uint32_t *out_counts, int threads);

@@ -203,6 +203,11 @@ const void *coso_index_codes(const coso_index *ix) { return ix->codes; }
 const float *coso_index_mags(const coso_index *ix) { return ix->mags; }
 void coso_index_set_ef_search(coso_index *ix, uint32_t ef) { ix->p.ef_search = ef; }
 void coso_index_set_visited_mode(coso_index *ix, uint32_t mode) { ix->p.visited_mode = mode; }
+/* drop every level (the vectors stay): lets one quantized corpus take several imported graphs in turn */
+void coso_index_clear_graph(coso_index *ix) {
+    if (!ix) return;
+    for (uint32_t l = 0; l <= ix->p.num_layers; l++) level_free(&ix->lv[l]);
+}
 uint32_t coso_index_level_count(const coso_index *ix, uint32_t level) { return level <= ix->p.num_layers ? ix->lv[level].n : 0; }
 
 /* ------------------------------------------------------------------------------------------
@@ -978,50 +983,91 @@ int coso_index_import_level(coso_index *ix, uint32_t level, uint32_t n_nodes, co
  * remove_duplicates_and_filter (desc, larger id first), cut to 5k and handed to finalize_ann_results' exact
  * f32 rerank.  It is what the walk would return if it visited every node.
  * ---------------------------------------------------------------------------------------- */
+/* the best min(n, 5*top_k) stored vectors of one query by (order key desc, id desc): identical to sorting every
+ * (similarity, id) pair like remove_duplicates_and_filter and truncating, without the n-element sort */
+static int flat_candidates_one(const coso_index *ix, const float *q, uint32_t top_k, uint8_t *qcode, hent *best, uint32_t *out_m) {
+    const int d = (int)ix->p.dim;
+    const uint32_t cap = 5 * top_k;
+    float qmag;
+    int rc = coso_quantize(q, d, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo, ix->p.range_hi, qcode, &qmag);
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < ix->n && rc == COSO_OK; i++) {
+        float sv;
+        rc = node_distance(ix, qcode, qmag, i, &sv);
+        if (rc != COSO_OK) break;
+        hent e = {order_key((int)ix->p.metric, sv), i, i, sv};
+        if (m == cap && cmp_hent_desc(&e, &best[cap - 1]) >= 0) continue;
+        uint32_t pos = m < cap ? m : cap - 1; /* insertion into a sorted (desc) list */
+        while (pos > 0 && cmp_hent_desc(&e, &best[pos - 1]) < 0) { best[pos] = best[pos - 1]; pos--; }
+        best[pos] = e;
+        if (m < cap) m++;
+    }
+    *out_m = rc == COSO_OK ? m : 0;
+    return rc;
+}
+
+/* ids [B][5*top_k] of the candidates whose raw rows the flat search's exact rerank reads (corpora streamed through
+ * coso_index_quantize_rows have no raw table on the host: fetch these rows, coso_index_set_raw_subset, then search) */
+int coso_flat_candidates_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
+                               uint32_t *out_counts, int threads) {
+    if (!ix || !ix->codes || top_k == 0) return COSO_ERR_INVALID;
+    if (threads < 1) threads = 1;
+    int first_err = COSO_OK;
+#pragma omp parallel num_threads(threads)
+    {
+        hent *best = (hent *)malloc((size_t)(5 * top_k + 1) * sizeof(hent));
+        uint8_t *qcode = (uint8_t *)malloc(ix->cb);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            uint32_t m = 0;
+            int rc = flat_candidates_one(ix, queries + (size_t)b * ix->p.dim, top_k, qcode, best, &m);
+            for (uint32_t i = 0; i < 5 * top_k; i++) out_ids[(size_t)b * 5 * top_k + i] = i < m ? best[i].id : 0xFFFFFFFFu;
+            out_counts[b] = m;
+            if (rc != COSO_OK) {
+#pragma omp critical
+                if (first_err == COSO_OK) first_err = rc;
+            }
+        }
+        free(best); free(qcode);
+    }
+    return first_err;
+}
+
 int coso_flat_search_batch(const coso_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
                            float *out_scores, uint32_t *out_counts, int threads) {
-    if (!ix || !ix->raw || top_k == 0) return COSO_ERR_INVALID;
+    if (!ix || !ix->codes || (!ix->raw && !ix->sub_rows) || top_k == 0) return COSO_ERR_INVALID;
     if (threads < 1) threads = 1;
     int first_err = COSO_OK;
     const int d = (int)ix->p.dim;
 #pragma omp parallel num_threads(threads)
     {
-        hent *all = (hent *)malloc((size_t)(ix->n ? ix->n : 1) * sizeof(hent));
+        hent *best = (hent *)malloc((size_t)(5 * top_k + 1) * sizeof(hent));
         fent *f = (fent *)malloc((size_t)(5 * top_k + 1) * sizeof(fent));
         uint8_t *qcode = (uint8_t *)malloc(ix->cb);
 #pragma omp for schedule(dynamic, 1)
         for (int64_t b = 0; b < (int64_t)B; b++) {
             const float *q = queries + (size_t)b * d;
-            float qmag;
-            int rc = coso_quantize(q, d, (int)ix->p.storage, (int)ix->p.resolution, ix->p.range_lo, ix->p.range_hi, qcode, &qmag);
             uint32_t m = 0;
-            for (uint32_t i = 0; i < ix->n && rc == COSO_OK; i++) {
-                float sv;
-                rc = node_distance(ix, qcode, qmag, i, &sv);
-                if (rc != COSO_OK) break;
-                hent e = {order_key((int)ix->p.metric, sv), i, i, sv};
-                all[m++] = e;
-            }
+            int rc = flat_candidates_one(ix, q, top_k, qcode, best, &m);
             out_counts[b] = 0;
+            float mag_query = coso_seq_norm_f32(q, d);
+            for (uint32_t i = 0; i < m && rc == COSO_OK; i++) {
+                const float *rv = raw_row(ix, best[i].id);
+                if (!rv) { rc = COSO_ERR_INVALID; break; }   /* a streamed corpus without this candidate's raw row */
+                fent t = {coso_dot_f32(q, rv, d) / (mag_query * coso_seq_norm_f32(rv, d)), best[i].id};
+                f[i] = t;
+            }
             if (rc != COSO_OK) {
 #pragma omp critical
                 if (first_err == COSO_OK) first_err = rc;
                 continue;
-            }
-            qsort(all, m, sizeof(hent), cmp_hent_desc);
-            if (m > 5 * top_k) m = 5 * top_k;
-            float mag_query = coso_seq_norm_f32(q, d);
-            for (uint32_t i = 0; i < m; i++) {
-                const float *rv = ix->raw + (size_t)all[i].id * d;
-                fent t = {coso_dot_f32(q, rv, d) / (mag_query * coso_seq_norm_f32(rv, d)), all[i].id};
-                f[i] = t;
             }
             qsort(f, m, sizeof(fent), cmp_fent_desc);
             if (m > top_k) m = top_k;
             for (uint32_t i = 0; i < m; i++) { out_ids[(size_t)b * top_k + i] = f[i].id; out_scores[(size_t)b * top_k + i] = f[i].cs; }
             out_counts[b] = m;
         }
-        free(all); free(f); free(qcode);
+        free(best); free(f); free(qcode);
     }
     return first_err;
 }

@@ -95,6 +95,8 @@ def lib():
         "coso_search_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_int]),
         "coso_ann_search": (C.c_int, [vp, vp, vp, vp, vp]),
         "coso_flat_search_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_int]),
+        "coso_flat_candidates_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
+        "coso_index_clear_graph": (None, [vp]),
         "coso_bruteforce_topk": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
         "coso_meta_enable": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "coso_meta_set_nodes": (C.c_int, [vp, C.c_uint32, vp, vp]),
@@ -360,6 +362,7 @@ class OracleIndex:
             raise ValueError(f"import status {rc} (level {level})")
 
     def import_graph(self, levels, root_raw):
+        lib().coso_index_clear_graph(self._h)          # a second graph over the same vectors replaces the first
         self.set_root_raw(root_raw)
         for l, (ids, nbr) in enumerate(levels):
             self.import_level(l, ids, nbr)
@@ -420,6 +423,17 @@ class OracleIndex:
         if rc != OK:
             raise ValueError(f"flat search status {rc}")
         return ids, scores, counts
+
+    def flat_candidates_batch(self, queries, top_k, threads=1):
+        """ids [B][5k] (+ counts [B]) of the flat search's rerank candidates (streamed corpora: fetch those raw rows first)"""
+        q = _c(queries, np.float32)
+        B = q.shape[0]
+        ids = np.full((B, 5 * top_k), 0xFFFFFFFF, np.uint32)
+        counts = np.zeros(B, np.uint32)
+        rc = lib().coso_flat_candidates_batch(self._h, _p(q), B, top_k, _p(ids), _p(counts), threads)
+        if rc != OK:
+            raise ValueError(f"flat candidates status {rc}")
+        return ids, counts
 
     # ---- metadata-filtered search (f4a) ----
     def meta_enable(self, mdim, max_replicas):

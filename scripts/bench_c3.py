@@ -1,94 +1,153 @@
 #!/usr/bin/env python3
 """Config c3 (BASELINE.json configs[2]): 10M x 768 quaternary-quantized distance on one MI355X.
-(i) exhaustive scan of the 2-bit codes (i8 MFMA GEMM, cos_flat_search_batch) and (ii) HNSW walk with
-quaternary distance + f32 rerank on a 1M subset; recall@10 vs exact f32 brute force for both.
-Prints one JSON line.  Not the driver's bench (that is bench.py / c2)."""
+(i) exhaustive scan of the 2-bit codes (i8 MFMA GEMM, cos_flat_search_batch) and, with --walk-n, (ii) HNSW walk with
+quaternary distance + f32 rerank on a subset; recall@10 vs exact f32 brute force for both.  `run()` returns the record
+bench.py appends under configs.c3 (roofline of the scan kernel, the oracle's exhaustive scan on the host cores as the CPU
+baseline, and bit-for-bit parity of the GPU answers with it on the same sample at the FULL corpus size); run as a script
+it prints that record as one JSON line."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
-import cosdata_amd as ca
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--n", type=int, default=10_000_000)
-ap.add_argument("--dim", type=int, default=768)
-ap.add_argument("--batch", type=int, default=256)
-ap.add_argument("--walk-n", type=int, default=1_000_000)
-ap.add_argument("--reps", type=int, default=3)
-a = ap.parse_args()
-dev = torch.device("cuda:0")
-g = torch.Generator(device=dev); g.manual_seed(7)
-n, d, B = a.n, a.dim, a.batch
-nc = max(64, n // 1000)
-centers = torch.rand(nc, d, generator=g, device=dev) * 1.6 - 0.8
-def draw(m, seed):
-    gg = torch.Generator(device=dev); gg.manual_seed(seed)
-    out = torch.empty(m, d, device=dev)
-    for s in range(0, m, 1 << 18):
-        k = min(1 << 18, m - s)
-        idx = torch.randint(0, nc, (k,), generator=gg, device=dev)
-        out[s:s + k] = (centers[idx] + 0.2 * torch.randn(k, d, generator=gg, device=dev)).clamp_(-0.999, 0.999)
+I8_PEAK_TOPS = 5000.0
+
+
+def _cores():
+    import bench
+    return bench.effective_cores()
+
+
+def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, device=0):
+    import torch
+    import cosdata_amd as ca
+    t_all = time.time()
+    dev = torch.device(f"cuda:{device}")
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    d, B = dim, batch
+    nc = max(64, n // 1000)
+    centers = torch.rand(nc, d, generator=g, device=dev) * 1.6 - 0.8
+
+    def draw(m, seed):
+        gg = torch.Generator(device=dev); gg.manual_seed(seed)
+        out = torch.empty(m, d, device=dev)
+        for s in range(0, m, 1 << 18):
+            k = min(1 << 18, m - s)
+            idx = torch.randint(0, nc, (k,), generator=gg, device=dev)
+            out[s:s + k] = (centers[idx] + 0.2 * torch.randn(k, d, generator=gg, device=dev)).clamp_(-0.999, 0.999)
+        return out
+    X = draw(n, 42)
+    Q = draw(B, 43)
+    torch.cuda.synchronize()
+    st_q2 = ca.StorageType.SubByte(2)
+    ix = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, st_q2, (-1.0, 1.0), device=device)
+    t = time.time(); ix.upload_vectors_device(X.data_ptr(), n, keepalive=X); t_up = time.time() - t
+    Qh = Q.cpu().numpy()
+    gt, _ = ix.bruteforce_topk(Qh, 10)
+    ix.flat_search(Qh, 10)                       # first call sizes the per-index workspace: not timed
+    runs = []
+    for _ in range(reps):
+        t = time.time()
+        ids, sc, cnt, st = ix.flat_search(Qh, 10, with_stats=True)
+        runs.append((st.gemm_ms, time.time() - t, st))
+    gemm_ms = float(np.median([r[0] for r in runs])); wall = float(np.median([r[1] for r in runs])); st = runs[-1][2]
+    # full-size parity property: three implementations of the scan (query-resident kernel, 256x128 tile kernel with the fused
+    # epilogue, unfused score-matrix path) must return the same ids / score bits / counts
+    same = {}
+    for env in ("COS_FLAT_TILE_KERNEL", "COS_FLAT_UNFUSED"):
+        os.environ[env] = "1"
+        i2, s2, c2 = ix.flat_search(Qh, 10)
+        del os.environ[env]
+        same[env] = bool(np.array_equal(i2, ids) and np.array_equal(s2.view(np.uint32), sc.view(np.uint32)) and np.array_equal(c2, cnt))
+    rec_flat = float(np.mean([len(set(ids[i].tolist()) & set(gt[i].tolist())) / 10 for i in range(B)]))
+    tops = st.int8_ops / gemm_ms / 1e9
+    out = {"config": {"workload": f"c3: BASELINE configs[2]: {n} x {d} quaternary (SubByte 2, values_range (-1,1)), exhaustive scan of the codes, "
+                                  f"query batch {B}", "standard_size": n == 10_000_000 and d == 768 and B == 256, "vectors": n, "dim": d, "query_batch": B,
+                      "step": "one cos_flat_search_batch call = i8-MFMA scan of every code row + top-5k selection + exact f32 rerank + top-k"},
+           "qps": B / wall, "unit": "queries/s", "ms_per_step": wall * 1e3, "steps": reps, "warmup": 1, "dtype": "i8 (2-bit digits)",
+           "recall_at_10": rec_flat, "recall_note": "vs exact f32 brute force; the reference's fixed-range 2-bit quantizer with MSB-first planes "
+                                                    "multiplied LSB-first bounds it — the GPU reproduces the oracle exactly, the recall is the reference's",
+           "roofline": {"bound": "mfma", "achieved": tops, "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_PEAK_TOPS, "traffic": None,
+                        "kernel": "flat_scan_q2_areg<KC> (query-resident i8 MFMA scan)",
+                        "per_launch": {"gemm_ms_all_launches": gemm_ms, "gemm_launches": st.gemm_launches, "int8_ops": float(st.int8_ops),
+                                       "code_bytes": float(st.code_bytes), "code_GBps": st.code_bytes / gemm_ms / 1e6},
+                        "note": "achieved = 2 x B x N x dim integer ops / the scan kernels' HIP-event time inside the call (median of the timed calls)"},
+           "flat": {"gemm_ms": gemm_ms, "gemm_launches": st.gemm_launches, "int8_tops": tops, "int8_peak_tops_dense": I8_PEAK_TOPS,
+                    "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall,
+                    "timing": f"median of {reps} calls after one untimed call", "qps_end_to_end": B / wall, "upload_quantize_s": t_up,
+                    "same_answer_as_tile_kernel": same["COS_FLAT_TILE_KERNEL"], "same_answer_as_unfused_path": same["COS_FLAT_UNFUSED"]},
+           "cpu_baseline": None, "parity_vs_oracle": None}
+
+    # ---- CPU baseline + parity at the full corpus size: the oracle quantizes the corpus itself (streamed: no 30 GB host table),
+    # scans every code row per query and reranks the best 5k from the raw rows of exactly those candidates
+    if cpu_seconds > 0:
+        from oracle import oracle as O
+        cores = _cores()
+        op = O.HNSWParams(dim=d, storage=O.STORAGE_SUBBYTE, resolution=2, range_lo=-1.0, range_hi=1.0)
+        oix = O.OracleIndex(op).alloc_vectors(n)
+        for s0 in range(0, n, 1 << 18):
+            oix.quantize_rows(s0, X[s0:s0 + (1 << 18)].cpu().numpy())
+        pm = min(B, cores)
+        t = time.perf_counter()
+        oix.flat_candidates_batch(Qh[:pm], 10, threads=cores)
+        rate = pm / (time.perf_counter() - t)
+        m = int(min(B, max(pm, rate * cpu_seconds)))
+        cand, _ = oix.flat_candidates_batch(Qh[:m], 10, threads=cores)
+        u = np.unique(cand[cand != 0xFFFFFFFF])
+        oix.set_raw_subset(u, X[torch.from_numpy(u.astype(np.int64)).to(dev)].cpu().numpy())
+        t = time.perf_counter()
+        oi, osc, ocnt = oix.flat_search_batch(Qh[:m], 10, threads=cores)
+        cpu_s = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": m / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
+                               "sample": f"{m} of the {B} queries against all {n} code rows ({cpu_s:.1f} s wall on {cores} threads): the oracle's "
+                                         "exhaustive scan (AVX2 nibble-LUT popcount dot_product_quaternary per row, bounded top-5k, exact rerank); "
+                                         "corpus quantized by the oracle in streamed chunks"}
+        out["parity_vs_oracle"] = {"queries": m, "id_mismatch_queries": int((ids[:m] != oi).any(axis=1).sum()),
+                                   "score_bit_mismatches": int((sc[:m].view(np.uint32) != osc.view(np.uint32)).sum()),
+                                   "count_mismatches": int((cnt[:m] != ocnt).sum())}
+        del oix
+    del ix
+    if walk_n > 0:  # (ii) HNSW walk with quaternary distance on a subset
+        m = min(walk_n, n)
+        Xs = X[:m].contiguous()
+        ix2 = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, st_q2, (-1.0, 1.0), device=device)
+        ix2.upload_vectors_device(Xs.data_ptr(), m, keepalive=Xs)
+        t = time.time(); ix2.build(4096); t_build = time.time() - t
+        gt2, _ = ix2.bruteforce_topk(Qh, 10)
+        Bq = 8192
+        Qb = draw(Bq, 44)
+        o_i = torch.zeros(Bq, 10, dtype=torch.int32, device=dev); o_s = torch.zeros(Bq, 10, device=dev)
+        o_c = torch.zeros(Bq, dtype=torch.int32, device=dev); o_t = torch.zeros(Bq, dtype=torch.int32, device=dev)
+        s0 = torch.cuda.Stream()
+        for _ in range(2):
+            ix2.batch_search_device(Qb.data_ptr(), Bq, 10, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), o_t.data_ptr(), s0.cuda_stream)
+        torch.cuda.synchronize()
+        ix2.enable_timing(True)
+        t = time.time()
+        for _ in range(8):
+            ix2.batch_search_device(Qb.data_ptr(), Bq, 10, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), o_t.data_ptr(), s0.cuda_stream)
+        torch.cuda.synchronize()
+        el = time.time() - t
+        stt = ix2.last_stats(s0.cuda_stream)
+        ids2 = ix2.batch_search(Qh, 10)[0]
+        rec_walk = float(np.mean([len(set(ids2[i].tolist()) & set(gt2[i].tolist())) / 10 for i in range(B)]))
+        row_b = 2 * ((d + 63) // 64) * 8 + 4
+        out["hnsw_walk_quaternary"] = {"n": m, "build_s": t_build, "qps": 8 * Bq / el, "walk_ms_per_8192": stt.walk_ms,
+                                       "algorithmic_GBps": (stt.evals * row_b + stt.adj_bytes) / stt.walk_ms / 1e6,
+                                       "evals_per_query": stt.evals / Bq, "recall_at_10_vs_f32_bruteforce": rec_walk}
+        del ix2
+    del X
+    torch.cuda.empty_cache()
+    out["seconds"] = time.time() - t_all
     return out
-X = draw(n, 42)
-Q = draw(B, 43)
-torch.cuda.synchronize()
-st_q2 = ca.StorageType.SubByte(2)
-ix = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, st_q2, (-1.0, 1.0))
-t = time.time(); ix.upload_vectors_device(X.data_ptr(), n, keepalive=X); t_up = time.time() - t
-Qh = Q.cpu().numpy()
-gt, _ = ix.bruteforce_topk(Qh, 10)
-ix.flat_search(Qh, 10)                       # first call sizes the per-index workspace: not timed
-runs = []
-for _ in range(a.reps):
-    t = time.time()
-    ids, sc, cnt, st = ix.flat_search(Qh, 10, with_stats=True)
-    runs.append((st.gemm_ms, time.time() - t, st))
-gemm_ms = float(np.median([r[0] for r in runs])); wall = float(np.median([r[1] for r in runs])); st = runs[-1][2]
-# full-size parity property: three implementations of the scan (query-resident kernel, 256x128 tile kernel with the fused
-# epilogue, unfused score-matrix path) must return the same ids / score bits / counts; the oracle checks each of them at the
-# sizes it can finish (tests/test_gpu_flat.py)
-same = {}
-for env in ("COS_FLAT_TILE_KERNEL", "COS_FLAT_UNFUSED"):
-    os.environ[env] = "1"
-    i2, s2, c2 = ix.flat_search(Qh, 10)
-    del os.environ[env]
-    same[env] = bool(np.array_equal(i2, ids) and np.array_equal(s2.view(np.uint32), sc.view(np.uint32)) and np.array_equal(c2, cnt))
-rec_flat = float(np.mean([len(set(ids[i].tolist()) & set(gt[i].tolist())) / 10 for i in range(B)]))
-out = {"config": f"c3: {n} x {d} quaternary (SubByte 2), flat scan of the codes, query batch {B}",
-       "flat": {"gemm_ms": gemm_ms, "gemm_launches": st.gemm_launches, "int8_tops": st.int8_ops / gemm_ms / 1e9,
-                "int8_peak_tops_dense": 5000.0, "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall, "timing": f"median of {a.reps} calls after one untimed call",
-                "qps_end_to_end": B / wall, "recall_at_10_vs_f32_bruteforce": rec_flat, "upload_quantize_s": t_up,
-                "same_answer_as_tile_kernel": same["COS_FLAT_TILE_KERNEL"], "same_answer_as_unfused_path": same["COS_FLAT_UNFUSED"]}}
-del ix
-if a.walk_n <= 0:   # flat scan only
-    print(json.dumps(out))
-    sys.exit(0)
-# (ii) HNSW walk with quaternary distance on a 1M subset
-m = min(a.walk_n, n)
-Xs = X[:m].contiguous()
-ix2 = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, st_q2, (-1.0, 1.0))
-ix2.upload_vectors_device(Xs.data_ptr(), m, keepalive=Xs)
-t = time.time(); ix2.build(4096); t_build = time.time() - t
-gt2, _ = ix2.bruteforce_topk(Qh, 10)
-Bq = 8192
-Qb = draw(Bq, 44)
-o_i = torch.zeros(Bq, 10, dtype=torch.int32, device=dev); o_s = torch.zeros(Bq, 10, device=dev)
-o_c = torch.zeros(Bq, dtype=torch.int32, device=dev); o_t = torch.zeros(Bq, dtype=torch.int32, device=dev)
-s0 = torch.cuda.Stream()
-for _ in range(2):
-    ix2.batch_search_device(Qb.data_ptr(), Bq, 10, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), o_t.data_ptr(), s0.cuda_stream)
-torch.cuda.synchronize()
-ix2.enable_timing(True)
-t = time.time()
-for _ in range(8):
-    ix2.batch_search_device(Qb.data_ptr(), Bq, 10, o_i.data_ptr(), o_s.data_ptr(), o_c.data_ptr(), o_t.data_ptr(), s0.cuda_stream)
-torch.cuda.synchronize()
-el = time.time() - t
-stt = ix2.last_stats(s0.cuda_stream)
-ids2 = ix2.batch_search(Qh, 10)[0]
-rec_walk = float(np.mean([len(set(ids2[i].tolist()) & set(gt2[i].tolist())) / 10 for i in range(B)]))
-row_b = 2 * ((d + 63) // 64) * 8 + 4
-out["hnsw_walk_quaternary_1M"] = {"n": m, "build_s": t_build, "qps": 8 * Bq / el, "walk_ms_per_8192": stt.walk_ms,
-                                  "algorithmic_GBps": (stt.evals * row_b + stt.adj_bytes) / stt.walk_ms / 1e6,
-                                  "evals_per_query": stt.evals / Bq, "recall_at_10_vs_f32_bruteforce": rec_walk}
-print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--walk-n", type=int, default=1_000_000)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--cpu-seconds", type=float, default=5.0)
+    a = ap.parse_args()
+    print(json.dumps(run(a.n, a.dim, a.batch, a.walk_n, a.reps, a.cpu_seconds)))

@@ -38,3 +38,23 @@ def test_effective_cores_is_bounded_by_affinity():
     import bench
     n = bench.effective_cores()
     assert 1 <= n <= len(os.sched_getaffinity(0))
+
+
+def test_resolve_configs_auto_all_none_and_world_rules():
+    import bench
+    assert bench.resolve_configs("auto", 1, "c2") == bench.ALL_CONFIGS                  # every BASELINE config at N = 1
+    assert bench.resolve_configs("auto", 8, "c2") == ["c4shard_exact"]                  # N > 1: configs[3] itself
+    assert bench.resolve_configs("auto", 1, "smoke") == [] and bench.resolve_configs("none", 1, "c2") == []
+    assert bench.resolve_configs("c3,c5", 1, "c2") == ["c3", "c5"]
+    assert bench.resolve_configs("all", 2, "c2") == ["c4shard_ref", "c4shard_exact"]    # single-GPU configs are dropped at N > 1
+    import pytest
+    with pytest.raises(SystemExit):
+        bench.resolve_configs("c9", 1, "c2")
+
+
+def test_launcher_command_is_the_drivers_own():
+    import bench
+    cmd = bench.launcher_command(4, 29999, ["--gpus", "4", "--steps", "3"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert cmd[cmd.index("--master-port") + 2].endswith("bench.py")

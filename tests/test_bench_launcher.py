@@ -1,0 +1,39 @@
+"""`bench.py --gpus N` must start N ranks itself when no launcher did (the flag used to be parsed and ignored, so
+`python bench.py --gpus 8` silently ran one rank).  Checked on CPU with the launcher self-test mode: two real processes, gloo
+rendezvous on 127.0.0.1, the packed all-gather of cosdata_amd/sharding.py, MAX-over-ranks timing, ONE JSON line from rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env=None, timeout=300):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+
+
+def test_gpus_2_without_world_size_launches_two_gloo_ranks():
+    r = _run(["--gpus", "2", "--launcher-selftest", "--steps", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                     # exactly one JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["asked_gpus"] == 2
+    assert j["distinct_processes"] == 2 and len(set(j["rank_pids"])) == 2   # two real processes took part
+    assert j["shards_in_merged_answer"] == [0, 1]                          # the merged answer draws on both shards
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+
+
+def test_gpus_flag_must_agree_with_the_launchers_world_size():
+    r = _run(["--gpus", "4", "--launcher-selftest"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE" in r.stderr
+
+
+def test_more_gpus_than_visible_is_refused_loudly():
+    # no GPU in the CPU container (or fewer than 64 anywhere): the launcher must refuse instead of running fewer ranks
+    r = _run(["--gpus", "64"])
+    assert r.returncode != 0 and "refusing to run fewer ranks" in r.stderr

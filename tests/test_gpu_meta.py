@@ -91,3 +91,33 @@ def test_filtered_search_argument_and_error_contract():
         plain.mdim = MH.MDIM
         plain.search_filtered(Q[:1], off[:2], rows[:off[1]].astype(np.int8), 5)
     assert ei.value.status == 6                                    # NotReady: no metadata component
+
+
+def test_reuploading_vectors_resets_the_whole_metadata_component():
+    """cos_index_upload_vectors freed the metadata LEVELS but kept id_stride, mdim, the node table and the metadata
+    dimensions, so a later cos_index_upload_meta_graph_level passed its checks and mapped stale replica ids to rows beyond the new n.
+    Now the handle is a plain collection again after a re-upload, and a node table with out-of-range replicas is refused."""
+    import ctypes as C
+    import cosdata_amd as ca
+    sc = MH.Scenario(n=1200, dim=64, seed=3)
+    oix = sc.oracle()
+    dix = sc.device(oix)
+    levels = oix.meta_export_graph()
+    X_small = sc.X[:300]
+    dix.upload_vectors(X_small)                              # fewer vectors than the stale replica ids refer to
+    lid, nbr = np.ascontiguousarray(levels[0][0], np.uint32), np.ascontiguousarray(levels[0][1], np.uint32)
+    rc = ca._lib.lib().cos_index_upload_meta_graph_level(dix._h, 0, lid.size, lid.ctypes.data_as(C.c_void_p), nbr.ctypes.data_as(C.c_void_p))
+    assert rc == 6                                           # no schema any more: NotReady, not an out-of-bounds walk
+    with pytest.raises(ca.CosdataError) as ei:
+        dix.mdim = MH.MDIM
+        dix.upload_meta_graph(sc.node_ids, sc.mbits, levels)
+    assert ei.value.status == 6
+    # the handle works as a plain (stride-1) collection: ids are rows again
+    dix.build(64)
+    ids = dix.batch_search(X_small[:8], 3)[0]
+    assert (ids[:, 0] == np.arange(8)).all()
+    # with the schema enabled again, the stale node table (replicas of rows >= 300) is refused by its range check
+    dix.upload_vectors(X_small).enable_metadata(MH.MDIM, MH.REPLICAS)
+    with pytest.raises(ca.CosdataError) as ei:
+        dix.upload_meta_graph(sc.node_ids, sc.mbits, levels)
+    assert ei.value.status == 3

@@ -69,6 +69,37 @@ def test_reader_rejects_damaged_directories(tmp_path):
     assert L.cos_reference_dir_level_counts(b"/nonexistent", 3, 8, 16, counts.ctypes.data_as(C.c_void_p)) == _lib.ERR_INVALID
 
 
+def _craft_first_prop(d, tail_of):
+    """overwrite the FIRST prop record (the root's: id u32::MAX) in place, keeping its length: {"id": .., "value": <tail>}"""
+    from tests.ref_index_writer import cbor_text, cbor_uint
+    p = bytearray(open(os.path.join(d, "prop.data"), "rb").read())
+    head = b"\xa2" + cbor_text("id") + cbor_uint(0xFFFFFFFF) + cbor_text("value")
+    # length of the first record = offset of the second one: records are back to back and start with the map header 0xA2
+    first_len = p.index(b"\xa2" + cbor_text("id") + cbor_uint(0), 1)
+    tail = tail_of(first_len - len(head))
+    assert len(head) + len(tail) == first_len
+    p[:first_len] = head + tail
+    open(os.path.join(d, "prop.data"), "wb").write(bytes(p))
+
+
+def test_reader_survives_crafted_cbor_lengths_and_nesting(tmp_path):
+    """array lengths from the file were trusted (resize before any element is read) and skip() recursed without a
+    limit; a corrupt prop.data must come back as COS_ERR_INVALID through the C ABI, never as an exception / stack overflow"""
+    from cosdata_amd import _lib
+    X, oix, hp = _oracle(O.STORAGE_U8, 0, n=120)
+    L = _lib.lib()
+    counts = np.zeros(4, np.uint32)
+    for tail_of in (lambda m: b"\x9b" + (1 << 40).to_bytes(8, "big") + b"\x00" * (m - 9),       # array claiming 2^40 elements
+                    lambda m: b"\xbb" + (1 << 63).to_bytes(8, "big") + b"\x00" * (m - 9),       # map claiming 2^63 pairs
+                    lambda m: b"\x81" * m,                                                        # arrays nested to the record's end
+                    lambda m: b"\xc1" * m):                                                       # tags nested to the record's end
+        d = str(tmp_path / f"dense_hnsw_{len(os.listdir(tmp_path))}")
+        write_dense_hnsw_dir(d, oix.export_graph(), oix.codes(), oix.mags(), O.STORAGE_U8, 0, X.shape[1])
+        assert L.cos_reference_dir_level_counts(d.encode(), 3, 8, 16, counts.ctypes.data_as(C.c_void_p)) == 0
+        _craft_first_prop(d, tail_of)
+        assert L.cos_reference_dir_level_counts(d.encode(), 3, 8, 16, counts.ctypes.data_as(C.c_void_p)) == _lib.ERR_INVALID
+
+
 def test_cbor_float_encoding_follows_serde_cbor():
     assert cbor_f32(1.0) == b"\xf9\x3c\x00"                 # lossless as half
     assert cbor_f32(0.1)[0] == 0xFA and len(cbor_f32(0.1)) == 5
@@ -103,3 +134,17 @@ def test_loaded_directory_searches_like_the_oracle(tmp_path, storage, res):
     assert ei.value.status == 1
     with pytest.raises(ca.CosdataError):                       # a ptr offset that is not the root's
         dix2.load_reference_dir(d, root_ptr + 8)
+    # a stored vector whose CBOR array claims more elements than the record holds / than any code of this index has
+    from tests.ref_index_writer import cbor_map, cbor_text, cbor_f32
+    variant = {0: "UnsignedByte", 1: "SubByte", 2: "HalfPrecisionFP", 3: "FullPrecisionFP"}[storage]
+    key = "vec" if storage == 3 else "quant_vec"
+    for claimed in (1 << 40, 96 * 4 + 1):
+        def tail_of(m, claimed=claimed):
+            t = b"\xa1" + cbor_text(variant) + b"\xa2" + cbor_text("mag") + cbor_f32(1.0) + cbor_text(key) + b"\x9b" + claimed.to_bytes(8, "big")
+            return t + b"\x01" * (m - len(t))
+        d3 = str(tmp_path / f"crafted_{claimed}")
+        rp = write_dense_hnsw_dir(d3, oix.export_graph(), oix.codes(), oix.mags(), storage, res, 96, index_file_min_size=1 << 20)
+        _craft_first_prop(d3, tail_of)
+        with pytest.raises(ca.CosdataError) as ei:
+            ca.HNSWIndex(96, h, ca.DistanceMetric.Cosine, ca.StorageType(ca.StorageKind(storage), res), (-1.0, 1.0)).upload_vectors(X).load_reference_dir(d3, rp)
+        assert ei.value.status == 3
