@@ -142,6 +142,7 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
     if (p->device < 0 || p->device >= ndev) return cos_fail(COS_ERR_INVALID, "device %d out of range (%d visible)", p->device, ndev);
     cos_index *ix = new cos_index();
     if (const char *e = getenv("COS_WALK_CHAIN_MIN_B")) ix->chain_min_B = (u32)strtoul(e, nullptr, 10); // experiments: 0 = always, 4294967295 = never
+    if (const char *e = getenv("COS_WALK_SIDE_MIN_B")) ix->walk_side_min_B = (u32)strtoul(e, nullptr, 10); // 0 = walks stay on the caller's stream
     ix->p = *p;
     ix->eng = eng;
     ix->row_stride = row_stride;
@@ -195,6 +196,9 @@ static void free_ws(Workspace *w) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : w->ev) if (e) (void)hipEventDestroy(e);
     if (w->walk_done) (void)hipEventDestroy(w->walk_done);
+    if (w->walk_fin) (void)hipEventDestroy(w->walk_fin);
+    if (w->prep_done) (void)hipEventDestroy(w->prep_done);
+    if (w->walk_stream) (void)hipStreamDestroy(w->walk_stream);
     delete w;
 }
 
@@ -630,6 +634,7 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         for (auto &e : w->ev) HIP_TRY(hipEventCreate(&e));
     }
     if (!w->walk_done) HIP_TRY(hipEventCreateWithFlags(&w->walk_done, hipEventDisableTiming));
+    if (!w->walk_fin) HIP_TRY(hipEventCreateWithFlags(&w->walk_fin, hipEventDisableTiming));
     *out = w;
     return COS_OK;
 }
@@ -671,21 +676,39 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     wa.out_counts = w->walk_counts;
     wa.out_status = w->walk_status;
     wa.out_stats = w->stats;
+    // Big walks run on the workspace's own LOW-PRIORITY stream (ordered after the quantize and before the finalize of `st` by
+    // events): the short kernels around a walk — the neighbouring launch's quantize and, above all, its finalize, which used to
+    // take 11-16 ms instead of 1.2 when its waves queued behind 32 768 walk waves of the next launch — are dispatched ahead of
+    // the walk's pending workgroups.  The caller sees the same stream order.
+    hipStream_t sw = st;
+    if (ix->walk_side_min_B && B >= ix->walk_side_min_B) {
+        if (!w->walk_stream) {
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi)); // numerically largest = lowest priority
+            HIP_TRY(hipStreamCreateWithPriority(&w->walk_stream, hipStreamNonBlocking, lo));
+            HIP_TRY(hipEventCreateWithFlags(&w->prep_done, hipEventDisableTiming));
+        }
+        sw = w->walk_stream;
+        HIP_TRY(hipEventRecord(w->prep_done, st));
+        HIP_TRY(hipStreamWaitEvent(sw, w->prep_done, 0));
+    }
     if (chain && B >= ix->chain_min_B) { // walk chain (engine_internal.h): wait for the previous big walk, whichever stream it ran on
         std::lock_guard<std::mutex> g(ix->chain_mu);
-        if (ix->chain_ev && ix->chain_ev != w->walk_done) HIP_TRY(hipStreamWaitEvent(st, ix->chain_ev, 0));
-        if (timed) HIP_TRY(hipEventRecord(ev[1], st)); // the kernel's own duration: after the wait
-        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, st));
-        HIP_TRY(hipEventRecord(w->walk_done, st));
+        if (ix->chain_ev && ix->chain_ev != w->walk_done) HIP_TRY(hipStreamWaitEvent(sw, ix->chain_ev, 0));
+        if (timed) HIP_TRY(hipEventRecord(ev[1], sw)); // the kernel's own duration: after the wait
+        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, sw));
+        HIP_TRY(hipEventRecord(w->walk_done, sw));
         ix->chain_ev = w->walk_done;
-    } else
-        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, st));
-    if (timed) HIP_TRY(hipEventRecord(ev[2], st));
-    hipStream_t sf = st;
-    if (st_fin && st_fin != st) { // finalize on its own stream, ordered after this walk
-        HIP_TRY(hipEventRecord(walk_ev, st));
-        HIP_TRY(hipStreamWaitEvent(st_fin, walk_ev, 0));
-        sf = st_fin;
+    } else {
+        if (timed && sw != st) HIP_TRY(hipEventRecord(ev[1], sw));
+        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, sw));
+    }
+    if (timed) HIP_TRY(hipEventRecord(ev[2], sw));
+    hipStream_t sf = st_fin ? st_fin : st;
+    if (sf != sw) { // finalize on another stream than the walk's, ordered after it
+        hipEvent_t we = walk_ev ? walk_ev : w->walk_fin;
+        HIP_TRY(hipEventRecord(we, sw));
+        HIP_TRY(hipStreamWaitEvent(sf, we, 0));
     }
     if (do_finalize) {
         HIP_TRY(launch_finalize(dev, d_queries, ix->p.dim, w->q_raw_mags, w->walk_ids, w->walk_sims, w->walk_counts, w->walk_status, B, top_k,

@@ -98,6 +98,8 @@ struct Workspace {
     std::vector<hipEvent_t> ev; // [EV_RING][4]
     u32 ev_count = 0;           // timed launches since timing was switched on (ring position = ev_count % EV_RING)
     hipEvent_t walk_done = nullptr; // recorded after this workspace's walk kernel (walk chain, see cos_index::chain_*)
+    hipStream_t walk_stream = nullptr; // low-priority stream big walks run on (cos_index::walk_side_min_B), created on first use
+    hipEvent_t prep_done = nullptr, walk_fin = nullptr; // caller's stream -> walk stream -> finalize stream
     u32 lastB = 0;
     bool timed = false;
 };
@@ -167,6 +169,7 @@ struct cos_index {
     std::mutex chain_mu;
     hipEvent_t chain_ev = nullptr; // walk_done of the most recent chained walk
     u32 chain_min_B = 16384;
+    u32 walk_side_min_B = 4096; // launches of at least this many queries walk on the workspace's low-priority stream; 0 = never
     // launches of at most this many queries run the latency variant of the walk (kernels_walk_lat.hip) where it applies; 0 = never
     u32 lat_max_B = COS_LATENCY_MODE_DEFAULT_MAX_B;
     struct FlatWs *flat_ws = nullptr; // cos_flat_search_batch's buffers (kernels_flat.hip), created on first use under `mu`

@@ -92,7 +92,10 @@ def run(n=1_000_000, dim=768, vocab=200_000, doc_len=120.0, batch=256, top_k=10,
     st_bm.synchronize()
     el_bm_dev = (time.time() - t) / reps
     bm_kernel_ms = ev0.elapsed_time(ev1) / reps
-    dev_equal_host = bool(np.array_equal(o_i.cpu().numpy().view(np.uint32), bm.search_batch(q_terms, q_off, 3 * k)[0]))
+    h_i, h_s, h_c = bm.search_batch(q_terms, q_off, 3 * k)
+    d_i, d_s, d_c = o_i.cpu().numpy().view(np.uint32), o_s.cpu().numpy(), o_c.cpu().numpy().view(np.uint32)
+    live = np.arange(3 * k)[None, :] < h_c[:, None]      # entries past a query's count are not part of the answer
+    dev_equal_host = bool(np.array_equal(d_c, h_c) and np.array_equal(d_i[live], h_i[live]) and np.array_equal(d_s[live].view(np.uint32), h_s[live].view(np.uint32)))
     # dense half alone through the device entry point: walk kernel time + counters (what bounds the one-call hybrid)
     dd_i = torch.zeros(B, 3 * k, dtype=torch.int32, device=dev); dd_s = torch.zeros(B, 3 * k, device=dev)
     dd_c = torch.zeros(B, dtype=torch.int32, device=dev); dd_t = torch.zeros(B, dtype=torch.int32, device=dev)

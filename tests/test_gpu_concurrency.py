@@ -82,9 +82,10 @@ def test_big_host_batch_runs_as_a_chunk_pipeline_with_the_answers_of_small_calls
         big = dix.batch_search(Q, 10)
         for j in range(3):
             assert np.array_equal(big[j].view(np.uint32), np.concatenate([p[j] for p in small]).view(np.uint32))
-        again = dix.batch_search(Q[:8192], 7)                # workspaces re-used with another shape
-        assert np.array_equal(again[0], big[0][:8192, :7])
+        again = dix.batch_search(Q[:8192], 7)                # workspaces re-used with another shape (top_k 7 reranks 35 candidates, not 50)
+        assert np.array_equal(again[0], np.concatenate([dix.batch_search(Q[s:s + 1024], 7)[0] for s in range(0, 8192, 1024)]))
     dix.set_visited_mode(ca.VISITED_REF)
+    big = dix.batch_search(Q, 10)
     Qbad = Q.copy()
     Qbad[8500, :] = -1.0                                     # zero-norm u8 code in the LAST chunk
     ids, sc, cnt, rc, status = dix.batch_search(Qbad, 10, return_status=True)
