@@ -4,9 +4,9 @@
 //   InvertedIndex::search_internal / finalize_sparse_ann_results (raw-value rerank)   indexes/inverted/mod.rs:278-381
 // The reference keeps, per dimension, one list of vector ids per QUANTIZED value (key); a query dimension with quantized value qq
 // adds qq * key to every vector of every key list it visits (all keys when qq is above the early-termination threshold, the
-// upper keys otherwise).  Restated as CSR — dims[T] ascending, key_off[T][2^bits + 1], vec_ids — the lists a query term visits
-// are one contiguous range, so the kernel streams it once, coalesced (HBM-bound, 4 B per posting; no MFMA: integer adds).
-// Sums are exact u32 -> atomic adds in any order give the reference's value.  The reference returns the survivors of
+// upper keys otherwise).  The caller hands the lists over as CSR — dims[T] ascending, key_off[T][2^bits + 1], vec_ids; the device
+// keeps one id-sorted (id, key) list per dimension and accumulates in LDS tiles of the vector-id space (below): HBM-bound streaming
+// of the postings, no MFMA (integer adds).  Sums are exact u32 -> atomic adds in any order give the reference's value.  The reference returns the survivors of
 // select_nth_unstable in hash-map order; here (as in the oracle) they are ordered by similarity descending, larger id first.
 #include <hip/hip_runtime.h>
 
@@ -46,80 +46,194 @@ __device__ __forceinline__ u32 sparse_quantize(float value, float upper, u32 bit
     return q < quantization ? q : quantization;
 }
 
-// grid (B, terms_max): block (b, i) streams the posting range of query b's i-th term
-__global__ __launch_bounds__(256) void sparse_accumulate_kernel(const SparseDev ix, const u32 *__restrict__ q_dims, const float *__restrict__ q_vals,
-                                                                const u32 *__restrict__ q_off, float early_terminate_threshold, u32 *__restrict__ acc /*[B][n]*/,
-                                                                uint8_t *__restrict__ touched /*[B][n]: reached with weight 0*/) {
-    const u32 b = blockIdx.x, i = blockIdx.y;
-    const u32 t0 = q_off[b], nt = q_off[b + 1] - t0;
-    if (i >= nt) return;
-    const u32 dim = q_dims[t0 + i];
-    u32 lo = 0, hi = ix.T; // find_node
-    while (lo < hi) { const u32 mid = lo + (hi - lo) / 2; if (ix.dims[mid] < dim) lo = mid + 1; else hi = mid; }
-    if (lo == ix.T || ix.dims[lo] != dim) return;
-    const float qf = (float)ix.Q;
-    float etv = __fmul_rn(qf, early_terminate_threshold);
-    etv = etv > 255.0f ? 255.0f : etv;
-    const u32 early_terminate_value = f32_as_u8(etv), low_threshold = f32_as_u32(__fmul_rn(early_terminate_threshold, qf));
-    const u32 qq = sparse_quantize(q_vals[t0 + i], ix.upper, ix.bits);
-    const u32 k0 = qq > low_threshold ? 0u : early_terminate_value;
-    if (k0 >= ix.Q) return;
-    const u64 *ko = ix.key_off + (u64)lo * (ix.Q + 1);
-    const u64 beg = ko[k0], end = ko[ix.Q];
-    u32 *ab = acc + (u64)b * ix.n;
-    uint8_t *tb = touched + (u64)b * ix.n;
-    // key of posting p = the last key whose list starts at or before p.  A thread's postings ascend, so after one binary search the
-    // key pointer only moves forward (the first version searched the 2^bits + 1 offsets again for every posting).
-    // A vector is a result as soon as any visited list holds it, also with similarity 0 (key 0, or a query value that quantizes
-    // to 0): weight-0 postings set a BYTE flag with a plain store — idempotent, no read-modify-write — and everything else is one
-    // atomic add; the first version OR-ed a bit into a bitmap for every posting, and the ids of a list ascend: up to 32 lanes of a
-    // wave hit the same word, which same-address atomics serialise (the BM25 kernel's lesson, kernels_hybrid.hip).
-    u32 l2 = k0;
-    bool first = true;
-    for (u64 p = beg + threadIdx.x; p < end; p += blockDim.x) {
-        if (first) {
-            u32 h2 = ix.Q;
-            while (l2 + 1 < h2) { const u32 mid = (l2 + h2) / 2; if (ko[mid] <= p) l2 = mid; else h2 = mid; }
-            first = false;
-        } else {
-            while (l2 + 1 < ix.Q && ko[l2 + 1] <= p) l2++;
-        }
-        const u32 v = ix.vec_ids[p];
-        const u32 w = qq * l2;
-        if (w) atomicAdd(&ab[v], w);
-        else tb[v] = 1;
-    }
-}
+// ---- device layout ----------------------------------------------------------------------------------------------------------
+// The caller's CSR keeps, per dimension, one list per key (the reference's map key -> Vec<vec_id>).  On the device every dimension
+// is ONE list sorted by vector id, the key of a posting next to it (m_ids u32 + m_keys u8 = 5 B per posting): the vector-id space
+// can then be cut into tiles whose accumulators live in LDS, exactly like the BM25 kernel (kernels_hybrid.hip) —
+//   * no [B][n] accumulator array in HBM at all (round 2: 268 M scattered global atomics into 410 MB + 512 MB cleared and scanned
+//     per 256-query batch = 10.3 ms, 0.013 of the HBM roof on the postings);
+//   * a term's early termination (keys below k0 are not visited) is a compare on the key byte.
+// Sums are exact u32 adds (qq * key), so the order in which a tile's terms and postings arrive is irrelevant: LDS atomic adds,
+// no barrier between terms.  A vector is a result as soon as any visited list holds it, also with similarity 0 (key 0, or a query
+// value that quantizes to 0): those rare postings set a bit in a per-tile flag word instead.
+constexpr u32 STILE = 8192;      // vector ids per LDS accumulator tile (32 KB of u32)
+constexpr u32 SDIR_MIN = 256;    // dimensions with more postings get a tile directory; shorter lists are scanned whole per tile
+constexpr u32 SNO_DIR = 0xFFFFFFFFu;
+constexpr int SPU = 8;           // postings per thread per chunk
+constexpr u32 SLICES = 256;      // (tile, term) slices a block resolves up front (LDS table); beyond that they are looked up on the way
 
-// one wave per (query, segment): top-SEL of the reached vectors (non-zero sum, or the weight-0 flag) by (similarity, id);
-// key = (sim + 1) << 32 | id (0 = empty)
-__global__ __launch_bounds__(64) void sparse_select_segments(const u32 *__restrict__ acc, const uint8_t *__restrict__ touched, u32 n, u32 seg_len,
-                                                             u64 *__restrict__ part /*[B][S][64]*/) {
-    const int lane = threadIdx.x;
-    const u32 q = blockIdx.x, seg = blockIdx.y, S = gridDim.y;
+struct STerm { // one resolved query term (host: find_node, quantize, early-termination rule)
+    u64 begin, end; // the dimension's posting list in m_ids / m_keys
+    u32 dir;        // row in the tile directory, SNO_DIR for short lists
+    u32 qq_k0;      // quantized query value | first visited key << 8
+};
+
+struct SCursor { // block-uniform
+    u32 tile, t;
+    u64 base, e; // postings [base, min(base + SPU * 256, e)) of term t's slice of the tile
+    bool valid;
+};
+
+// grid = B * splits blocks, heaviest query first: block (q, s) owns the tiles s, s + splits, ...; every wave keeps a private pool
+// of the best SEL keys ((similarity + 1) << 32 | id) it has flushed, the block's four pools are merged into part[q][s][64].
+__global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict__ m_ids, const uint8_t *__restrict__ m_keys, const STerm *__restrict__ terms,
+                                                          const u32 *__restrict__ qt_off, u32 n, const u32 *__restrict__ tile_dir,
+                                                          const u32 *__restrict__ order, u32 splits, u64 *__restrict__ part /*[B][splits][64]*/) {
+    __shared__ u32 acc[STILE];
+    __shared__ u32 zflag[STILE / 32];
+    __shared__ u64 wpool[4][SEL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 q = order[blockIdx.x / splits];
+    const u32 split = blockIdx.x % splits;
+    const u32 t0 = qt_off[q], nt = qt_off[q + 1] - t0;
+    const u32 n_tiles = (n + STILE - 1) / STILE;
+    u64 *out = part + ((u64)q * splits + split) * SEL;
+    if (nt == 0 || split >= n_tiles) { // nothing to visit: an empty pool (the finish kernel reads every split)
+        if (threadIdx.x < SEL) out[threadIdx.x] = 0ull;
+        return;
+    }
+    for (u32 i = threadIdx.x; i < STILE; i += blockDim.x) acc[i] = 0u;
+    for (u32 i = threadIdx.x; i < STILE / 32; i += blockDim.x) zflag[i] = 0u;
+    const STerm *qt = terms + t0;
     Pool<1> pool;
     pool.clear();
     u64 thr = 0ull;
-    const u32 c0 = seg * seg_len, c1 = (u64)c0 + seg_len < n ? c0 + seg_len : n;
-    for (u32 c = c0; c < c1; c += 64) {
-        const u32 v = c + lane;
-        u64 key = 0ull;
-        if (v < c1) {
-            const u32 a = acc[(u64)q * n + v];
-            if (a != 0u || touched[(u64)q * n + v]) key = ((u64)a + 1ull) << 32 | v;
+
+    auto slice_global = [&](u32 tile, u32 t, u64 &b, u64 &e) {
+        const u32 dr = qt[t].dir;
+        b = qt[t].begin;
+        e = qt[t].end;
+        if (dr != SNO_DIR) {
+            const u32 *row = tile_dir + (u64)dr * (n_tiles + 1);
+            e = b + row[tile + 1];
+            b = b + row[tile];
         }
-        u64 m = __ballot(key > thr);
-        while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const u64 kk = readlane_u64(key, l);
-            if (kk > thr) {
-                pool.insert_at(kk, pool.rank_of(kk), lane);
-                thr = readlane_u64(pool.e[0], SEL - 1);
+    };
+    // The (tile, term) slices of this block, resolved once, all lookups in flight together: a chunk used to start with two
+    // DEPENDENT global loads (the term's directory row, then its two entries) that nothing overlapped — with ~900 postings per slice
+    // the kernel spent more time finding its slices than streaming them (0.95 ms per 256-query batch, 0.14 of the HBM roof).
+    __shared__ u64 sl_b[SLICES], sl_e[SLICES];
+    __shared__ u32 sl_w[SLICES];
+    const u32 my_tiles = (n_tiles - split + splits - 1) / splits;
+    const bool tabled = (u64)my_tiles * nt <= SLICES;
+    if (tabled)
+        for (u32 p = threadIdx.x; p < my_tiles * nt; p += blockDim.x) {
+            u64 b, e;
+            slice_global(split + (p / nt) * splits, p % nt, b, e);
+            sl_b[p] = b;
+            sl_e[p] = e;
+            sl_w[p] = qt[p % nt].qq_k0;
+        }
+    auto slice = [&](u32 tile, u32 t, u64 &b, u64 &e) {
+        if (tabled) {
+            const u32 p = ((tile - split) / splits) * nt + t;
+            b = sl_b[p];
+            e = sl_e[p];
+        } else
+            slice_global(tile, t, b, e);
+    };
+    auto advance = [&](const SCursor &c) -> SCursor {
+        SCursor nx = c;
+        if (c.base + (u64)SPU * 256 < c.e) { nx.base = c.base + (u64)SPU * 256; return nx; }
+        if (c.t + 1 < nt) nx.t = c.t + 1;
+        else { nx.t = 0; nx.tile = c.tile + splits; }
+        nx.valid = nx.tile < n_tiles;
+        if (nx.valid) slice(nx.tile, nx.t, nx.base, nx.e);
+        return nx;
+    };
+    // every load is issued unconditionally (masked lanes read posting 0 and drop it): a fixed number of loads per chunk lets the
+    // compiler wait for exactly the older chunk while the newer one stays in flight (see bm25_score_kernel)
+    auto fetch = [&](const SCursor &c, u32 (&iv)[SPU], u32 (&kv)[SPU]) -> u32 {
+        u32 mask = 0;
+#pragma unroll
+        for (int u = 0; u < SPU; u++) {
+            const u64 i = c.base + threadIdx.x + (u64)u * 256;
+            const bool in = c.valid && i < c.e;
+            const u64 ii = in ? i : 0ull;
+            iv[u] = m_ids[ii];
+            kv[u] = m_keys[ii];
+            mask |= (in ? 1u : 0u) << u;
+        }
+        return mask;
+    };
+    auto apply = [&](const SCursor &c, const SCursor &nx, const u32 (&iv)[SPU], const u32 (&kv)[SPU], const u32 mask) {
+        const u32 d0 = c.tile * STILE;
+        const u32 w_t = tabled ? sl_w[c.t] : qt[c.t].qq_k0;
+        const u32 qq = w_t & 255u, k0 = w_t >> 8;
+#pragma unroll
+        for (int u = 0; u < SPU; u++) {
+            const u32 slot = iv[u] - d0; // a short list's postings of other tiles wrap to >= STILE
+            if (((mask >> u) & 1u) && slot < STILE && kv[u] >= k0) {
+                const u32 w = qq * kv[u];
+                if (w) atomicAdd(&acc[slot], w);
+                else atomicOr(&zflag[slot >> 5], 1u << (slot & 31u));
             }
         }
+        const bool tile_done = !nx.valid || nx.tile != c.tile;
+        if (tile_done) {
+            __syncthreads();
+            // flush: wave w scans slots [w * 2048, (w + 1) * 2048) of the tile, 64 at a time, into its pool
+            for (u32 s0 = (u32)wave * (STILE / 4); s0 < (u32)(wave + 1) * (STILE / 4); s0 += 64) {
+                const u32 slot = s0 + (u32)lane;
+                const u32 a = acc[slot];
+                const u32 fw = zflag[slot >> 5];
+                acc[slot] = 0u;
+                const bool reached = a != 0u || ((fw >> (slot & 31u)) & 1u);
+                const u64 key = reached ? (((u64)a + 1ull) << 32 | (u64)(d0 + slot)) : 0ull;
+                u64 m = __ballot(key > thr);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const u64 kk = readlane_u64(key, l);
+                    if (kk > thr) {
+                        pool.insert_at(kk, pool.rank_of(kk), lane);
+                        thr = readlane_u64(pool.e[0], SEL - 1);
+                    }
+                }
+            }
+            __syncthreads(); // everybody has read the flag words of its slots
+            for (u32 i = threadIdx.x; i < STILE / 32; i += blockDim.x) zflag[i] = 0u;
+            __syncthreads();
+        }
+    };
+
+    __syncthreads(); // the slice table
+    SCursor cur;
+    cur.tile = split; cur.t = 0; cur.valid = true;
+    slice(cur.tile, 0, cur.base, cur.e);
+    u32 ia[SPU], ib[SPU], ka[SPU], kb[SPU];
+    u32 ma = fetch(cur, ia, ka), mb;
+    __syncthreads();
+    for (;;) { // ping-pong between the two register sets
+        const SCursor n1 = advance(cur);
+        mb = fetch(n1, ib, kb);
+        apply(cur, n1, ia, ka, ma);
+        if (!n1.valid) break;
+        const SCursor n2 = advance(n1);
+        ma = fetch(n2, ia, ka);
+        apply(n1, n2, ib, kb, mb);
+        if (!n2.valid) break;
+        cur = n2;
     }
-    part[((u64)q * S + seg) * SEL + lane] = pool.e[0];
+    // merge the four wave pools
+    wpool[wave][lane] = pool.e[0];
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 4; w++) {
+            const u64 key = wpool[w][lane];
+            u64 m = __ballot(key > thr);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const u64 kk = readlane_u64(key, l);
+                if (kk > thr) {
+                    pool.insert_at(kk, pool.rank_of(kk), lane);
+                    thr = readlane_u64(pool.e[0], SEL - 1);
+                }
+            }
+        }
+        out[lane] = pool.e[0];
+    }
 }
 
 // one wave per query: merge the segment pools, optional raw-value rerank, write the top k
@@ -183,15 +297,25 @@ __global__ __launch_bounds__(64) void sparse_finish_kernel(const SparseDev ix, c
 
 struct cos_sparse {
     int32_t device = 0;
-    u32 bits = 0, T = 0, n = 0;
+    u32 bits = 0, T = 0, n = 0, n_tiles = 0;
     float upper = 1.0f;
     bool have_raw = false;
-    u32 *d_dims = nullptr, *d_vec_ids = nullptr, *d_raw_dims = nullptr;
-    u64 *d_key_off = nullptr, *d_row_off = nullptr;
+    // host side of a query's preparation: find_node, the early-termination rule, posting counts
+    std::vector<u32> h_dims;    // [T] ascending
+    std::vector<u64> h_key_off; // [T][Q + 1] (the caller's CSR offsets: list begin/end and the postings a term visits from key k0 on)
+    std::vector<u32> h_dir;     // [T] row in the tile directory or SNO_DIR
+    // device: one id-sorted list per dimension (same offsets as the caller's CSR: list t = [key_off[t][0], key_off[t][Q]))
+    u32 *d_ids = nullptr;
+    uint8_t *d_keys = nullptr;
+    u32 *d_tile_dir = nullptr; // [rows][n_tiles + 1], offsets relative to the list's begin
+    u32 *d_raw_dims = nullptr;
+    u64 *d_row_off = nullptr;
     float *d_raw_vals = nullptr;
     // grow-only workspace of cos_sparse_search_batch (no allocation on the query path once warm); `mu` serialises callers
     std::mutex mu;
-    struct Buf { void *p = nullptr; size_t cap = 0; } w_qd, w_qv, w_qo, w_acc, w_touched, w_part, w_oi, w_os, w_oc;
+    struct Buf { void *p = nullptr; size_t cap = 0; } w_qd, w_qv, w_qo, w_terms, w_qt_off, w_order, w_part, w_oi, w_os, w_oc;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    cos_sparse_stats last{};
 };
 
 struct SparseView { void *p; template <typename T> T *as() const { return (T *)p; } };
@@ -209,9 +333,11 @@ static hipError_t sparse_grow(cos_sparse::Buf &b, size_t need) {
 extern "C" int32_t cos_sparse_destroy(cos_sparse *s) {
     if (!s) return COS_OK;
     (void)hipSetDevice(s->device);
-    void *ptrs[] = {s->d_dims, s->d_vec_ids, s->d_raw_dims, s->d_key_off, s->d_row_off, s->d_raw_vals, s->w_qd.p, s->w_qv.p, s->w_qo.p,
-                    s->w_acc.p, s->w_touched.p, s->w_part.p, s->w_oi.p, s->w_os.p, s->w_oc.p};
+    void *ptrs[] = {s->d_ids, s->d_keys, s->d_tile_dir, s->d_raw_dims, s->d_row_off, s->d_raw_vals, s->w_qd.p, s->w_qv.p, s->w_qo.p,
+                    s->w_terms.p, s->w_qt_off.p, s->w_order.p, s->w_part.p, s->w_oi.p, s->w_os.p, s->w_oc.p};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
     return COS_OK;
 }
@@ -229,6 +355,7 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
             if (key_offsets[(size_t)t * (Q + 1) + k] > key_offsets[(size_t)t * (Q + 1) + k + 1]) return cos_fail(COS_ERR_INVALID, "key offsets of dimension %u decrease", dims[t]);
         if (t && key_offsets[(size_t)t * (Q + 1)] != key_offsets[(size_t)(t - 1) * (Q + 1) + Q]) return cos_fail(COS_ERR_INVALID, "posting ranges of consecutive dimensions must be contiguous");
     }
+    if (key_offsets[0] != 0) return cos_fail(COS_ERR_INVALID, "the first posting list must start at offset 0");
     const u64 nnz = key_offsets[(size_t)(n_dims - 1) * (Q + 1) + Q];
     for (u64 p = 0; p < nnz; p++)
         if (vec_ids[p] >= n_vectors) return cos_fail(COS_ERR_INVALID, "posting %llu names vector %u of %u", (unsigned long long)p, vec_ids[p], n_vectors);
@@ -238,13 +365,46 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
     HIP_TRY(hipSetDevice(device));
     cos_sparse *s = new cos_sparse();
     s->device = device; s->bits = quantization_bits; s->T = n_dims; s->n = n_vectors; s->upper = values_upper_bound;
+    s->n_tiles = (n_vectors + STILE - 1) / STILE;
+    s->h_dims.assign(dims, dims + n_dims);
+    s->h_key_off.assign(key_offsets, key_offsets + (size_t)n_dims * (Q + 1));
+    // device layout: per dimension the Q key lists merged into one list sorted by vector id ((id, key) pairs; a stable order among
+    // equal ids is irrelevant, the sums commute), and a tile directory for the long lists
+    std::vector<u32> m_ids((size_t)std::max<u64>(nnz, 1));
+    std::vector<uint8_t> m_keys((size_t)std::max<u64>(nnz, 1));
+    std::vector<u32> tile_dir;
+    s->h_dir.assign(n_dims, SNO_DIR);
+    std::vector<u64> tmp;
+    u32 rows = 0;
+    const u32 nt1 = s->n_tiles + 1;
+    for (u32 t = 0; t < n_dims; t++) {
+        const uint64_t *ko = key_offsets + (size_t)t * (Q + 1);
+        const u64 b = ko[0], e = ko[Q];
+        tmp.clear();
+        for (u32 k = 0; k < Q; k++)
+            for (u64 p = ko[k]; p < ko[k + 1]; p++) tmp.push_back((u64)vec_ids[p] << 8 | k);
+        std::sort(tmp.begin(), tmp.end());
+        for (u64 p = b; p < e; p++) { m_ids[p] = (u32)(tmp[p - b] >> 8); m_keys[p] = (uint8_t)(tmp[p - b] & 255u); }
+        if (e - b > SDIR_MIN) {
+            if (e - b > 0xFFFFFFFFull) { cos_sparse_destroy(s); return cos_fail(COS_ERR_UNIMPLEMENTED, "dimension %u holds more than 2^32 postings", dims[t]); }
+            s->h_dir[t] = rows++;
+            tile_dir.resize((size_t)rows * nt1);
+            u32 *row = tile_dir.data() + (size_t)(rows - 1) * nt1;
+            u64 p = b;
+            for (u32 tile = 0; tile <= s->n_tiles; tile++) {
+                const u64 first = (u64)tile * STILE;
+                while (p < e && m_ids[p] < first) p++;
+                row[tile] = (u32)(p - b);
+            }
+        }
+    }
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, bytes ? bytes : 1);
-        return e == hipSuccess ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : e;
+        return e == hipSuccess && bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : e;
     };
-    hipError_t e = up((void **)&s->d_dims, dims, (size_t)n_dims * 4);
-    if (e == hipSuccess) e = up((void **)&s->d_key_off, key_offsets, (size_t)n_dims * (Q + 1) * 8);
-    if (e == hipSuccess) e = up((void **)&s->d_vec_ids, vec_ids, (size_t)nnz * 4);
+    hipError_t e = up((void **)&s->d_ids, m_ids.data(), (size_t)nnz * 4);
+    if (e == hipSuccess) e = up((void **)&s->d_keys, m_keys.data(), (size_t)nnz);
+    if (e == hipSuccess) e = up((void **)&s->d_tile_dir, tile_dir.data(), tile_dir.size() * 4);
     if (e == hipSuccess && row_offsets) {
         const u64 rnnz = row_offsets[n_vectors];
         e = up((void **)&s->d_row_off, row_offsets, ((size_t)n_vectors + 1) * 8);
@@ -252,6 +412,8 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
         if (e == hipSuccess) e = up((void **)&s->d_raw_vals, raw_vals, (size_t)rnnz * 4);
         s->have_raw = true;
     }
+    if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
     if (e != hipSuccess) { cos_sparse_destroy(s); HIP_TRY(e); }
     *out = s;
     return COS_OK;
@@ -331,6 +493,10 @@ extern "C" int32_t cos_sparse_create_from_vectors(int32_t device, uint32_t quant
                              keep_raw ? row_offsets : nullptr, keep_raw ? raw_dims : nullptr, keep_raw ? raw_vals : nullptr, out);
 }
 
+// Rust `as u8` / `as u32` on f32 (saturating, NaN -> 0), host side
+static inline uint32_t host_f32_as_u8(float v) { return !(v == v) || v <= 0.0f ? 0u : (v >= 255.0f ? 255u : (uint32_t)(int)v); }
+static inline uint32_t host_f32_as_u32(float v) { return !(v == v) || v <= 0.0f ? 0u : (v >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)v); }
+
 extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims, const float *q_vals, const uint32_t *q_offsets, uint32_t B, uint32_t top_k,
                                            float early_terminate_threshold, uint32_t reranking_factor, uint32_t *out_ids, float *out_scores,
                                            uint32_t *out_counts) {
@@ -340,49 +506,82 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     const u32 kwr = top_k * (rerank ? reranking_factor : 1u);
     if (kwr > SEL) return cos_fail(COS_ERR_UNIMPLEMENTED, "top_k x reranking_factor must be <= %u", SEL);
     HIP_TRY(hipSetDevice(s->device));
-    u32 max_terms = 0;
-    for (u32 b = 0; b < B; b++) {
+    for (u32 b = 0; b < B; b++)
         if (q_offsets[b + 1] < q_offsets[b]) return cos_fail(COS_ERR_INVALID, "query offsets decrease");
-        max_terms = std::max(max_terms, q_offsets[b + 1] - q_offsets[b]);
+    const u32 nq = q_offsets[B], Q = 1u << s->bits;
+    // ---- resolve the query terms on the host (sparse_ann_query.rs:80-125): find_node, quantize, which keys the term visits ----
+    const float qf = (float)Q;
+    float etv = qf * early_terminate_threshold;
+    etv = etv > 255.0f ? 255.0f : etv;
+    const u32 early_terminate_value = host_f32_as_u8(etv), low_threshold = host_f32_as_u32(early_terminate_threshold * qf);
+    std::vector<STerm> terms;
+    terms.reserve(nq);
+    std::vector<u32> qt_off(B + 1, 0), order(B);
+    std::vector<u64> weight(B, 0);
+    u64 visited = 0;
+    for (u32 b = 0; b < B; b++) {
+        for (u32 i = q_offsets[b]; i < q_offsets[b + 1]; i++) {
+            auto it = std::lower_bound(s->h_dims.begin(), s->h_dims.end(), q_dims[i]);
+            if (it == s->h_dims.end() || *it != q_dims[i]) continue;
+            const u32 t = (u32)(it - s->h_dims.begin());
+            const u32 qq = host_sparse_quantize(q_vals[i], s->upper, s->bits);
+            const u32 k0 = qq > low_threshold ? 0u : early_terminate_value;
+            if (k0 >= Q) continue;
+            const u64 *ko = s->h_key_off.data() + (size_t)t * (Q + 1);
+            if (ko[Q] == ko[0]) continue;
+            terms.push_back(STerm{ko[0], ko[Q], s->h_dir[t], qq | k0 << 8});
+            weight[b] += ko[Q] - ko[0];
+            visited += ko[Q] - ko[k0];
+        }
+        qt_off[b + 1] = (u32)terms.size();
     }
-    const u32 nq = q_offsets[B];
-    SparseDev dev{s->d_dims, s->d_key_off, s->d_vec_ids, s->d_row_off, s->d_raw_dims, s->d_raw_vals, s->T, 1u << s->bits, s->n, s->bits, s->upper};
-    // queries are processed in chunks so that the per-query accumulators stay below 2 GiB
-    const u32 chunkB = (u32)std::max<u64>(1, std::min<u64>(B, (2ull << 30) / ((u64)s->n * 4)));
-    u32 Sg = std::max<u32>(1u, std::min<u32>(64u, std::min<u32>((s->n + 4095) / 4096, (4096 + chunkB - 1) / chunkB)));
-    const u32 seg_len = ((s->n + Sg - 1) / Sg + 63) / 64 * 64;
+    for (u32 b = 0; b < B; b++) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 c) { return weight[a] > weight[c]; }); // heaviest query first
+    // blocks: enough to fill the chip several times over, at most one per tile
+    const u32 splits = std::max<u32>(1u, std::min<u32>(s->n_tiles, (4096u + B - 1) / B));
     std::lock_guard<std::mutex> guard(s->mu);
     HIP_TRY(sparse_grow(s->w_qd, (size_t)std::max(nq, 1u) * 4));
     HIP_TRY(sparse_grow(s->w_qv, (size_t)std::max(nq, 1u) * 4));
     HIP_TRY(sparse_grow(s->w_qo, ((size_t)B + 1) * 4));
-    HIP_TRY(sparse_grow(s->w_acc, (size_t)chunkB * s->n * 4));
-    HIP_TRY(sparse_grow(s->w_touched, (size_t)chunkB * s->n));
-    HIP_TRY(sparse_grow(s->w_part, (size_t)chunkB * Sg * SEL * 8));
+    HIP_TRY(sparse_grow(s->w_terms, std::max<size_t>(terms.size(), 1) * sizeof(STerm)));
+    HIP_TRY(sparse_grow(s->w_qt_off, ((size_t)B + 1) * 4));
+    HIP_TRY(sparse_grow(s->w_order, (size_t)B * 4));
+    HIP_TRY(sparse_grow(s->w_part, (size_t)B * splits * SEL * 8));
     HIP_TRY(sparse_grow(s->w_oi, (size_t)B * top_k * 4));
     HIP_TRY(sparse_grow(s->w_os, (size_t)B * top_k * 4));
     HIP_TRY(sparse_grow(s->w_oc, (size_t)B * 4));
-    const SparseView d_qd{s->w_qd.p}, d_qv{s->w_qv.p}, d_qo{s->w_qo.p}, d_acc{s->w_acc.p}, d_touched{s->w_touched.p}, d_part{s->w_part.p}, d_oi{s->w_oi.p},
-        d_os{s->w_os.p}, d_oc{s->w_oc.p};
+    const SparseView d_qd{s->w_qd.p}, d_qv{s->w_qv.p}, d_qo{s->w_qo.p}, d_terms{s->w_terms.p}, d_qt_off{s->w_qt_off.p}, d_order{s->w_order.p},
+        d_part{s->w_part.p}, d_oi{s->w_oi.p}, d_os{s->w_os.p}, d_oc{s->w_oc.p};
     HIP_TRY(hipMemcpy(d_qd.p, q_dims, (size_t)nq * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_qv.p, q_vals, (size_t)nq * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_qo.p, q_offsets, ((size_t)B + 1) * 4, hipMemcpyHostToDevice));
-    for (u32 b0 = 0; b0 < B; b0 += chunkB) {
-        const u32 nb = std::min(chunkB, B - b0);
-        HIP_TRY(hipMemsetAsync(d_acc.p, 0, (size_t)nb * s->n * 4, 0));
-        HIP_TRY(hipMemsetAsync(d_touched.p, 0, (size_t)nb * s->n, 0));
-        if (max_terms) {
-            hipLaunchKernelGGL(sparse_accumulate_kernel, dim3(nb, max_terms), dim3(256), 0, 0, dev, d_qd.as<u32>(), d_qv.as<float>(), d_qo.as<u32>() + b0,
-                               early_terminate_threshold, d_acc.as<u32>(), d_touched.as<uint8_t>());
-            HIP_TRY(hipGetLastError());
-        }
-        hipLaunchKernelGGL(sparse_select_segments, dim3(nb, Sg), dim3(64), 0, 0, d_acc.as<u32>(), d_touched.as<uint8_t>(), s->n, seg_len, d_part.as<u64>());
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(sparse_finish_kernel, dim3(nb), dim3(64), 0, 0, dev, d_part.as<u64>(), Sg, d_qd.as<u32>(), d_qv.as<float>(), d_qo.as<u32>() + b0, top_k, kwr,
-                           rerank ? 1 : 0, d_oi.as<u32>() + (size_t)b0 * top_k, d_os.as<float>() + (size_t)b0 * top_k, d_oc.as<u32>() + b0);
-        HIP_TRY(hipGetLastError());
-    }
+    HIP_TRY(hipMemcpy(d_terms.p, terms.data(), terms.size() * sizeof(STerm), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_qt_off.p, qt_off.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_order.p, order.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    SparseDev dev{nullptr, nullptr, nullptr, s->d_row_off, s->d_raw_dims, s->d_raw_vals, s->T, Q, s->n, s->bits, s->upper};
+    HIP_TRY(hipEventRecord(s->ev0, 0));
+    hipLaunchKernelGGL(sparse_tile_kernel, dim3(B * splits), dim3(256), 0, 0, s->d_ids, s->d_keys, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,
+                       d_order.as<u32>(), splits, d_part.as<u64>());
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sparse_finish_kernel, dim3(B), dim3(64), 0, 0, dev, d_part.as<u64>(), splits, d_qd.as<u32>(), d_qv.as<float>(), d_qo.as<u32>(), top_k, kwr,
+                       rerank ? 1 : 0, d_oi.as<u32>(), d_os.as<float>(), d_oc.as<u32>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev1, 0));
     HIP_TRY(hipMemcpy(out_ids, d_oi.p, (size_t)B * top_k * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_scores, d_os.p, (size_t)B * top_k * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_counts, d_oc.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    s->last.kernel_ms = ms;
+    s->last.postings_visited = visited;
+    s->last.posting_bytes = visited * 4;
+    s->last.blocks = B * splits;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_sparse_last_stats(cos_sparse *s, cos_sparse_stats *out) {
+    if (!s || !out) return cos_fail(COS_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(s->mu);
+    *out = s->last;
     return COS_OK;
 }

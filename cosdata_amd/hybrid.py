@@ -144,6 +144,16 @@ class InvertedIndex:
         return ids, scores, counts
 
 
+def _sparse_last_stats(self):
+    """kernel time + visited postings of the most recent search_batch on this handle"""
+    st = _lib.CosSparseStats()
+    check(_lib.lib().cos_sparse_last_stats(self._h, C.byref(st)))
+    return st
+
+
+InvertedIndex.last_stats = _sparse_last_stats
+
+
 def sparse_build_csr(quantization_bits: int, values_upper_bound: float, row_offsets, raw_dims, raw_vals):
     """cos_sparse_build_csr (host code, no device): raw sparse vectors in id order -> (dims, key_offsets, vec_ids)"""
     ro, rd, rv = _c(row_offsets, np.uint64), _c(raw_dims, np.uint32), _c(raw_vals, np.float32)

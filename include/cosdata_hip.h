@@ -336,6 +336,17 @@ int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims, const flo
                                 uint32_t top_k, float early_terminate_threshold, uint32_t reranking_factor, uint32_t *out_ids,
                                 float *out_scores, uint32_t *out_counts);
 
+/* Figures of the most recent cos_sparse_search_batch on this handle: HIP-event time of its kernels, and the postings the
+ * reference's traversal visits for that batch (sparse_ann_query.rs:92-125: every list of a term from its first visited key on;
+ * 4 B each — SURVEY.md §8d counts algorithmic bytes, not what the device layout happens to read). */
+typedef struct cos_sparse_stats {
+    float kernel_ms;
+    uint32_t blocks;
+    uint64_t postings_visited;
+    uint64_t posting_bytes;
+} cos_sparse_stats;
+int32_t cos_sparse_last_stats(cos_sparse *s, cos_sparse_stats *out);
+
 /* ---- multi-GPU helper ----------------------------------------------------------------------- */
 /* S-way merge of per-shard top-k lists gathered by the caller's RCCL all-gather
  * (SURVEY.md §8e): in [S][B][k] -> out [B][k], total_cmp desc, larger id first on ties.

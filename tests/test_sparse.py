@@ -164,3 +164,38 @@ def test_index_created_from_vectors_answers_like_the_index_created_from_the_csr(
     for k, rf in ((10, 0), (8, 4)):
         ra, rb = a.search_batch(qd, qv, qo, k, 0.2, rf), b.search_batch(qd, qv, qo, k, 0.2, rf)
         assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+
+
+@pytest.mark.gpu
+def test_device_edge_cases_single_query_empty_queries_zero_weights_ragged_last_tile():
+    """one query per launch (a block per tile), a query without terms / with unknown dimensions only (no results), query values
+    that quantize to 0 (every visited vector is a result with similarity 0), n not a multiple of the 8192-id tile or of 64,
+    a duplicate dimension inside one query (visited twice, like the reference's loop), out-of-order ids inside a key list"""
+    import cosdata_amd as ca
+    bits, upper, n = 6, 3.0, 16411
+    rows, dims, key_off, vec_ids, row_off, raw_dims, raw_vals = _corpus(n=n, vocab=90, nnz=10, bits=bits, upper=upper, seed=77)
+    vec_ids = vec_ids.copy()
+    ko = np.asarray(key_off).reshape(len(dims), (1 << bits) + 1)
+    lo, hi = int(ko[3, 10]), int(ko[3, 11])
+    vec_ids[lo:hi] = vec_ids[lo:hi][::-1]                     # the order inside a (dimension, key) list is the caller's: sums commute
+    ix = ca.InvertedIndex(bits, upper, dims, key_off, vec_ids, n)
+    d0, d1 = int(dims[0]), int(dims[1])
+    queries = [(np.array([d0], np.uint32), np.array([0.0], np.float32)),                       # quantizes to 0: all similarities 0
+               (np.array([100000, 100001], np.uint32), np.array([1.0, 2.0], np.float32)),      # unknown dimensions only
+               (np.array([], np.uint32), np.array([], np.float32)),                             # no terms at all
+               (np.array([d0, d1, d0], np.uint32), np.array([1.5, 0.7, 0.2], np.float32)),      # the same dimension twice
+               (np.array([d1], np.uint32), np.array([2.9], np.float32))]
+    for thr in (0.0, 0.6):
+        for batch in ([0], [1], [2], [3], [4], [0, 1, 2, 3, 4]):
+            qs = [queries[i] for i in batch]
+            qo = np.cumsum([0] + [len(q[0]) for q in qs]).astype(np.uint32)
+            qd = np.concatenate([q[0] for q in qs] + [np.zeros(1, np.uint32)])[:qo[-1] if qo[-1] else 1]
+            qv = np.concatenate([q[1] for q in qs] + [np.zeros(1, np.float32)])[:qo[-1] if qo[-1] else 1]
+            ids, sc, cnt = ix.search_batch(qd, qv, qo, 12, thr, 0)
+            for b, q in enumerate(qs):
+                cand, sims = O.sparse_search(dims, key_off, vec_ids, n, bits, upper, thr, q[0], q[1], k_with_reranking=12)
+                c = int(cnt[b])
+                assert c == min(12, len(cand)), (thr, batch, b, c, len(cand))
+                assert np.array_equal(ids[b, :c], cand[:c]) and np.array_equal(sc[b, :c], sims[:c].astype(np.float32)), (thr, batch, b)
+    st = ix.last_stats()
+    assert st.blocks > 0 and st.kernel_ms > 0
