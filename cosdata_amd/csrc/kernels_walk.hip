@@ -280,19 +280,37 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
             u32 kwin = npool < (u32)LA ? npool : (u32)LA;
             if (kwin > wa.ef - npop) kwin = wa.ef - npop;
             // the window lives in LDS so the consume loop below is a runtime loop (small code, no extra VGPRs)
-            static_for<0, LA>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const u64 wk = pool.template peek<i>();
-                u32 v = ROW_EMPTY, nn = ROW_EMPTY;
-                if ((u32)i < kwin && (u32)lane < slots) {
-                    const u32 nd = (u32)wk;
-                    v = lv.adj_vec[(u64)nd * M + lane];
-                    nn = level == 0 ? v : lv.adj_node[(u64)nd * M + lane];
+            // All loads of the window are issued before the first value is looked at, and none is predicated (entries past kwin
+            // re-read node 0's row, lanes past `slots` the last slot; both become ROW_EMPTY afterwards).  Rounds 1-2 wrote
+            // `v = load; nn = level == 0 ? v : load2; LDS store` inside a per-entry `if`: the generated code waited for every
+            // load (s_waitcnt vmcnt(0)) before issuing the next entry's — up to eight DEPENDENT round trips per round where the
+            // comment above promised one.
+            {
+                u32 wv_[LA], wn_[LA];
+                u64 wk_[LA];
+                const u32 slot_l = (u32)lane < slots ? (u32)lane : slots - 1u;
+                static_for<0, LA>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    wk_[i] = pool.template peek<i>();
+                    const u32 nd = (u32)i < kwin ? (u32)wk_[i] : 0u;
+                    wv_[i] = lv.adj_vec[(u64)nd * M + slot_l];
+                });
+                if (level != 0) {
+                    static_for<0, LA>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const u32 nd = (u32)i < kwin ? (u32)wk_[i] : 0u;
+                        wn_[i] = lv.adj_node[(u64)nd * M + slot_l];
+                    });
                 }
-                sm.win_vec[i * 64 + lane] = v;
-                sm.win_node[i * 64 + lane] = nn;
-                if (lane == 0) sm.win_key[i] = wk;
-            });
+                static_for<0, LA>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const bool live = (u32)i < kwin && (u32)lane < slots;
+                    const u32 v = live ? wv_[i] : ROW_EMPTY;
+                    sm.win_vec[i * 64 + lane] = v;
+                    sm.win_node[i * 64 + lane] = live ? (level == 0 ? v : wn_[i]) : ROW_EMPTY;
+                    if (lane == 0) sm.win_key[i] = wk_[i];
+                });
+            }
             for (u32 wi = 0; wi < kwin; wi++) {
                 const u64 cur = sm.win_key[wi];
                 pool.pop_head(lane);

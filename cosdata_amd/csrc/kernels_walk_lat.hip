@@ -41,7 +41,7 @@ constexpr int GL = 16;  // lanes per code row
 constexpr int RPL = 64 / GL; // rows per wave pass
 constexpr int PBL = 8;  // passes in flight before the dots are consumed (32 rows)
 
-template <int ENG, int CH, int R>
+template <int ENG, int CH, int R, bool PREFETCH_ADJ>
 __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const WalkArgs wa, const u32 la) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x;
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
     u64 n_evals = 0, n_exp = 0, adj_bytes = 0, n_rounds = 0;
     int32_t status = COS_OK;
     u32 entry = ix.lv[L].root_idx;
+    u32 warm = 0; // see the L2 warm-up in step 2
 
     // similarity of ONE row, computed by lane group 0; result in every lane
     auto single_distance = [&](u32 row, float &sim_out) -> bool {
@@ -147,20 +148,34 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
             // ---- 1. adjacency rows of the window entries: independent loads, one latency -----------------------------------
             u32 av[LAL], an[LAL];
             u64 wkey[LAL]; // wave-uniform: the window entries' (key, node); entries past kwin are never looked at
+            // Every load is issued before the first value is looked at, and none is predicated: entries past kwin re-read node 0's
+            // row, lanes past `slots` re-read the last slot (both replaced by ROW_EMPTY afterwards).  The first version wrote
+            // `an[i] = level == 0 ? av[i] : ...` inside the per-entry `if`: the copy made the compiler wait for av[i] (s_waitcnt
+            // vmcnt(0)) before it issued entry i+1's load — four DEPENDENT round trips per round instead of one.
+            const u32 slot_l = (u32)lane < slots ? (u32)lane : slots - 1u;
             static_for<0, LAL>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 wkey[i] = pool.template peek<i>();
-                av[i] = ROW_EMPTY;
-                an[i] = ROW_EMPTY;
-                if ((u32)i < kwin && (u32)lane < slots) {
-                    const u32 nd = (u32)wkey[i];
-                    av[i] = lv.adj_vec[(u64)nd * M + lane];
-                    an[i] = level == 0 ? av[i] : lv.adj_node[(u64)nd * M + lane];
-                }
+                const u32 nd = (u32)i < kwin ? (u32)wkey[i] : 0u;
+                av[i] = lv.adj_vec[(u64)nd * M + slot_l];
+            });
+            if (level != 0) {
+                static_for<0, LAL>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const u32 nd = (u32)i < kwin ? (u32)wkey[i] : 0u;
+                    an[i] = lv.adj_node[(u64)nd * M + slot_l];
+                });
+            }
+            static_for<0, LAL>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const bool live = (u32)i < kwin && (u32)lane < slots;
+                av[i] = live ? av[i] : ROW_EMPTY;
+                an[i] = live ? (level == 0 ? av[i] : an[i]) : ROW_EMPTY;
             });
 
             // ---- 2. candidates: unvisited under the filter as it stands now (read only), compacted entry by entry ----------
             u32 T = 0;
+            u32 wv[2 * LAL]; // L2 warm-up loads (below)
             u32 vword[LAL]; // the filter words first (one LDS round trip for the window), then the ballots
             static_for<0, LAL>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -174,6 +189,17 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
                 const u64 cm = __ballot(c);
                 if (c) s_cl[T + (u32)__popcll(cm & lt_mask)] = (u64)av[i] | ((u64)(u32)(i * 64 + lane) << 32);
                 T += (u32)__popcll(cm);
+                // L2 warm-up: a candidate that is evaluated now is expanded a few rounds later, and its adjacency row is then the
+                // FIRST of the round's two dependent HBM round trips.  One dword per 128-byte line of that row, requested now (a lane
+                // per candidate: two load instructions per window entry, on a chip a small launch leaves idle), turns that trip
+                // into an L2 / Infinity Cache hit.  The values are folded into `warm` AFTER step 3 (loads complete in order, so by
+                // then they have arrived with the code rows and nothing waits for them on their own); `warm` is only ever written
+                // out under a condition that cannot hold, so the loads survive the optimizer.
+                if (PREFETCH_ADJ) {
+                    const u32 *arow = lv.adj_vec + (u64)(c ? an[i] : 0u) * M;
+                    wv[i] = arow[0];
+                    wv[LAL + i] = arow[M > 32 ? 32 : 0];
+                }
             });
             __builtin_amdgcn_wave_barrier();
 
@@ -227,6 +253,10 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
                     }
                     if (lig == 0 && ppos[p] != 0xFFFFFFFFu) s_spec[ppos[p]] = (u64)metric_key(metric, sim) | (bad ? (1ull << 32) : 0ull);
                 }
+            }
+            if (PREFETCH_ADJ) {
+#pragma unroll
+                for (int i = 0; i < 2 * LAL; i++) warm ^= wv[i];
             }
             __builtin_amdgcn_wave_barrier();
 
@@ -336,6 +366,7 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
         }
     }
 
+    if (warm == 0x9E3779B9u && wa.keep == 0xFFFFFFFFu) wa.out_status[qi] = (int32_t)warm; // keep is 100 / 64: never true, but not provably — keeps the warm-up loads alive
     if (lane == 0) {
         wa.out_status[qi] = status;
         if (wa.out_stats) {
@@ -356,8 +387,14 @@ template <int ENG, int CH>
 hipError_t launch_lat_r(const IndexDev &ix, const WalkArgs &wa, u32 la, hipStream_t st) {
     const size_t smem = walk_lat_smem_bytes(ix, wa.ef);
     dim3 grid(wa.B), block(64);
-    if (wa.ef <= 64) hipLaunchKernelGGL((walk_lat_kernel<ENG, CH, 1>), grid, block, smem, st, ix, wa, la);
-    else hipLaunchKernelGGL((walk_lat_kernel<ENG, CH, 4>), grid, block, smem, st, ix, wa, la);
+    static const bool warm = [] { const char *e = getenv("COS_WALK_LAT_WARM"); return !e || atoi(e) != 0; }(); // experiments: 0 = off
+    if (warm) {
+        if (wa.ef <= 64) hipLaunchKernelGGL((walk_lat_kernel<ENG, CH, 1, true>), grid, block, smem, st, ix, wa, la);
+        else hipLaunchKernelGGL((walk_lat_kernel<ENG, CH, 4, true>), grid, block, smem, st, ix, wa, la);
+    } else {
+        if (wa.ef <= 64) hipLaunchKernelGGL((walk_lat_kernel<ENG, CH, 1, false>), grid, block, smem, st, ix, wa, la);
+        else hipLaunchKernelGGL((walk_lat_kernel<ENG, CH, 4, false>), grid, block, smem, st, ix, wa, la);
+    }
     return hipGetLastError();
 }
 

@@ -1,5 +1,10 @@
 #!/bin/bash
-# GPU-box check used while developing (run from the repo root through gpurun)
-OUT=gpurun_out; mkdir -p $OUT
-timeout 600 python -m pytest tests/test_sparse.py tests/test_abi.py -m gpu -q > $OUT/r3_pytest_sparse.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/r3_pytest_sparse.log
-timeout 600 python scripts/bench_sparse.py > $OUT/r3_sparse_400k.json 2> $OUT/r3_sparse.err; echo "sparse rc=$?"; cat $OUT/r3_sparse_400k.json; tail -3 $OUT/r3_sparse.err
+# GPU-box check used while developing (run from the repo root through gpurun): one 256-query batch at a time under rocprofv3
+R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python $R/scripts/single_batch_trace.py > $OUT/r3_sb.log 2>&1
+python $R/scripts/rocprof_summary.py /tmp/p_kt/kt_results.db > $OUT/r3_single_batch_kernel_trace.txt
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d /tmp/p_s1 -o s1 -- python $R/scripts/single_batch_trace.py >> $OUT/r3_sb.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM --kernel-trace -d /tmp/p_s2 -o s2 -- python $R/scripts/single_batch_trace.py >> $OUT/r3_sb.log 2>&1
+python $R/scripts/rocprof_summary.py /tmp/p_s1/s1_results.db /tmp/p_s2/s2_results.db | grep -v "link_kernel\|evict\|claim" > $OUT/r3_single_batch_sq_counters.txt
+grep "single batch" $OUT/r3_sb.log; head -8 $OUT/r3_single_batch_kernel_trace.txt; grep "walk_lat" $OUT/r3_single_batch_sq_counters.txt

@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 n, d, B, k = 1_000_000, 768, 256, 10
 g = torch.Generator(device=dev); g.manual_seed(41)
 c = torch.randn(1000, d, generator=g, device=dev); c = c / c.norm(dim=1, keepdim=True)
-X = mixture(n, d, 42, dev, c); Q = mixture(B, d, 43, dev, c)
+X = mixture(torch, n, d, 42, dev, c); Q = mixture(torch, B, d, 43, dev, c)
 vr = ca.sample_values_range(X[:1000].cpu().numpy(), 1.0)
 ix = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), vr, 64, device=0, seed=42)
 ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
