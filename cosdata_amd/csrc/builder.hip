@@ -242,7 +242,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
         wa.out_nodes = d_out_nodes.as<u32>();
         wa.out_counts = d_out_counts.as<u32>();
         wa.out_status = d_status.as<int32_t>();
-        HIP_TRY(launch_walk(ix->eng, dev, wa, ix->lat_max_B, st));
+        HIP_TRY(launch_walk(ix->eng, dev, wa, ix->lat_max_B, ix->lat4_max_B, st));
         HIP_TRY(hipMemcpyAsync(h_status.p, d_status.p, (size_t)bs * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st)); // a failed walk leaves its lower levels unwritten: never link from it
         for (u32 b = 0; b < bs; b++)

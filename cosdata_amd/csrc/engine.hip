@@ -542,6 +542,13 @@ extern "C" int32_t cos_index_set_latency_mode(cos_index *ix, uint32_t max_querie
     ix->lat_max_B = max_queries;
     return COS_OK;
 }
+
+extern "C" int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queries) {
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->lat4_max_B = max_queries;
+    return COS_OK;
+}
 extern "C" int32_t cos_index_enable_timing(cos_index *ix, int32_t on) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null");
     std::lock_guard<std::mutex> g(ix->mu);
@@ -647,12 +654,13 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
                           hipEvent_t walk_ev = nullptr, bool chain = true) {
     IndexDev dev = cos_make_index_dev(ix);
     bool timed;
-    u32 ef, lat_max_B;
+    u32 ef, lat_max_B, lat4_max_B;
     { // one consistent snapshot of the knobs cos_index_set_* may change from another thread
         std::lock_guard<std::mutex> g(ix->mu);
         timed = ix->timing;
         ef = ix->p.ef_search;
         lat_max_B = ix->lat_max_B;
+        lat4_max_B = ix->lat4_max_B;
         dev.visited_mode = ix->p.visited_mode;
     }
     WalkArgs wa;
@@ -696,12 +704,12 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
         std::lock_guard<std::mutex> g(ix->chain_mu);
         if (ix->chain_ev && ix->chain_ev != w->walk_done) HIP_TRY(hipStreamWaitEvent(sw, ix->chain_ev, 0));
         if (timed) HIP_TRY(hipEventRecord(ev[1], sw)); // the kernel's own duration: after the wait
-        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, sw));
+        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, lat4_max_B, sw));
         HIP_TRY(hipEventRecord(w->walk_done, sw));
         ix->chain_ev = w->walk_done;
     } else {
         if (timed && sw != st) HIP_TRY(hipEventRecord(ev[1], sw));
-        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, sw));
+        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, lat4_max_B, sw));
     }
     if (timed) HIP_TRY(hipEventRecord(ev[2], sw));
     hipStream_t sf = st_fin ? st_fin : st;

@@ -20,7 +20,7 @@ hipError_t launch_link_round(const LinkArgs &a, u32 maxM, const u32 *pend, const
                              u32 count_ub, u32 round, hipStream_t st);
 hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
                                 u64 row_stride, float *mags, float *raw_mags, hipStream_t st);
-hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, hipStream_t st);
+hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, hipStream_t st);
 hipError_t launch_walk_meta(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
@@ -172,6 +172,8 @@ struct cos_index {
     u32 walk_side_min_B = 4096; // launches of at least this many queries walk on the workspace's low-priority stream; 0 = never
     // launches of at most this many queries run the latency variant of the walk (kernels_walk_lat.hip) where it applies; 0 = never
     u32 lat_max_B = COS_LATENCY_MODE_DEFAULT_MAX_B;
+    // ... and the smallest of them (one client batch) give every query four waves (kernels_walk_lat4.hip); 0 = never
+    u32 lat4_max_B = COS_LATENCY_WAVES_DEFAULT_MAX_B;
     struct FlatWs *flat_ws = nullptr; // cos_flat_search_batch's buffers (kernels_flat.hip), created on first use under `mu`
 };
 

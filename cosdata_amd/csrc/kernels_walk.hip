@@ -820,12 +820,20 @@ static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStrea
 bool walk_lat_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 max_B);
 hipError_t launch_walk_lat(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
 
+// kernels_walk_lat4.hip
+bool walk_lat4_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 max_B);
+hipError_t launch_walk_lat4(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
+
 // lat_max_B: launches of at most this many queries take the latency kernel where it applies (cos_index_set_latency_mode; 0 = never);
-// COS_WALK_LAT=<n> overrides the handle's value (experiments: 0 = off, 4294967295 = always)
-hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, hipStream_t st) {
+// lat4_max_B: the smallest of them give every query four waves (cos_index_set_latency_waves; 0 = never).
+// COS_WALK_LAT=<n> / COS_WALK_LAT4=<n> override the handle's values (experiments: 0 = off, 4294967295 = always)
+hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, hipStream_t st) {
     if (wa.B == 0) return hipSuccess;
     static const long long lat_env = [] { const char *e = getenv("COS_WALK_LAT"); return e ? atoll(e) : -1ll; }();
+    static const long long lat4_env = [] { const char *e = getenv("COS_WALK_LAT4"); return e ? atoll(e) : -1ll; }();
     if (lat_env >= 0) lat_max_B = lat_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat_env;
+    if (lat4_env >= 0) lat4_max_B = lat4_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat4_env;
+    if (walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return launch_walk_lat4(eng, ix, wa, st);
     if (walk_lat_applicable(eng, ix, wa, lat_max_B)) return launch_walk_lat(eng, ix, wa, st);
     const u32 ch = (eng == ENG_F32 || eng == ENG_F16) ? 1 : (ix.nchunks + ix.G - 1) / ix.G;
     switch (eng) {

@@ -180,6 +180,13 @@ int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode);
  * at a time per worker (indexes/mod.rs:260-272); bigger launches (coalesced batches) keep the throughput kernel. */
 #define COS_LATENCY_MODE_DEFAULT_MAX_B 2048u
 int32_t cos_index_set_latency_mode(cos_index *ix, uint32_t max_queries);
+/* Four waves per query (kernels_walk_lat4.hip) for launches of at most max_queries queries (default COS_LATENCY_WAVES_DEFAULT_MAX_B =
+ * 0: off): every query gets a workgroup of four waves — the speculative half of a round splits over the waves, the window doubles,
+ * the commit is data-parallel over the window.  Same conditions and same results, bit for bit, as the one-wave latency variant.
+ * Measured SLOWER than the one-wave kernel on MI355X (one 256-query batch, 1M x 768 u8, ef 64: 0.86 vs 0.74 ms of walk; DESIGN.md
+ * says why), so nothing selects it by default; it stays as a tested variant. */
+#define COS_LATENCY_WAVES_DEFAULT_MAX_B 0u
+int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queries);
 /* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
 int32_t cos_index_enable_timing(cos_index *ix, int32_t on);
 int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Latency variant of the walk (kernels_walk_lat.hip) against the throughput kernel on the c2 index (1M x 768 u8, ef 64 and 256):
-ms per launch for launches of 64 .. 16384 queries, window sizes 4 and 8, results compared bit for bit at every size.
+"""Latency variants of the walk (one wave per query: kernels_walk_lat.hip; four waves per query: kernels_walk_lat4.hip) against the
+throughput kernel on the c2 index (1M x 768 u8, ef 64 and 256): ms per launch for launches of 64 .. 16384 queries, results compared
+bit for bit at every size.
 Writes one JSON line per (ef, B, variant)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,9 +13,9 @@ dev = torch.device("cuda:0")
 n, d, k = int(os.environ.get("SWEEP_N", 1_000_000)), 768, 10
 g = torch.Generator(device=dev); g.manual_seed(41)
 c = torch.randn(1000, d, generator=g, device=dev); c = c / c.norm(dim=1, keepdim=True)
-X = mixture(n, d, 42, dev, c)
+X = mixture(torch, n, d, 42, dev, c)
 BMAX = 16384
-Q = mixture(BMAX, d, 43, dev, c)
+Q = mixture(torch, BMAX, d, 43, dev, c)
 vr = ca.sample_values_range(X[:1000].cpu().numpy(), 1.0)
 ix = ca.HNSWIndex(d, ca.HNSWHyperParams(), ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), vr, 64, device=0, seed=42)
 ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
@@ -42,6 +43,7 @@ for ef in (64, 256):
     ix.set_ef_search(ef)
     for B in [int(x) for x in os.environ.get("SWEEP_BS", "64,256,1024,2048,4096,8192,16384").split(",")]:
         reps = max(3, min(40, 16384 // B))
+        ix.set_latency_waves(0)
         ix.set_latency_mode(0)
         ms0, ref, st0 = run(B, reps)
         print(json.dumps({"ef": ef, "B": B, "variant": "throughput", "ms": ms0, "qps": B / ms0 * 1e3, "evals_per_q": st0.evals / B,
@@ -55,3 +57,13 @@ for ef in (64, 256):
                               "identical_to_throughput_kernel": same, "evals_per_q": st1.evals / B, "pops_per_q": st1.expansions / B,
                               "rounds_per_q": st1.reserved / B}), flush=True)
             assert same, (ef, B, la)
+        if B <= int(os.environ.get("SWEEP_LAT4_MAX_B", 4096)):
+            ix.set_latency_mode(0xFFFFFFFF)
+            ix.set_latency_waves(0xFFFFFFFF)
+            ms4, out4, st4 = run(B, reps)
+            same = all(bool(torch.equal(a, b)) for a, b in zip(ref, out4))
+            print(json.dumps({"ef": ef, "B": B, "variant": "four waves per query", "ms": ms4, "qps": B / ms4 * 1e3, "speedup": ms0 / ms4,
+                              "identical_to_throughput_kernel": same, "evals_per_q": st4.evals / B, "pops_per_q": st4.expansions / B,
+                              "rounds_per_q": st4.reserved / B}), flush=True)
+            assert same, (ef, B, "lat4")
+            ix.set_latency_waves(0)

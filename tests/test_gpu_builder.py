@@ -19,6 +19,7 @@ def _device_index(X, storage, res, metric=0, shortlist_size=64, **kw):
     dix.upload_vectors(X)
     if "latency" in kw:
         dix.set_latency_mode(kw["latency"])
+    dix.set_latency_waves(kw.get("waves", 0))   # four waves per new vector only where a test asks for it
     return dix
 
 
@@ -32,15 +33,15 @@ def _assert_same_graph(dix, oix):
 
 
 @pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2), (O.STORAGE_F32, 0), (O.STORAGE_F16, 0), (O.STORAGE_SUBBYTE, 1), (O.STORAGE_SUBBYTE, 3)])
-@pytest.mark.parametrize("n,dim,bs,latency", [(1500, 96, 64, 0), (4000, 128, 512, 0), (4000, 128, 512, 2048)])
-def test_device_build_equals_oracle_rounds(storage, res, n, dim, bs, latency):
+@pytest.mark.parametrize("n,dim,bs,latency,waves", [(1500, 96, 64, 0, 0), (4000, 128, 512, 0, 0), (4000, 128, 512, 2048, 0), (4000, 128, 512, 2048, 2048)])
+def test_device_build_equals_oracle_rounds(storage, res, n, dim, bs, latency, waves):
     """latency = cos_index_set_latency_mode: the builder's walks run on walk_kernel (0) or, for u8 / quaternary codes, on
     walk_lat_kernel (batches of <= 2048 new vectors) — same graph either way"""
     if latency and storage not in (O.STORAGE_U8,) and not (storage == O.STORAGE_SUBBYTE and res == 2):
         pytest.skip("the latency kernel covers u8 and quaternary codes")
     X = H.clustered_corpus(n, dim, n_centers=16, seed=9)
     kw = dict(num_layers=5, ef_construction=64, ef_search=64, seed=77)
-    dix = _device_index(X, storage, res, latency=latency, **kw).build(bs)
+    dix = _device_index(X, storage, res, latency=latency, waves=waves, **kw).build(bs)
     oix = O.OracleIndex(O.HNSWParams(dim=dim, storage=storage, resolution=res, **kw)).set_vectors(X).build_rounds(bs, greedy=False)[0]
     _assert_same_graph(dix, oix)
     # and the freshly built device graph answers exactly like the oracle on it
@@ -61,8 +62,8 @@ def test_device_link_graph_shapes(M, M0, shortlist, bs):
     X = H.clustered_corpus(3000, 64, n_centers=6, seed=M + M0)
     kw = dict(num_layers=4, ef_construction=48, ef_search=48, seed=5, neighbors_count=M, level0_neighbors_count=M0)
     oix = O.OracleIndex(O.HNSWParams(dim=64, shortlist_size=shortlist, **kw)).set_vectors(X).build_rounds(bs, greedy=False)[0]
-    for latency in (0, 0xFFFFFFFF):
-        dix = _device_index(X, O.STORAGE_U8, 0, shortlist_size=shortlist, latency=latency, **kw).build(bs)
+    for latency, waves in ((0, 0), (0xFFFFFFFF, 0), (0xFFFFFFFF, 0xFFFFFFFF)):
+        dix = _device_index(X, O.STORAGE_U8, 0, shortlist_size=shortlist, latency=latency, waves=waves, **kw).build(bs)
         _assert_same_graph(dix, oix)
 
 

@@ -44,21 +44,34 @@ def test_resident_codes_match_oracle(name, storage, res, dim):
     assert np.array_equal(np.asarray(mags).view(np.uint32), omags.view(np.uint32))
 
 
-WALK_VARIANTS = [("throughput kernel", 0), ("latency kernel where it applies", 0xFFFFFFFF)]
+# (name, cos_index_set_latency_mode, cos_index_set_latency_waves)
+WALK_VARIANTS = [("throughput kernel", 0, 0), ("one-wave latency kernel where it applies", 0xFFFFFFFF, 0),
+                 ("four-wave latency kernel where it applies", 0xFFFFFFFF, 0xFFFFFFFF)]
+
+
+def _set_variant(dix, max_b, max_b4):
+    dix.set_latency_mode(max_b)
+    dix.set_latency_waves(max_b4)
+
+
+def _reset_variant(dix):
+    import cosdata_amd as ca
+    dix.set_latency_mode(ca.HNSWIndex.LATENCY_MODE_DEFAULT_MAX_B)
+    dix.set_latency_waves(ca.HNSWIndex.LATENCY_WAVES_DEFAULT_MAX_B)
 
 
 def _assert_same_search(oix, dix, Q, top_k):
-    """both variants of the walk (cos_index_set_latency_mode: walk_kernel / walk_lat_kernel) must give the oracle's answer"""
+    """every variant of the walk (cos_index_set_latency_mode / _waves: walk_kernel / walk_lat_kernel / walk_lat4_kernel) must give the oracle's answer"""
     oids, osc, ocnt = oix.search_batch(Q, top_k, threads=4)[:3]
-    for vname, max_b in WALK_VARIANTS:
-        dix.set_latency_mode(max_b)
+    for vname, max_b, max_b4 in WALK_VARIANTS:
+        _set_variant(dix, max_b, max_b4)
         ids, sc, cnt = dix.batch_search(Q, top_k)
         assert np.array_equal(cnt, ocnt), vname
         for b in range(Q.shape[0]):
             c = int(cnt[b])
             assert np.array_equal(ids[b, :c], oids[b, :c]), f"{vname}: query {b}: ids differ\n{ids[b,:c]}\n{oids[b,:c]}"
             assert np.array_equal(sc[b, :c].view(np.uint32), osc[b, :c].view(np.uint32)), f"{vname}: query {b}: scores differ"
-    dix.set_latency_mode(ca_default_latency())
+    _reset_variant(dix)
 
 
 def ca_default_latency():
@@ -68,8 +81,8 @@ def ca_default_latency():
 
 def _assert_same_walk(oix, dix, Q):
     ow = [oix.ann_search(Q[b]) for b in range(Q.shape[0])]
-    for vname, max_b in WALK_VARIANTS:
-        dix.set_latency_mode(max_b)
+    for vname, max_b, max_b4 in WALK_VARIANTS:
+        _set_variant(dix, max_b, max_b4)
         ids, sims, counts = dix.ann_search_batch(Q)
         for b in range(Q.shape[0]):
             oi, osim, olc = ow[b]
@@ -80,7 +93,7 @@ def _assert_same_walk(oix, dix, Q):
                 assert np.array_equal(ids[b, s, :c], oi[off:off + c]), f"{vname}: query {b} slot {s}: walk ids differ"
                 assert np.array_equal(sims[b, s, :c].view(np.uint32), osim[off:off + c].view(np.uint32)), f"{vname}: query {b} slot {s}: sims differ"
                 off += c
-    dix.set_latency_mode(ca_default_latency())
+    _reset_variant(dix)
 
 
 @pytest.mark.parametrize("name,storage,res", STORAGES)
@@ -113,8 +126,8 @@ def test_zero_norm_query_is_calculation_error():
     Q = H.queries_from(X, 4)
     Q[2, :] = -1.0  # quantizes to all-zero bytes -> |q| = 0 -> DistanceError::CalculationError (cosine.rs:228-232)
     o = oix.search_batch(Q, 5, raise_on_error=False)
-    for _, max_b in WALK_VARIANTS:
-        dix.set_latency_mode(max_b)
+    for _, max_b, max_b4 in WALK_VARIANTS:
+        _set_variant(dix, max_b, max_b4)
         with pytest.raises(ca.CosdataError) as ei:
             dix.batch_search(Q, 5)
         assert ei.value.status == 2
