@@ -567,15 +567,15 @@ class DenseWorkload:
                 rate = 8 * Bc / (time.perf_counter() - t1)
                 return rate, (o_ids[0][:Bc].clone(), o_sc[0][:Bc].clone().view(torch.int32), o_cnt[0][:Bc].clone(), o_st[0][:Bc].clone())
             torch.cuda.synchronize(dev)
-            serial_qps, serial_out = serial_rate()              # default: one-wave latency kernel
-            ix.set_latency_waves(0xFFFFFFFF)
-            serial_qps_4w, serial_out_4w = serial_rate()        # four waves per query (walk_lat4_kernel; off by default: slower)
-            ix.set_latency_waves(ca.HNSWIndex.LATENCY_WAVES_DEFAULT_MAX_B)
+            serial_qps, serial_out = serial_rate()              # default: four waves per query (walk_lat4_kernel)
+            ix.set_latency_waves(0)
+            serial_qps_1w, serial_out_1w = serial_rate()        # one-wave latency kernel
             ix.set_latency_mode(0)
             serial_qps_tk, serial_out_tk = serial_rate()        # throughput kernel
             ix.set_latency_mode(ca.HNSWIndex.LATENCY_MODE_DEFAULT_MAX_B)
-            serial = {"qps": serial_qps, "qps_four_waves_per_query": serial_qps_4w, "qps_throughput_kernel": serial_qps_tk,
-                      "identical": all(bool(torch.equal(a, b_)) and bool(torch.equal(a, c_)) for a, b_, c_ in zip(serial_out, serial_out_tk, serial_out_4w))}
+            ix.set_latency_waves(ca.HNSWIndex.LATENCY_WAVES_DEFAULT_MAX_B)
+            serial = {"qps": serial_qps, "qps_one_wave_latency_kernel": serial_qps_1w, "qps_throughput_kernel": serial_qps_tk,
+                      "identical": all(bool(torch.equal(a, b_)) and bool(torch.equal(a, c_)) for a, b_, c_ in zip(serial_out, serial_out_tk, serial_out_1w))}
 
         # ---- optional ef_search sweep (same index, same launch shape): QPS and hold-out recall per setting ----------------------
         sweep = []
@@ -905,7 +905,7 @@ def main():
         "value_note": ("n_gpus == 1: value = queries/s over the whole corpus" if world == 1 else
                        "value = merged answers/s over the GLOBAL corpus (n_gpus x vectors_per_gpu; every query is searched on every "
                        "shard, then all-gathered and merged); shard_searches_per_s = value x n_gpus is the shard-level work"),
-        "single_batch_qps": rec["serial"]["qps"], "single_batch_qps_four_waves_per_query": rec["serial"]["qps_four_waves_per_query"],
+        "single_batch_qps": rec["serial"]["qps"], "single_batch_qps_one_wave_latency_kernel": rec["serial"]["qps_one_wave_latency_kernel"],
         "single_batch_qps_throughput_kernel": rec["serial"]["qps_throughput_kernel"],
         "single_batch_latency_walk_identical_to_throughput_walk": rec["serial"]["identical"],
         "ef_selection": rec["ef_table"], "ef_sweep": rec["sweep"], "build_seconds": rec["build_s"], "setup_seconds": time.time() - t_setup,

@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
     // The (tile, term) slices of this block, resolved once, all lookups in flight together: a chunk used to start with two
     // DEPENDENT global loads (the term's directory row, then its two entries) that nothing overlapped — with ~900 postings per slice
     // the kernel spent more time finding its slices than streaming them (0.95 ms per 256-query batch, 0.14 of the HBM roof).
-    __shared__ u64 sl_b[SLICES], sl_e[SLICES];
-    __shared__ u32 sl_w[SLICES];
+    __shared__ u64 sl_b[SLICES];
+    __shared__ u32 sl_n[SLICES], sl_w[SLICES]; // slice = [sl_b, sl_b + sl_n); a list has < 2^32 postings (cos_sparse_create)
     const u32 my_tiles = (n_tiles - split + splits - 1) / splits;
     const bool tabled = (u64)my_tiles * nt <= SLICES;
     if (tabled)
@@ -121,14 +121,14 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
             u64 b, e;
             slice_global(split + (p / nt) * splits, p % nt, b, e);
             sl_b[p] = b;
-            sl_e[p] = e;
-            sl_w[p] = qt[p % nt].qq_k0;
+            sl_n[p] = (u32)(e - b);
+            if (p < nt) sl_w[p] = qt[p].qq_k0;
         }
     auto slice = [&](u32 tile, u32 t, u64 &b, u64 &e) {
         if (tabled) {
             const u32 p = ((tile - split) / splits) * nt + t;
             b = sl_b[p];
-            e = sl_e[p];
+            e = b + sl_n[p];
         } else
             slice_global(tile, t, b, e);
     };
@@ -198,6 +198,136 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
     };
 
     __syncthreads(); // the slice table
+    // ---- stepped path (the usual case: the table holds every slice of the block and a query has <= 64 terms) --------------------
+    // A tile's slices average ~900 postings, so the block-wide chunks below (2048 posting slots per (tile, term)) ran 43 % full and
+    // the kernel was instruction-bound (135 lane-instructions per posting, profiles/r03_sparse_*_sq_counters.txt).  Here every WAVE
+    // pulls STEPS — 512 consecutive postings of one slice — from a per-tile counter in LDS: a slice of L postings is ceil(L / 512)
+    // steps, waves never wait for each other inside a tile (LDS atomic adds commute), a long slice spreads over the four waves, and
+    // the next step's postings are in flight while the current one is applied.
+    if (tabled && nt <= 64u) {
+        __shared__ u32 st_pre[65]; // exclusive prefix of the tile's per-term step counts; [nt] = total
+        __shared__ u32 st_ctr;
+        constexpr u32 STEP = 64u * SPU;
+        for (u32 ti = 0; ti < my_tiles; ti++) {
+            const u32 tile = split + ti * splits, d0 = tile * STILE;
+            if (wave == 0) { // step counts of this tile's slices -> exclusive prefix (one lane per term)
+                u32 ns = 0;
+                if ((u32)lane < nt) ns = (sl_n[ti * nt + lane] + STEP - 1u) / STEP;
+                u32 incl = ns;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const u32 o = (u32)__shfl_up((int)incl, dd, 64);
+                    if (lane >= dd) incl += o;
+                }
+                if ((u32)lane < nt) st_pre[lane] = incl - ns;
+                if ((u32)lane == nt - 1u) st_pre[nt] = incl;
+                if (lane == 0) st_ctr = 0u;
+            }
+            __syncthreads();
+            const u32 total = st_pre[nt];
+            // which slice does step k belong to: one lane per term tests its range, a ballot finds it (no dependent LDS chain)
+            const u32 my_lo = (u32)lane < nt ? st_pre[lane] : 0xFFFFFFFFu, my_hi = (u32)lane < nt ? st_pre[lane + 1] : 0u;
+            auto pull = [&]() -> u32 {
+                u32 k = 0;
+                if (lane == 0) k = atomicAdd(&st_ctr, 1u);
+                return readlane_u32(k, 0);
+            };
+            struct Step { u64 base; u32 len, w; bool valid; };
+            auto locate = [&](u32 k) -> Step {
+                Step sp;
+                sp.valid = k < total;
+                sp.base = 0; sp.len = 0; sp.w = 0;
+                if (sp.valid) {
+                    const u64 m = __ballot(k >= my_lo && k < my_hi);
+                    const u32 t = (u32)(__ffsll((long long)m) - 1);
+                    const u32 p = ti * nt + t;
+                    const u32 done = (k - readlane_u32(my_lo, (int)t)) * STEP, left = sl_n[p] - done;
+                    sp.base = sl_b[p] + done;
+                    sp.len = left < STEP ? left : STEP;
+                    sp.w = sl_w[t];
+                }
+                return sp;
+            };
+            auto fetch_s = [&](const Step &sp, u32 (&iv)[SPU], u32 (&kv)[SPU]) {
+                const u32 *ip = m_ids + sp.base;
+                const uint8_t *kp = m_keys + sp.base;
+#pragma unroll
+                for (int u = 0; u < SPU; u++) {
+                    const u32 o = (u32)lane + (u32)u * 64u;
+                    const u32 oo = o < sp.len ? o : 0u; // masked lanes re-read the step's first posting (dropped below)
+                    iv[u] = ip[oo];
+                    kv[u] = kp[oo];
+                }
+            };
+            auto apply_s = [&](const Step &sp, const u32 (&iv)[SPU], const u32 (&kv)[SPU]) {
+                const u32 qq = sp.w & 255u, k0 = sp.w >> 8;
+#pragma unroll
+                for (int u = 0; u < SPU; u++) {
+                    const u32 slot = iv[u] - d0; // a short list's postings of other tiles wrap to >= STILE
+                    if ((u32)lane + (u32)u * 64u < sp.len && slot < STILE && kv[u] >= k0) {
+                        const u32 w = qq * kv[u];
+                        if (w) atomicAdd(&acc[slot], w);
+                        else atomicOr(&zflag[slot >> 5], 1u << (slot & 31u));
+                    }
+                }
+            };
+            u32 ia[SPU], ib[SPU], ka[SPU], kb[SPU];
+            Step sa = locate(pull()), sb;
+            if (sa.valid) fetch_s(sa, ia, ka);
+            while (sa.valid) { // ping-pong between the two register sets
+                sb = locate(pull());
+                if (sb.valid) fetch_s(sb, ib, kb);
+                apply_s(sa, ia, ka);
+                if (!sb.valid) break;
+                sa = locate(pull());
+                if (sa.valid) fetch_s(sa, ia, ka);
+                apply_s(sb, ib, kb);
+            }
+            __syncthreads();
+            // flush: wave w scans slots [w * 2048, (w + 1) * 2048) of the tile, 64 at a time, into its pool
+            for (u32 s0 = (u32)wave * (STILE / 4); s0 < (u32)(wave + 1) * (STILE / 4); s0 += 64) {
+                const u32 slot = s0 + (u32)lane;
+                const u32 a = acc[slot];
+                const u32 fw = zflag[slot >> 5];
+                acc[slot] = 0u;
+                const bool reached = a != 0u || ((fw >> (slot & 31u)) & 1u);
+                const u64 key = reached ? (((u64)a + 1ull) << 32 | (u64)(d0 + slot)) : 0ull;
+                u64 m = __ballot(key > thr);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const u64 kk = readlane_u64(key, l);
+                    if (kk > thr) {
+                        pool.insert_at(kk, pool.rank_of(kk), lane);
+                        thr = readlane_u64(pool.e[0], SEL - 1);
+                    }
+                }
+            }
+            __syncthreads(); // everybody has read the flag words of its slots
+            for (u32 i = threadIdx.x; i < STILE / 32; i += blockDim.x) zflag[i] = 0u;
+            // (the next tile's prefix barrier orders these stores before its first atomic)
+        }
+        wpool[wave][lane] = pool.e[0];
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 1; w < 4; w++) {
+                const u64 key = wpool[w][lane];
+                u64 m = __ballot(key > thr);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const u64 kk = readlane_u64(key, l);
+                    if (kk > thr) {
+                        pool.insert_at(kk, pool.rank_of(kk), lane);
+                        thr = readlane_u64(pool.e[0], SEL - 1);
+                    }
+                }
+            }
+            out[lane] = pool.e[0];
+        }
+        return;
+    }
+    // ---- block-wide chunks: queries of more than 64 terms, or more (tile, term) slices than the table holds ----------------------
     SCursor cur;
     cur.tile = split; cur.t = 0; cur.valid = true;
     slice(cur.tile, 0, cur.base, cur.e);

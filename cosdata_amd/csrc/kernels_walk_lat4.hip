@@ -4,9 +4,9 @@
 // The one-wave latency kernel (kernels_walk_lat.hip) spends half of a lone batch issuing instructions — 229 k per query at ~4.5
 // clocks each (profiles/r03_single_batch_sq_counters_one_wave_latency_walk.txt) — and the other half parked on two dependent HBM
 // round trips per round.  A workgroup of four waves (one per SIMD of the query's CU) attacks both:
-//   * the window is NW x E entries (E = 2: eight), wave w owns entries w, w + 4: its adjacency rows, its candidates under the
-//     filter as it stands at the start of the round, their similarities — the whole speculative half of a round splits four ways
-//     with no exchange, and a wider window (fewer rounds, fewer dependent round trips) no longer costs a lone wave's issue time;
+//   * the window is NW x E entries (E = 1: four, the default; E = 2: eight), wave w owns entries w (, w + 4): its adjacency rows,
+//     its candidates under the filter as it stands at the start of the round, their similarities — the whole speculative half of
+//     a round splits four ways with no exchange;
 //   * the COMMIT is data-parallel over the window instead of sequential per entry (model-checked in
 //     tests/test_commit_equivalence.py: same pops, same filter, same pool wherever it can still be popped):
 //       - a candidate wins iff no EARLIER (entry, slot) of the round holds its filter bit: one LDS atomicMin of the rank
@@ -451,8 +451,9 @@ bool walk_lat4_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 m
 }
 
 hipError_t launch_walk_lat4(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
-    // window: 8 entries (two per wave) by default; COS_WALK_LAT4_E=1 -> 4 entries (experiments)
-    static const int e_env = [] { const char *e = getenv("COS_WALK_LAT4_E"); return e ? atoi(e) : 2; }();
+    // window: 4 entries (one per wave).  8 (two per wave, COS_WALK_LAT4_E=2) needs 24 % fewer rounds but measured 2.6x slower per
+    // round (profiles/r03_latency_sweep_*): the wasted evaluations and the wider merge cost every wave more than the rounds save
+    static const int e_env = [] { const char *e = getenv("COS_WALK_LAT4_E"); return e ? atoi(e) : 1; }();
     const u32 ch = (ix.nchunks + GL4 - 1) / GL4;
     if (e_env == 1) {
         if (eng == ENG_U8) return launch_lat4_ch<ENG_U8, 1>(ix, wa, ch, st);

@@ -242,7 +242,7 @@ class HNSWIndex:
         """Launches of at most `max_queries` queries take the latency variant of the walk (0 = never); same results."""
         check(_lib.lib().cos_index_set_latency_mode(self._h, max_queries))
 
-    LATENCY_WAVES_DEFAULT_MAX_B = 0  # COS_LATENCY_WAVES_DEFAULT_MAX_B (include/cosdata_hip.h): off, measured slower than one wave
+    LATENCY_WAVES_DEFAULT_MAX_B = 512  # COS_LATENCY_WAVES_DEFAULT_MAX_B (include/cosdata_hip.h)
 
     def set_latency_waves(self, max_queries: int):
         """Launches of at most `max_queries` queries give every query four waves (kernels_walk_lat4.hip; 0 = never); same results."""

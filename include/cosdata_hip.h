@@ -180,12 +180,13 @@ int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode);
  * at a time per worker (indexes/mod.rs:260-272); bigger launches (coalesced batches) keep the throughput kernel. */
 #define COS_LATENCY_MODE_DEFAULT_MAX_B 2048u
 int32_t cos_index_set_latency_mode(cos_index *ix, uint32_t max_queries);
-/* Four waves per query (kernels_walk_lat4.hip) for launches of at most max_queries queries (default COS_LATENCY_WAVES_DEFAULT_MAX_B =
- * 0: off): every query gets a workgroup of four waves — the speculative half of a round splits over the waves, the window doubles,
- * the commit is data-parallel over the window.  Same conditions and same results, bit for bit, as the one-wave latency variant.
- * Measured SLOWER than the one-wave kernel on MI355X (one 256-query batch, 1M x 768 u8, ef 64: 0.86 vs 0.74 ms of walk; DESIGN.md
- * says why), so nothing selects it by default; it stays as a tested variant. */
-#define COS_LATENCY_WAVES_DEFAULT_MAX_B 0u
+/* Four waves per query (kernels_walk_lat4.hip) for the smallest launches — at most max_queries queries (default
+ * COS_LATENCY_WAVES_DEFAULT_MAX_B: one or two client batches; 0 = never): every query gets a workgroup of four waves, each owning one
+ * entry of the lookahead window for the speculative half of a round, and the commit is data-parallel over the window.  Same conditions
+ * and same results, bit for bit, as the one-wave latency variant; it exists for the reference's literal unit of work, one
+ * `query-batch = 256` per worker (indexes/mod.rs:260-272): 0.94 vs 1.05 ms per batch at ef 64, 1.87 vs 2.35 ms at ef 256 (1M x 768 u8);
+ * from 1024 queries per launch on the one-wave kernel is faster (two of these workgroups fill a CU's registers). */
+#define COS_LATENCY_WAVES_DEFAULT_MAX_B 512u
 int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queries);
 /* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
 int32_t cos_index_enable_timing(cos_index *ix, int32_t on);

@@ -1,11 +1,13 @@
 #!/bin/bash
 # GPU-box check used while developing (run from the repo root through gpurun)
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_builder.py -m gpu -q -x > $OUT/r3_pytest_lat4.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/r3_pytest_lat4.log
-cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python $R/scripts/lat4_profile.py > $OUT/r3_l4.log 2>&1
-python $R/scripts/rocprof_summary.py /tmp/p_kt/kt_results.db | grep "walk_lat" > $OUT/r3_lat4_kernel_trace.txt
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/p_s1 -o s1 -- python $R/scripts/lat4_profile.py >> $OUT/r3_l4.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM --kernel-trace -d /tmp/p_s2 -o s2 -- python $R/scripts/lat4_profile.py >> $OUT/r3_l4.log 2>&1
-python $R/scripts/rocprof_summary.py /tmp/p_s1/s1_results.db /tmp/p_s2/s2_results.db | grep "walk_lat.*| *256 " > $OUT/r3_lat4_sq_counters.txt
-grep "single batch" $OUT/r3_l4.log; cat $OUT/r3_lat4_kernel_trace.txt; cat $OUT/r3_lat4_sq_counters.txt
+timeout 600 python -m pytest tests/test_sparse.py -m gpu -q > $OUT/r3_pytest_sparse.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/r3_pytest_sparse.log
+timeout 300 python scripts/bench_sparse.py > $OUT/r3_sparse_400k_steps.json 2> $OUT/r3_sparse.err; echo "sparse rc=$?"
+SWEEP_BS=64,256,512,1024,2048 timeout 600 python scripts/latency_sweep.py > $OUT/r3_latency_sweep_e1.jsonl 2> $OUT/r3_sweep.err; echo "sweep rc=$?"
+python - <<'P'
+import json
+j=json.loads(open("gpurun_out/r3_sparse_400k_steps.json").read()); print("sparse host ms", j["ms_per_batch_host_api"], "kernel ms", j["roofline"]["per_launch"]["avg_ms"], "frac", j["roofline"]["frac"], j["parity_vs_oracle"])
+for l in open("gpurun_out/r3_latency_sweep_e1.jsonl"):
+    j=json.loads(l)
+    if "variant" in j: print(j["ef"], j["B"], j["variant"], "ms %.3f qps %.0f" % (j["ms"], j["qps"]))
+P
