@@ -610,14 +610,18 @@ class DenseWorkload:
             def caller(j):
                 for _ in range(reps_h):
                     ix.batch_search(qh[j % len(qh)], k)
-            for j in range(S):
-                ix.batch_search(qh[j % len(qh)], k)
-            th = [threading.Thread(target=caller, args=(j,)) for j in range(S)]
-            t1 = time.perf_counter()
-            [t.start() for t in th]
-            [t.join() for t in th]
-            el_c = time.perf_counter() - t1
+            def concurrent(nc):
+                for j in range(nc):
+                    ix.batch_search(qh[j % len(qh)], k)
+                th = [threading.Thread(target=caller, args=(j,)) for j in range(nc)]
+                t1 = time.perf_counter()
+                [t.start() for t in th]
+                [t.join() for t in th]
+                return time.perf_counter() - t1
+            el_c = concurrent(S)
+            el_c1 = concurrent(S + 1)   # one caller more than launches in flight: a call's finalize + copies never delay the next walk
             host = {"queries_per_call": B, "callers": S, "qps": S * reps_h * B / el_c, "ms_per_call_per_caller": el_c / reps_h * 1e3,
+                    "qps_with_one_more_caller": (S + 1) * reps_h * B / el_c1,
                     "single_caller_qps": B / el_h, "single_caller_ms_per_call": el_h * 1e3,
                     "h2d_bytes_per_call": int(B) * d * 4, "d2h_bytes_per_call": int(B) * (k * 8 + 4),
                     "note": "cos_search_batch on pageable host memory, PCIe-inclusive.  qps: %d concurrent synchronous callers (the launches in "

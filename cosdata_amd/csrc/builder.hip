@@ -279,3 +279,240 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     guard.armed = false;
     return COS_OK; // the id-format host copy is made on demand (cos_index_download_graph_level)
 }
+
+// ================================================================================================================================
+// The pseudo-root component of a collection with a metadata schema, built on the device (rounds 1-2 took it from the
+// oracle and uploaded it).
+//   insert order: pseudo nodes, then the Metadata replicas of every embedding      api_service.rs:135-210, vector_store.rs:484-640
+//   index_embedding for such a node: every level walked from the pseudo root with the node's OWN metadata dimensions as the
+//   query's filter (walk_meta_kernel<.., INDEXING>), keep 64, its id pre-inserted in the visited filter
+//   create_node_edges with the two refusal rules of vector_store.rs:1017-1041     (link_kernel, LinkLevelDev::kind)
+// Same batch-synchronous schedule as cos_index_build — batches of min(Bmax, max(1, inserted / 4)) nodes walk the snapshot that
+// precedes them, then the round-synchronous claim / link / evict kernels connect them; oracle/cosdata_oracle_hnsw.c:
+// coso_meta_build_rounds is the CPU statement and tests/test_gpu_meta.py asserts identical graphs.  The level of every node comes
+// from the caller (the reference draws it with thread_rng; pseudo nodes from pseudo_level_probs, metadata/mod.rs:182-209).
+// ================================================================================================================================
+extern "C" int32_t cos_index_build_meta(cos_index *ix, uint32_t n_nodes, const uint32_t *node_ids, const int32_t *mbits, const uint8_t *max_levels,
+                                        uint32_t batch_size) {
+    if (!ix || !node_ids || !mbits || !max_levels || n_nodes == 0) return cos_fail(COS_ERR_INVALID, "null/empty node table");
+    constexpr u32 PSEUDO_LO = 0xFFFFFEFEu, PSEUDO_HI = 0xFFFFFFFDu;
+    u32 vmode;
+    { std::lock_guard<std::mutex> g(ix->mu); vmode = ix->p.visited_mode; }
+    if (vmode != COS_VISITED_REF) return cos_fail(COS_ERR_UNIMPLEMENTED, "the metadata component is built and searched with the reference's PerformantFixedSet filter only");
+    int32_t rc = cos_index_upload_meta_nodes(ix, n_nodes, node_ids, mbits); // validates, uploads mbits / norms, drops the old levels
+    if (rc) return rc;
+    rc = cos_set_device(ix);
+    if (rc) return rc;
+    const u32 n = ix->n, Ltop = ix->p.num_layers, L1 = Ltop + 1, metric = ix->p.metric, md = ix->meta.mdim;
+    const u32 Bmax = std::min<u32>(batch_size ? batch_size : 4096u, LINK_MAX_BATCH);
+    hipStream_t st = ix->own_stream;
+    auto is_pseudo = [&](u32 id) { return id >= PSEUDO_LO && id <= PSEUDO_HI; };
+    const std::vector<u32> &tab = ix->meta.node_ids;
+    if (!std::binary_search(tab.begin(), tab.end(), PSEUDO_LO)) return cos_fail(COS_ERR_INVALID, "the node table has no pseudo root (u32::MAX - 257)");
+    for (u32 i = 0; i < n_nodes; i++)
+        if (max_levels[i] > Ltop) return cos_fail(COS_ERR_INVALID, "node %u: level %u above num_layers %u", node_ids[i], max_levels[i], Ltop);
+    // Metadata::from (types.rs:112-126): a node whose metadata dimensions are all zero is a Base replica — it lives under the main root
+    std::vector<float> mmag(n_nodes);
+    std::vector<uint8_t> kind(n_nodes);
+    for (u32 i = 0; i < n_nodes; i++) {
+        float acc = -0.0f;
+        for (u32 j = 0; j < md; j++) { const float x = (float)mbits[(size_t)i * md + j]; acc = acc + x * x; }
+        mmag[i] = sqrtf(acc);
+        kind[i] = mmag[i] == 0.0f ? 0 : (is_pseudo(node_ids[i]) ? 1 : 2);
+    }
+    std::vector<u32> ord; // insertion order: pseudo nodes (ascending id, the root excluded), then the Metadata replicas (ascending id)
+    for (int pass = 0; pass < 2; pass++)
+        for (u32 i = 0; i < n_nodes; i++) {
+            const bool ps = is_pseudo(node_ids[i]);
+            if (node_ids[i] == PSEUDO_LO || ps != (pass == 0) || kind[i] == 0) continue;
+            ord.push_back(i);
+        }
+    const u32 total = (u32)ord.size();
+
+    struct Guard { // a failed build leaves the handle without the component (filtered search: NotReady)
+        cos_index *ix;
+        bool armed = true;
+        ~Guard() { if (armed) { (void)hipStreamSynchronize(ix->own_stream); cos_meta_free_levels(ix); } }
+    } guard{ix};
+
+    // ---- level skeletons: the root + every node whose level reaches l, ascending id; every slot empty ------------------------------
+    u32 maxM = 0;
+    std::vector<DevBuf> key(L1), low_idx(L1), low_key(L1), owner(L1), d_kind(L1);
+    std::vector<std::vector<u32>> tab_of(L1); // per level: node index -> row of the node table
+    LinkArgs la;
+    memset(&la, 0, sizeof(la));
+    ix->meta.lv.resize(L1);
+    for (u32 l = 0; l <= Ltop; l++) {
+        LevelHost &H = ix->meta.lv[l];
+        H.M = l == 0 ? ix->p.level0_neighbors_count : ix->p.neighbors_count;
+        std::vector<u32> rows; // node-table rows of this level, ascending id (the table is ascending)
+        for (u32 i = 0; i < n_nodes; i++)
+            if (node_ids[i] == PSEUDO_LO || (kind[i] != 0 && max_levels[i] >= l)) rows.push_back(i);
+        const u32 nl = (u32)rows.size(), M = H.M;
+        maxM = std::max(maxM, M);
+        H.node_ids.resize(nl);
+        std::vector<u32> node_vec(nl), node_meta(nl), child(nl);
+        std::vector<uint8_t> kd(nl);
+        for (u32 i = 0; i < nl; i++) {
+            const u32 id = node_ids[rows[i]];
+            H.node_ids[i] = id;
+            node_vec[i] = is_pseudo(id) ? n + 1 : id / ix->id_stride;
+            node_meta[i] = rows[i];
+            kd[i] = kind[rows[i]];
+            if (id == PSEUDO_LO) { H.root_idx = i; kd[i] = 1; }
+            if (l > 0) {
+                const std::vector<u32> &D = ix->meta.lv[l - 1].node_ids;
+                child[i] = (u32)(std::lower_bound(D.begin(), D.end(), id) - D.begin());
+            }
+        }
+        tab_of[l] = std::move(rows);
+        auto up = [&](u32 *&dst, const std::vector<u32> &src) -> hipError_t {
+            hipError_t e = hipMalloc((void **)&dst, std::max<size_t>(src.size(), 1) * 4);
+            return e == hipSuccess ? hipMemcpy(dst, src.data(), src.size() * 4, hipMemcpyHostToDevice) : e;
+        };
+        HIP_TRY(hipMalloc((void **)&H.d_adj_vec, (size_t)nl * M * 4));
+        HIP_TRY(hipMalloc((void **)&H.d_adj_node, (size_t)nl * M * 4));
+        HIP_TRY(hipMemsetAsync(H.d_adj_vec, 0xFF, (size_t)nl * M * 4, st));
+        HIP_TRY(hipMemsetAsync(H.d_adj_node, 0xFF, (size_t)nl * M * 4, st));
+        HIP_TRY(up(H.d_node_vec, node_vec));
+        HIP_TRY(up(H.d_node_id, H.node_ids));
+        HIP_TRY(up(H.d_node_meta, node_meta));
+        if (l > 0) HIP_TRY(up(H.d_child, child));
+        H.n = nl;
+        H.host_valid = false;
+        HIP_TRY(key[l].alloc((size_t)nl * M * 4));
+        HIP_TRY(low_idx[l].alloc(nl));
+        HIP_TRY(low_key[l].alloc((size_t)nl * 4));
+        HIP_TRY(owner[l].alloc((size_t)nl * 4));
+        HIP_TRY(d_kind[l].alloc(nl));
+        HIP_TRY(launch_fill_i32(key[l].as<int32_t>(), (u64)nl * M, INT32_MIN, st));
+        HIP_TRY(hipMemsetAsync(low_idx[l].p, 0, nl, st));
+        HIP_TRY(launch_fill_i32(low_key[l].as<int32_t>(), nl, order_key(metric, metric_min(metric)), st));
+        HIP_TRY(hipMemsetAsync(owner[l].p, 0, (size_t)nl * 4, st));
+        HIP_TRY(hipMemcpy(d_kind[l].p, kd.data(), nl, hipMemcpyHostToDevice));
+        LinkLevelDev &D = la.lv[l];
+        D.adj_vec = H.d_adj_vec;
+        D.adj_node = H.d_adj_node;
+        D.node_vec = H.d_node_vec;
+        D.key = key[l].as<int32_t>();
+        D.low_idx = low_idx[l].as<uint8_t>();
+        D.low_key = low_key[l].as<int32_t>();
+        D.owner = owner[l].as<u32>();
+        D.kind = d_kind[l].as<uint8_t>();
+        D.M = M;
+    }
+    if (maxM > 256) return cos_fail(COS_ERR_UNIMPLEMENTED, "more than 256 neighbour slots per node");
+    HIP_TRY(hipStreamSynchronize(st));
+
+    const u32 KEEP = (u32)KEEP_INDEX;
+    DevBuf d_rows, d_self, d_foff, d_fdims, d_fmags, d_qc, d_qm, d_out_ids, d_out_nodes, d_out_sims, d_out_counts, d_status, d_me, d_pend[2], d_cnt, d_evq;
+    const size_t pend_cap = (size_t)Bmax * L1, evq_cap = pend_cap * 2 * KEEP;
+    HIP_TRY(d_rows.alloc((size_t)Bmax * 4));
+    HIP_TRY(d_self.alloc((size_t)Bmax * 4));
+    HIP_TRY(d_foff.alloc(((size_t)Bmax + 1) * 4));
+    HIP_TRY(d_fdims.alloc((size_t)Bmax * md * 4));
+    HIP_TRY(d_fmags.alloc((size_t)Bmax * 4));
+    HIP_TRY(d_out_ids.alloc((size_t)Bmax * L1 * KEEP * 4));
+    HIP_TRY(d_out_nodes.alloc((size_t)Bmax * L1 * KEEP * 4));
+    HIP_TRY(d_out_sims.alloc((size_t)Bmax * L1 * KEEP * 4));
+    HIP_TRY(d_out_counts.alloc((size_t)Bmax * L1 * 4));
+    HIP_TRY(d_status.alloc((size_t)Bmax * 4));
+    HIP_TRY(d_me.alloc((size_t)Bmax * L1 * 4));
+    HIP_TRY(d_pend[0].alloc(pend_cap * 4));
+    HIP_TRY(d_pend[1].alloc(pend_cap * 4));
+    HIP_TRY(d_cnt.alloc(4 * 4));
+    HIP_TRY(d_evq.alloc(evq_cap * 3 * 4));
+    std::vector<u32> h_rows(Bmax), h_self(Bmax), h_foff(Bmax + 1), h_me((size_t)Bmax * L1), h_pend(pend_cap);
+    std::vector<int32_t> h_fdims((size_t)Bmax * md), h_status(Bmax);
+    std::vector<float> h_fmags(Bmax);
+    u32 h_cnt[4];
+
+    la.L1 = L1;
+    la.z_nodes = d_out_nodes.as<u32>();
+    la.z_sims = d_out_sims.as<float>();
+    la.z_counts = d_out_counts.as<u32>();
+    la.me = d_me.as<u32>();
+    la.metric = metric;
+    la.kmin = order_key(metric, metric_min(metric));
+    la.kmax = order_key(metric, metric_max(metric));
+
+    IndexDev dev = cos_make_meta_dev(ix);
+    dev.visited_mode = COS_VISITED_REF;
+    u32 inserted = 0, round = 0;
+    u32 *cnt = d_cnt.as<u32>();
+    while (inserted < total) {
+        const u32 bs = std::min({Bmax, std::max(1u, inserted / 4u), total - inserted});
+        u32 np = 0;
+        for (u32 b = 0; b < bs; b++) {
+            const u32 t = ord[inserted + b], id = node_ids[t];
+            h_rows[b] = is_pseudo(id) ? n + 1 : id / ix->id_stride;
+            h_self[b] = id;
+            h_foff[b] = b;
+            for (u32 j = 0; j < md; j++) h_fdims[(size_t)b * md + j] = mbits[(size_t)t * md + j];
+            h_fmags[b] = mmag[t];
+            for (u32 l = 0; l <= Ltop; l++) {
+                u32 m = NONE;
+                if (max_levels[t] >= l) {
+                    const std::vector<u32> &ids = ix->meta.lv[l].node_ids;
+                    m = (u32)(std::lower_bound(ids.begin(), ids.end(), id) - ids.begin());
+                    h_pend[np++] = (l << 16) | b;
+                }
+                h_me[(size_t)b * L1 + l] = m;
+            }
+        }
+        h_foff[bs] = bs;
+        HIP_TRY(hipMemcpyAsync(d_rows.p, h_rows.data(), (size_t)bs * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_self.p, h_self.data(), (size_t)bs * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_foff.p, h_foff.data(), ((size_t)bs + 1) * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_fdims.p, h_fdims.data(), (size_t)bs * md * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_fmags.p, h_fmags.data(), (size_t)bs * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_me.p, h_me.data(), (size_t)bs * L1 * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_pend[0].p, h_pend.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
+        h_cnt[0] = np; h_cnt[1] = 0; h_cnt[2] = 0; h_cnt[3] = 0;
+        HIP_TRY(hipMemcpyAsync(cnt, h_cnt, 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st)); // the staging vectors are pageable and rewritten by the next batch
+        WalkArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.qcodes = ix->d_codes;
+        wa.qmags = ix->d_mags;
+        wa.q_rows = d_rows.as<u32>();
+        wa.self_ids = d_self.as<u32>();
+        wa.B = bs;
+        wa.ef = ix->p.ef_construction;
+        wa.keep = KEEP;
+        wa.out_ids = d_out_ids.as<u32>();
+        wa.out_sims = d_out_sims.as<float>();
+        wa.out_nodes = d_out_nodes.as<u32>();
+        wa.out_counts = d_out_counts.as<u32>();
+        wa.out_status = d_status.as<int32_t>();
+        wa.f_dims = d_fdims.as<int32_t>();
+        wa.f_mags = d_fmags.as<float>();
+        wa.f_off = d_foff.as<u32>();
+        HIP_TRY(launch_walk_meta_index(ix->eng, dev, wa, st));
+        HIP_TRY(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)bs * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (u32 b = 0; b < bs; b++)
+            if (h_status[b] != COS_OK)
+                return cos_fail(h_status[b], "node %u of the metadata component cannot be indexed (status %d)", node_ids[ord[inserted + b]], h_status[b]);
+        u32 pending_ub = np, cur = 0;
+        while (pending_ub > 0) {
+            const u32 chunk = pending_ub > 64 ? 2 : 4;
+            for (u32 r = 0; r < chunk; r++) {
+                if (++round > LINK_MAX_ROUND) {
+                    for (u32 l = 0; l <= Ltop; l++) HIP_TRY(hipMemsetAsync(owner[l].p, 0, (size_t)ix->meta.lv[l].n * 4, st));
+                    round = 1;
+                }
+                HIP_TRY(launch_link_round(la, maxM, d_pend[cur].as<u32>(), cnt + cur, d_pend[cur ^ 1].as<u32>(), cnt + (cur ^ 1), d_evq.as<u32>(), cnt + 2,
+                                          pending_ub, round, st));
+                cur ^= 1;
+            }
+            HIP_TRY(hipMemcpyAsync(h_cnt, cnt, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            pending_ub = h_cnt[cur];
+        }
+        inserted += bs;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    guard.armed = false;
+    return COS_OK;
+}

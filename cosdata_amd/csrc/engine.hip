@@ -202,6 +202,10 @@ static void free_ws(Workspace *w) {
     delete w;
 }
 
+void cos_meta_free_levels(cos_index *ix) {
+    for (auto &l : ix->meta.lv) free_level(l);
+}
+
 // the whole pseudo-root component: levels, node table, metadata dimensions, and the id stride it imposed on the base graph.
 // After this the handle is a collection without a metadata schema again (cos_index_enable_metadata re-creates row n + 1).
 static void reset_meta(cos_index *ix) {
@@ -1351,5 +1355,33 @@ extern "C" int32_t cos_quantize_batch(uint32_t storage, uint32_t resolution, uin
     HIP_TRY(hipMemcpy(mags, bm.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     const size_t cb = cos_code_bytes(storage, resolution, dim);
     for (size_t r = 0; r < n; r++) row_to_reference_layout(eng, dim, dev.data() + r * row_stride, (uint8_t *)codes + r * cb);
+    return COS_OK;
+}
+
+
+// ---- the pseudo-root component back to the host (what cos_index_build_meta built, or what was uploaded) ------------------------------
+extern "C" int32_t cos_index_meta_level_count(cos_index *ix, uint32_t level, uint32_t *out) {
+    if (!ix || !out) return cos_fail(COS_ERR_INVALID, "null argument");
+    if (level > ix->p.num_layers || ix->meta.lv.size() != ix->p.num_layers + 1) return cos_fail(COS_ERR_INVALID, "bad level / no metadata component");
+    *out = ix->meta.lv[level].n;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_download_meta_graph_level(cos_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids) {
+    if (!ix || !node_ids || !nbr_ids) return cos_fail(COS_ERR_INVALID, "null argument");
+    if (level > ix->p.num_layers || ix->meta.lv.size() != ix->p.num_layers + 1) return cos_fail(COS_ERR_INVALID, "bad level / no metadata component");
+    const LevelHost &L = ix->meta.lv[level];
+    if (L.n == 0 || !L.d_adj_node) return cos_fail(COS_ERR_NOT_READY, "level %u of the metadata component is not resident", level);
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    std::vector<u32> adj((size_t)L.n * L.M);
+    HIP_TRY(hipMemcpy(adj.data(), L.d_adj_node, adj.size() * 4, hipMemcpyDeviceToHost));
+    for (u32 i = 0; i < L.n; i++) {
+        node_ids[i] = L.node_ids[i];
+        for (u32 j = 0; j < L.M; j++) {
+            const u32 nb = adj[(size_t)i * L.M + j];
+            nbr_ids[(size_t)i * L.M + j] = nb == ROW_EMPTY ? COS_SLOT_EMPTY : L.node_ids[nb];
+        }
+    }
     return COS_OK;
 }

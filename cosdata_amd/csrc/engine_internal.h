@@ -22,6 +22,7 @@ hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u3
                                 u64 row_stride, float *mags, float *raw_mags, hipStream_t st);
 hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, hipStream_t st);
 hipError_t launch_walk_meta(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
+hipError_t launch_walk_meta_index(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
                            u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
@@ -183,3 +184,4 @@ void cos_flat_ws_release(cos_index *ix);
 cosdev::IndexDev cos_make_index_dev(const cos_index *ix);
 cosdev::IndexDev cos_make_meta_dev(const cos_index *ix);
 int32_t cos_set_device(const cos_index *ix);
+void cos_meta_free_levels(cos_index *ix); // device arrays + host lists of every level of the pseudo-root component

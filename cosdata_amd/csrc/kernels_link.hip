@@ -208,6 +208,24 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkArgs a, const u32 *_
         return;
     }
 
+    // The candidate loop below is sequential by nature (create_node_edges), and every iteration used to start with DEPENDENT HBM
+    // round trips: the candidate's cached (lowest index, lowest key), then its row — 64 candidates x 2 trips x ~900 cycles is what a
+    // round cost (72-145 us per link_kernel call, rounds 1-2).  Everything those trips fetch is known up front:
+    //   * lane i reads candidate i's cached lowest entry NOW (all 64 in flight together) and the loop takes it from the lane's
+    //     registers — exact, because this wave owns row c for the round, a candidate appears once in the walk result, and the only
+    //     writer of c's cache is the iteration that processes c (evictions do not refresh caches, prob_node.rs:285-306);
+    //   * lane i touches both 128-byte lines of candidate i's adjacency row and key row, so the loop's row loads hit L2.
+    u32 pre_low_idx = 0, warm = 0, pre_kind = 0;
+    int32_t pre_low_key = 0;
+    const u32 self_kind = lv.kind ? (u32)lv.kind[node] : 0u;
+    if ((u32)lane < cnt) {
+        if (lv.kind) pre_kind = (u32)lv.kind[cz];
+        pre_low_idx = (u32)ld(&lv.low_idx[cz]);
+        pre_low_key = (int32_t)ld(&lv.low_key[cz]);
+        const u64 o = (u64)cz * M;
+        warm = ld(&lv.adj_node[o]) ^ (u32)ld(&lv.key[o]);
+        if (M > 32) warm ^= ld(&lv.adj_node[o + 32]) ^ (u32)ld(&lv.key[o + 32]);
+    }
     Row<SL> self;
     self.load(lv, node, lane);
     u32 s_low_idx = ld_uniform_u32(&lv.low_idx[node], lane);
@@ -234,14 +252,20 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkArgs a, const u32 *_
     for (u32 i = 0; i < cnt; i++) { // walk results in descending order until M edges succeeded (vector_store.rs:995-1074)
         if (succ >= M) break;
         const u32 c = readlane_u32(cz, (int)i);
-        const int32_t dk = order_key(a.metric, __uint_as_float(readlane_u32(__float_as_uint(cs), (int)i)));
+        const float csim = __uint_as_float(readlane_u32(__float_as_uint(cs), (int)i));
+        const int32_t dk = order_key(a.metric, csim);
+        if (lv.kind && a.metric == 0u) { // pseudo-root component, cosine: edges the reference refuses outright (vector_store.rs:1017-1041)
+            const u32 nk = readlane_u32(pre_kind, (int)i);
+            if (nk == 1u && self_kind == 2u && csim != 1.0f) continue;  // a Metadata replica links to a pseudo node only on an exact match
+            if (nk == 2u && self_kind == 2u && csim == -1.0f) continue; // two Metadata replicas whose metadata dimensions disagree
+        }
         u32 ev;
         const int r = add_neighbor<SL>(self, M, a.kmin, a.kmax, s_low_idx, s_low_key, c, dk, lane, ev);
         if (ev != NONE) drop_back_edge(ev, node);
         if (r < 0) continue;
-        // the back edge on the candidate's row
-        u32 c_low_idx = ld_uniform_u32(&lv.low_idx[c], lane);
-        int32_t c_low_key = (int32_t)ld_uniform_u32(&lv.low_key[c], lane);
+        // the back edge on the candidate's row (its cached lowest entry was read up front, see above)
+        u32 c_low_idx = readlane_u32(pre_low_idx, (int)i);
+        int32_t c_low_key = (int32_t)readlane_u32((u32)pre_low_key, (int)i);
         int r2 = -1;
         if (dk > c_low_key) {
             Row<SL> cr;
@@ -272,6 +296,7 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkArgs a, const u32 *_
     }
     self.store_all(lv, node, lane);
     if (lane == 0) { st(&lv.low_idx[node], (uint8_t)s_low_idx); st(&lv.low_key[node], s_low_key); }
+    if (warm == 0x9E3779B9u && round == 0xFFFFFFFFu) next[0] = warm; // never true (rounds stay below 2^19): keeps the warm-up loads alive
 }
 
 // ---- phase 3: evictees outside the evictor's claim drop their back edges ---------------------------------------------

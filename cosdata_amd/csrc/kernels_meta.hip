@@ -58,7 +58,11 @@ struct MetaSmem {
     float *qf;    // float engines: the query vector
 };
 
-template <int ENG, int CH, int R>
+// INDEXING = the walk of index_embedding for a node of the component itself (vector_store.rs:484-640): the "query" is a pseudo node
+// or a Metadata replica — its vector row is wa.q_rows[b], its id wa.self_ids[b] (pre-inserted in the visited filter, :807; the id
+// also says whether it is a pseudo node), its own metadata dimensions are the ONE filter of the query — the list is cut to wa.keep
+// (64), nothing is dropped for being -1.0, and the node indices are returned for the link kernels (wa.out_nodes).
+template <int ENG, int CH, int R, bool INDEXING>
 __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const WalkArgs wa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x;
@@ -79,8 +83,12 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
         p = (unsigned char *)(((size_t)p + 15) & ~(size_t)15);
         sm.qf = (float *)p;
     }
-    const uint8_t *qcode = wa.qcodes + (u64)qi * ix.row_stride;
-    const float qmag = wa.qmags[qi];
+    const u32 qrow = (INDEXING && wa.q_rows) ? wa.q_rows[qi] : qi;
+    const u32 self_id = INDEXING ? wa.self_ids[qi] : COS_QUERY_ID;
+    const bool self_pseudo = INDEXING && self_id >= PSEUDO_LO && self_id <= PSEUDO_HI;
+    const u32 keep_n = INDEXING ? wa.keep : (u32)KEEP_SEARCH;
+    const uint8_t *qcode = wa.qcodes + (u64)qrow * ix.row_stride;
+    const float qmag = wa.qmags[qrow];
     const u32 f0 = wa.f_off[qi], f1 = wa.f_off[qi + 1];
 
     constexpr bool FLOAT_ENG = ENG == ENG_F32 || ENG == ENG_F16;
@@ -151,6 +159,13 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
             sim = eq ? 1.0f : -1.0f;
             return 0;
         }
+        if (ykind == KIND_PSEUDO && xkind == KIND_PSEUDO) { // two pseudo nodes (index time only): cosine_similarity_mdims (cosine.rs:243-262)
+            const float dp = mdims_dot_ref(sm.fq, yb, md);
+            const float den = __fmul_rn(fmag, ymag);
+            if (den == 0.0f) return -COS_ERR_CALCULATION;
+            sim = __fdiv_rn(dp, den);
+            return 0;
+        }
         if (ykind == KIND_BASE && xkind == KIND_BASE) return 1;
         if (ykind == KIND_METADATA && xkind == KIND_METADATA) {
             const float dp = mdims_dot_ref(sm.fq, yb, md);
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
         const u32 bitmask = 64u * M - 1u;
         const u32 out_slot = L - (u32)level;
         for (u32 w = lane; w < 2 * M; w += 64) sm.vis[w] = 0;
-        if (lane == 0) { const u32 b = COS_QUERY_ID & bitmask; sm.vis[b >> 5] |= 1u << (b & 31); }
+        if (lane == 0) { const u32 b = self_id & bitmask; sm.vis[b >> 5] |= 1u << (b & 31); }
         u32 nacc = 0; // merged candidates so far (sm.acc)
 
         for (u32 f = f0; f < f1 && status == COS_OK; f++) {
@@ -184,7 +199,8 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
             const float fmag = wa.f_mags[f];
-            const int xkind = fmag == 0.0f ? KIND_BASE : KIND_METADATA; // a query has no id (types.rs:227-236)
+            // a query has no id (types.rs:227-236); a node being indexed has one: VectorData::replica_node_kind (types.rs:219-241)
+            const int xkind = fmag == 0.0f ? KIND_BASE : (self_pseudo ? KIND_PSEUDO : KIND_METADATA);
 
             Pool<R> pool;
             pool.clear();
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                 rk[r] = e < npop ? sm.res[e] : 0ull;
             }
             bitonic_sort_desc<R>(rk, lane);
-            const u32 keepn = npop < (u32)KEEP_SEARCH ? npop : (u32)KEEP_SEARCH;
+            const u32 keepn = npop < keep_n ? npop : keep_n;
             const u32 minus1 = metric_key(metric, -1.0f);
             u64 mk[4]; // 256 >= 100 (so far) + 100 (this walk)
 #pragma unroll
@@ -339,7 +355,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const u32 e = (u32)lane * R + r;
-                okf[r] = e < keepn && !(metric == 0u && (u32)(rk[r] >> 32) == minus1);
+                okf[r] = e < keepn && (INDEXING || !(metric == 0u && (u32)(rk[r] >> 32) == minus1));
                 mine += okf[r] ? 1u : 0u;
             }
             u32 incl = mine;
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                 if (e >= nacc && e < nacc + nsurv) mk[r] = sm.res[e - nacc];
             }
             bitonic_sort_desc<4>(mk, lane);
-            nacc = nacc + nsurv < (u32)KEEP_SEARCH ? nacc + nsurv : (u32)KEEP_SEARCH;
+            nacc = nacc + nsurv < keep_n ? nacc + nsurv : keep_n;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                 __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
                 const float fmag = wa.f_mags[f];
-                const int xkind = fmag == 0.0f ? KIND_BASE : KIND_METADATA;
+                const int xkind = fmag == 0.0f ? KIND_BASE : KIND_METADATA; // (vector_store.rs:329-367: the fallback builds the query without an id)
                 const u32 eid = lv.node_id[entry];
                 float s0 = 0.0f;
                 int dec = 0;
@@ -405,6 +421,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
             const u64 kv = sm.acc[e];
             wa.out_ids[obase + e] = lv.node_id[(u32)kv];
             wa.out_sims[obase + e] = metric_key_inv(metric, (u32)(kv >> 32));
+            if (INDEXING && wa.out_nodes) wa.out_nodes[obase + e] = (u32)kv;
         }
         if (lane == 0) wa.out_counts[(u64)qi * (L + 1) + out_slot] = nacc;
         if (level > 0) entry = lv.child[(u32)sm.acc[0]];
@@ -427,29 +444,34 @@ size_t walk_meta_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     return b + 16;
 }
 
-template <int ENG, int CH>
+template <int ENG, int CH, bool INDEXING>
 static hipError_t launch_meta_r(const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     const size_t smem = walk_meta_smem_bytes(ix, wa.ef, ENG);
     dim3 grid(wa.B), block(64);
-    if (wa.ef <= 64) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 1>), grid, block, smem, st, ix, wa);
-    else if (wa.ef <= 256) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 4>), grid, block, smem, st, ix, wa);
-    else if (wa.ef <= 512) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 8>), grid, block, smem, st, ix, wa);
+    if (wa.ef <= 64) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 1, INDEXING>), grid, block, smem, st, ix, wa);
+    else if (wa.ef <= 256) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 4, INDEXING>), grid, block, smem, st, ix, wa);
+    else if (wa.ef <= 512) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 8, INDEXING>), grid, block, smem, st, ix, wa);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
-hipError_t launch_walk_meta(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
+template <bool INDEXING>
+static hipError_t launch_walk_meta_t(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     if (wa.B == 0) return hipSuccess;
     const u32 ch = (eng == ENG_F32 || eng == ENG_F16) ? 1 : (ix.nchunks + ix.G - 1) / ix.G;
     switch (eng) {
-    case ENG_U8: return ch == 1 ? launch_meta_r<ENG_U8, 1>(ix, wa, st) : (ch == 2 ? launch_meta_r<ENG_U8, 2>(ix, wa, st) : hipErrorInvalidValue);
-    case ENG_Q2: return ch == 1 ? launch_meta_r<ENG_Q2, 1>(ix, wa, st) : hipErrorInvalidValue;
-    case ENG_Q1: return ch == 1 ? launch_meta_r<ENG_Q1, 1>(ix, wa, st) : hipErrorInvalidValue;
-    case ENG_Q3: return ch == 1 ? launch_meta_r<ENG_Q3, 1>(ix, wa, st) : hipErrorInvalidValue;
-    case ENG_F32: return launch_meta_r<ENG_F32, 1>(ix, wa, st);
-    case ENG_F16: return launch_meta_r<ENG_F16, 1>(ix, wa, st);
+    case ENG_U8: return ch == 1 ? launch_meta_r<ENG_U8, 1, INDEXING>(ix, wa, st) : (ch == 2 ? launch_meta_r<ENG_U8, 2, INDEXING>(ix, wa, st) : hipErrorInvalidValue);
+    case ENG_Q2: return ch == 1 ? launch_meta_r<ENG_Q2, 1, INDEXING>(ix, wa, st) : hipErrorInvalidValue;
+    case ENG_Q1: return ch == 1 ? launch_meta_r<ENG_Q1, 1, INDEXING>(ix, wa, st) : hipErrorInvalidValue;
+    case ENG_Q3: return ch == 1 ? launch_meta_r<ENG_Q3, 1, INDEXING>(ix, wa, st) : hipErrorInvalidValue;
+    case ENG_F32: return launch_meta_r<ENG_F32, 1, INDEXING>(ix, wa, st);
+    case ENG_F16: return launch_meta_r<ENG_F16, 1, INDEXING>(ix, wa, st);
     default: return hipErrorInvalidValue;
     }
 }
+
+hipError_t launch_walk_meta(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) { return launch_walk_meta_t<false>(eng, ix, wa, st); }
+// the walks of the component's builder (cos_index_build_meta): wa.q_rows / self_ids / keep / out_nodes as described at the kernel
+hipError_t launch_walk_meta_index(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) { return launch_walk_meta_t<true>(eng, ix, wa, st); }
 
 } // namespace cosdev

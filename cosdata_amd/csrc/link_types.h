@@ -16,6 +16,7 @@ struct LinkLevelDev {
     uint8_t *low_idx;    // [n]
     int32_t *low_key;    // [n]
     u32 *owner;          // [n] claim tag of the round that last claimed the row: (round << 13) | (8191 - batch position)
+    const uint8_t *kind; // pseudo-root component only: ReplicaNodeKind of every node (0 Base, 1 Pseudo, 2 Metadata); nullptr on base graphs
     u32 M;
 };
 

@@ -304,6 +304,24 @@ class HNSWIndex:
             check(_lib.lib().cos_index_upload_meta_graph_level(self._h, l, lid.size, _p(lid), _p(nbr)))
         return self
 
+    def build_meta(self, node_ids, mbits, max_levels, batch_size: int = 0):
+        """the pseudo-root component built on the device (cos_index_build_meta): node table + the level every node was drawn"""
+        ids, mb, ml = _c(node_ids, np.uint32), _c(mbits, np.int32), _c(max_levels, np.uint8)
+        assert mb.shape == (ids.size, self.mdim) and ml.size == ids.size
+        check(_lib.lib().cos_index_build_meta(self._h, ids.size, _p(ids), _p(mb), _p(ml), batch_size))
+        return self
+
+    def download_meta_graph(self):
+        out = []
+        for l in range(self.hnsw_params.num_layers + 1):
+            n = C.c_uint32()
+            check(_lib.lib().cos_index_meta_level_count(self._h, l, C.byref(n)))
+            ids = np.zeros(n.value, np.uint32)
+            nbr = np.zeros((n.value, self.level_M(l)), np.uint32)
+            check(_lib.lib().cos_index_download_meta_graph_level(self._h, l, _p(ids), _p(nbr)))
+            out.append((ids, nbr))
+        return out
+
     def _filters(self, filter_offsets, filter_dims):
         off, fd = _c(filter_offsets, np.uint32), _c(np.atleast_2d(filter_dims), np.int8)
         if fd.shape[1] != self.mdim or off[-1] != fd.shape[0]:

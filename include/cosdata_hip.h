@@ -216,6 +216,18 @@ int32_t cos_index_upload_meta_nodes(cos_index *ix, uint32_t n_nodes, const uint3
 /* one level of the component, same conventions as cos_index_upload_graph_level (the pseudo root is on every level) */
 int32_t cos_index_upload_meta_graph_level(cos_index *ix, uint32_t level, uint32_t n_nodes, const uint32_t *node_ids,
                                           const uint32_t *nbr_ids);
+/* The component BUILT on the device instead of uploaded: index_embedding for the pseudo nodes (ascending id), then for the
+ * Metadata replicas (ascending id) of the node table — every level walked from the pseudo root with the node's own metadata
+ * dimensions as the filter, keep 64, then create_node_edges with the refusal rules of vector_store.rs:1017-1041 (a Metadata replica
+ * links to a pseudo node only on an exact match; two Metadata replicas whose dimensions disagree are not linked) — in the same
+ * batch-synchronous schedule as cos_index_build.  max_levels[n_nodes] = the level each node was drawn (the reference draws with
+ * thread_rng: replicas from generate_level_probs, pseudo nodes from pseudo_level_probs, metadata/mod.rs:182-209); rows whose
+ * metadata dimensions are all zero are Base replicas and stay out of the component.  Replaces the node table and every level. */
+int32_t cos_index_build_meta(cos_index *ix, uint32_t n_nodes, const uint32_t *node_ids, const int32_t *mbits, const uint8_t *max_levels,
+                             uint32_t batch_size /* 0 = 4096 */);
+/* the component back on the host: node count of a level; (node_ids ascending [n_l], nbr_ids [n_l][M_l], COS_SLOT_EMPTY = null slot) */
+int32_t cos_index_meta_level_count(cos_index *ix, uint32_t level, uint32_t *out);
+int32_t cos_index_download_meta_graph_level(cos_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids);
 /* HNSWIndex::search_internal with DenseSearchInput(query, Some(filter)): the filters of query b are rows
  * [filter_offsets[b], filter_offsets[b+1]) of filter_dims[][mdim] (values -1 / 0 / 1, filter_encoded_dimensions'
  * output).  Host buffers; error behaviour as cos_search_batch. */

@@ -121,3 +121,32 @@ def test_reuploading_vectors_resets_the_whole_metadata_component():
     with pytest.raises(ca.CosdataError) as ei:
         dix.upload_meta_graph(sc.node_ids, sc.mbits, levels)
     assert ei.value.status == 3
+
+
+@pytest.mark.parametrize("storage,res,dim,bs", [(O.STORAGE_U8, 0, 64, 1), (O.STORAGE_U8, 0, 64, 48), (O.STORAGE_U8, 0, 96, 4096), (O.STORAGE_SUBBYTE, 2, 128, 256),
+                                                (O.STORAGE_F32, 0, 48, 200), (O.STORAGE_F16, 0, 72, 128)])
+def test_component_built_on_the_device_equals_the_oracle_rounds_builder(storage, res, dim, bs):
+    """cos_index_build_meta (index-mode walk_meta_kernel + the link kernels with the refusal rules of vector_store.rs:1017-1041) ==
+    coso_meta_build_rounds with the same batch size, slot for slot on every level; batches of one == the sequential reference
+    order; filtered search on the device-built component == the oracle on its own"""
+    import cosdata_amd as ca
+    sc = MH.Scenario(n=1300, dim=dim, seed=11, storage=storage, res=res)
+    oix = O.OracleIndex(sc.params).set_vectors(sc.X)
+    oix.meta_enable(MH.MDIM, MH.REPLICAS)
+    oix.build()
+    oix.meta_set_nodes(sc.node_ids, sc.mbits).meta_build_rounds(sc.max_levels, bs)
+    p = sc.params
+    hp = ca.HNSWHyperParams(num_layers=p.num_layers, ef_construction=p.ef_construction, ef_search=p.ef_search,
+                            level_0_neighbors_count=p.level0_neighbors_count, neighbors_count=p.neighbors_count)
+    dix = ca.HNSWIndex(sc.dim, hp, ca.DistanceMetric(p.metric), ca.StorageType(ca.StorageKind(p.storage), p.resolution), (p.range_lo, p.range_hi),
+                       p.shortlist_size)
+    dix.upload_vectors(sc.X).enable_metadata(MH.MDIM, MH.REPLICAS)
+    dix.upload_graph(oix.export_graph(), oix.root_raw())
+    dix.build_meta(sc.node_ids, sc.mbits, sc.max_levels, bs)
+    want = oix.meta_export_graph()
+    got = dix.download_meta_graph()
+    for l, ((gi, gn), (ei, en)) in enumerate(zip(got, want)):
+        assert np.array_equal(gi, ei), f"level {l}: node sets differ"
+        assert np.array_equal(gn, en), f"level {l}: adjacency differs in {np.count_nonzero((gn != en).any(axis=1))} of {len(en)} rows"
+    Q, off, rows, desc = sc.queries(nq=24, seed=5)
+    _assert_same_filtered(sc, oix, dix, Q, off, rows, 10)
