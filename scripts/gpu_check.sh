@@ -1,4 +1,5 @@
 #!/bin/bash
 # GPU-box check used while developing (run from the repo root through gpurun)
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_meta.py tests/test_gpu_builder.py -m gpu -q -x > $OUT/r3_pytest_meta.log 2>&1; echo "pytest rc=$?"; tail -12 $OUT/r3_pytest_meta.log
+timeout 600 python scripts/bench_meta.py > $OUT/r3_meta_200k.json 2> $OUT/r3_meta.err; echo "meta rc=$?"; cat $OUT/r3_meta_200k.json; tail -3 $OUT/r3_meta.err
+timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/r3_bench_full2.json 2> $OUT/r3_bench_full2.err; echo "bench rc=$?"; tail -3 $OUT/r3_bench_full2.err

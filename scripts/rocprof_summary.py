@@ -5,7 +5,8 @@ import sys
 
 
 def short(name):
-    for key in ("walk_lat_kernel", "walk_kernel", "finalize_kernel", "quantize_rows_kernel", "scatter_rows_kernel", "merge_topk_kernel", "flat_", "bm25_"):
+    for key in ("walk_lat4_kernel", "walk_lat_kernel", "walk_meta_kernel", "walk_kernel", "finalize_kernel", "quantize_rows_kernel", "scatter_rows_kernel",
+                "merge_topk_kernel", "flat_", "bm25_", "rrf_kernel", "sparse_tile_kernel", "sparse_finish_kernel", "link_kernel", "claim_kernel", "evict_kernel"):
         if key in name:
             i = name.index(key)
             j = name.find("(", i)
