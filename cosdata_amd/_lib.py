@@ -66,8 +66,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(_PKG, "..", "include", "cosdata_hip.h"))
     stale = force or not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force:  # every translation unit again (about a minute): the "does it build" check must not be satisfied by a shipped .so
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
     if stale:
-        cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+        cmd = ["make", "-C", CSRC, "-j", str(max(2, min(16, 2 * (os.cpu_count() or 1))))]
         if not verbose:
             cmd.append("-s")
         subprocess.check_call(cmd)
