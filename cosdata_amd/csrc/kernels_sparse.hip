@@ -79,7 +79,7 @@ struct SCursor { // block-uniform
 __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict__ m_ids, const uint8_t *__restrict__ m_keys, const STerm *__restrict__ terms,
                                                           const u32 *__restrict__ qt_off, u32 n, const u32 *__restrict__ tile_dir,
                                                           const u32 *__restrict__ order, u32 splits, u64 *__restrict__ part /*[B][splits][64]*/) {
-    __shared__ u32 acc[STILE];
+    __shared__ u32 acc[STILE + 64]; // [STILE + lane] = the lane's dummy slot for postings that do not count (one per lane: same-address LDS atomics serialise)
     __shared__ u32 zflag[STILE / 32];
     __shared__ u64 wpool[4][SEL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -248,26 +248,38 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
                 }
                 return sp;
             };
+            // The posting arrays carry STEP entries of padding (cos_sparse_create), so a step's 8 loads per lane are one base address
+            // plus compile-time offsets, never clamped; lanes past the step's end read something and drop it below.
             auto fetch_s = [&](const Step &sp, u32 (&iv)[SPU], u32 (&kv)[SPU]) {
-                const u32 *ip = m_ids + sp.base;
-                const uint8_t *kp = m_keys + sp.base;
+                const u32 *ip = m_ids + sp.base + lane;
+                const uint8_t *kp = m_keys + sp.base + lane;
 #pragma unroll
                 for (int u = 0; u < SPU; u++) {
-                    const u32 o = (u32)lane + (u32)u * 64u;
-                    const u32 oo = o < sp.len ? o : 0u; // masked lanes re-read the step's first posting (dropped below)
-                    iv[u] = ip[oo];
-                    kv[u] = kp[oo];
+                    iv[u] = ip[u * 64];
+                    kv[u] = kp[u * 64];
                 }
             };
+            // Branch-free: every lane issues its ds_add — a posting that does not count (past the step's end, another tile of a short
+            // list, a key below the term's first visited key) adds 0 to the lane's dummy slot behind the tile.  The block-chunk version spent
+            // ~70 instructions per posting slot on exec-mask bookkeeping around two predicated atomics (89 lane-instructions per posting,
+            // profiles/r03_sparse_tile_kernel_sq_counters_wave_steps.txt).  Weight-0 postings (key 0, or a query value that
+            // quantizes to 0) are rare: one wave-level test per step.
             auto apply_s = [&](const Step &sp, const u32 (&iv)[SPU], const u32 (&kv)[SPU]) {
                 const u32 qq = sp.w & 255u, k0 = sp.w >> 8;
+                bool zero_any = false;
 #pragma unroll
                 for (int u = 0; u < SPU; u++) {
                     const u32 slot = iv[u] - d0; // a short list's postings of other tiles wrap to >= STILE
-                    if ((u32)lane + (u32)u * 64u < sp.len && slot < STILE && kv[u] >= k0) {
-                        const u32 w = qq * kv[u];
-                        if (w) atomicAdd(&acc[slot], w);
-                        else atomicOr(&zflag[slot >> 5], 1u << (slot & 31u));
+                    const bool ok = (u32)lane + (u32)u * 64u < sp.len && slot < STILE && kv[u] >= k0;
+                    const u32 w = __umul24(qq, kv[u]); // both < 256: the full-rate 24-bit multiply
+                    atomicAdd(&acc[ok ? slot : STILE + (u32)lane], ok ? w : 0u);
+                    zero_any |= ok && w == 0u;
+                }
+                if (__any(zero_any)) {
+#pragma unroll
+                    for (int u = 0; u < SPU; u++) {
+                        const u32 slot = iv[u] - d0;
+                        if ((u32)lane + (u32)u * 64u < sp.len && slot < STILE && kv[u] >= k0 && qq * kv[u] == 0u) atomicOr(&zflag[slot >> 5], 1u << (slot & 31u));
                     }
                 }
             };
@@ -500,8 +512,9 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
     s->h_key_off.assign(key_offsets, key_offsets + (size_t)n_dims * (Q + 1));
     // device layout: per dimension the Q key lists merged into one list sorted by vector id ((id, key) pairs; a stable order among
     // equal ids is irrelevant, the sums commute), and a tile directory for the long lists
-    std::vector<u32> m_ids((size_t)std::max<u64>(nnz, 1));
-    std::vector<uint8_t> m_keys((size_t)std::max<u64>(nnz, 1));
+    constexpr size_t PAD = 64 * SPU; // one step of padding behind the last posting: the kernel's loads are never clamped
+    std::vector<u32> m_ids((size_t)nnz + PAD, 0u);
+    std::vector<uint8_t> m_keys((size_t)nnz + PAD, 0);
     std::vector<u32> tile_dir;
     s->h_dir.assign(n_dims, SNO_DIR);
     std::vector<u64> tmp;
@@ -532,8 +545,8 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
         hipError_t e = hipMalloc(dst, bytes ? bytes : 1);
         return e == hipSuccess && bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : e;
     };
-    hipError_t e = up((void **)&s->d_ids, m_ids.data(), (size_t)nnz * 4);
-    if (e == hipSuccess) e = up((void **)&s->d_keys, m_keys.data(), (size_t)nnz);
+    hipError_t e = up((void **)&s->d_ids, m_ids.data(), m_ids.size() * 4);
+    if (e == hipSuccess) e = up((void **)&s->d_keys, m_keys.data(), m_keys.size());
     if (e == hipSuccess) e = up((void **)&s->d_tile_dir, tile_dir.data(), tile_dir.size() * 4);
     if (e == hipSuccess && row_offsets) {
         const u64 rnnz = row_offsets[n_vectors];
