@@ -294,10 +294,32 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
             }
             if ((u32)tid <= j) s_res[npop + (u32)tid] = pool[tid];
             const u64 pk = (u32)tid < npool ? pool[tid] : 0ull; // this thread's pool entry (read before the barrier: one LDS round trip)
-            __syncthreads(); // B3: the winner list
+            if (n_valid) __syncthreads(); // B3: the winner list (uniform: nobody wrote one if no committed entry has a winner)
 
-            // ---- D. merge: pool := top-CAP of (pool minus the popped heads) U winners.  Every wave holds the winners in registers
-            // (lane l of register r = winner r * 64 + l) and broadcasts them with v_readlane: no LDS round trip inside the loops.
+            // ---- D. merge: pool := top-CAP of (pool minus the popped heads) U winners ---------------------------------------------------
+            if (n_valid == 0u) {
+                // nothing was inserted (most pops discover nothing new): the pool just loses its heads
+                if ((u32)tid > j && (u32)tid < npool) pool_nx[(u32)tid - (j + 1u)] = pk;
+            } else if (n_valid <= 64u && npool <= 64u) {
+                // the usual case at ef <= 64: pool and winners both fit ONE wave's lanes, so wave 0 merges alone with ballots and
+                // v_readlane — no LDS round trip inside the loop, no binary search (8 dependent LDS reads), the other waves wait at B4
+                if (wave == 0) {
+                    const u64 kw_l = (u32)lane < n_valid ? s_win[lane] : 0ull; // lane l = winner l
+                    const bool live_p = (u32)lane > j && (u32)lane < npool;    // lane l = pool entry l
+                    u32 pos_p = (u32)lane - (j + 1u), pos_w = 0;
+                    for (u32 w = 0; w < n_valid; w++) {
+                        const u64 kw = readlane_u64(kw_l, (int)w);
+                        pos_p += kw > pk ? 1u : 0u;                              // a pool entry moves up by the winners above it
+                        pos_w += kw > kw_l ? 1u : 0u;                            // a winner lands behind the winners above it ...
+                        const u32 above = (u32)__popcll(__ballot(live_p && pk > kw));
+                        if ((u32)lane == w) pos_w += above;                      // ... and behind the pool entries above it
+                    }
+                    if (live_p && pos_p < CAP) pool_nx[pos_p] = pk;
+                    if ((u32)lane < n_valid && pos_w < CAP) pool_nx[pos_w] = kw_l;
+                }
+            } else {
+            // general case: every wave holds the winners in registers (lane l of register r = winner r * 64 + l) and broadcasts them with
+            // v_readlane; pool entries are spread over the workgroup's threads, winners' registers over the waves
             constexpr int WR = (int)((LA * 64u + 63u) / 64u); // registers for up to LA * 64 winners
             u64 wreg[WR];
 #pragma unroll
@@ -343,6 +365,7 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
 #pragma unroll
             for (int r = 0; r < WR; r++)
                 if ((u32)(r * 64 + lane) < n_valid && wave == (r & (NW - 1)) && pos_w[r] < CAP) pool_nx[pos_w[r]] = wreg[r];
+            }
             n_evals += n_valid;
             n_exp += j + 1u;
             adj_bytes += (u64)(j + 1u) * M * 4;
