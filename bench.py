@@ -309,7 +309,7 @@ class DenseWorkload:
         self.quantization, self.build_batch = quantization, build_batch
         self.k, self.Bc, self.C = args.top_k, args.batch, max(1, args.coalesce)
         self.B = self.Bc * self.C
-        self.S = max(1, args.inflight)
+        self.S = args.inflight if args.inflight > 0 else (3 if env.dist_on else 2)
         self.nrq = args.recall_queries
         dev, rank, world = env.dev, env.rank, env.world
         n = self.n
@@ -829,7 +829,9 @@ def main():
     ap.add_argument("--coalesce", type=int, default=128, help="client batches fused per launch (dynamic batching); 128 x 256 = 32768 queries "
                     "refill the chip's 7168 wave slots several times over, so one launch runs the walk kernel at 0.9 of the HBM roof "
                     "(8192-query launches: 0.71 — every wave is resident at once and the chip drains as they finish)")
-    ap.add_argument("--inflight", type=int, default=2, help="launches kept in flight (HIP streams)")
+    ap.add_argument("--inflight", type=int, default=0, help="launches kept in flight (HIP streams); 0 = auto: 2, or 3 when every launch is followed by "
+                    "the exchange step (N > 1): the all-gather waits for a finalize that shares the HBM with the next walk, a third launch keeps "
+                    "the walk chain fed meanwhile (forced-dist run: 0.96 of the non-dist rate against 0.91 with two)")
     ap.add_argument("--ef", default="auto", help="ef_search: an integer, or 'auto' = smallest of 32,48,64,96,128,192,256,384,512 whose recall@10 "
                     "on the SELECTION query set clears --recall-target with 95 %% confidence (the metric is QPS AT recall@10 >= 0.95); "
                     "config.toml default is 256")

@@ -50,13 +50,25 @@ __device__ __forceinline__ int32_t order_key(u32 metric, float v) {
     return (metric == 1u || metric == 2u) ? ~b : b;
 }
 
+// minimum over the wave of a u32, in the VALU (DPP) like group_reduce_add_u32: no ds_bpermute round trips.  The candidate loop of
+// link_kernel is a dependent chain per wave, and its two `lowest` scans per candidate used to be 12 ds_bpermute each (~60 clocks a
+// piece): more than the row loads they sit between.
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+    u32 o;
+    o = dpp_mov<0xB1>(0xFFFFFFFFu, v); v = o < v ? o : v;   // quad_perm [1,0,3,2]
+    o = dpp_mov<0x4E>(0xFFFFFFFFu, v); v = o < v ? o : v;   // quad_perm [2,3,0,1]
+    o = dpp_mov<0x141>(0xFFFFFFFFu, v); v = o < v ? o : v;  // row_half_mirror
+    o = dpp_mov<0x140>(0xFFFFFFFFu, v); v = o < v ? o : v;  // row_mirror: every lane of a 16-lane row holds the row's minimum
+    const u32 a = readlane_u32(v, 0), b = readlane_u32(v, 16), c = readlane_u32(v, 32), d = readlane_u32(v, 48);
+    const u32 ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+// minimum of (hi, lo) pairs in lexicographic order = two u32 reductions (the second over the lanes that hold the minimal hi)
 __device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        const u64 o = shfl_xor_u64(v, m);
-        v = o < v ? o : v;
-    }
-    return v;
+    const u32 hi = (u32)(v >> 32), lo = (u32)v;
+    const u32 mh = wave_min_u32(hi);
+    const u32 ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((u64)mh << 32) | ml;
 }
 
 // One row of a level (M slots: slot j lives in lane j % 64, register j / 64) — the wave-level mirror of ProbNode.neighbors.
@@ -107,8 +119,8 @@ struct Row {
 #pragma unroll
         for (int s = 0; s < SL; s++)
             if ((slot >> 6) == (u32)s) { n = nb[s]; k = nk[s]; }
-        n_out = (u32)__shfl((int)n, (int)(slot & 63u), 64);
-        k_out = __shfl(k, (int)(slot & 63u), 64);
+        n_out = readlane_u32(n, (int)(slot & 63u)); // `slot` is wave-uniform (a cached lowest index / a returned slot)
+        k_out = (int32_t)readlane_u32((u32)k, (int)(slot & 63u));
     }
     __device__ __forceinline__ void set(u32 slot, u32 n, int32_t k, int lane) {
 #pragma unroll
@@ -232,19 +244,23 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkArgs a, const u32 *_
     int32_t s_low_key = (int32_t)ld_uniform_u32(&lv.low_key[node], lane);
     const u32 node_vec = lv.adj_vec != lv.adj_node ? lv.node_vec[node] : node;
 
-    // evictee `old` drops its back edge to `target`: now if the row is in this node's claim, else at the end of the round
-    auto drop_back_edge = [&](u32 old, u32 target) {
-        const bool own = ld_uniform_u32(&lv.owner[old], lane) == tag;
+    // evictee `old` drops its back edge to `target`: now if the row is in this node's claim, else at the end of the round.
+    // Whether the row is ours needs no memory access: a runnable node owns exactly the rows it claimed — itself and its candidates —
+    // so the test is a ballot over the candidate registers (it used to be a dependent load of owner[old]: an HBM miss per eviction,
+    // and in a mature graph nearly every accepted edge evicts somebody).  Evictions outside the claim are parked in the lane of the
+    // candidate that caused them (one for the node's own row, one for the candidate's row) and queued with ONE atomic at the end
+    // (the queue counter used to be bumped, and waited for, once per eviction).
+    u32 q_old[2] = {NONE, NONE}, q_tgt[2] = {NONE, NONE}; // lane i: evictions caused while processing candidate i
+    auto drop_back_edge = [&](u32 old, u32 target, u32 i, int which) {
+        const bool own = old == node || __any((u32)lane < cnt && cz == old);
         if (own) {
             Row<SL> r;
             r.load(lv, old, lane);
             const u32 j = r.find(target, M, lane);
             if (j != NONE) { r.set(j, NONE, EMPTY_KEY, lane); r.store_slot(lv, old, j, lane); }
-        } else if (lane == 0) {
-            const u32 q = atomicAdd(evq_count, 1u);
-            evq[3 * (u64)q + 0] = level;
-            evq[3 * (u64)q + 1] = old;
-            evq[3 * (u64)q + 2] = target;
+        } else if ((u32)lane == i) {
+            q_old[which] = old;
+            q_tgt[which] = target;
         }
     };
 
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkArgs a, const u32 *_
         }
         u32 ev;
         const int r = add_neighbor<SL>(self, M, a.kmin, a.kmax, s_low_idx, s_low_key, c, dk, lane, ev);
-        if (ev != NONE) drop_back_edge(ev, node);
+        if (ev != NONE) drop_back_edge(ev, node, i, 0);
         if (r < 0) continue;
         // the back edge on the candidate's row (its cached lowest entry was read up front, see above)
         u32 c_low_idx = readlane_u32(pre_low_idx, (int)i);
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkArgs a, const u32 *_
                 }
             }
             if (lane == 0) { st(&lv.low_idx[c], (uint8_t)c_low_idx); st(&lv.low_key[c], c_low_key); }
-            if (ev != NONE) drop_back_edge(ev, c);
+            if (ev != NONE) drop_back_edge(ev, c, i, 1);
         }
         if (r2 >= 0) succ++;
         else { // remove_neighbor_by_index_and_id: the forward half is rolled back if the slot still holds the candidate
@@ -296,6 +312,24 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkArgs a, const u32 *_
     }
     self.store_all(lv, node, lane);
     if (lane == 0) { st(&lv.low_idx[node], (uint8_t)s_low_idx); st(&lv.low_key[node], s_low_key); }
+    { // queue the parked evictions: one counter bump per wave
+        const u64 m0 = __ballot(q_old[0] != NONE), m1 = __ballot(q_old[1] != NONE);
+        const u32 n0 = (u32)__popcll(m0), n1 = (u32)__popcll(m1);
+        if (n0 + n1) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(evq_count, n0 + n1);
+            base = readlane_u32(base, 0);
+            const u64 lt = (1ull << lane) - 1ull;
+            if (q_old[0] != NONE) {
+                const u64 q = (u64)base + (u32)__popcll(m0 & lt);
+                evq[3 * q + 0] = level; evq[3 * q + 1] = q_old[0]; evq[3 * q + 2] = q_tgt[0];
+            }
+            if (q_old[1] != NONE) {
+                const u64 q = (u64)base + n0 + (u32)__popcll(m1 & lt);
+                evq[3 * q + 0] = level; evq[3 * q + 1] = q_old[1]; evq[3 * q + 2] = q_tgt[1];
+            }
+        }
+    }
     if (warm == 0x9E3779B9u && round == 0xFFFFFFFFu) next[0] = warm; // never true (rounds stay below 2^19): keeps the warm-up loads alive
 }
 
