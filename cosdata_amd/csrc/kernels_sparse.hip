@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
     __shared__ u32 acc[STILE + 64]; // [STILE + lane] = the lane's dummy slot for postings that do not count (one per lane: same-address LDS atomics serialise)
     __shared__ u32 zflag[STILE / 32];
     __shared__ u64 wpool[4][SEL];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u32 q = order[blockIdx.x / splits];
     const u32 split = blockIdx.x % splits;
     const u32 t0 = qt_off[q], nt = qt_off[q + 1] - t0;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr u32 CAP = 64u * R;
     constexpr u32 LA = (u32)(NW * E);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index in an SGPR: its tests are scalar branches
     const u32 qi = blockIdx.x;
     if (qi >= wa.B) return;
 
@@ -263,24 +263,25 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
             // ---- C. commit horizon; the winners of the committed entries are appended; filter bits; popped list --------------------
             // (the flags are read by one lane each and combined with ballots: a loop of dependent LDS reads costs a lone wave
             // ~130 clocks per iteration)
-            u32 j, n_valid = 0, my_base[E];
-            {
+            u32 j = kwin - 1u, n_valid = 0, my_base[E];
+            {   // the <= LA flags are read by one lane each, broadcast with v_readlane and combined in scalar registers (a scan with
+                // __shfl_up is five ds_bpermute round trips, ~300 clocks for a lone wave)
                 const u32 f = (u32)lane < kwin ? s_flag[lane] : 0u;
-                const u64 stale_m = __ballot(f & 1u);
-                j = stale_m ? (u32)(__ffsll((long long)stale_m) - 1) : kwin - 1u;
-                const u64 upto = j >= 63u ? ~0ull : ((2ull << j) - 1ull); // entries 0..j
-                if (__ballot(f & 2u) & upto) failed = true; // a committed entry has a winner with a zero denominator -> CalculationError
-                // winners of entries 0..j, and where each committed entry's winners start in the list (entry order)
-                u32 cntl = ((u32)lane <= j) ? (f >> 8) : 0u;
-                u32 incl = cntl;
+                bool found = false;
 #pragma unroll
-                for (int d = 1; d < 16; d <<= 1) { // LA <= 8 < 16 lanes: inclusive scan over the first lanes
-                    const u32 o = (u32)__shfl_up((int)incl, d, 64);
-                    if (lane >= d) incl += o;
+                for (int i = 0; i < E; i++) my_base[i] = 0;
+#pragma unroll
+                for (int e = 0; e < (int)LA; e++) {
+                    const u32 fe = readlane_u32(f, e);
+                    if ((u32)e < kwin && !found) {
+#pragma unroll
+                        for (int i = 0; i < E; i++)
+                            if ((u32)(i * NW + wave) == (u32)e) my_base[i] = n_valid; // where this wave's committed entry puts its winners
+                        n_valid += fe >> 8;
+                        if (fe & 2u) failed = true; // a committed entry has a winner with a zero denominator -> CalculationError
+                        if (fe & 1u) { j = (u32)e; found = true; }
+                    }
                 }
-                n_valid = readlane_u32(incl, 15);
-#pragma unroll
-                for (int i = 0; i < E; i++) my_base[i] = (u32)__shfl((int)(incl - cntl), i * NW + wave, 64);
             }
             if (failed) break; // uniform
 #pragma unroll
