@@ -740,10 +740,9 @@ class DenseWorkload:
             oix.search_batch(Qh[:nq], k, threads=cores)
         cpu_s = time.perf_counter() - t2
         cpu = {"value": reps * nq / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
-               "sample": f"{reps} passes over {nq} queries of the same workload ({cpu_s:.1f} s wall on {cores} threads = usable "
-                         f"cores: affinity/cgroup quota; host reports {os.cpu_count()} logical CPUs), C/AVX2 restatement of the Rust "
-                         f"path (oracle/), one OpenMP thread per core like batch_search's rayon fan-out"
-                         + ("" if full_raw else "; corpus quantized by the oracle in streamed chunks, rerank rows fetched per candidate")}
+               "sample": f"{reps} passes over {nq} queries of the same workload ({cpu_s:.1f} s wall on {cores} usable cores of {os.cpu_count()} logical "
+                         f"CPUs), oracle/ (C/AVX2 restatement of the Rust path), one OpenMP thread per core like rayon's fan-out"
+                         + ("" if full_raw else "; corpus quantized by the oracle in streamed chunks")}
         # parity check on the same sample: GPU ids/scores vs oracle, bit for bit
         o_ids, o_sc, o_cnt, o_st, streams = self.o_ids, self.o_sc, self.o_cnt, self.o_st, self.streams
         gi = np.zeros((nq, k), np.uint32)
@@ -766,14 +765,88 @@ class DenseWorkload:
 
 
 def compact_dense_record(rec, world):
-    """a dense workload's record as it appears under `configs` (same fields as the main line, trimmed)"""
+    """a dense workload's record as it appears under `configs`: the main line's fields, trimmed to what differs (the line is parsed by
+    the driver from the process's stdout: the five records together stay around 10 KB)"""
     r, se, lo = rec["recall"]
-    return {"config": rec["config"], "qps": rec["value"], "unit": "queries/s", "ms_per_step": rec["elapsed"] / rec["steps"] * 1e3,
+    c = rec["config"]
+    roof = {k: v for k, v in rec["roofline"].items() if k not in ("note", "aggregate", "empirical")}
+    return {"config": {k: c[k] for k in ("workload", "standard_size", "vectors_per_gpu", "dim", "queries_per_step", "launches_in_flight", "top_k", "ef_search",
+                                          "ef_construction", "build_visited", "visited", "storage", "corpus", "parallelism")},
+            "qps": rec["value"], "unit": "queries/s", "ms_per_step": rec["elapsed"] / rec["steps"] * 1e3,
             "steps": rec["steps"], "warmup": rec["warmup"], "dtype": "u8",
             "recall_at_10": r, "recall_stderr": se, "recall_lower95": lo, "meets_recall_target": bool(lo >= 0.95),
-            "ef_selection": rec["ef_table"], "failed_queries": rec["status_bad"], "build_seconds": rec["build_s"], "seconds": rec["seconds"],
+            "ef_selection": [[e["ef_search"], round(e["recall_at_10"], 4)] for e in rec["ef_table"]],
+            "failed_queries": rec["status_bad"], "build_seconds": rec["build_s"], "seconds": rec["seconds"],
             "shard_searches_per_s": rec["value"] * world,
-            "roofline": rec["roofline"], "cpu_baseline": rec["cpu"], "parity_vs_oracle": rec["parity"], "result_properties": rec["props"]}
+            "roofline": roof, "cpu_baseline": rec["cpu"], "parity_vs_oracle": rec["parity"], "result_properties": rec["props"]}
+
+
+def _slim_roofline(r):
+    if not r:
+        return r
+    keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel") if k in r}
+    pl = r.get("per_launch") or {}
+    keep["per_launch"] = {k: pl[k] for k in ("algorithmic_bytes", "avg_ms", "gemm_ms_all_launches", "int8_ops", "launches_sampled", "finalize_ms") if k in pl}
+    if r.get("empirical"):
+        keep["empirical"] = {k: r["empirical"][k] for k in ("stream_read_GBps", "row_gather_GBps") if k in r["empirical"]}
+    return keep
+
+
+def _slim_cpu(c):
+    return {k: (v if k != "sample" else v[:120]) for k, v in c.items()} if c else c
+
+
+def slim_line(out):
+    """the stdout line: every result of the full record, none of its prose"""
+    o = dict(out)
+    o["config"] = {k: v for k, v in out["config"].items() if k not in ("step", "ef_policy", "exchange", "corpus", "storage", "parallelism")}
+    o["config"]["storage"] = out["config"]["storage"][:48]
+    o["config"]["parallelism"] = out["config"]["parallelism"]
+    for k in ("value_note", "recall_sets"):
+        o.pop(k, None)
+    o["roofline"] = _slim_roofline(out.get("roofline"))
+    o["cpu_baseline"] = _slim_cpu(out.get("cpu_baseline"))
+    o["ef_selection"] = [[e["ef_search"], round(e["recall_at_10"], 4)] for e in out.get("ef_selection", [])]
+    o["ef_sweep"] = [{k: e[k] for k in ("ef_search", "visited", "qps", "recall_at_10", "walk_ms")} for e in out.get("ef_sweep", [])]
+    if out.get("host_api_pcie_inclusive"):
+        o["host_api_pcie_inclusive"] = {k: v for k, v in out["host_api_pcie_inclusive"].items() if k != "note"}
+    if out.get("flat_scan_ground_truth"):
+        o["flat_scan_ground_truth"] = {k: v for k, v in out["flat_scan_ground_truth"].items() if k != "note"}
+    cfgs = {}
+    for name, c in (out.get("configs") or {}).items():
+        if "error" in c:
+            cfgs[name] = c
+            continue
+        cc = c.get("config", {})
+        e = {"workload": cc.get("workload", "")[:110], "standard_size": c.get("standard_size", cc.get("standard_size")),
+             "qps": c.get("qps"), "ms_per_step": c.get("ms_per_step"), "seconds": c.get("seconds")}
+        for k in ("recall_at_10", "meets_recall_target", "build_seconds"):
+            if k in c:
+                e[k] = c[k]
+        for k in ("ef_search", "visited", "build_visited"):
+            if k in cc:
+                e[k] = cc[k][:40] if isinstance(cc[k], str) else cc[k]
+        e["roofline"] = _slim_roofline(c.get("roofline"))
+        if c.get("roofline_dense_half"):
+            e["roofline_dense_half"] = {k: c["roofline_dense_half"][k] for k in ("achieved", "frac", "kernel")}
+        e["cpu_baseline"] = _slim_cpu(c.get("cpu_baseline"))
+        e["parity_vs_oracle"] = {k: v for k, v in (c.get("parity_vs_oracle") or {}).items() if k not in ("oracle_mode", "checked", "collection")} or None
+        if c.get("same_graph_exact_visited_set"):
+            e["same_graph_exact_visited_set"] = [{k: x[k] for k in ("ef_search", "qps", "recall_at_10")} for x in c["same_graph_exact_visited_set"]]
+        cfgs[name] = e
+    o["configs"] = cfgs
+    return o
+
+
+def rounded(obj, digits=9):
+    """floats of the output line at `digits` significant digits (json.dumps prints 17): a third of the line's bytes"""
+    if isinstance(obj, float):
+        return float(f"{obj:.{digits}g}") if obj == obj and abs(obj) != float("inf") else obj
+    if isinstance(obj, dict):
+        return {k: rounded(v, digits) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [rounded(v, digits) for v in obj]
+    return obj
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -793,7 +866,22 @@ class Emitter:
 
     def _write(self):
         if self.rank == 0 and self.out is not None:
-            os.write(self.fd, (json.dumps(self.out) + "\n").encode())
+            full = rounded(self.out)
+            # the complete record (every per-launch figure, ef tables, notes) goes to a file next to the other run artefacts; the ONE
+            # line on stdout carries the same results without the prose, so that it stays a few KB whatever reads it
+            path = None
+            for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+                try:
+                    os.makedirs(d, exist_ok=True)
+                    path = os.path.join(d, "bench_full_record.json")
+                    with open(path, "w") as fh:
+                        json.dump(full, fh)
+                    break
+                except OSError:
+                    path = None
+            line = slim_line(full)
+            line["full_record_file"] = os.path.relpath(path, ROOT) if path else None
+            os.write(self.fd, (json.dumps(line) + "\n").encode())
 
     def _deadline(self):
         with self.lock:

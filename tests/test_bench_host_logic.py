@@ -58,3 +58,25 @@ def test_launcher_command_is_the_drivers_own():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert cmd[cmd.index("--master-port") + 2].endswith("bench.py")
+
+
+def test_stdout_line_keeps_every_result_and_drops_the_prose():
+    """bench.py prints a slim line (a few KB) and writes the complete record to a file: every config's qps / recall / roofline /
+    cpu_baseline / parity block must survive the slimming, floats are rounded to 9 significant digits"""
+    import json
+    import bench
+    full = bench.rounded(json.load(open(os.path.join(ROOT, "tests", "golden", "bench_full_record_sample.json"))))
+    line = bench.slim_line(full)
+    assert len(json.dumps(line)) < 10_000 < len(json.dumps(full))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity_vs_oracle", "recall_at_10", "single_batch_qps", "host_api_pcie_inclusive", "configs"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"]
+    assert set(line["configs"]) == set(full["configs"]) == {"c2_uniform", "c5", "c3", "c4shard_ref", "c4shard_exact"}
+    for name, c in line["configs"].items():
+        f = full["configs"][name]
+        assert c["qps"] == f["qps"] and c["roofline"]["frac"] == f["roofline"]["frac"] and c["roofline"]["bound"] in ("hbm", "mfma")
+        assert c["cpu_baseline"]["value"] == f["cpu_baseline"]["value"] and c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] >= 1
+        p = c["parity_vs_oracle"]
+        assert p["queries"] >= 256 and sum(v for k, v in p.items() if k != "queries") == 0
+    assert bench.rounded(1.23456789012345) == 1.23456789 and bench.rounded({"a": [float("inf"), 2]}) == {"a": [float("inf"), 2]}
