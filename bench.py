@@ -870,10 +870,11 @@ class Emitter:
             # the complete record (every per-launch figure, ef tables, notes) goes to a file next to the other run artefacts; the ONE
             # line on stdout carries the same results without the prose, so that it stays a few KB whatever reads it
             path = None
+            name = os.environ.get("COS_BENCH_FULL_RECORD", "bench_full_record.json")   # a script that runs bench.py several times names each record
             for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
                 try:
                     os.makedirs(d, exist_ok=True)
-                    path = os.path.join(d, "bench_full_record.json")
+                    path = os.path.join(d, os.path.basename(name))
                     with open(path, "w") as fh:
                         json.dump(full, fh)
                     break

@@ -9,8 +9,9 @@
 #      only collected where the script does little else).
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
 timeout 900 python -m pytest tests -m gpu -q > $OUT/final_pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/final_pytest.log
-timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/final_bench_all_configs.json 2> $OUT/final_bench_all_configs.err; echo "bench rc=$?"
+COS_BENCH_FULL_RECORD=final_bench_all_configs_full_record.json timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/final_bench_all_configs.json 2> $OUT/final_bench_all_configs.err; echo "bench rc=$?"
 cd /tmp; export TMPDIR=/tmp
+export COS_BENCH_FULL_RECORD=bench_full_record_of_a_profiler_pass.json
 MAIN="--steps 20 --warmup 5 --configs none --no-cpu-baseline --no-hbm-probe"
 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python $R/bench.py $MAIN > $OUT/final_bench_c2_under_rocprofv3.json 2> $OUT/final_kt.err
 python $R/scripts/rocprof_summary.py /tmp/p_kt/kt_results.db > $OUT/final_kernel_trace_c2.txt
