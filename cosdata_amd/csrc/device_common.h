@@ -85,12 +85,77 @@ __device__ __forceinline__ u32 group_reduce_add_u32(u32 v, int G) {
     return v;
 }
 
+// ---- sums of several vectors at once ---------------------------------------------------------------------------------
+// wave_reduce_rows<NP>(a): NP vectors in, ONE vector out; every lane of the aligned group g (64/NP lanes, g = 0..NP-1) ends with
+// the sum of a[g] over the whole wave.  A butterfly that halves the number of live vectors at each of the wide strides
+// (gfx950's v_permlane32_swap / v_permlane16_swap move half of each of two vectors in one instruction, the add folds both),
+// then finishes inside the groups with DPP.  18 VALU for 8 rows where group_reduce_add_u32(., 64) spends 8 per row (4 DPP adds,
+// each waiting on the last, + 4 v_readlane) plus 3 scalar adds: the walk's evaluation block was its largest VALU consumer.
+// Integer adds: order-independent, exact.
+__device__ __forceinline__ u32 fold_halves(u32 a, u32 b) { // lanes 0-31: a[l] + a[l+32]; lanes 32-63: b[l-32] + b[l]
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); // r[0] = {a.lo, b.lo}, r[1] = {a.hi, b.hi}
+    return r[0] + r[1];
+}
+__device__ __forceinline__ u32 fold_row_pairs(u32 a, u32 b) { // 16-lane rows: {a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3}
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); // r[0] = {a.r0, b.r0, a.r2, b.r2}, r[1] = {a.r1, b.r1, a.r3, b.r3}
+    return r[0] + r[1];
+}
+__device__ __forceinline__ u32 fold_row_halves(u32 c, u32 d) { // lanes 0-7 of a row: c[l] + c[l+8]; lanes 8-15: d[l-8] + d[l]
+    // row_ror:8 (0x128) is "xor 8" inside a 16-lane row; bank_mask picks the half of the row a DPP move writes
+    const u32 x = (u32)__builtin_amdgcn_update_dpp((int)d, (int)c, 0x128, 0xf, 0x3, false); // lanes 0-7: c[l^8]; lanes 8-15: d[l]
+    const u32 y = (u32)__builtin_amdgcn_update_dpp((int)c, (int)d, 0x128, 0xf, 0xc, false); // lanes 0-7: c[l];   lanes 8-15: d[l^8]
+    return x + y;
+}
+template <int NP>
+__device__ __forceinline__ u32 wave_reduce_rows(const u32 (&a)[NP]) {
+    static_assert(NP == 4 || NP == 8, "4 or 8 rows");
+    if constexpr (NP == 8) {
+        // group g must end with row g: {a0|a4} {a1|a5} {a2|a6} {a3|a7} -> rows {a0,a2,a4,a6} {a1,a3,a5,a7} -> halves in row order
+        const u32 b0 = fold_halves(a[0], a[4]), b1 = fold_halves(a[1], a[5]), b2 = fold_halves(a[2], a[6]), b3 = fold_halves(a[3], a[7]);
+        const u32 c = fold_row_pairs(b0, b2), d = fold_row_pairs(b1, b3);
+        u32 e = fold_row_halves(c, d);
+        e += dpp_mov<0xB1>(0u, e);  // xor 1
+        e += dpp_mov<0x4E>(0u, e);  // xor 2
+        e += dpp_mov<0x141>(0u, e); // row_half_mirror: the other quad of the 8-lane group
+        return e;
+    } else {
+        const u32 b0 = fold_halves(a[0], a[2]), b1 = fold_halves(a[1], a[3]); // {a0|a2} {a1|a3}
+        u32 e = fold_row_pairs(b0, b1);                                       // rows {a0, a1, a2, a3}
+        e += dpp_mov<0xB1>(0u, e);
+        e += dpp_mov<0x4E>(0u, e);
+        e += dpp_mov<0x141>(0u, e);
+        e += dpp_mov<0x140>(0u, e); // row_mirror: the other half of the 16-lane row
+        return e;
+    }
+}
+
 __device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
     u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, lane);
     u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), lane);
     return ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ u32 readlane_u32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+// base + row * stride for wave-uniform operands, on the scalar ALU (4 SALU, result in an SGPR pair), as a GLOBAL pointer: the row
+// load then takes it as its saddr operand with a 32-bit per-lane offset.  Left to the compiler, `base + (u64)row * stride +
+// lane_offset` becomes v_mov + v_mad_u64_u32 (quarter rate) + v_add per row address.
+__device__ __forceinline__ const uint8_t *row_ptr_scalar(const uint8_t *base, u32 row, u32 stride) {
+    u32 lo, hi;
+    const u32 blo = (u32)(u64)base, bhi = (u32)((u64)base >> 32);
+    asm("s_mul_i32 %0, %2, %3\n\ts_mul_hi_u32 %1, %2, %3\n\ts_add_u32 %0, %0, %4\n\ts_addc_u32 %1, %1, %5"
+        : "=&s"(lo), "=&s"(hi) : "s"(row), "s"(stride), "s"(blo), "s"(bhi) : "scc");
+    return (const uint8_t *)(const __attribute__((address_space(1))) uint8_t *)(((u64)hi << 32) | lo);
+}
+// m with bit l cleared, one s_bitset0_b64 (the compiler's m & (m - 1) is three scalar instructions)
+__device__ __forceinline__ u64 clear_bit_u64(u64 m, int l) {
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(l));
+    return m;
+}
+// lane LANE of `old` <- the wave-uniform `val` (v_writelane_b32 with an immediate lane select; this clang has no builtin for it)
+template <int LANE>
+__device__ __forceinline__ u32 writelane_u32(u32 old, u32 val) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(LANE));
+    return old;
+}
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
 template <int I, int N, typename F>

@@ -194,6 +194,15 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
         for (int c = 0; c < CH; c++) qreg[c] = make_uint4(0, 0, 0, 0);
     }
 
+    // G = 64 evaluation block: byte offset of this lane's 16-byte chunk inside a code row, per chunk pass; lanes past the last
+    // chunk point at chunk 0 (their query register is zero, so what they read does not matter)
+    u32 loff64[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const u32 chunk = (u32)lane + (u32)c * 64u;
+        loff64[c] = (chunk < ix.nchunks ? chunk : 0u) * 16u;
+    }
+
     u64 n_evals = 0, n_exp = 0, adj_bytes = 0, n_rounds = 0;
     int32_t status = COS_OK;
     u32 entry = ix.lv[L].root_idx;
@@ -365,50 +374,75 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                 const u64 wmask = __ballot(win);
                 const int W = __popcll(wmask);
                 if constexpr (G64 && !FLOAT_ENG) {
-                    // One code row per wave pass (64 lanes x 16 B cover the row): the winner's row index is
-                    // wave-uniform, so it is taken straight from the owning lane with v_readlane, the row base
-                    // lives in SGPRs and nothing goes through LDS.  PB64 rows are in flight before the dots.
+                    // One code row per wave pass (64 lanes x 16 B cover the row): the winner's row index is wave-uniform, so it
+                    // is taken straight from the owning lane with v_readlane and the row base lives in SGPRs (the load is the
+                    // saddr + 32-bit lane offset form: no vector address arithmetic).  PB64 rows are in flight before the dots;
+                    // their PB64 dot vectors are summed TOGETHER (wave_reduce_rows: 18 VALU for 8 rows), row p of the block
+                    // landing in the lanes of group p — rounds 1-3 reduced row by row (4 dependent DPP adds + 4 v_readlane + a
+                    // select per row) and fetched |v| and the node index with one predicated scalar-indexed load per row: 24 VALU
+                    // and 32 SALU per evaluation of the 38 + 36 the whole walk spent (profiles/r03_final_pmc_sq_instruction_mix).
+                    // Lanes past the row's last chunk re-read chunk 0 against a zero query register instead of being masked off.
                     n_evals += (u64)W;
+                    float magw = 1.0f; // |v| of every winner of the expansion: one vector load, in the winner's own lane
+                    if (win) magw = ix.mags[nb_vec];
                     u64 m = wmask;
                     while (m && !failed) {
-                        uint4 buf[PB64][CH];
-                        int cnt = 0;
-                        float magv = 1.0f, dotv = 0.0f; // lane p <- winner p of this block: |v| and the integer dot as f32
-                        u32 nodev = 0;
+                        u32 lsel = 0;  // landing lane of winner p of this block <- 4 * (the lane that owns the winner): a ds_bpermute address
+                        u32 tot = 0;   // landing lanes: the winner's integer dot
+                        bool lead = false; // first lane of the landing group of a winner of this block
+                        // A block of up to NP winners, row p landing in lanes p*(64/NP)...: the rows are fetched together, dotted,
+                        // and the NP partial-sum vectors reduced at once.  The dots of rows a short block does not have are
+                        // skipped by real branches (the empty asm keeps the compiler from turning them into 5 VALU + a select each).
+                        auto eval_block = [&](auto npc) {
+                            constexpr int NP = decltype(npc)::value;
+                            constexpr int LS = 64 / NP;
+                            uint4 buf[NP][CH];
+                            int cnt = 0;
+                            static_for<0, NP>([&](auto pc) {
+                                constexpr int p = decltype(pc)::value;
+                                if (m) {
+                                    const int l = __ffsll((long long)m) - 1;
+                                    m = clear_bit_u64(m, l);
+                                    const uint8_t *rp = row_ptr_scalar(ix.codes, readlane_u32(nb_vec, l), (u32)ix.row_stride);
+                                    lsel = writelane_u32<p * LS>(lsel, (u32)l << 2);
 #pragma unroll
-                        for (int p = 0; p < PB64; p++) {
-                            if (m) {
-                                const int l = __ffsll((long long)m) - 1;
-                                m &= m - 1;
-                                const u32 row = readlane_u32(nb_vec, l);
-                                const u32 nd = readlane_u32(nb_node, l);
-                                const uint8_t *rp = ix.codes + (u64)row * ix.row_stride;
-                                if (lane == p) { magv = ix.mags[row]; nodev = nd; }
-#pragma unroll
-                                for (int c = 0; c < CH; c++) {
-                                    const u32 chunk = (u32)lane + (u32)c * 64u;
-                                    buf[p][c] = make_uint4(0, 0, 0, 0);
-                                    if (chunk < ix.nchunks) buf[p][c] = *(const uint4 *)(rp + (u64)chunk * 16);
+                                    for (int c = 0; c < CH; c++) {
+                                        u32 lo = loff64[c];
+                                        asm("" : "+v"(lo)); // keeps the zero-extension in this block: saddr + 32-bit voffset addressing
+                                        buf[p][c] = *(const uint4 *)(rp + lo);
+                                    }
+                                    cnt++;
                                 }
-                                cnt++;
-                            }
-                        }
+                            });
+                            u32 acc[NP];
+                            static_for<0, NP>([&](auto pc) {
+                                constexpr int p = decltype(pc)::value;
+                                acc[p] = 0;
+                                if (p < cnt) {
+                                    asm volatile("");
 #pragma unroll
-                        for (int p = 0; p < PB64; p++) {
-                            if (p < cnt) {
-                                u32 acc = 0;
-#pragma unroll
-                                for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
-                                acc = group_reduce_add_u32(acc, 64);
-                                if (lane == p) dotv = (float)acc; // integer dot `as f32` (RNE)
-                            }
+                                    for (int c = 0; c < CH; c++) acc[p] = chunk_dot<ENG>(qreg[c], buf[p][c], acc[p]);
+                                }
+                            });
+                            tot = wave_reduce_rows<NP>(acc);
+                            lead = (lane & (LS - 1)) == 0 && (lane / LS) < cnt;
+                        };
+                        if constexpr (PB64 == 8) {
+                            if (__popcll(m) > 4) eval_block(std::integral_constant<int, 8>{});
+                            else eval_block(std::integral_constant<int, 4>{});
+                        } else {
+                            eval_block(std::integral_constant<int, 4>{});
                         }
+                        // |v| and node index of the block's winners move to the landing lanes (two ds_bpermute)
+                        const float magv = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)lsel, (int)__float_as_uint(magw)));
+                        const u32 nodev = (u32)__builtin_amdgcn_ds_bpermute((int)lsel, (int)nb_node);
+                        const float dotv = (float)tot; // integer dot `as f32` (RNE)
                         // one vector epilogue for the whole block: cosine_similarity_from_dot_product (cosine.rs:223-235)
                         float sim = dotv;
                         bool bad = false;
                         if (metric == 0u) {
                             const float den = __fmul_rn(qmag, magv);
-                            bad = lane < cnt && den == 0.0f;
+                            bad = lead && den == 0.0f;
                             sim = __fdiv_rn(dotv, den);
                         }
                         if (__any(bad)) { failed = true; break; }
@@ -416,9 +450,9 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
                         // One vector compare screens the block's winners against the entry that closes the poppable part of the
                         // pool (position limit - 1): a key below it has at least `limit` entries above it, the loop would rank it
                         // only to reject it.  The bar can only rise while winners go in, so the screen is conservative and the
-                        // loop's own test stays.  Winners are visited in lane = slot order as before.
+                        // loop's own test stays.  Winners are visited in landing-lane = slot order as before.
                         const u64 bar = limit > 0 ? pool.peek_dyn((u32)(limit - 1)) : ~0ull;
-                        u64 pm = __ballot(lane < cnt && pack_key(keyv, nodev) > bar);
+                        u64 pm = __ballot(lead && pack_key(keyv, nodev) > bar);
                         while (pm) {
                             const int p = __ffsll((long long)pm) - 1;
                             pm &= pm - 1;
