@@ -83,6 +83,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
         }
     } guard{ix};
 
+    ix->order_rank_valid = false; // the order key's table follows the graph (engine.hip, ensure_order_rank)
     // ---- root + level draws (same RNG stream as the oracle builders) ----------------------------
     uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
     std::vector<float> root(ix->p.dim);

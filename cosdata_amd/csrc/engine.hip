@@ -142,6 +142,7 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
     if (p->device < 0 || p->device >= ndev) return cos_fail(COS_ERR_INVALID, "device %d out of range (%d visible)", p->device, ndev);
     cos_index *ix = new cos_index();
     if (const char *e = getenv("COS_WALK_CHAIN_MIN_B")) ix->chain_min_B = (u32)strtoul(e, nullptr, 10); // experiments: 0 = always, 4294967295 = never
+    if (const char *e = getenv("COS_WALK_ORDER_MIN_B")) ix->walk_order_min_B = (u32)strtoul(e, nullptr, 10); // 0 = one launch, arrival order
     if (const char *e = getenv("COS_WALK_SIDE_MIN_B")) ix->walk_side_min_B = (u32)strtoul(e, nullptr, 10); // 0 = walks stay on the caller's stream
     ix->p = *p;
     ix->eng = eng;
@@ -194,6 +195,7 @@ static void free_ws(Workspace *w) {
     void *ptrs[] = {w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
                     w->rerank_rows, w->vis.bits, w->vis.log, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    cosdev::walk_order_free(w->order);
     for (auto &e : w->ev) if (e) (void)hipEventDestroy(e);
     if (w->walk_done) (void)hipEventDestroy(w->walk_done);
     if (w->walk_fin) (void)hipEventDestroy(w->walk_fin);
@@ -244,6 +246,7 @@ extern "C" int32_t cos_index_destroy(cos_index *ix) {
     if (ix->d_raw_mags) (void)hipFree(ix->d_raw_mags);
     if (ix->d_codes) (void)hipFree(ix->d_codes);
     if (ix->d_mags) (void)hipFree(ix->d_mags);
+    for (u32 *p : ix->d_order_rank) if (p) (void)hipFree(p);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
     return COS_OK;
@@ -266,6 +269,7 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     cos_flat_ws_release(ix); // cached sums of the stored codes, scan buffers sized for the old corpus
     ix->have_root = false;
     for (auto &l : ix->lv) free_level(l); // a graph refers to vector rows: new vectors invalidate it
+    ix->order_rank_valid = false;
     reset_meta(ix);                       // ... and so do the pseudo-root component, its node table and the id stride
     const u64 dim = ix->p.dim;
     struct Rollback { // a failed upload leaves the handle empty instead of half-populated
@@ -362,6 +366,7 @@ static int32_t push_level_to_device(cos_index *ix, u32 level) {
     }
     L.n = n;
     L.host_valid = true;
+    ix->order_rank_valid = false; // the order key's table follows the graph (ensure_order_rank)
     return COS_OK;
 }
 
@@ -553,6 +558,12 @@ extern "C" int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queri
     ix->lat4_max_B = max_queries;
     return COS_OK;
 }
+extern "C" int32_t cos_index_set_walk_order(cos_index *ix, uint32_t min_queries) {
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->walk_order_min_B = min_queries;
+    return COS_OK;
+}
 extern "C" int32_t cos_index_enable_timing(cos_index *ix, int32_t on) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null");
     std::lock_guard<std::mutex> g(ix->mu);
@@ -612,6 +623,79 @@ int32_t vis_tab_prepare(VisTab &vt, const cos_index *ix, u32 B, u32 ef, hipStrea
 
 // the workspace registered under `key` (a caller's stream, or a HostPipe slot), grown to B queries; `st` is the stream the
 // workspace's previous launches ran on (drained before a buffer is replaced)
+// The tables behind the order keys of big launches (WalkArgs::order_rank): every node of a key level -> its position in a
+// depth-first order of that level's graph.  Consecutive positions are graph neighbours or a short backtrack apart, so queries
+// whose best key-level nodes have close positions walk the same region of the levels below — a one-dimensional locality order
+// that needs nothing but the graph (the vectors' geometry is in its edges).
+// Key levels (the walk is cut AFTER each of them): by default ONE, the lowest level whose code rows take at most 64 MB — a
+// quarter of the 256 MB memory-side cache, so the levels walked in arrival order stay cache-resident whatever the order, and the
+// key is as fine as that allows (c2: level 2, 62 500 nodes x 768 B = 48 MB, levels 1 and 0 walked in order; a 12.5M x 1024
+// shard: level 4, 48 829 nodes).  Every further cut costs the tail of one more launch (~0.3 ms per 32768 queries) and measured
+// slower: profiles/r03_locality_probe_split_levels.jsonl (cuts after 1 | 2 | 3 | 4 | 3,1 | 4,1 | 5,1 | 4,2,1 | 5,3,1).
+// COS_WALK_SPLIT=a,b,.. overrides (descending levels; "0" = no split).
+// Built on the host from the adjacency, once per graph: milliseconds for levels this small (<= 2^20 nodes).  Caller holds ix->mu.
+static int32_t ensure_order_rank(cos_index *ix) {
+    if (ix->order_rank_valid) return COS_OK;
+    for (u32 l = 0; l < cosdev::MAX_LEVELS; l++) {
+        if (ix->d_order_rank[l]) (void)hipFree(ix->d_order_rank[l]);
+        ix->d_order_rank[l] = nullptr;
+        ix->order_rank_n[l] = 0;
+    }
+    ix->order_levels.clear();
+    const u32 Ltop = ix->p.num_layers;
+    auto usable = [&](u32 l) { return l >= 1 && l <= Ltop && ix->lv[l].n > 1 && ix->lv[l].n <= (1u << 20) && ix->lv[l].d_adj_node; };
+    std::vector<u32> want;
+    if (const char *e = getenv("COS_WALK_SPLIT")) {
+        for (const char *p = e; *p;) {
+            char *q;
+            const unsigned long v = strtoul(p, &q, 10);
+            if (q == p) break;
+            want.push_back((u32)v);
+            p = *q == ',' ? q + 1 : q;
+        }
+    } else {
+        for (u32 l = 1; l <= Ltop; l++)
+            if (usable(l) && (size_t)ix->lv[l].n * ix->row_stride <= ((size_t)64 << 20)) { want.push_back(l); break; }
+    }
+    u32 prev = Ltop + 1;
+    for (u32 l : want) { // descending, distinct, usable; a level that is not is skipped, not an error
+        if (!usable(l) || l >= prev) continue;
+        ix->order_levels.push_back(l);
+        prev = l;
+    }
+    if (!ix->order_levels.empty()) HIP_TRY(hipDeviceSynchronize()); // a build or an upload on another stream may still be writing the adjacency
+    for (u32 kl : ix->order_levels) {
+        const LevelHost &H = ix->lv[kl];
+        const u32 n = H.n, M = H.M;
+        std::vector<u32> adj((size_t)n * M), rank(n, 0u), stack;
+        HIP_TRY(hipMemcpy(adj.data(), H.d_adj_node, adj.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> seen(n, 0);
+        u32 next = 0;
+        auto dfs_from = [&](u32 start) {
+            stack.push_back(start);
+            while (!stack.empty()) {
+                const u32 v = stack.back();
+                stack.pop_back();
+                if (seen[v]) continue;
+                seen[v] = 1;
+                rank[v] = next++;
+                const u32 *row = &adj[(size_t)v * M];
+                for (u32 j = M; j-- > 0;) { // pushed last = visited first: slot order
+                    const u32 u = row[j];
+                    if (u != cosdev::ROW_EMPTY && u < n && !seen[u]) stack.push_back(u);
+                }
+            }
+        };
+        dfs_from(n - 1); // the root (last node of every level): where every walk of the level starts
+        for (u32 v = 0; v < n; v++) if (!seen[v]) dfs_from(v);
+        HIP_TRY(hipMalloc((void **)&ix->d_order_rank[kl], (size_t)n * 4));
+        HIP_TRY(hipMemcpy(ix->d_order_rank[kl], rank.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        ix->order_rank_n[kl] = n;
+    }
+    ix->order_rank_valid = true;
+    return COS_OK;
+}
+
 static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u32 top_k, bool host_api, Workspace **out) {
     std::lock_guard<std::mutex> g(ix->mu);
     Workspace *&w = ix->ws[key];
@@ -634,6 +718,13 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         HIP_TRY(regrow(w->d_out_status, cap));
         w->capB = cap;
         w->cap_topk = 0;
+    }
+    if (ix->walk_order_min_B && B >= ix->walk_order_min_B) {
+        if (w->order.cap < w->capB) {
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(cosdev::walk_order_reserve(w->order, w->capB));
+        }
+        if (int32_t rc = ensure_order_rank(ix)) return rc;
     }
     if (host_api && (size_t)top_k * w->capB > (size_t)w->cap_topk * w->capB) {
         HIP_TRY(regrow(w->d_out_ids, (size_t)w->capB * top_k));
@@ -658,9 +749,16 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
                           hipEvent_t walk_ev = nullptr, bool chain = true) {
     IndexDev dev = cos_make_index_dev(ix);
     bool timed;
-    u32 ef, lat_max_B, lat4_max_B;
+    u32 ef, lat_max_B, lat4_max_B, order_min_B, n_keys = 0, key_level[cosdev::MAX_LEVELS], key_n[cosdev::MAX_LEVELS];
+    const u32 *order_rank[cosdev::MAX_LEVELS];
     { // one consistent snapshot of the knobs cos_index_set_* may change from another thread
         std::lock_guard<std::mutex> g(ix->mu);
+        order_min_B = ix->order_rank_valid && !ix->order_levels.empty() ? ix->walk_order_min_B : 0u;
+        for (u32 l : ix->order_levels) {
+            key_level[n_keys] = l;
+            key_n[n_keys] = ix->order_rank_n[l];
+            order_rank[n_keys++] = ix->d_order_rank[l];
+        }
         timed = ix->timing;
         ef = ix->p.ef_search;
         lat_max_B = ix->lat_max_B;
@@ -704,16 +802,41 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
         HIP_TRY(hipEventRecord(w->prep_done, st));
         HIP_TRY(hipStreamWaitEvent(sw, w->prep_done, 0));
     }
+    // Big launches walk in locality order (kernels_order.hip): the levels down to the first key level in arrival order, then, after
+    // every key level, a sort of the launch by the key that level left and the levels below with the sorted queries dealt to the
+    // XCDs.  Same walks, same results.
+    const bool ordered = order_min_B && B >= order_min_B && n_keys > 0 && w->order.cap >= B;
+    auto walk = [&](hipStream_t s) -> int32_t {
+        if (!ordered) { HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, lat4_max_B, s)); return COS_OK; }
+        wa.phase = 1;
+        wa.entry0 = w->order.entry0;
+        wa.order_key = w->order.order_key;
+        wa.order_iota = w->order.iota;
+        u32 first = dev.num_layers;
+        for (u32 i = 0; i <= n_keys; i++) {
+            const bool last = i == n_keys;
+            wa.level_first = first;
+            wa.level_last = last ? 0u : key_level[i];
+            wa.key_n = last ? 0u : key_n[i];
+            wa.order_rank = last ? nullptr : order_rank[i];
+            HIP_TRY(launch_walk(ix->eng, dev, wa, 0, 0, s));
+            if (last) break;
+            HIP_TRY(cosdev::launch_walk_order(w->order, B, key_n[i], s));
+            wa.q_order = w->order.q_order;
+            first = key_level[i] - 1;
+        }
+        return COS_OK;
+    };
     if (chain && B >= ix->chain_min_B) { // walk chain (engine_internal.h): wait for the previous big walk, whichever stream it ran on
         std::lock_guard<std::mutex> g(ix->chain_mu);
         if (ix->chain_ev && ix->chain_ev != w->walk_done) HIP_TRY(hipStreamWaitEvent(sw, ix->chain_ev, 0));
         if (timed) HIP_TRY(hipEventRecord(ev[1], sw)); // the kernel's own duration: after the wait
-        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, lat4_max_B, sw));
+        if (int32_t rc = walk(sw)) return rc;
         HIP_TRY(hipEventRecord(w->walk_done, sw));
         ix->chain_ev = w->walk_done;
     } else {
         if (timed && sw != st) HIP_TRY(hipEventRecord(ev[1], sw));
-        HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, lat4_max_B, sw));
+        if (int32_t rc = walk(sw)) return rc;
     }
     if (timed) HIP_TRY(hipEventRecord(ev[2], sw));
     hipStream_t sf = st_fin ? st_fin : st;
@@ -724,7 +847,7 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     }
     if (do_finalize) {
         HIP_TRY(launch_finalize(dev, d_queries, ix->p.dim, w->q_raw_mags, w->walk_ids, w->walk_sims, w->walk_counts, w->walk_status, B, top_k,
-                                d_out_ids, d_out_scores, d_out_counts, d_out_status, w->rerank_rows, sf));
+                                d_out_ids, d_out_scores, d_out_counts, d_out_status, w->rerank_rows, sf, ordered ? w->order.q_order : nullptr));
     }
     if (timed) { HIP_TRY(hipEventRecord(ev[3], sf)); w->ev_count++; }
     w->lastB = B;

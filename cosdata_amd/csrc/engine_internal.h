@@ -26,7 +26,20 @@ hipError_t launch_walk_meta_index(int eng, const IndexDev &ix, const WalkArgs &w
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
                            u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
-                           hipStream_t st);
+                           hipStream_t st, const u32 *q_order = nullptr);
+// buffers of the locality order of one workspace's big launches (kernels_order.hip)
+struct WalkOrder {
+    u32 cap = 0;
+    u32 *entry0 = nullptr;      // [cap] level-0 entry node per query
+    u32 *order_key = nullptr;   // [cap]
+    u32 *keys_sorted = nullptr; // [cap]
+    u32 *iota = nullptr, *vals_sorted = nullptr, *q_order = nullptr; // [cap]
+    void *tmp = nullptr;        // radix sort scratch
+    size_t tmp_bytes = 0;
+};
+hipError_t walk_order_reserve(WalkOrder &o, u32 B); // synchronous (re)allocation
+void walk_order_free(WalkOrder &o);
+hipError_t launch_walk_order(WalkOrder &o, u32 B, u32 key_max, hipStream_t st);
 int32_t quantize_ref_layout(uint32_t storage, uint32_t res, uint32_t dim, const float *x, uint32_t n, void *codes, float *mags);
 int32_t distance_ref_layout(uint32_t metric, uint32_t storage, uint32_t res, uint32_t dim, const void *x_codes, const float *x_mags, uint32_t nx,
                             const void *y_codes, const float *y_mags, uint32_t ny, const uint32_t *pair_x, const uint32_t *pair_y, uint32_t n_pairs,
@@ -88,6 +101,7 @@ struct Workspace {
     u64 *stats = nullptr;       // [B][4]
     u64 *rerank_rows = nullptr; // [B]
     VisTab vis; // EXACT mode visited filters
+    cosdev::WalkOrder order; // locality order of big launches (cos_index::walk_order_min_B)
     // host-API staging (device)
     float *d_queries = nullptr;
     u32 *d_out_ids = nullptr, *d_out_counts = nullptr;
@@ -170,6 +184,15 @@ struct cos_index {
     std::mutex chain_mu;
     hipEvent_t chain_ev = nullptr; // walk_done of the most recent chained walk
     u32 chain_min_B = 16384;
+    // launches of at least this many queries split their walk in two (upper levels | level 0) and run level 0 in locality order
+    // (kernels_order.hip); 0 = never.  Env COS_WALK_ORDER_MIN_B.
+    u32 walk_order_min_B = COS_WALK_ORDER_DEFAULT_MIN_B;
+    // the order keys' tables: position of every node of a key level in a depth-first order of that level's graph, and the key
+    // levels themselves, descending (ensure_order_rank, engine.hip); rebuilt after the graph changes
+    u32 *d_order_rank[cosdev::MAX_LEVELS] = {};
+    u32 order_rank_n[cosdev::MAX_LEVELS] = {};
+    std::vector<u32> order_levels; // empty = the graph has no level the order could use
+    bool order_rank_valid = false;
     u32 walk_side_min_B = 4096; // launches of at least this many queries walk on the workspace's low-priority stream; 0 = never
     // launches of at most this many queries run the latency variant of the walk (kernels_walk_lat.hip) where it applies; 0 = never
     u32 lat_max_B = COS_LATENCY_MODE_DEFAULT_MAX_B;

@@ -71,6 +71,22 @@ struct WalkArgs {
     const float *f_mags;
     const u32 *f_off;
     u64 *out_stats;      // [B][4]: evals, expansions, adj_bytes, reserved
+    // Locality-ordered walk (big search launches; kernels_order.hip, engine.hip run_search).  The walk of a launch is split
+    // into launches of the same kernel over consecutive level ranges [level_first .. level_last]; between two of them the
+    // launch's queries are sorted by an ORDER KEY and dealt to the XCDs in contiguous runs (workgroup b runs on XCD b % 8, each
+    // XCD has its own L2), so the waves resident on one XCD walk the same region of the graph and find each other's rows in
+    // cache.  The key a range leaves: the position, in a depth-first order of level_last's graph (order_rank, built once per
+    // graph on the host), of the best node the query found on level_last.  A range that does not start at the top level reads
+    // its entry node from entry0 (the child link of the previous range's best node).  Every query's walk is what it was: only
+    // WHEN and WHERE it runs changes.  phase 0 = the whole walk in one launch, arrival order (everything else).
+    u32 phase;             // 0 | 1 = this launch walks [level_first .. level_last]
+    u32 level_first, level_last;
+    u32 key_n;             // nodes of level_last (level_last >= 1); also the key of a failed query (sorts last)
+    const u32 *order_rank; // [key_n] node of level_last -> position in the depth-first order
+    const u32 *q_order;    // [B] workgroup -> query; nullptr = arrival order
+    u32 *entry0;           // [B] entry node of the next range: read when level_first < L, written when level_last >= 1
+    u32 *order_key;        // [B] written when level_last >= 1
+    u32 *order_iota;       // [B] order_iota[b] = b (the values the sort carries), written with the key
 };
 
 } // namespace cosdev

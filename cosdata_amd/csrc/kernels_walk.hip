@@ -133,11 +133,13 @@ struct WalkSmem {
 };
 
 template <int ENG, int CH, int R, bool G64, bool EXACT, int PB64 = 4>
-__global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkArgs wa) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 : (R <= 4 ? 5 : 4), 8))) void walk_kernel(const IndexDev ix, const WalkArgs wa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x;
-    const u32 qi = blockIdx.x;
-    if (qi >= wa.B) return;
+    if (blockIdx.x >= wa.B) return;
+    const u32 qi = wa.q_order ? wa.q_order[blockIdx.x] : blockIdx.x; // split walk: locality order (engine_types.h)
+    const bool resume = wa.phase != 0u && wa.level_first < ix.num_layers; // a level range below the top: entry node from the range above
+    if (resume && wa.out_status[qi] != COS_OK) return;                   // failed in the levels above: nothing below is read
 
     const u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
     WalkSmem sm;
@@ -205,7 +207,9 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
 
     u64 n_evals = 0, n_exp = 0, adj_bytes = 0, n_rounds = 0;
     int32_t status = COS_OK;
-    u32 entry = ix.lv[L].root_idx;
+    u32 entry = resume ? wa.entry0[qi] : ix.lv[L].root_idx;
+    const int level_first = wa.phase ? (int)wa.level_first : (int)L, level_last = wa.phase ? (int)wa.level_last : 0;
+    u32 order_key = wa.key_n; // split walk: depth-first position of the best node of level_last
 
     // distance of ONE row computed by group 0 (entry node); result valid in every lane
     auto single_distance = [&](u32 row, float &sim_out) -> bool {
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
         return true;
     };
 
-    for (int level = (int)L; level >= 0; level--) {
+    for (int level = level_first; level >= level_last; level--) {
         const LevelDev lv = ix.lv[level];
         const u32 M = lv.M;
         const u32 slots = M < ix.shortlist ? M : ix.shortlist;
@@ -608,16 +612,23 @@ __global__ __launch_bounds__(64) void walk_kernel(const IndexDev ix, const WalkA
         if (level > 0) {
             const u32 best = (u32)readlane_u64(rk[0], 0);
             entry = lv.child[best];
+            if (wa.phase != 0u && level == level_last) order_key = wa.order_rank[best];
         }
     }
 
     if (lane == 0) {
         wa.out_status[qi] = status;
+        if (wa.phase != 0u && level_last > 0) {
+            wa.entry0[qi] = entry;
+            wa.order_key[qi] = status == COS_OK ? order_key : wa.key_n;
+            wa.order_iota[qi] = qi;
+        }
         if (wa.out_stats) {
-            wa.out_stats[(u64)qi * 4 + 0] = n_evals;
-            wa.out_stats[(u64)qi * 4 + 1] = n_exp;
-            wa.out_stats[(u64)qi * 4 + 2] = adj_bytes;
-            wa.out_stats[(u64)qi * 4 + 3] = n_rounds;
+            const bool add = resume; // the counters of the levels above are already there
+            wa.out_stats[(u64)qi * 4 + 0] = n_evals + (add ? wa.out_stats[(u64)qi * 4 + 0] : 0ull);
+            wa.out_stats[(u64)qi * 4 + 1] = n_exp + (add ? wa.out_stats[(u64)qi * 4 + 1] : 0ull);
+            wa.out_stats[(u64)qi * 4 + 2] = adj_bytes + (add ? wa.out_stats[(u64)qi * 4 + 2] : 0ull);
+            wa.out_stats[(u64)qi * 4 + 3] = n_rounds + (add ? wa.out_stats[(u64)qi * 4 + 3] : 0ull);
         }
     }
 }
@@ -641,14 +652,16 @@ struct FinalizeArgs {
     u32 *out_counts;
     int32_t *out_status;
     u64 *out_rerank_rows; // [B]
+    const u32 *q_order;   // optional [B]: workgroup -> query, the locality order the walk of this launch ended with (engine_types.h):
+                          // neighbouring queries rerank many of the same raw rows
 };
 
 template <int FR>
 __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const FinalizeArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x;
-    const u32 qi = blockIdx.x;
-    if (qi >= fa.B) return;
+    if (blockIdx.x >= fa.B) return;
+    const u32 qi = fa.q_order ? fa.q_order[blockIdx.x] : blockIdx.x;
     const u32 L = ix.num_layers;
     const u32 metric = ix.metric;
     float *qf = (float *)smem_raw;                                   // dim floats (padded to 16 B)
@@ -867,8 +880,10 @@ hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_
     static const long long lat4_env = [] { const char *e = getenv("COS_WALK_LAT4"); return e ? atoll(e) : -1ll; }();
     if (lat_env >= 0) lat_max_B = lat_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat_env;
     if (lat4_env >= 0) lat4_max_B = lat4_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat4_env;
-    if (walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return launch_walk_lat4(eng, ix, wa, st);
-    if (walk_lat_applicable(eng, ix, wa, lat_max_B)) return launch_walk_lat(eng, ix, wa, st);
+    if (wa.phase == 0u) { // the split (locality-ordered) walk exists in the throughput kernel only
+        if (walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return launch_walk_lat4(eng, ix, wa, st);
+        if (walk_lat_applicable(eng, ix, wa, lat_max_B)) return launch_walk_lat(eng, ix, wa, st);
+    }
     const u32 ch = (eng == ENG_F32 || eng == ENG_F16) ? 1 : (ix.nchunks + ix.G - 1) / ix.G;
     switch (eng) {
     case ENG_U8:
@@ -893,10 +908,10 @@ hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
                            u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
-                           hipStream_t st) {
+                           hipStream_t st, const u32 *q_order) {
     if (B == 0) return hipSuccess;
     FinalizeArgs fa{queries, q_stride, q_raw_mags, walk_ids, walk_sims, walk_counts, walk_status, B, top_k,
-                    out_ids, out_scores, out_counts, out_status, out_rerank_rows};
+                    out_ids, out_scores, out_counts, out_status, out_rerank_rows, q_order};
     const u32 per_level = std::min<u32>(KEEP_SEARCH, 5u * top_k + 1u);
     const u32 total = (ix.num_layers + 1) * per_level;
     dim3 grid(B), block(64);

@@ -188,6 +188,14 @@ int32_t cos_index_set_latency_mode(cos_index *ix, uint32_t max_queries);
  * from 1024 queries per launch on the one-wave kernel is faster (two of these workgroups fill a CU's registers). */
 #define COS_LATENCY_WAVES_DEFAULT_MAX_B 512u
 int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queries);
+/* Locality order of big launches — at least min_queries queries (default COS_WALK_ORDER_DEFAULT_MIN_B; 0 = never).  Not a reference
+ * interface: the reference answers each query on its own rayon task (indexes/mod.rs:260-272) and has no launch whose order could
+ * matter; on the device the order decides which rows a query finds in cache.  Such a launch walks in two steps: levels L..1 in
+ * arrival order, then level 0 with the launch sorted by the path the upper levels found (best node of levels 3, 2, 1) and dealt to
+ * the XCDs in contiguous runs (workgroup b runs on XCD b % 8, each XCD has its own L2), so the waves resident on an XCD walk
+ * neighbouring regions of the graph.  Every query's walk, and so every result, is bit for bit what it is without the order. */
+#define COS_WALK_ORDER_DEFAULT_MIN_B 4096u
+int32_t cos_index_set_walk_order(cos_index *ix, uint32_t min_queries);
 /* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
 int32_t cos_index_enable_timing(cos_index *ix, int32_t on);
 int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out);

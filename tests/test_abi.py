@@ -88,3 +88,5 @@ def test_python_mirror_of_header_constants():
     assert m and int(m.group(1)) == ca.HNSWIndex.LATENCY_MODE_DEFAULT_MAX_B
     m = re.search(r"#define\s+COS_LATENCY_WAVES_DEFAULT_MAX_B\s+(\d+)u", hdr)
     assert m and int(m.group(1)) == ca.HNSWIndex.LATENCY_WAVES_DEFAULT_MAX_B
+    m = re.search(r"#define\s+COS_WALK_ORDER_DEFAULT_MIN_B\s+(\d+)u", hdr)
+    assert m and int(m.group(1)) == ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B
