@@ -543,6 +543,7 @@ class DenseWorkload:
                     "rounds": float(np.mean([c[3] for c in cnts]))}
 
         tr = timed_run()
+        cuts = ix.walk_order_cuts() if B >= ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B else []  # the locality order of big launches
         elapsed = tr["elapsed"]
         merged_qps = n_launch * B / elapsed        # answers over the global (world x n) corpus per second
         avg_ms, avg_bytes = tr["walk_ms"], tr["bytes"]
@@ -682,14 +683,21 @@ class DenseWorkload:
             "roofline": {"bound": "hbm", "achieved": kernel_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": kernel_gbps / HBM_PEAK_GBPS,
                          "traffic": traffic, "empirical": empirical,
                          "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64, %s>" % (1 if ef <= 64 else (4 if ef <= 256 else 8), visited),
+                         "kernel_launches_per_step": 1 + len(cuts),
+                         "walk_order": ({"cut_after_levels": cuts,
+                                         "meaning": "one walk = %d launches of the kernel over consecutive level ranges; after each cut level the %d queries "
+                                                    "of the step are sorted by the depth-first position of the best node they found on it and dealt to the "
+                                                    "XCDs in contiguous runs (cos_index_set_walk_order; same walks, same results); avg_ms spans all of it, "
+                                                    "the sort included" % (1 + len(cuts), B)} if cuts else None),
                          "aggregate": {"achieved": aggregate_gbps, "frac": aggregate_gbps / HBM_PEAK_GBPS, "in_flight": overlap,
                                        "note": "algorithmic bytes of ALL timed launches / timed wall time; exceeds the kernel-level figure "
                                                "only through launches overlapping on different streams"},
                          "per_launch": {"algorithmic_bytes": avg_bytes, "avg_ms": avg_ms, "min_ms": tr["walk_ms_min"], "max_ms": tr["walk_ms_max"],
                                         "launches_sampled": tr["timed_launches_sampled"], "evals": tr["evals"], "expansions": tr["expansions"],
                                         "finalize_ms": tr["finalize_ms"], "prep_ms": tr["prep_ms"], "adjacency_rounds": tr["rounds"]},
-                         "note": "achieved = algorithmic bytes of one walk launch (evals x (dim+4) + expansions x M x 4, counted by the kernel) / "
-                                 "that launch's average HIP-event duration on its own stream over the timed region"},
+                         "note": "achieved = algorithmic bytes of one step's walk (evals x (dim+4) + expansions x M x 4, counted by the kernel) / "
+                                 "its average HIP-event duration on its own stream over the timed region (kernel_launches_per_step launches of the "
+                                 "kernel: a rocprofv3 trace shows that many dispatches per step, their durations add up to avg_ms)"},
         }
         del ix
         return rec
@@ -784,7 +792,9 @@ def compact_dense_record(rec, world):
 def _slim_roofline(r):
     if not r:
         return r
-    keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel") if k in r}
+    keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_launches_per_step") if k in r}
+    if r.get("walk_order"):
+        keep["walk_order_cut_after_levels"] = r["walk_order"]["cut_after_levels"]
     pl = r.get("per_launch") or {}
     keep["per_launch"] = {k: pl[k] for k in ("algorithmic_bytes", "avg_ms", "gemm_ms_all_launches", "int8_ops", "launches_sampled", "finalize_ms") if k in pl}
     if r.get("empirical"):

@@ -696,6 +696,21 @@ static int32_t ensure_order_rank(cos_index *ix) {
     return COS_OK;
 }
 
+extern "C" int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t cap, uint32_t *out_n) {
+    if (!ix || !out_n || (cap && !out_levels)) return cos_fail(COS_ERR_INVALID, "null argument");
+    *out_n = 0;
+    if (!graph_ready(ix)) return cos_fail(COS_ERR_NOT_READY, "index needs vectors, root and every graph level");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if ((rc = ensure_order_rank(ix))) return rc;
+    for (u32 l : ix->order_levels) {
+        if (*out_n < cap) out_levels[*out_n] = l;
+        (*out_n)++;
+    }
+    return COS_OK;
+}
+
 static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u32 top_k, bool host_api, Workspace **out) {
     std::lock_guard<std::mutex> g(ix->mu);
     Workspace *&w = ix->ws[key];

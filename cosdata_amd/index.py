@@ -254,6 +254,13 @@ class HNSWIndex:
         """Launches of at least `min_queries` queries walk level 0 in locality order (kernels_order.hip; 0 = never); same results."""
         check(_lib.lib().cos_index_set_walk_order(self._h, min_queries))
 
+    def walk_order_cuts(self):
+        """Levels after which a locality-ordered launch is cut and re-sorted (descending); [] if the graph has none it can use."""
+        lv = (C.c_uint32 * 16)()
+        n = C.c_uint32()
+        check(_lib.lib().cos_index_walk_order_cuts(self._h, lv, 16, C.byref(n)))
+        return [int(lv[i]) for i in range(min(n.value, 16))]
+
     def batch_search(self, queries, top_k: int, return_status: bool = False):
         """IndexOps::batch_search: [B][dim] raw f32 -> (ids [B][k], scores [B][k], counts [B]).
         Raises CosdataError (status 2 = CalculationError) if any query fails, like the

@@ -196,6 +196,9 @@ int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queries);
  * neighbouring regions of the graph.  Every query's walk, and so every result, is bit for bit what it is without the order. */
 #define COS_WALK_ORDER_DEFAULT_MIN_B 4096u
 int32_t cos_index_set_walk_order(cos_index *ix, uint32_t min_queries);
+/* The levels after which such a launch is cut (descending; the launch is re-sorted after each): by default ONE, the lowest level whose
+ * code rows take at most 64 MB; none (*out_n = 0) if the graph has no level the order can use.  Diagnostic: bench.py reports it. */
+int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t cap, uint32_t *out_n);
 /* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
 int32_t cos_index_enable_timing(cos_index *ix, int32_t on);
 int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out);

@@ -127,7 +127,7 @@ def run(n=1_000_000, dim=768, vocab=200_000, doc_len=120.0, batch=256, top_k=10,
                         "note": "achieved = 8 B x the postings of every query term of the batch / the HIP-event time of one cos_bm25_search_batch_device "
                                 "call on its stream (score + top-k kernels)"},
            "roofline_dense_half": {"bound": "hbm", "achieved": dense_bytes / (stt.walk_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                   "frac": dense_bytes / (stt.walk_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": "walk_lat_kernel (one 256-query batch, ef 256)",
+                                   "frac": dense_bytes / (stt.walk_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": "walk_lat4_kernel (one 256-query batch, ef 256: four waves per query)",
                                    "per_launch": {"algorithmic_bytes": float(dense_bytes), "avg_ms": stt.walk_ms, "evals": float(stt.evals),
                                                   "expansions": float(stt.expansions)},
                                    "note": "the one-call hybrid is bounded by this launch: a single 256-query batch cannot fill the chip"},

@@ -21,8 +21,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- python $R/bench.py
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d /tmp/p_s1 -o s1 -- python $R/bench.py $PM > $OUT/pmc_sq1_bench.json 2> $OUT/pmc_sq1.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d /tmp/p_s2 -o s2 -- python $R/bench.py $PM > $OUT/pmc_sq2_bench.json 2> $OUT/pmc_sq2.err
 cd $R
-python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" /tmp/p_w/w_results.db > $OUT/pmc_traffic_ef64.json
-python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "walk_kernel<0, 1, 4, true, false, 8>" /tmp/p_w/w_results.db > $OUT/pmc_traffic_ef256.json
+# the walk of a 32768-query step is two dispatches of the kernel (cut after level 2, cos_index_walk_order_cuts): bytes per step = 2 x the average
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" /tmp/p_w/w_results.db 2 > $OUT/pmc_traffic_ef64.json
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "walk_kernel<0, 1, 4, true, false, 8>" /tmp/p_w/w_results.db 2 > $OUT/pmc_traffic_ef256.json
 python scripts/rocprof_summary.py /tmp/p_f/f_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_fetch_size.txt
 python scripts/rocprof_summary.py /tmp/p_w/w_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_write_size.txt
 python scripts/rocprof_summary.py /tmp/p_s1/s1_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_sq_wave_cycles.txt 2>> $OUT/pmc_sq1.err

@@ -6,7 +6,7 @@ import sys
 
 def short(name):
     for key in ("walk_lat4_kernel", "walk_lat_kernel", "walk_meta_kernel", "walk_kernel", "finalize_kernel", "quantize_rows_kernel", "scatter_rows_kernel",
-                "merge_topk_kernel", "flat_", "bm25_", "rrf_kernel", "sparse_tile_kernel", "sparse_finish_kernel", "link_kernel", "claim_kernel", "evict_kernel"):
+                "merge_topk_kernel", "deal_to_xcds_kernel", "flat_", "bm25_", "rrf_kernel", "sparse_tile_kernel", "sparse_finish_kernel", "link_kernel", "claim_kernel", "evict_kernel"):
         if key in name:
             i = name.index(key)
             j = name.find("(", i)
@@ -23,6 +23,22 @@ def main(path):
                        "from kernels group by name, grid_x/workgroup_x order by sum(duration) desc limit 14").fetchall()
     for name, grid, calls, avg, mn, mx, tot in rows:
         print(f"{short(name):45s} | {grid:8d} | {calls:6d} | {avg/1e3:10.1f} | {mn/1e3:10.1f} | {mx/1e3:10.1f} | {tot/1e6:10.2f}")
+    # a locality-ordered walk is several dispatches of one kernel per step (WalkArgs::phase): split them by what preceded them
+    try:
+        seq = cur.execute("select name, grid_x/workgroup_x, duration from kernels order by start").fetchall()
+    except sqlite3.Error:
+        seq = []
+    parts = {}
+    prev = ""
+    for name, grid, dur in seq:
+        if "walk_kernel" in name and grid >= 4096:
+            part = "lower levels, after deal_to_xcds (locality order)" if "deal_to_xcds" in prev else "upper levels (arrival order) or unsplit walk"
+            parts.setdefault((short(name), grid, part), []).append(dur)
+        prev = name
+    if any("after deal_to_xcds" in k[2] for k in parts):
+        print("## walk_kernel dispatches by position in the step: name | grid | part | calls | avg_us | total_ms")
+        for (nm, grid, part), ds in sorted(parts.items()):
+            print(f"{nm:45s} | {grid:8d} | {part} | {len(ds)} | {sum(ds)/len(ds)/1e3:.1f} | {sum(ds)/1e6:.2f}")
     try:
         pm = cur.execute("select kernel_name, grid_size/workgroup_size, counter_name, count(*), avg(value), sum(value) from counters_collection "
                          "where kernel_name like '%cosdev%' or kernel_name like '%anonymous namespace%' "
