@@ -248,7 +248,7 @@ class HNSWIndex:
         """Launches of at most `max_queries` queries give every query four waves (kernels_walk_lat4.hip; 0 = never); same results."""
         check(_lib.lib().cos_index_set_latency_waves(self._h, max_queries))
 
-    WALK_ORDER_DEFAULT_MIN_B = 4096  # COS_WALK_ORDER_DEFAULT_MIN_B (include/cosdata_hip.h)
+    WALK_ORDER_DEFAULT_MIN_B = 8192  # COS_WALK_ORDER_DEFAULT_MIN_B (include/cosdata_hip.h)
 
     def set_walk_order(self, min_queries: int):
         """Launches of at least `min_queries` queries walk level 0 in locality order (kernels_order.hip; 0 = never); same results."""

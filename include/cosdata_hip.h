@@ -194,7 +194,7 @@ int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queries);
  * arrival order, then level 0 with the launch sorted by the path the upper levels found (best node of levels 3, 2, 1) and dealt to
  * the XCDs in contiguous runs (workgroup b runs on XCD b % 8, each XCD has its own L2), so the waves resident on an XCD walk
  * neighbouring regions of the graph.  Every query's walk, and so every result, is bit for bit what it is without the order. */
-#define COS_WALK_ORDER_DEFAULT_MIN_B 4096u
+#define COS_WALK_ORDER_DEFAULT_MIN_B 8192u
 int32_t cos_index_set_walk_order(cos_index *ix, uint32_t min_queries);
 /* The levels after which such a launch is cut (descending; the launch is re-sorted after each): by default ONE, the lowest level whose
  * code rows take at most 64 MB; none (*out_n = 0) if the graph has no level the order can use.  Diagnostic: bench.py reports it. */
