@@ -543,7 +543,8 @@ class DenseWorkload:
                     "rounds": float(np.mean([c[3] for c in cnts]))}
 
         tr = timed_run()
-        cuts = ix.walk_order_cuts() if B >= ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B else []  # the locality order of big launches
+        # the locality order of big launches (cos_index_set_walk_order: from WALK_ORDER_DEFAULT_MIN_B queries, ef <= 256)
+        cuts = ix.walk_order_cuts() if B >= ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B and ef <= 256 else []
         elapsed = tr["elapsed"]
         merged_qps = n_launch * B / elapsed        # answers over the global (world x n) corpus per second
         avg_ms, avg_bytes = tr["walk_ms"], tr["bytes"]

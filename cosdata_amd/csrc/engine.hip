@@ -820,7 +820,11 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     // Big launches walk in locality order (kernels_order.hip): the levels down to the first key level in arrival order, then, after
     // every key level, a sort of the launch by the key that level left and the levels below with the sorted queries dealt to the
     // XCDs.  Same walks, same results.
-    const bool ordered = order_min_B && B >= order_min_B && n_keys > 0 && w->order.cap >= B;
+    // Beam widths above 256 keep the single launch: the cut costs the tail of one more launch, a fixed ~3 % of the walk whatever
+    // the ef, while what the order saves shrinks as the walk turns from memory-bound to bound by its own serial work (c2: +16 % at
+    // ef 64, +3.6 % at 128, +2.6 % at 256, +1 % at 512; nothing measurable at ef 512 on the uniform corpus or on a 12.5M shard:
+    // profiles/r03_order_probe_*.jsonl and the two r03_final_bench_default_* lines, taken with and without this rule).
+    const bool ordered = order_min_B && B >= order_min_B && n_keys > 0 && w->order.cap >= B && ef <= 256u;
     auto walk = [&](hipStream_t s) -> int32_t {
         if (!ordered) { HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, lat4_max_B, s)); return COS_OK; }
         wa.phase = 1;

@@ -193,7 +193,8 @@ int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queries);
  * matter; on the device the order decides which rows a query finds in cache.  Such a launch walks in two steps: levels L..1 in
  * arrival order, then level 0 with the launch sorted by the path the upper levels found (best node of levels 3, 2, 1) and dealt to
  * the XCDs in contiguous runs (workgroup b runs on XCD b % 8, each XCD has its own L2), so the waves resident on an XCD walk
- * neighbouring regions of the graph.  Every query's walk, and so every result, is bit for bit what it is without the order. */
+ * neighbouring regions of the graph.  Every query's walk, and so every result, is bit for bit what it is without the order.
+ * Applies at ef_search <= 256: wider beams are bound by their own serial work and the second launch's tail costs more than the order saves. */
 #define COS_WALK_ORDER_DEFAULT_MIN_B 8192u
 int32_t cos_index_set_walk_order(cos_index *ix, uint32_t min_queries);
 /* The levels after which such a launch is cut (descending; the launch is re-sorted after each): by default ONE, the lowest level whose
