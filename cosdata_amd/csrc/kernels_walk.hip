@@ -829,11 +829,13 @@ size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     return b + 16;
 }
 
-// rows in flight per wave on the G = 64 u8 path (see PB64 above); COS_WALK_PB=4|8 overrides the default (experiments)
-static int walk_pb_policy(u32 B) {
+// rows in flight per wave on the G = 64 u8 path (see PB64 above); COS_WALK_PB=4|8 overrides the default (experiments).
+// The widest pool (ef > 256: 16 VGPRs of pool) with eight row buffers needs 110 VGPRs = 4 waves per SIMD; with four it fits 5 waves
+// without spills and measured 3.3 % faster (c2 at ef 512: 50.9 vs 52.6 ms per 32768 queries, profiles/r03_order_probe_c2_ef512_pb4.jsonl).
+static int walk_pb_policy(u32 B, u32 ef) {
     static const int forced = [] { const char *e = getenv("COS_WALK_PB"); return e ? atoi(e) : 0; }();
     if (forced == 4 || forced == 8) return forced;
-    return 8;
+    return ef > 256u ? 4 : 8;
 }
 
 template <int ENG, int CH, bool G64>
@@ -842,7 +844,7 @@ static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStrea
     dim3 grid(wa.B), block(64);
     const bool exact = ix.visited_mode != 0;
     constexpr bool HAS_PB8 = ENG == ENG_U8 && G64 && CH == 1; // the headline path (u8, 513..1024 dims)
-    const bool pb8 = HAS_PB8 && walk_pb_policy(wa.B) == 8;
+    const bool pb8 = HAS_PB8 && walk_pb_policy(wa.B, wa.ef) == 8;
 #define WALK(R_)                                                                                                          \
     do {                                                                                                                  \
         if constexpr (HAS_PB8) {                                                                                          \
