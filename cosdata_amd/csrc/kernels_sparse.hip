@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
     __syncthreads(); // the slice table
     // ---- stepped path (the usual case: the table holds every slice of the block and a query has <= 64 terms) --------------------
     // A tile's slices average ~900 postings, so the block-wide chunks below (2048 posting slots per (tile, term)) ran 43 % full and
-    // the kernel was instruction-bound (135 lane-instructions per posting, profiles/r03_sparse_*_sq_counters.txt).  Here every WAVE
+    // the kernel was instruction-bound (135 lane-instructions per posting, profiles/r03_sparse_tile_kernel_sq_counters_*.txt).  Here every WAVE
     // pulls STEPS — 512 consecutive postings of one slice — from a per-tile counter in LDS: a slice of L postings is ceil(L / 512)
     // steps, waves never wait for each other inside a tile (LDS atomic adds commute), a long slice spreads over the four waves, and
     // the next step's postings are in flight while the current one is applied.

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                     // their PB64 dot vectors are summed TOGETHER (wave_reduce_rows: 18 VALU for 8 rows), row p of the block
                     // landing in the lanes of group p — rounds 1-3 reduced row by row (4 dependent DPP adds + 4 v_readlane + a
                     // select per row) and fetched |v| and the node index with one predicated scalar-indexed load per row: 24 VALU
-                    // and 32 SALU per evaluation of the 38 + 36 the whole walk spent (profiles/r03_final_pmc_sq_instruction_mix).
+                    // and 32 SALU per evaluation of the 38 + 36 the whole walk spent (profiles/r03_mid_round_pmc_sq_instruction_mix_rocprofv3.txt).
                     // Lanes past the row's last chunk re-read chunk 0 against a zero query register instead of being masked off.
                     n_evals += (u64)W;
                     float magw = 1.0f; // |v| of every winner of the expansion: one vector load, in the winner's own lane
