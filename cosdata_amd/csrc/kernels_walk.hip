@@ -115,8 +115,10 @@ constexpr int PB = 4; // code rows in flight per lane group before the dots are 
 constexpr int LA = 4; // lookahead window: adjacency rows prefetched per round
 // G = 64 path: code rows in flight per wave = template parameter PB64.  An expansion discovers ~7 new neighbours on average:
 // with 4 rows in flight that is two dependent HBM round trips per pop, with 8 it is one.  Measured on c2 (profiles/
-// r02_c2_launch_shape_sweep_pb8.jsonl): 8 is faster at every launch size (+6 % at ef 64, +2 % at ef 256; the 16 extra VGPRs do
-// not change the occupancy, which the 106 SGPRs pin at 7 waves/SIMD), so 8 is the default where the variant exists.
+// r02_c2_launch_shape_sweep_pb8.jsonl): 8 is faster at every launch size (+6 % at ef 64, +2 % at ef 256), so 8 is the default where
+// the variant exists and the registers allow it: round 3's evaluation block holds the kernel at 80 VGPRs = 6 waves per SIMD for ef <= 64
+// (amdgpu_waves_per_eu below; 7 waves spill inside the loops and measured 7 % slower), 96 = 5 waves up to ef 256, and above that the
+// widest pool takes the 4-row variant (walk_pb_policy).
 
 // ------------------------------------------------------------------------------------------------
 // walk kernel
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                     // is taken straight from the owning lane with v_readlane and the row base lives in SGPRs (the load is the
                     // saddr + 32-bit lane offset form: no vector address arithmetic).  PB64 rows are in flight before the dots;
                     // their PB64 dot vectors are summed TOGETHER (wave_reduce_rows: 18 VALU for 8 rows), row p of the block
-                    // landing in the lanes of group p — rounds 1-3 reduced row by row (4 dependent DPP adds + 4 v_readlane + a
+                    // landing in the lanes of group p — until late in round 3 the block reduced row by row (4 dependent DPP adds + 4 v_readlane + a
                     // select per row) and fetched |v| and the node index with one predicated scalar-indexed load per row: 24 VALU
                     // and 32 SALU per evaluation of the 38 + 36 the whole walk spent (profiles/r03_mid_round_pmc_sq_instruction_mix_rocprofv3.txt).
                     // Lanes past the row's last chunk re-read chunk 0 against a zero query register instead of being masked off.
