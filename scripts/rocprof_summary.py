@@ -23,20 +23,29 @@ def main(path):
                        "from kernels group by name, grid_x/workgroup_x order by sum(duration) desc limit 14").fetchall()
     for name, grid, calls, avg, mn, mx, tot in rows:
         print(f"{short(name):45s} | {grid:8d} | {calls:6d} | {avg/1e3:10.1f} | {mn/1e3:10.1f} | {mx/1e3:10.1f} | {tot/1e6:10.2f}")
-    # a locality-ordered walk is several dispatches of one kernel per step (WalkArgs::phase): split them by what preceded them
+    # A locality-ordered walk is several dispatches of one kernel per step (WalkArgs::phase): split them by what preceded them ON THE
+    # SAME STREAM / QUEUE (the sort's deal_to_xcds_kernel precedes every level range but the first); with several steps in flight the
+    # global start order interleaves streams, so the trace's stream or queue column is used when it has one.
     try:
-        seq = cur.execute("select name, grid_x/workgroup_x, duration from kernels order by start").fetchall()
+        cols = [d[0] for d in cur.execute("select * from kernels limit 1").description]
+    except sqlite3.Error:
+        cols = []
+    lane_col = next((c for c in ("stream_id", "stream", "queue_id", "queue") if c in cols), None)
+    try:
+        seq = cur.execute(f"select name, grid_x/workgroup_x, duration, {lane_col or '0'} from kernels order by start").fetchall()
     except sqlite3.Error:
         seq = []
     parts = {}
-    prev = ""
-    for name, grid, dur in seq:
+    prev = {}
+    for name, grid, dur, lane in seq:
         if "walk_kernel" in name and grid >= 4096:
-            part = "lower levels, after deal_to_xcds (locality order)" if "deal_to_xcds" in prev else "upper levels (arrival order) or unsplit walk"
+            after_deal = "deal_to_xcds" in prev.get(lane, "")
+            part = "lower levels, after deal_to_xcds (locality order)" if after_deal else "upper levels (arrival order) or unsplit walk"
             parts.setdefault((short(name), grid, part), []).append(dur)
-        prev = name
+        prev[lane] = name
     if any("after deal_to_xcds" in k[2] for k in parts):
-        print("## walk_kernel dispatches by position in the step: name | grid | part | calls | avg_us | total_ms")
+        how = f"previous dispatch with the same {lane_col}" if lane_col else "previous dispatch in global start order: approximate when steps overlap"
+        print(f"## walk_kernel dispatches by position in the step ({how}): name | grid | part | calls | avg_us | total_ms")
         for (nm, grid, part), ds in sorted(parts.items()):
             print(f"{nm:45s} | {grid:8d} | {part} | {len(ds)} | {sum(ds)/len(ds)/1e3:.1f} | {sum(ds)/1e6:.2f}")
     try:
