@@ -48,6 +48,18 @@ class CosSearchStats(C.Structure):
     ]
 
 
+class CosWalkSplit(C.Structure):
+    """cos_walk_split: the last batch of a stream split by dispatch (level-table GEMM | levels above the cut | levels below it)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("queries", C.c_uint32), ("table_level_min", C.c_uint32), ("table_cols", C.c_uint32),
+        ("cut_after_level", C.c_uint32), ("reserved", C.c_uint32),
+        ("table_ms", C.c_float), ("upper_ms", C.c_float), ("sort_ms", C.c_float), ("lower_ms", C.c_float),
+        ("table_int8_ops", C.c_double), ("table_evals", C.c_uint64),
+        ("upper_evals", C.c_uint64), ("upper_expansions", C.c_uint64), ("upper_adj_bytes", C.c_uint64),
+        ("lower_evals", C.c_uint64), ("lower_expansions", C.c_uint64), ("lower_adj_bytes", C.c_uint64),
+    ]
+
+
 class CosTimingSummary(C.Structure):
     _fields_ = [("launches", C.c_uint32), ("prep_ms_sum", C.c_float), ("walk_ms_sum", C.c_float), ("finalize_ms_sum", C.c_float),
                 ("walk_ms_min", C.c_float), ("walk_ms_max", C.c_float)]
@@ -85,7 +97,7 @@ ABI_SYMBOLS = [
     "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build", "cos_index_enable_metadata", "cos_index_upload_meta_nodes", "cos_index_upload_meta_graph_level", "cos_index_build_meta", "cos_index_meta_level_count", "cos_index_download_meta_graph_level", "cos_search_filtered_batch",
     "cos_ann_search_filtered_batch", "cos_index_load_reference_dir", "cos_reference_dir_level_counts", "cos_reference_dir_read_level",
     "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_coalescing", "cos_index_set_ef_search",
-    "cos_index_set_visited_mode", "cos_index_set_latency_mode", "cos_index_set_latency_waves", "cos_index_set_walk_order", "cos_index_walk_order_cuts", "cos_index_enable_timing", "cos_index_last_stats", "cos_index_timing_summary", "cos_quantize_batch",
+    "cos_index_set_visited_mode", "cos_index_set_latency_mode", "cos_index_set_latency_waves", "cos_index_set_walk_order", "cos_index_walk_order_cuts", "cos_index_set_walk_table", "cos_index_walk_table_info", "cos_index_last_walk_split", "cos_index_enable_timing", "cos_index_last_stats", "cos_index_timing_summary", "cos_quantize_batch",
     "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
     "cos_bm25_search_batch", "cos_bm25_search_batch_device", "cos_rrf_fuse_batch", "cos_hybrid_search_batch", "cos_text_process", "cos_text_count_tokens", "cos_bm25_term_frequency", "cos_xxhash32", "cos_stem_english", "cos_sparse_create", "cos_sparse_build_csr", "cos_sparse_create_from_vectors", "cos_sparse_destroy", "cos_sparse_search_batch", "cos_sparse_last_stats", "cos_merge_topk_device", "cos_merge_topk_packed_device", "cos_hbm_probe",
     "cos_shardset_unique_id", "cos_shardset_create", "cos_shardset_destroy", "cos_shardset_search_batch", "cos_shardset_exchange_device",
@@ -143,6 +155,9 @@ def lib():
         "cos_index_walk_order_cuts": [vp, C.POINTER(u32), u32, C.POINTER(u32)],
         "cos_index_enable_timing": [vp, i32],
         "cos_index_last_stats": [vp, vp, C.POINTER(CosSearchStats)],
+        "cos_index_set_walk_table": [vp, u32, u32],
+        "cos_index_walk_table_info": [vp, C.POINTER(u32), C.POINTER(u32)],
+        "cos_index_last_walk_split": [vp, vp, C.POINTER(CosWalkSplit)],
         "cos_index_timing_summary": [vp, vp, C.POINTER(CosTimingSummary)],
         "cos_quantize_batch": [u32, u32, u32, f32, f32, vp, u32, vp, vp],
         "cos_sample_values_range": [vp, u32, u32, f32, C.POINTER(f32), C.POINTER(f32)],

@@ -84,6 +84,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     } guard{ix};
 
     ix->order_rank_valid = false; // the order key's table follows the graph (engine.hip, ensure_order_rank)
+    ix->level_table_valid = false; // and so does the level table's operand (ensure_level_table)
     // ---- root + level draws (same RNG stream as the oracle builders) ----------------------------
     uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
     std::vector<float> root(ix->p.dim);

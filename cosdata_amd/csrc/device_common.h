@@ -61,6 +61,11 @@ template <int CTRL>
 __device__ __forceinline__ u32 dpp_mov(u32 fill, u32 v) {
     return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, CTRL, 0xf, 0xf, false);
 }
+// the same moves with bound_ctrl: the lane without a source reads 0 and no `old` operand has to be prepared
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_mov_z(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
 __device__ __forceinline__ u64 dpp_wave_shr1_u64(u64 v, u64 fill) { // lane l <- lane l-1, lane 0 <- fill
     u32 lo = dpp_mov<0x138>((u32)fill, (u32)v), hi = dpp_mov<0x138>((u32)(fill >> 32), (u32)(v >> 32));
     return ((u64)hi << 32) | lo;
@@ -135,6 +140,23 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
     return ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ u32 readlane_u32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+// A value every lane of the wave holds alike, handed to the compiler as such (v_readfirstlane: the result lives in an SGPR).  A
+// wave-uniform value that arrives through a vector load (a pointer the kernel also writes through cannot take the scalar cache) is
+// "divergent" to the compiler, and so is every branch, loop counter and exit condition that depends on it: the loop is then
+// run with exec-mask bookkeeping (s_and_saveexec / s_andn2 exec chains, counters in VGPRs) instead of scalar branches.
+// Wave vote straight from the compare's SGPR mask.  hip's __ballot / __any take an int: the bool is first turned into 0 / 1
+// (v_cndmask) and compared again (v_cmp_ne) — two VALU instructions per vote, and the walk votes half a dozen times per expansion.
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// lane `lane` of `old` <- `val`, both wave-uniform (handed over through v_readfirstlane, which folds away when the compiler already
+// holds them in SGPRs).  gfx9 reads one SGPR per VALU instruction over the constant bus: the lane select goes through M0.
+__device__ __forceinline__ u32 writelane_dyn(u32 old, u32 val, int lane) {
+    const u32 sv = (u32)__builtin_amdgcn_readfirstlane((int)val);
+    const int sl = __builtin_amdgcn_readfirstlane(lane);
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sv), "s"(sl) : "m0");
+    return old;
+}
+__device__ __forceinline__ u32 uniform_u32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uniform_f32(float v) { return __uint_as_float((u32)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
 // base + row * stride for wave-uniform operands, on the scalar ALU (4 SALU, result in an SGPR pair), as a GLOBAL pointer: the row
 // load then takes it as its saddr operand with a 32-bit per-lane offset.  Left to the compiler, `base + (u64)row * stride +
 // lane_offset` becomes v_mov + v_mad_u64_u32 (quarter rate) + v_add per row address.
@@ -233,8 +255,12 @@ struct Pool {
         }
         return v;
     }
+    // node index (low half) of the entry at sorted position I: one v_readlane
+    template <int I>
+    __device__ __forceinline__ u32 peek_node() const { return readlane_u32((u32)e[I % R], I / R); }
     __device__ __forceinline__ void pop_head(int lane) {
-        const u64 nxt = dpp_wave_shl1_u64(e[0], 0ull); // lane l <- lane l+1's first entry; lane 63 <- empty
+        // lane l <- lane l+1's first entry; lane 63 <- empty (bound_ctrl zero fill: two DPP moves, nothing else)
+        const u64 nxt = ((u64)dpp_mov_z<0x130>((u32)(e[0] >> 32)) << 32) | dpp_mov_z<0x130>((u32)e[0]);
 #pragma unroll
         for (int r = 0; r + 1 < R; r++) e[r] = e[r + 1];
         e[R - 1] = nxt;
@@ -248,6 +274,19 @@ struct Pool {
     }
     // insert wave-uniform key k at position p (entries >= p shift up by one, the last one drops)
     __device__ __forceinline__ void insert_at(u64 k, int p, int lane) {
+        if constexpr (R == 1) {
+            // one entry per lane: lanes above p take their lower neighbour's entry (two DPP moves + one compare + two selects),
+            // lane p takes k by v_writelane (no compare against p, no broadcast of k into a VGPR pair)
+            u32 lo = (u32)e[0], hi = (u32)(e[0] >> 32);
+            const u32 slo = dpp_mov_z<0x138>(lo), shi = dpp_mov_z<0x138>(hi); // lane 0 has no lower neighbour and never shifts
+            const bool up = lane > p;
+            lo = up ? slo : lo;
+            hi = up ? shi : hi;
+            lo = writelane_dyn(lo, (u32)k, p);
+            hi = writelane_dyn(hi, (u32)(k >> 32), p);
+            e[0] = ((u64)hi << 32) | lo;
+            return;
+        }
         const int lp = p / R, rp = p % R;
         const u64 prev_last = dpp_wave_shr1_u64(e[R - 1], 0ull); // lane l <- lane l-1's last entry
 #pragma unroll

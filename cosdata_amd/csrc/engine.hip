@@ -192,7 +192,7 @@ static void free_level(LevelHost &l) {
     l.host_valid = false;
 }
 static void free_ws(Workspace *w) {
-    void *ptrs[] = {w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
+    void *ptrs[] = {w->stats2, w->tab, w->qsums, w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
                     w->rerank_rows, w->vis.bits, w->vis.log, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     cosdev::walk_order_free(w->order);
@@ -247,6 +247,9 @@ extern "C" int32_t cos_index_destroy(cos_index *ix) {
     if (ix->d_codes) (void)hipFree(ix->d_codes);
     if (ix->d_mags) (void)hipFree(ix->d_mags);
     for (u32 *p : ix->d_order_rank) if (p) (void)hipFree(p);
+    if (ix->d_tcodes) (void)hipFree(ix->d_tcodes);
+    if (ix->d_tmags) (void)hipFree(ix->d_tmags);
+    if (ix->d_tcsums) (void)hipFree(ix->d_tcsums);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
     return COS_OK;
@@ -270,6 +273,7 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     ix->have_root = false;
     for (auto &l : ix->lv) free_level(l); // a graph refers to vector rows: new vectors invalidate it
     ix->order_rank_valid = false;
+    ix->level_table_valid = false;
     reset_meta(ix);                       // ... and so do the pseudo-root component, its node table and the id stride
     const u64 dim = ix->p.dim;
     struct Rollback { // a failed upload leaves the handle empty instead of half-populated
@@ -367,6 +371,7 @@ static int32_t push_level_to_device(cos_index *ix, u32 level) {
     L.n = n;
     L.host_valid = true;
     ix->order_rank_valid = false; // the order key's table follows the graph (ensure_order_rank)
+    ix->level_table_valid = false;
     return COS_OK;
 }
 
@@ -696,6 +701,84 @@ static int32_t ensure_order_rank(cos_index *ix) {
     return COS_OK;
 }
 
+// The level table's per-graph operand (WalkArgs::tab, cosdata_hip.h cos_index_set_walk_table): which levels it covers and the code
+// rows, norms and code sums of their nodes, level by level from the top, gathered on the device.  Caller holds ix->mu.
+static void free_level_table(cos_index *ix) {
+    if (ix->d_tcodes) (void)hipFree(ix->d_tcodes);
+    if (ix->d_tmags) (void)hipFree(ix->d_tmags);
+    if (ix->d_tcsums) (void)hipFree(ix->d_tcsums);
+    ix->d_tcodes = nullptr;
+    ix->d_tmags = nullptr;
+    ix->d_tcsums = nullptr;
+    ix->table_cols = 0;
+    ix->table_level_min = 0;
+    ix->table_stride = 0;
+}
+static u32 walk_table_max_cols(const cos_index *ix) {
+    static const long long env = [] { const char *e = getenv("COS_WALK_TABLE_COLS"); return e ? atoll(e) : -1ll; }();
+    return env >= 0 ? (u32)std::min<long long>(env, 1ll << 20) : ix->walk_table_max_cols;
+}
+static u32 walk_table_min_B(const cos_index *ix) {
+    static const long long env = [] { const char *e = getenv("COS_WALK_TABLE_MIN_B"); return e ? atoll(e) : -1ll; }();
+    return env >= 0 ? (u32)std::min<long long>(env, 0xFFFFFFFFll) : ix->walk_table_min_B;
+}
+static int32_t ensure_level_table(cos_index *ix) {
+    const u32 max_cols = walk_table_max_cols(ix);
+    if (ix->level_table_valid && ix->table_built_for_cols == max_cols) return COS_OK;
+    free_level_table(ix);
+    ix->level_table_valid = true;
+    ix->table_built_for_cols = max_cols;
+    if (ix->eng != ENG_U8 || max_cols == 0) return COS_OK; // u8 codes only
+    const u32 Ltop = ix->p.num_layers;
+    u32 cols = 0, lmin = 0;
+    for (u32 l = Ltop; l >= 1; l--) { // level 0 (every vector) never takes part
+        if (!ix->lv[l].d_node_vec || ix->lv[l].n == 0 || cols + ix->lv[l].n > max_cols) break;
+        cols += ix->lv[l].n;
+        lmin = l;
+    }
+    if (lmin == 0) return COS_OK;
+    HIP_TRY(hipDeviceSynchronize()); // a build or an upload on another stream may still be writing the levels
+    HIP_TRY(hipMalloc((void **)&ix->d_tcodes, (size_t)cols * ix->row_stride));
+    HIP_TRY(hipMalloc((void **)&ix->d_tmags, (size_t)cols * 4));
+    HIP_TRY(hipMalloc((void **)&ix->d_tcsums, (size_t)cols * 4));
+    u32 c0 = 0;
+    for (u32 l = Ltop; l >= lmin; l--) {
+        ix->table_col0[l] = c0;
+        HIP_TRY(cosdev::launch_level_table_gather(ix->d_codes, ix->d_mags, ix->row_stride, ix->lv[l].d_node_vec, ix->lv[l].n, c0, ix->d_tcodes,
+                                                  ix->d_tmags, nullptr));
+        c0 += ix->lv[l].n;
+    }
+    HIP_TRY(cosdev::launch_code_sums(ix->d_tcodes, ix->row_stride, cols, ix->d_tcsums, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    ix->table_cols = cols;
+    ix->table_level_min = lmin;
+    ix->table_stride = ((u64)cols + 31) / 32 * 32;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_set_walk_table(cos_index *ix, uint32_t max_cols, uint32_t min_queries) {
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null argument");
+    if (max_cols > (1u << 20)) return cos_fail(COS_ERR_INVALID, "max_cols must be <= 2^20");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->walk_table_max_cols = max_cols;
+    ix->walk_table_min_B = min_queries;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_walk_table_info(cos_index *ix, uint32_t *out_level_min, uint32_t *out_cols) {
+    if (!ix || !out_level_min || !out_cols) return cos_fail(COS_ERR_INVALID, "null argument");
+    *out_level_min = *out_cols = 0;
+    if (!graph_ready(ix)) return cos_fail(COS_ERR_NOT_READY, "index needs vectors, root and every graph level");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (walk_table_min_B(ix) == 0) return COS_OK;
+    if ((rc = ensure_level_table(ix))) return rc;
+    *out_level_min = ix->table_level_min;
+    *out_cols = ix->table_cols;
+    return COS_OK;
+}
+
 extern "C" int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t cap, uint32_t *out_n) {
     if (!ix || !out_n || (cap && !out_levels)) return cos_fail(COS_ERR_INVALID, "null argument");
     *out_n = 0;
@@ -727,6 +810,8 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         HIP_TRY(regrow(w->walk_counts, (size_t)cap * L1));
         HIP_TRY(regrow(w->walk_status, cap));
         HIP_TRY(regrow(w->stats, (size_t)cap * 4));
+        HIP_TRY(regrow(w->stats2, (size_t)cap * 4));
+        HIP_TRY(regrow(w->qsums, cap));
         HIP_TRY(regrow(w->rerank_rows, cap));
         HIP_TRY(regrow(w->d_queries, (size_t)cap * ix->p.dim));
         HIP_TRY(regrow(w->d_out_counts, cap));
@@ -741,13 +826,25 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         }
         if (int32_t rc = ensure_order_rank(ix)) return rc;
     }
+    if (const u32 tmin = walk_table_min_B(ix); tmin && B >= tmin) {
+        if (int32_t rc = ensure_level_table(ix)) return rc;
+        const size_t need = (size_t)w->capB * ix->table_stride;
+        if (need > w->tab_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (w->tab) HIP_TRY(hipFree(w->tab));
+            w->tab = nullptr;
+            w->tab_cap = 0;
+            HIP_TRY(hipMalloc((void **)&w->tab, need * 4));
+            w->tab_cap = need;
+        }
+    }
     if (host_api && (size_t)top_k * w->capB > (size_t)w->cap_topk * w->capB) {
         HIP_TRY(regrow(w->d_out_ids, (size_t)w->capB * top_k));
         HIP_TRY(regrow(w->d_out_scores, (size_t)w->capB * top_k));
         w->cap_topk = top_k;
     }
     if (w->ev.empty()) {
-        w->ev.assign((size_t)Workspace::EV_RING * 4, nullptr);
+        w->ev.assign((size_t)Workspace::EV_RING * Workspace::EV_PER, nullptr);
         for (auto &e : w->ev) HIP_TRY(hipEventCreate(&e));
     }
     if (!w->walk_done) HIP_TRY(hipEventCreateWithFlags(&w->walk_done, hipEventDisableTiming));
@@ -766,6 +863,11 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     bool timed;
     u32 ef, lat_max_B, lat4_max_B, order_min_B, n_keys = 0, key_level[cosdev::MAX_LEVELS], key_n[cosdev::MAX_LEVELS];
     const u32 *order_rank[cosdev::MAX_LEVELS];
+    u32 tab_level_min = 0, tab_cols = 0, tab_col0[cosdev::MAX_LEVELS] = {};
+    u64 tab_stride = 0;
+    const uint8_t *tcodes = nullptr;
+    const float *tmags = nullptr;
+    const u32 *tcsums = nullptr;
     { // one consistent snapshot of the knobs cos_index_set_* may change from another thread
         std::lock_guard<std::mutex> g(ix->mu);
         order_min_B = ix->order_rank_valid && !ix->order_levels.empty() ? ix->walk_order_min_B : 0u;
@@ -773,6 +875,16 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
             key_level[n_keys] = l;
             key_n[n_keys] = ix->order_rank_n[l];
             order_rank[n_keys++] = ix->d_order_rank[l];
+        }
+        if (const u32 tmin = walk_table_min_B(ix); tmin && B >= tmin && ix->level_table_valid && ix->table_level_min &&
+                                                    w->tab && (size_t)B * ix->table_stride <= w->tab_cap) {
+            tab_level_min = ix->table_level_min;
+            tab_cols = ix->table_cols;
+            tab_stride = ix->table_stride;
+            memcpy(tab_col0, ix->table_col0, sizeof(tab_col0));
+            tcodes = ix->d_tcodes;
+            tmags = ix->d_tmags;
+            tcsums = ix->d_tcsums;
         }
         timed = ix->timing;
         ef = ix->p.ef_search;
@@ -786,10 +898,18 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
         int32_t rc = vis_tab_prepare(w->vis, ix, B, ef, st, wa);
         if (rc) return rc;
     }
-    hipEvent_t *ev = &w->ev[(size_t)(w->ev_count % Workspace::EV_RING) * 4];
+    hipEvent_t *ev = &w->ev[(size_t)(w->ev_count % Workspace::EV_RING) * Workspace::EV_PER];
     if (timed) HIP_TRY(hipEventRecord(ev[0], st));
     HIP_TRY(launch_quantize_rows(ix->eng, d_queries, ix->p.dim, B, ix->p.dim, ix->p.range_lo, ix->p.range_hi, w->q_codes, ix->row_stride,
                                  w->q_mags, w->q_raw_mags, st));
+    // Level table: on the caller's stream, i.e. BEFORE the walk takes its place in the walk chain — the GEMM of this launch runs
+    // on the matrix cores next to the previous launch's walk, which leaves them idle.
+    if (tab_level_min) {
+        if (timed) HIP_TRY(hipEventRecord(ev[4], st));
+        HIP_TRY(cosdev::launch_level_table(w->q_codes, w->q_mags, w->qsums, B, tcodes, tmags, tcsums, ix->row_stride, tab_cols, ix->p.metric, w->tab,
+                                           tab_stride, st));
+        if (timed) HIP_TRY(hipEventRecord(ev[5], st));
+    }
     if (timed) HIP_TRY(hipEventRecord(ev[1], st));
     wa.qcodes = w->q_codes;
     wa.qmags = w->q_mags;
@@ -801,6 +921,14 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     wa.out_counts = w->walk_counts;
     wa.out_status = w->walk_status;
     wa.out_stats = w->stats;
+    wa.out_stats2 = w->stats2;
+    HIP_TRY(hipMemsetAsync(w->stats2, 0, (size_t)B * 32, st)); // the latency kernels do not write it
+    if (tab_level_min) {
+        wa.tab = w->tab;
+        wa.tab_stride = tab_stride;
+        wa.tab_level_min = tab_level_min;
+        memcpy(wa.tab_col0, tab_col0, sizeof(tab_col0));
+    }
     // Big walks run on the workspace's own LOW-PRIORITY stream (ordered after the quantize and before the finalize of `st` by
     // events): the short kernels around a walk — the neighbouring launch's quantize and, above all, its finalize, which used to
     // take 11-16 ms instead of 1.2 when its waves queued behind 32 768 walk waves of the next launch — are dispatched ahead of
@@ -840,7 +968,9 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
             wa.order_rank = last ? nullptr : order_rank[i];
             HIP_TRY(launch_walk(ix->eng, dev, wa, 0, 0, s));
             if (last) break;
+            if (timed && i == 0) HIP_TRY(hipEventRecord(ev[6], s));
             HIP_TRY(cosdev::launch_walk_order(w->order, B, key_n[i], s));
+            if (timed && i == 0) HIP_TRY(hipEventRecord(ev[7], s));
             wa.q_order = w->order.q_order;
             first = key_level[i] - 1;
         }
@@ -871,6 +1001,10 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     if (timed) { HIP_TRY(hipEventRecord(ev[3], sf)); w->ev_count++; }
     w->lastB = B;
     w->timed = timed;
+    w->last_tab = tab_level_min != 0;
+    w->last_tab_cols = tab_cols;
+    w->last_split = ordered;
+    w->last_cut_level = ordered ? key_level[0] : 0u;
     { std::lock_guard<std::mutex> g(ix->mu); ix->last_ws = w; }
     return COS_OK;
 }
@@ -1200,7 +1334,7 @@ extern "C" int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_
     }
     if (w->lastB == 0) return cos_fail(COS_ERR_NOT_READY, "no batch has run on this stream");
     if (w->timed && w->ev_count) {
-        hipEvent_t *ev = &w->ev[(size_t)((w->ev_count - 1) % Workspace::EV_RING) * 4];
+        hipEvent_t *ev = &w->ev[(size_t)((w->ev_count - 1) % Workspace::EV_RING) * Workspace::EV_PER];
         HIP_TRY(hipEventSynchronize(ev[3]));
         HIP_TRY(hipEventElapsedTime(&out->prep_ms, ev[0], ev[1]));
         HIP_TRY(hipEventElapsedTime(&out->walk_ms, ev[1], ev[2]));
@@ -1221,6 +1355,61 @@ extern "C" int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_
     return COS_OK;
 }
 
+extern "C" int32_t cos_index_last_walk_split(cos_index *ix, void *stream, cos_walk_split *out) {
+    if (!ix || !out) return cos_fail(COS_ERR_INVALID, "null argument");
+    if (out->struct_size != sizeof(cos_walk_split)) return cos_fail(COS_ERR_INVALID, "cos_walk_split.struct_size mismatch");
+    memset(out, 0, sizeof(*out));
+    out->struct_size = sizeof(cos_walk_split);
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    Workspace *w = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        if (stream) {
+            auto it = ix->ws.find(stream);
+            if (it != ix->ws.end()) w = it->second;
+        } else
+            w = ix->last_ws;
+    }
+    if (!w || w->lastB == 0) return cos_fail(COS_ERR_NOT_READY, "no batch has run on this stream");
+    out->queries = w->lastB;
+    out->table_level_min = w->last_tab ? ix->table_level_min : 0u;
+    out->table_cols = w->last_tab ? w->last_tab_cols : 0u;
+    out->cut_after_level = w->last_cut_level;
+    if (w->timed && w->ev_count) {
+        hipEvent_t *ev = &w->ev[(size_t)((w->ev_count - 1) % Workspace::EV_RING) * Workspace::EV_PER];
+        HIP_TRY(hipEventSynchronize(ev[3]));
+        if (w->last_tab) HIP_TRY(hipEventElapsedTime(&out->table_ms, ev[4], ev[5]));
+        if (w->last_split) {
+            HIP_TRY(hipEventElapsedTime(&out->upper_ms, ev[1], ev[6]));
+            HIP_TRY(hipEventElapsedTime(&out->sort_ms, ev[6], ev[7]));
+            HIP_TRY(hipEventElapsedTime(&out->lower_ms, ev[7], ev[2]));
+        } else
+            HIP_TRY(hipEventElapsedTime(&out->lower_ms, ev[1], ev[2]));
+    } else {
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    const u32 kdims = (u32)((ix->row_stride + 63) / 64 * 64);
+    out->table_int8_ops = 2.0 * (double)w->lastB * (double)out->table_cols * (double)kdims;
+    std::vector<u64> st((size_t)w->lastB * 4), s2((size_t)w->lastB * 4);
+    HIP_TRY(hipMemcpy(st.data(), w->stats, st.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s2.data(), w->stats2, s2.size() * 8, hipMemcpyDeviceToHost));
+    u64 te = 0, tx = 0, ta = 0;
+    for (u32 b = 0; b < w->lastB; b++) {
+        te += st[(size_t)b * 4 + 0];
+        tx += st[(size_t)b * 4 + 1];
+        ta += st[(size_t)b * 4 + 2];
+        out->lower_evals += s2[(size_t)b * 4 + 0];
+        out->lower_expansions += s2[(size_t)b * 4 + 1];
+        out->lower_adj_bytes += s2[(size_t)b * 4 + 2];
+        out->table_evals += s2[(size_t)b * 4 + 3];
+    }
+    out->upper_evals = te - out->lower_evals;
+    out->upper_expansions = tx - out->lower_expansions;
+    out->upper_adj_bytes = ta - out->lower_adj_bytes;
+    return COS_OK;
+}
+
 extern "C" int32_t cos_index_timing_summary(cos_index *ix, void *stream, cos_timing_summary *out) {
     if (!ix || !out) return cos_fail(COS_ERR_INVALID, "null argument");
     memset(out, 0, sizeof(*out));
@@ -1237,7 +1426,7 @@ extern "C" int32_t cos_index_timing_summary(cos_index *ix, void *stream, cos_tim
     out->launches = n;
     out->walk_ms_min = 1e30f;
     for (u32 i = 0; i < n; i++) {
-        hipEvent_t *ev = &w->ev[(size_t)((w->ev_count - 1 - i) % Workspace::EV_RING) * 4];
+        hipEvent_t *ev = &w->ev[(size_t)((w->ev_count - 1 - i) % Workspace::EV_RING) * Workspace::EV_PER];
         float a = 0, b = 0, c = 0;
         HIP_TRY(hipEventSynchronize(ev[3]));
         HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));

@@ -40,6 +40,12 @@ struct WalkOrder {
 hipError_t walk_order_reserve(WalkOrder &o, u32 B); // synchronous (re)allocation
 void walk_order_free(WalkOrder &o);
 hipError_t launch_walk_order(WalkOrder &o, u32 B, u32 key_max, hipStream_t st);
+// level table of the walk (kernels_flat.hip; WalkArgs::tab)
+hipError_t launch_level_table_gather(const uint8_t *codes, const float *mags, u64 row_stride, const u32 *node_vec, u32 n, u32 col0,
+                                     uint8_t *tcodes, float *tmags, hipStream_t st);
+hipError_t launch_code_sums(const uint8_t *codes, u64 row_stride, u32 n, u32 *sums, hipStream_t st);
+hipError_t launch_level_table(const uint8_t *qcodes, const float *qmags, u32 *qsums, u32 B, const uint8_t *tcodes, const float *tmags,
+                              const u32 *tcsums, u64 row_stride, u32 ncols, u32 metric, float *tab, u64 tab_stride, hipStream_t st);
 int32_t quantize_ref_layout(uint32_t storage, uint32_t res, uint32_t dim, const float *x, uint32_t n, void *codes, float *mags);
 int32_t distance_ref_layout(uint32_t metric, uint32_t storage, uint32_t res, uint32_t dim, const void *x_codes, const float *x_mags, uint32_t nx,
                             const void *y_codes, const float *y_mags, uint32_t ny, const uint32_t *pair_x, const uint32_t *pair_y, uint32_t n_pairs,
@@ -99,6 +105,10 @@ struct Workspace {
     float *walk_sims = nullptr;
     int32_t *walk_status = nullptr;
     u64 *stats = nullptr;       // [B][4]
+    u64 *stats2 = nullptr;      // [B][4] WalkArgs::out_stats2
+    float *tab = nullptr;       // level table of this workspace's big launches [capB][tab_stride] (WalkArgs::tab), grown on demand
+    size_t tab_cap = 0;         // floats
+    u32 *qsums = nullptr;       // [capB] code sums of the queries (the table GEMM's recentring term)
     u64 *rerank_rows = nullptr; // [B]
     VisTab vis; // EXACT mode visited filters
     cosdev::WalkOrder order; // locality order of big launches (cos_index::walk_order_min_B)
@@ -109,14 +119,19 @@ struct Workspace {
     int32_t *d_out_status = nullptr;
     // timing: a ring of event quadruples (before prep | after prep | after walk | after finalize), one per launch, so a
     // run of launches can be summarised afterwards without synchronising between them (cos_index_timing_summary)
+    // + the inner marks of a big launch's walk: [4] before / [5] after the level-table GEMM (caller's stream), [6] after the upper
+    // level range, [7] after the order sort (walk stream); lastSplit says which of them the last launch recorded
     static constexpr u32 EV_RING = 128;
-    std::vector<hipEvent_t> ev; // [EV_RING][4]
+    static constexpr u32 EV_PER = 8;
+    std::vector<hipEvent_t> ev; // [EV_RING][EV_PER]
     u32 ev_count = 0;           // timed launches since timing was switched on (ring position = ev_count % EV_RING)
     hipEvent_t walk_done = nullptr; // recorded after this workspace's walk kernel (walk chain, see cos_index::chain_*)
     hipStream_t walk_stream = nullptr; // low-priority stream big walks run on (cos_index::walk_side_min_B), created on first use
     hipEvent_t prep_done = nullptr, walk_fin = nullptr; // caller's stream -> walk stream -> finalize stream
     u32 lastB = 0;
     bool timed = false;
+    bool last_tab = false, last_split = false; // the last launch used the level table / was cut into two level ranges
+    u32 last_tab_cols = 0, last_cut_level = 0;
 };
 
 // The pseudo-root component of a collection with a metadata schema: pseudo nodes + Metadata replicas, a graph of
@@ -193,6 +208,17 @@ struct cos_index {
     u32 order_rank_n[cosdev::MAX_LEVELS] = {};
     std::vector<u32> order_levels; // empty = the graph has no level the order could use
     bool order_rank_valid = false;
+    // Level table (WalkArgs::tab): launches of at least walk_table_min_B queries over u8 codes precompute the similarities to every
+    // node of the levels >= table_level_min with one i8 MFMA GEMM; table_level_min = the lowest level such that the levels from it
+    // to the top hold at most walk_table_max_cols nodes together (0 = no table).  Env COS_WALK_TABLE_COLS / COS_WALK_TABLE_MIN_B.
+    u32 walk_table_max_cols = COS_WALK_TABLE_DEFAULT_MAX_COLS, walk_table_min_B = COS_WALK_TABLE_DEFAULT_MIN_B;
+    bool level_table_valid = false;  // the arrays below follow the graph and walk_table_max_cols
+    u32 table_level_min = 0, table_cols = 0, table_built_for_cols = 0;
+    u64 table_stride = 0;            // floats per query row (cols padded to 32)
+    u32 table_col0[cosdev::MAX_LEVELS] = {};
+    uint8_t *d_tcodes = nullptr;     // [table_cols][row_stride] code rows of the table's nodes, level by level from the top
+    float *d_tmags = nullptr;        // [table_cols]
+    u32 *d_tcsums = nullptr;         // [table_cols]
     u32 walk_side_min_B = 4096; // launches of at least this many queries walk on the workspace's low-priority stream; 0 = never
     // launches of at most this many queries run the latency variant of the walk (kernels_walk_lat.hip) where it applies; 0 = never
     u32 lat_max_B = COS_LATENCY_MODE_DEFAULT_MAX_B;

@@ -70,7 +70,18 @@ struct WalkArgs {
     const int32_t *f_dims;
     const float *f_mags;
     const u32 *f_off;
-    u64 *out_stats;      // [B][4]: evals, expansions, adj_bytes, reserved
+    u64 *out_stats;      // [B][4]: evals, expansions, adj_bytes, rounds
+    u64 *out_stats2;     // optional [B][4] (walk_kernel only): evals, expansions, adj_bytes of the LAST level range of a split walk
+                         // (the whole walk when it is not split), evaluations served by the level table
+    // Level table (big search launches over u8 codes; kernels_flat.hip launch_level_table, engine.hip ensure_level_table): for the
+    // levels >= tab_level_min — few nodes, walked by every query — the similarity of every (query, node) pair is computed before
+    // the walk as ONE exact-integer i8 MFMA GEMM with the walk's own conversion and division, tab[q][tab_col0[level] + node].
+    // The walk of those levels reads 4 bytes per evaluation instead of gathering and dotting a code row; which nodes it visits, the
+    // lossy filter and every result are what they were (same bits: the integer dot is exact either way).  nullptr = no table.
+    const float *tab;
+    u64 tab_stride;       // floats per query row
+    u32 tab_level_min;
+    u32 tab_col0[MAX_LEVELS];
     // Locality-ordered walk (big search launches; kernels_order.hip, engine.hip run_search).  The walk of a launch is split
     // into launches of the same kernel over consecutive level ranges [level_first .. level_last]; between two of them the
     // launch's queries are sorted by an ORDER KEY and dealt to the XCDs in contiguous runs (workgroup b runs on XCD b % 8, each

@@ -895,3 +895,57 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     if (zero) return cos_fail(COS_ERR_CALCULATION, "zero-norm query or stored vector: DistanceError::CalculationError (cosine.rs:228-232)");
     return COS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Level table of the walk (WalkArgs::tab, engine.hip ensure_level_table / run_search): similarity of every query of a big launch to
+// every node of the graph's small upper levels, as ONE pass of the exact-integer i8 GEMM above with its unfused epilogue —
+// `(u32 dot) as f32` and the IEEE quotient by |q| * |v|, the very operations the walk applies to a row it dots itself
+// (cosine.rs:223-235), so the table holds the bits the walk would have computed.  The walk then reads 4 bytes per evaluation on
+// those levels.  The nodes' code rows are gathered once per graph into a compact operand (level_table_gather).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void level_table_gather_kernel(const uint8_t *__restrict__ codes, const float *__restrict__ mags, u64 row_stride,
+                                                                 const u32 *__restrict__ node_vec, u32 n, u32 col0, uint8_t *__restrict__ tcodes,
+                                                                 float *__restrict__ tmags) {
+    const int lane = threadIdx.x & 63;
+    const u32 node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= n) return;
+    const u32 row = node_vec[node];
+    const uint4 *src = (const uint4 *)(codes + (u64)row * row_stride);
+    uint4 *dst = (uint4 *)(tcodes + (u64)(col0 + node) * row_stride);
+    for (u32 c = lane; c < (u32)(row_stride / 16); c += 64) dst[c] = src[c];
+    if (lane == 0) tmags[col0 + node] = mags[row];
+}
+} // namespace
+
+namespace cosdev {
+
+hipError_t launch_level_table_gather(const uint8_t *codes, const float *mags, u64 row_stride, const u32 *node_vec, u32 n, u32 col0,
+                                     uint8_t *tcodes, float *tmags, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(level_table_gather_kernel, dim3((n + 3) / 4), dim3(256), 0, st, codes, mags, row_stride, node_vec, n, col0, tcodes, tmags);
+    return hipGetLastError();
+}
+
+hipError_t launch_code_sums(const uint8_t *codes, u64 row_stride, u32 n, u32 *sums, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(code_sums_kernel, dim3((n + 3) / 4), dim3(256), 0, st, codes, row_stride, n, sums);
+    return hipGetLastError();
+}
+
+// tab[q][c] = similarity(query q, table column c) for q < B, c < ncols; u8 codes only (a zero denominator shows as 0/0 = NaN)
+hipError_t launch_level_table(const uint8_t *qcodes, const float *qmags, u32 *qsums /*[B] scratch*/, u32 B, const uint8_t *tcodes,
+                              const float *tmags, const u32 *tcsums, u64 row_stride, u32 ncols, u32 metric, float *tab, u64 tab_stride,
+                              hipStream_t st) {
+    if (B == 0 || ncols == 0) return hipSuccess;
+    hipError_t e = launch_code_sums(qcodes, row_stride, B, qsums, st);
+    if (e != hipSuccess) return e;
+    const u32 kdims = (u32)((row_stride + 63) / 64 * 64);
+    dim3 grid((ncols + CN - 1) / CN, (B + CM - 1) / CM);
+    FusedOut fo{nullptr, nullptr, nullptr, 0u, nullptr};
+    hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, false, 2>), grid, dim3(512), 0, st, qcodes, qmags, (const u32 *)qsums, B, tcodes, tmags, tcsums,
+                       row_stride, 0u, ncols, kdims, metric, tab, tab_stride, fo);
+    return hipGetLastError();
+}
+
+} // namespace cosdev

@@ -130,7 +130,6 @@ struct WalkSmem {
     u32 *wl_node; //                                     node indices
     u32 *win_vec; // lookahead window: prefetched adjacency rows [LA][64]
     u32 *win_node;
-    u64 *win_key; // [LA]
     float *qf;    // F32 engine: the query vector
 };
 
@@ -153,7 +152,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
         sm.wl_node = (u32 *)p;  p += 64 * 4;
         sm.win_vec = (u32 *)p;  p += LA * 64 * 4;
         sm.win_node = (u32 *)p; p += LA * 64 * 4;
-        sm.win_key = (u64 *)p;  p += LA * 8;
         p = (unsigned char *)(((size_t)p + 15) & ~(size_t)15);
         sm.qf = (float *)p;
     }
@@ -173,6 +171,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
 
     // ---- engine set-up -------------------------------------------------------------------------
     constexpr bool FLOAT_ENG = ENG == ENG_F32 || ENG == ENG_F16; // ordered f32 chains instead of integer chunk dots
+    constexpr bool TABLE_OK = ENG == ENG_U8; // level tables exist for u8 codes (engine.hip, ensure_level_table)
     const int G = (ENG == ENG_F32) ? 8 : (ENG == ENG_F16 ? 1 : (int)ix.G); // f32: eight lanes per row, one per accumulator chain
     const int lig = lane & (G - 1);  // lane in group
     const int grp = lane / G;        // group index
@@ -207,9 +206,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
         loff64[c] = (chunk < ix.nchunks ? chunk : 0u) * 16u;
     }
 
-    u64 n_evals = 0, n_exp = 0, adj_bytes = 0, n_rounds = 0;
+    u64 n_evals = 0, n_exp = 0, adj_bytes = 0, n_rounds = 0, n_tab = 0;
     int32_t status = COS_OK;
-    u32 entry = resume ? wa.entry0[qi] : ix.lv[L].root_idx;
+    u32 entry = uniform_u32(resume ? wa.entry0[qi] : ix.lv[L].root_idx);
     const int level_first = wa.phase ? (int)wa.level_first : (int)L, level_last = wa.phase ? (int)wa.level_last : 0;
     u32 order_key = wa.key_n; // split walk: depth-first position of the best node of level_last
 
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
             dotf = __uint_as_float(readlane_u32(__float_as_uint(d), 0));
         }
         if (metric == 0u) { // cosine_similarity_from_dot_product (cosine.rs:223-235)
-            float den = __fmul_rn(qmag, ix.mags[row]);
+            const float den = uniform_f32(__fmul_rn(qmag, ix.mags[row]));
             if (den == 0.0f) return false;
             sim_out = __fdiv_rn(dotf, den);
         } else {
@@ -252,6 +251,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
         const u32 bitmask = 64u * M - 1u;
         const u32 out_slot = L - (u32)level;
         u32 nlog = 0; // EXACT mode: entries of the undo log (wave-uniform)
+        // table level (WalkArgs::tab): this query's row of precomputed similarities, columns of this level
+        const bool tab_level = TABLE_OK && wa.tab != nullptr && (u32)level >= wa.tab_level_min;
+        const float *tabq = wa.tab + (u64)qi * wa.tab_stride + wa.tab_col0[level];
 
         // fresh visited filter, pre-seeded with the query / new-node id (vector_store.rs:266-271, :807)
         if (!exact) {
@@ -265,13 +267,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
         Pool<R> pool;
         pool.clear();
         u32 npool = 0, npop = 0;
+        u32 res_lo = 0, res_hi = 0; // R == 1: the popped (key, node) list, entry i in lane i
 
         // start node (vector_store.rs:1144-1148)
         {
-            const u32 erow = lv.node_vec ? lv.node_vec[entry] : entry;
+            const u32 erow = uniform_u32(lv.node_vec ? lv.node_vec[entry] : entry);
             float s0;
             n_evals++;
-            if (!single_distance(erow, s0)) { status = COS_ERR_CALCULATION; break; }
+            if (tab_level) {
+                n_tab++;
+                s0 = uniform_f32(tabq[entry]);
+                if (metric == 0u && s0 != s0) { status = COS_ERR_CALCULATION; break; }
+            } else if (!single_distance(erow, s0)) { status = COS_ERR_CALCULATION; break; }
             const u32 eid = erow == N ? COS_ROOT_ID : erow * ix.id_stride;
             if (lane == 0) {
                 if (!exact) { u32 b = eid & bitmask; sm.vis[b >> 5] |= 1u << (b & 31); }
@@ -302,35 +309,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
             // comment above promised one.
             {
                 u32 wv_[LA], wn_[LA];
-                u64 wk_[LA];
                 const u32 slot_l = (u32)lane < slots ? (u32)lane : slots - 1u;
                 static_for<0, LA>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    wk_[i] = pool.template peek<i>();
-                    const u32 nd = (u32)i < kwin ? (u32)wk_[i] : 0u;
+                    const u32 nd = (u32)i < kwin ? pool.template peek_node<i>() : 0u;
                     wv_[i] = lv.adj_vec[(u64)nd * M + slot_l];
+                    if (level != 0) wn_[i] = lv.adj_node[(u64)nd * M + slot_l];
                 });
-                if (level != 0) {
-                    static_for<0, LA>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        const u32 nd = (u32)i < kwin ? (u32)wk_[i] : 0u;
-                        wn_[i] = lv.adj_node[(u64)nd * M + slot_l];
-                    });
-                }
                 static_for<0, LA>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     const bool live = (u32)i < kwin && (u32)lane < slots;
                     const u32 v = live ? wv_[i] : ROW_EMPTY;
                     sm.win_vec[i * 64 + lane] = v;
                     sm.win_node[i * 64 + lane] = live ? (level == 0 ? v : wn_[i]) : ROW_EMPTY;
-                    if (lane == 0) sm.win_key[i] = wk_[i];
                 });
             }
             for (u32 wi = 0; wi < kwin; wi++) {
-                const u64 cur = sm.win_key[wi];
+                // the window entry being consumed IS the pool's head (that is what "still provably the next pop" means): the
+                // popped list takes it from lane 0's register — until round 4 the window's keys made a detour through LDS
+                if constexpr (R == 1) { // ef <= 64: the popped list is one entry per lane, lane npop takes the head by v_writelane
+                    const u64 hd = pool.head();
+                    res_lo = writelane_dyn(res_lo, (u32)hd, (int)npop);
+                    res_hi = writelane_dyn(res_hi, (u32)(hd >> 32), (int)npop);
+                } else if (lane == 0) sm.res[npop] = pool.e[0];
                 pool.pop_head(lane);
                 npool--;
-                if (lane == 0) sm.res[npop] = cur;
                 npop++;
                 n_exp++;
                 adj_bytes += (u64)M * 4;
@@ -344,22 +347,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                 bool win;
                 if (!exact) {
                     // PerformantFixedSet: bucket=(id>>6)&(M-1), bit=id&63  <=> linear bit id & (64M-1)
-                    const u32 id = nb_vec == N ? COS_ROOT_ID : nb_vec * ix.id_stride;
+                    u32 id = nb_vec;
+                    if (ix.id_stride != 1u) { // wave-uniform branch (the empty asm keeps it one): v_mul_lo_u32 is a quarter-rate instruction
+                        asm volatile("");
+                        id = nb_vec * ix.id_stride;
+                    }
+                    id = nb_vec == N ? COS_ROOT_ID : id;
                     const u32 bit = id & bitmask;
                     const u32 word = bit >> 5, msk = 1u << (bit & 31);
-                    const bool pre = valid && (sm.vis[word] & msk);
-                    const bool cand = valid && !pre;
-                    if (!__any(cand)) continue; // nothing new: the next window entry is certainly the next pop
+                    u32 seen = sm.vis[word]; // unpredicated (an empty slot's word is in range too); the asm keeps the load out of an `if (valid)`
+                    asm volatile("" : "+v"(seen));
+                    const bool cand = valid && !(seen & msk);
+                    if (!ballot64(cand)) continue; // nothing new: the next window entry is certainly the next pop
                     u32 old = 0;
                     if (cand) old = atomicOr(&sm.vis[word], msk);
                     const bool lost = cand && (old & msk);
                     win = cand && !lost;
-                    u64 lostmask = __ballot(lost);
+                    u64 lostmask = ballot64(lost);
                     // two slots of this expansion alias the same residue: the LOWER slot wins (sequential scan order)
                     while (lostmask) {
                         const int l = __ffsll((long long)lostmask) - 1;
                         const u32 b = readlane_u32(bit, l);
-                        const u64 g = __ballot(cand && bit == b);
+                        const u64 g = ballot64(cand && bit == b);
                         const int w = __ffsll((long long)g) - 1;
                         if (cand && bit == b) win = (lane == w);
                         lostmask &= ~g;
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                     bool pre = false;
                     if (valid) pre = (__hip_atomic_load(&vis[nb_node >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (nb_node & 31)) & 1u;
                     win = valid && !pre;
-                    const u64 em = __ballot(win);
+                    const u64 em = ballot64(win);
                     if (!em) continue;
                     if (win) {
                         atomicOr(&vis[nb_node >> 5], 1u << (nb_node & 31));                    // fire and forget
@@ -377,8 +386,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                     nlog += (u32)__popcll(em);
                 }
 
-                const u64 wmask = __ballot(win);
+                const u64 wmask = ballot64(win);
                 const int W = __popcll(wmask);
+                // Winners whose similarity sits in a lane (`lead`), key and node index beside it, go into the pool in lane = slot
+                // order.  One vector compare first screens them against the entry that closes the poppable part of the pool
+                // (position limit - 1): a key below it has at least `limit` entries above it, the loop would rank it only to
+                // reject it.  The bar can only rise while winners go in, so the screen is conservative and the loop's own test stays.
+                auto commit = [&](u64 leadmask, u32 keyv, u32 nodev) { // votes are ANDed as scalars: a bool that crossed a branch costs two VALU to vote on
+                    const u64 bar = limit > 0 ? pool.peek_dyn((u32)(limit - 1)) : ~0ull;
+                    u64 pm = leadmask & ballot64(pack_key(keyv, nodev) > bar);
+                    while (pm) {
+                        const int p = __ffsll((long long)pm) - 1;
+                        pm &= pm - 1;
+                        const u64 kk = pack_key(readlane_u32(keyv, p), readlane_u32(nodev, p));
+                        const int pos = pool.rank_of(kk);
+                        if (pos < limit) {
+                            pool.insert_at(kk, pos, lane);
+                            if (npool < (u32)(64 * R)) npool++;
+                            if (pos < ahead) window_ok = false;
+                        }
+                    }
+                };
+                if (tab_level) {
+                    // Table level: the similarity of (query, node) was computed ahead of the walk for every node of the level
+                    // (level_table, kernels_flat.hip: exact integer dot on the i8 MFMA, the same conversion and division as
+                    // below), so an expansion's winners cost ONE 4-byte gather and no code row is fetched or dotted.  u8 codes:
+                    // |v| is the root of an integer, so a zero denominator is exactly a 0/0 = NaN in the table.
+                    n_evals += (u64)W;
+                    n_tab += (u64)W;
+                    float simv = 0.0f;
+                    if (win) simv = tabq[nb_node];
+                    if (metric == 0u && (wmask & ballot64(simv != simv))) { failed = true; break; }
+                    commit(wmask, metric_key(metric, simv), nb_node);
+                    if (!window_ok) break;
+                    continue;
+                }
                 if constexpr (G64 && !FLOAT_ENG) {
                     // One code row per wave pass (64 lanes x 16 B cover the row): the winner's row index is wave-uniform, so it
                     // is taken straight from the owning lane with v_readlane and the row base lives in SGPRs (the load is the
@@ -395,7 +437,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                     while (m && !failed) {
                         u32 lsel = 0;  // landing lane of winner p of this block <- 4 * (the lane that owns the winner): a ds_bpermute address
                         u32 tot = 0;   // landing lanes: the winner's integer dot
-                        bool lead = false; // first lane of the landing group of a winner of this block
+                        u64 leadmask = 0; // first lane of the landing group of every winner of this block
                         // A block of up to NP winners, row p landing in lanes p*(64/NP)...: the rows are fetched together, dotted,
                         // and the NP partial-sum vectors reduced at once.  The dots of rows a short block does not have are
                         // skipped by real branches (the empty asm keeps the compiler from turning them into 5 VALU + a select each).
@@ -431,7 +473,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                                 }
                             });
                             tot = wave_reduce_rows<NP>(acc);
-                            lead = (lane & (LS - 1)) == 0 && (lane / LS) < cnt;
+                            constexpr u64 firsts = NP == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
+                            leadmask = cnt == NP ? firsts : firsts & ((1ull << (cnt * LS)) - 1ull);
                         };
                         if constexpr (PB64 == 8) {
                             if (__popcll(m) > 4) eval_block(std::integral_constant<int, 8>{});
@@ -445,31 +488,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                         const float dotv = (float)tot; // integer dot `as f32` (RNE)
                         // one vector epilogue for the whole block: cosine_similarity_from_dot_product (cosine.rs:223-235)
                         float sim = dotv;
-                        bool bad = false;
                         if (metric == 0u) {
                             const float den = __fmul_rn(qmag, magv);
-                            bad = lead && den == 0.0f;
+                            if (leadmask & ballot64(den == 0.0f)) { failed = true; break; }
                             sim = __fdiv_rn(dotv, den);
                         }
-                        if (__any(bad)) { failed = true; break; }
-                        const u32 keyv = metric_key(metric, sim);
-                        // One vector compare screens the block's winners against the entry that closes the poppable part of the
-                        // pool (position limit - 1): a key below it has at least `limit` entries above it, the loop would rank it
-                        // only to reject it.  The bar can only rise while winners go in, so the screen is conservative and the
-                        // loop's own test stays.  Winners are visited in landing-lane = slot order as before.
-                        const u64 bar = limit > 0 ? pool.peek_dyn((u32)(limit - 1)) : ~0ull;
-                        u64 pm = __ballot(lead && pack_key(keyv, nodev) > bar);
-                        while (pm) {
-                            const int p = __ffsll((long long)pm) - 1;
-                            pm &= pm - 1;
-                            const u64 kk = pack_key(readlane_u32(keyv, p), readlane_u32(nodev, p));
-                            const int pos = pool.rank_of(kk);
-                            if (pos < limit) {
-                                pool.insert_at(kk, pos, lane);
-                                if (npool < (u32)(64 * R)) npool++;
-                                if (pos < ahead) window_ok = false;
-                            }
-                        }
+                        commit(leadmask, metric_key(metric, sim), nodev);
                     }
                     if (failed || !window_ok) break;
                     continue;
@@ -529,35 +553,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                         } else {
                             dotf = fdot[p];
                         }
-                        float sim;
-                        bool bad = false;
+                        // this pass's rows in winner order: the first lane of every group holds its row's key
+                        const int mine = base + p * RP + grp;
+                        const bool leadg = lig == 0 && mine < W;
+                        float sim = dotf;
                         if (metric == 0u) {
                             const float den = __fmul_rn(qmag, pmag[p]);
-                            const int my = base + p * RP + grp;
-                            bad = (my < W) && (den == 0.0f);
+                            if (ballot64(mine < W && den == 0.0f)) { failed = true; break; }
                             sim = __fdiv_rn(dotf, den);
-                        } else {
-                            sim = dotf;
                         }
-                        if (__any(bad)) { failed = true; break; }
-                        const u32 key = metric_key(metric, sim);
-                        // insert this pass's rows in winner order; the same conservative screen as on the G = 64 path: the first lane
-                        // of every group holds its row's key, rows below the entry at pool position limit - 1 are not visited
-                        const int mine = base + p * RP + grp;
-                        const u32 mynode = (lig == 0 && mine < W) ? sm.wl_node[mine] : 0u;
-                        const u64 bar = limit > 0 ? pool.peek_dyn((u32)(limit - 1)) : ~0ull;
-                        u64 pm = __ballot(lig == 0 && mine < W && pack_key(key, mynode) > bar);
-                        while (pm) {
-                            const int l = __ffsll((long long)pm) - 1; // first lane of the row's group: ascending lane = winner order
-                            pm &= pm - 1;
-                            const u64 kk = pack_key(readlane_u32(key, l), readlane_u32(mynode, l));
-                            const int pos = pool.rank_of(kk);
-                            if (pos < limit) {
-                                pool.insert_at(kk, pos, lane);
-                                if (npool < (u32)(64 * R)) npool++;
-                                if (pos < ahead) window_ok = false; // landed ahead of a prefetched entry: the window is stale
-                            }
-                        }
+                        const u32 mynode = leadg ? sm.wl_node[mine] : 0u;
+                        commit(ballot64(leadg), metric_key(metric, sim), mynode);
                     }
                     if (failed) break;
                 }
@@ -585,13 +591,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const u32 e = (u32)lane * R + r;
-            rk[r] = e < npop ? sm.res[e] : 0ull;
+            if constexpr (R == 1) rk[r] = e < npop ? pack_key(res_hi, res_lo) : 0ull;
+            else rk[r] = e < npop ? sm.res[e] : 0ull;
         }
         bitonic_sort_desc<R>(rk, lane);
         u32 cnt = npop < wa.keep ? npop : wa.keep;
         // npop == 0 only if ef == 0: fall back to the entry node's own distance (vector_store.rs:329-380)
         if (npop == 0) {
-            const u32 erow = lv.node_vec ? lv.node_vec[entry] : entry;
+            const u32 erow = uniform_u32(lv.node_vec ? lv.node_vec[entry] : entry);
             float s0;
             if (!single_distance(erow, s0)) { status = COS_ERR_CALCULATION; break; }
             rk[0] = lane == 0 ? pack_key(metric_key(metric, s0), entry) : 0ull;
@@ -613,8 +620,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
         // descend through the best hit's child link (vector_store.rs:382-385)
         if (level > 0) {
             const u32 best = (u32)readlane_u64(rk[0], 0);
-            entry = lv.child[best];
-            if (wa.phase != 0u && level == level_last) order_key = wa.order_rank[best];
+            entry = uniform_u32(lv.child[best]);
+            if (wa.phase != 0u && level == level_last) order_key = uniform_u32(wa.order_rank[best]);
         }
     }
 
@@ -631,6 +638,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
             wa.out_stats[(u64)qi * 4 + 1] = n_exp + (add ? wa.out_stats[(u64)qi * 4 + 1] : 0ull);
             wa.out_stats[(u64)qi * 4 + 2] = adj_bytes + (add ? wa.out_stats[(u64)qi * 4 + 2] : 0ull);
             wa.out_stats[(u64)qi * 4 + 3] = n_rounds + (add ? wa.out_stats[(u64)qi * 4 + 3] : 0ull);
+        }
+        if (wa.out_stats2) { // the split of a launch's counters the roofline report wants: the last level range on its own, table evaluations
+            if (resume || wa.phase == 0u) {
+                wa.out_stats2[(u64)qi * 4 + 0] = n_evals;
+                wa.out_stats2[(u64)qi * 4 + 1] = n_exp;
+                wa.out_stats2[(u64)qi * 4 + 2] = adj_bytes;
+            }
+            wa.out_stats2[(u64)qi * 4 + 3] = n_tab + (resume ? wa.out_stats2[(u64)qi * 4 + 3] : 0ull);
         }
     }
 }
@@ -824,7 +839,7 @@ hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u3
 
 size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
-    size_t b = (size_t)Mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2 + (size_t)LA * 64 * 4 * 2 + (size_t)LA * 8;
+    size_t b = (size_t)Mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2 + (size_t)LA * 64 * 4 * 2;
     b = (b + 15) & ~(size_t)15;
     if (eng == ENG_F32) b += (size_t)ix.row_stride;
     if (eng == ENG_F16) b += ((size_t)ix.dim * 4 + 15) & ~(size_t)15;

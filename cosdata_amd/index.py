@@ -23,7 +23,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import CosdataError, CosFlatStats, CosParams, CosSearchStats, CosTimingSummary, check
+from ._lib import CosdataError, CosFlatStats, CosParams, CosSearchStats, CosTimingSummary, CosWalkSplit, check
 
 ROOT_ID, QUERY_ID, SLOT_EMPTY = 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFFFD
 VISITED_REF, VISITED_EXACT = 0, 1
@@ -251,7 +251,9 @@ class HNSWIndex:
     WALK_ORDER_DEFAULT_MIN_B = 8192  # COS_WALK_ORDER_DEFAULT_MIN_B (include/cosdata_hip.h)
 
     def set_walk_order(self, min_queries: int):
-        """Launches of at least `min_queries` queries walk level 0 in locality order (kernels_order.hip; 0 = never); same results."""
+        """Launches of at least `min_queries` queries (0 = never) walk the levels down to the key level (walk_order_cuts) in arrival
+        order, are then sorted by the depth-first position of the best node found there and walk every level below it with the
+        sorted queries dealt to the XCDs in contiguous runs (kernels_order.hip); same results."""
         check(_lib.lib().cos_index_set_walk_order(self._h, min_queries))
 
     def walk_order_cuts(self):
@@ -260,6 +262,28 @@ class HNSWIndex:
         n = C.c_uint32()
         check(_lib.lib().cos_index_walk_order_cuts(self._h, lv, 16, C.byref(n)))
         return [int(lv[i]) for i in range(min(n.value, 16))]
+
+    WALK_TABLE_DEFAULT_MIN_B = 4096      # COS_WALK_TABLE_DEFAULT_MIN_B (include/cosdata_hip.h)
+    WALK_TABLE_DEFAULT_MAX_COLS = 8192   # COS_WALK_TABLE_DEFAULT_MAX_COLS
+
+    def set_walk_table(self, max_cols: int = WALK_TABLE_DEFAULT_MAX_COLS, min_queries: int = WALK_TABLE_DEFAULT_MIN_B):
+        """Launches of at least `min_queries` queries over u8 codes precompute similarity(query, node) for every node of the top
+        levels holding at most `max_cols` nodes together (one i8 MFMA GEMM) and walk those levels from the table; same results.
+        0 for either = never."""
+        check(_lib.lib().cos_index_set_walk_table(self._h, max_cols, min_queries))
+
+    def walk_table_info(self):
+        """(lowest level, columns) of the level table the next big launch would use; (0, 0) = none."""
+        lv, cols = C.c_uint32(), C.c_uint32()
+        check(_lib.lib().cos_index_walk_table_info(self._h, C.byref(lv), C.byref(cols)))
+        return int(lv.value), int(cols.value)
+
+    def last_walk_split(self, stream: int = 0) -> CosWalkSplit:
+        """The last batch on `stream` split by dispatch (roofline report): level-table GEMM, levels above / below the cut."""
+        st = CosWalkSplit()
+        st.struct_size = C.sizeof(CosWalkSplit)
+        check(_lib.lib().cos_index_last_walk_split(self._h, C.c_void_p(stream), C.byref(st)))
+        return st
 
     def batch_search(self, queries, top_k: int, return_status: bool = False):
         """IndexOps::batch_search: [B][dim] raw f32 -> (ids [B][k], scores [B][k], counts [B]).

@@ -190,16 +190,51 @@ int32_t cos_index_set_latency_mode(cos_index *ix, uint32_t max_queries);
 int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queries);
 /* Locality order of big launches — at least min_queries queries (default COS_WALK_ORDER_DEFAULT_MIN_B; 0 = never).  Not a reference
  * interface: the reference answers each query on its own rayon task (indexes/mod.rs:260-272) and has no launch whose order could
- * matter; on the device the order decides which rows a query finds in cache.  Such a launch walks in two steps: levels L..1 in
- * arrival order, then level 0 with the launch sorted by the path the upper levels found (best node of levels 3, 2, 1) and dealt to
- * the XCDs in contiguous runs (workgroup b runs on XCD b % 8, each XCD has its own L2), so the waves resident on an XCD walk
- * neighbouring regions of the graph.  Every query's walk, and so every result, is bit for bit what it is without the order.
+ * matter; on the device the order decides which rows a query finds in cache.  Such a launch walks in two steps of the same kernel:
+ * the levels from the top down to a KEY LEVEL in arrival order — the key level is the lowest level whose code rows take at most
+ * 64 MB (1M x 768 u8: level 2; cos_index_walk_order_cuts reports it; COS_WALK_SPLIT overrides) — then the launch is sorted by the
+ * position, in a depth-first order of the key level's graph, of the best node each query found there, and EVERY level below the
+ * key level (not only level 0) runs with the sorted queries dealt to the XCDs in contiguous runs (workgroup b runs on XCD b % 8,
+ * each XCD has its own L2), so the waves resident on an XCD walk neighbouring regions of the graph.  The rerank follows the same
+ * order.  Every query's walk, and so every result, is bit for bit what it is without the order.
  * Applies at ef_search <= 256: wider beams are bound by their own serial work and the second launch's tail costs more than the order saves. */
 #define COS_WALK_ORDER_DEFAULT_MIN_B 8192u
 int32_t cos_index_set_walk_order(cos_index *ix, uint32_t min_queries);
 /* The levels after which such a launch is cut (descending; the launch is re-sorted after each): by default ONE, the lowest level whose
  * code rows take at most 64 MB; none (*out_n = 0) if the graph has no level the order can use.  Diagnostic: bench.py reports it. */
 int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t cap, uint32_t *out_n);
+/* Level table of big launches — at least min_queries queries over u8 codes (default COS_WALK_TABLE_DEFAULT_MIN_B; 0 = never).  Not a
+ * reference interface.  The graph's top levels are small and walked by every query (1M vectors: levels >= 4 hold 5 300 nodes), so
+ * for the levels >= L_t — the lowest level such that the levels from it to the top hold at most max_cols nodes together (default
+ * COS_WALK_TABLE_DEFAULT_MAX_COLS; 0 = no table) — the launch first computes similarity(query, node) for EVERY node of those levels as
+ * one exact-integer i8 MFMA GEMM (dot_product_u8's integer, the same `as f32` and the same division by |q| * |v|, cosine.rs:223-235),
+ * and the walk of those levels reads the similarity (4 bytes) where it would have gathered and dotted a code row.  Which nodes a
+ * walk visits, the lossy visited filter and every result are bit for bit what they are without the table; a launch holds
+ * queries x columns x 4 bytes of it (32 768 x 5 312: 0.7 GB per stream in flight). */
+#define COS_WALK_TABLE_DEFAULT_MIN_B 4096u
+#define COS_WALK_TABLE_DEFAULT_MAX_COLS 8192u
+int32_t cos_index_set_walk_table(cos_index *ix, uint32_t max_cols, uint32_t min_queries);
+/* the table the next big launch would use: its lowest level and its columns (0, 0 = none).  Diagnostic: bench.py reports it. */
+int32_t cos_index_walk_table_info(cos_index *ix, uint32_t *out_level_min, uint32_t *out_cols);
+/* The last completed batch on `stream` split by dispatch, for the roofline report: a big launch is up to three
+ * pieces of work with three different bounds — the level-table GEMM (MFMA), the level range above the cut (rows that stay in
+ * L2 / the memory-side cache: a gather from cache) and the level range below it (HBM).  Times are HIP events on the streams the
+ * kernels ran on (0 without cos_index_enable_timing); counters as in cos_search_stats. */
+typedef struct {
+    uint32_t struct_size;       /* in: sizeof(cos_walk_split) */
+    uint32_t queries;
+    uint32_t table_level_min;   /* 0 = the launch used no table */
+    uint32_t table_cols;
+    uint32_t cut_after_level;   /* 0 = the walk was one dispatch (everything is in `lower`) */
+    uint32_t reserved;
+    float table_ms;             /* level-table GEMM (+ the queries' code sums) */
+    float upper_ms, sort_ms, lower_ms;
+    double table_int8_ops;      /* 2 * queries * cols * padded dims */
+    uint64_t table_evals;       /* evaluations the table served (all of them above the cut) */
+    uint64_t upper_evals, upper_expansions, upper_adj_bytes; /* levels above the cut, table evaluations included */
+    uint64_t lower_evals, lower_expansions, lower_adj_bytes; /* levels below the cut (or the whole walk) */
+} cos_walk_split;
+int32_t cos_index_last_walk_split(cos_index *ix, void *stream, cos_walk_split *out);
 /* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
 int32_t cos_index_enable_timing(cos_index *ix, int32_t on);
 int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out);

@@ -1,0 +1,98 @@
+"""GPU: the level table of big launches (cos_index_set_walk_table; WalkArgs::tab, kernels_flat.hip launch_level_table).  The similarity
+of every (query, node) pair of the graph's small upper levels is computed ahead of the walk by one exact-integer i8 MFMA GEMM and the
+walk of those levels reads it instead of gathering and dotting code rows: every per-level list and every result must keep its bits."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return all(np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)) for x, y in zip(a, b))
+
+
+def _check_against_oracle(oix, res, Q, top_k, sample):
+    ids, sc, cnt = res
+    oids, osc, ocnt = oix.search_batch(Q[sample], top_k, threads=4)[:3]
+    assert np.array_equal(cnt[sample], ocnt)
+    for j, b in enumerate(sample):
+        c = int(ocnt[j])
+        assert np.array_equal(ids[b, :c], oids[j, :c]), f"query {b}"
+        assert np.array_equal(sc[b, :c].view(np.uint32), osc[j, :c].view(np.uint32)), f"query {b}"
+
+
+@pytest.mark.parametrize("dim,visited,metric", [(96, 0, O.METRIC_COSINE), (96, 1, O.METRIC_COSINE), (768, 0, O.METRIC_COSINE),
+                                                (1024, 0, O.METRIC_DOT), (80, 0, O.METRIC_DOT)])
+def test_table_levels_keep_every_bit(dim, visited, metric):
+    import cosdata_amd as ca
+    n = 6000 if dim < 512 else 3000
+    X = H.clustered_corpus(n, dim, n_centers=24, seed=31 + dim)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=48, ef_search=32, metric=metric)
+    dix = H.device_index_from_oracle(oix, X, visited_mode=visited)
+    if visited:
+        oix.set_visited_mode(O.VISITED_EXACT)
+    B = ca.HNSWIndex.WALK_TABLE_DEFAULT_MIN_B + 37
+    Q = H.queries_from(X, B, noise=0.05, seed=5)
+    lmin, cols = dix.walk_table_info()
+    assert lmin == 1 and cols == sum(dix.level_count(l) for l in range(1, 5))   # every upper level fits the default 8192 columns
+    dix.enable_timing(True)
+    with_tab = dix.batch_search(Q, 10)
+    sp = dix.last_walk_split()
+    st = dix.last_stats()
+    assert sp.table_level_min == 1 and sp.table_cols == cols and sp.table_evals > 0 and sp.table_ms > 0
+    assert sp.upper_evals + sp.lower_evals == st.evals and sp.upper_expansions + sp.lower_expansions == st.expansions
+    walk_tab = dix.ann_search_batch(Q)
+    dix.set_walk_table(0, 0)
+    assert dix.walk_table_info() == (0, 0)
+    plain = dix.batch_search(Q, 10)
+    sp0 = dix.last_walk_split()
+    assert sp0.table_level_min == 0 and sp0.table_evals == 0
+    assert sp0.lower_evals + sp0.upper_evals == st.evals                       # the same walk, evaluation for evaluation
+    walk_plain = dix.ann_search_batch(Q)
+    assert _same(with_tab, plain)
+    assert _same(walk_tab, walk_plain)
+    _check_against_oracle(oix, with_tab, Q, 10, np.arange(0, B, 41))
+    # a table that stops above level 1: levels below it take the row path inside the same launch
+    top = sum(dix.level_count(l) for l in range(3, 5))
+    dix.set_walk_table(top + 1, 1)
+    assert dix.walk_table_info() == (3, top)
+    assert _same(dix.ann_search_batch(Q[:300]), tuple(np.asarray(a)[:300] for a in walk_plain))
+
+
+def test_table_with_locality_order_and_zero_query():
+    """a launch big enough for both the table and the locality order; a zero query fails with CalculationError either way"""
+    import cosdata_amd as ca
+    X = H.clustered_corpus(6000, 96, n_centers=24, seed=77)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=48, ef_search=32)
+    dix = H.device_index_from_oracle(oix, X)
+    B = ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B + 100
+    Q = H.queries_from(X, B, noise=0.05, seed=9)
+    Q[17] = oix.params.range_lo          # quantizes to the all-zero code: |q| = 0 -> 0/0 at the first evaluation (cosine.rs:228-232)
+    Q[B - 1] = oix.params.range_lo
+    ids, sc, cnt, status = dix.batch_search(Q, 10, return_status=True)
+    dix.set_walk_table(0, 0)
+    ids0, sc0, cnt0, status0 = dix.batch_search(Q, 10, return_status=True)
+    assert status[17] == 2 and status[B - 1] == 2 and np.count_nonzero(status) == 2
+    assert np.array_equal(status, status0) and _same((ids, sc, cnt), (ids0, sc0, cnt0))
+    ok = np.array([b for b in range(0, B, 53) if status[b] == 0])
+    _check_against_oracle(oix, (ids, sc, cnt), Q, 10, ok)
+
+
+def test_table_follows_the_graph():
+    """a new graph on the same handle: the table's operand (the nodes' code rows) is gathered again"""
+    import cosdata_amd as ca
+    X = H.clustered_corpus(5000, 64, n_centers=16, seed=8)
+    o1 = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=32, ef_search=32, seed=1)
+    o2 = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=32, ef_search=32, seed=2)
+    dix = H.device_index_from_oracle(o1, X)
+    B = ca.HNSWIndex.WALK_TABLE_DEFAULT_MIN_B
+    Q = H.queries_from(X, B, noise=0.05, seed=6)
+    _check_against_oracle(o1, dix.batch_search(Q, 5), Q, 5, np.arange(0, B, 61))
+    dix.upload_vectors(X)
+    dix.upload_graph(o2.export_graph(), o2.root_raw())
+    r2 = dix.batch_search(Q, 5)
+    assert dix.last_walk_split().table_evals > 0
+    _check_against_oracle(o2, r2, Q, 5, np.arange(0, B, 61))
