@@ -273,9 +273,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
         {
             const u32 erow = uniform_u32(lv.node_vec ? lv.node_vec[entry] : entry);
             float s0;
-            n_evals++;
             if (tab_level) {
-                n_tab++;
                 s0 = uniform_f32(tabq[entry]);
                 if (metric == 0u && s0 != s0) { status = COS_ERR_CALCULATION; break; }
             } else if (!single_distance(erow, s0)) { status = COS_ERR_CALCULATION; break; }
@@ -292,7 +290,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
             if (exact) nlog = 1;
         }
 
-        bool failed = false;
+        u32 failed = 0; // wave-uniform flags are u32 and lane sets u64 ballots: a bool that crosses a branch is kept as a lane mask
+                        // and merged with exec-mask arithmetic at every join, a bool that is voted on is first turned into 0 / 1
+        u32 lev_evals = 1; // distance evaluations of this level, the entry node's included
+        const u32 log2M = (u32)__ffs((int)M) - 1u; // M is a power of two (cos_params)
+        const u64 slotmask = slots >= 64u ? ~0ull : ((1ull << slots) - 1ull); // lanes that hold a scanned slot
         // Lookahead window: the adjacency rows of the next LA pool entries are fetched together (independent
         // loads, one latency); entry i+1 of the window is consumed only while it is still provably the next pop,
         // i.e. while no candidate has been inserted ahead of it.  Most pops of a walk discover nothing new
@@ -302,27 +304,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
             u32 kwin = npool < (u32)LA ? npool : (u32)LA;
             if (kwin > wa.ef - npop) kwin = wa.ef - npop;
             // the window lives in LDS so the consume loop below is a runtime loop (small code, no extra VGPRs)
-            // All loads of the window are issued before the first value is looked at, and none is predicated (entries past kwin
-            // re-read node 0's row, lanes past `slots` the last slot; both become ROW_EMPTY afterwards).  Rounds 1-2 wrote
-            // `v = load; nn = level == 0 ? v : load2; LDS store` inside a per-entry `if`: the generated code waited for every
-            // load (s_waitcnt vmcnt(0)) before issuing the next entry's — up to eight DEPENDENT round trips per round where the
-            // comment above promised one.
+            // All loads of the window are issued before the first value is looked at, and none is predicated: a pool position past
+            // the window holds a real node or the empty key (node 0) — its row is fetched and never looked at; lanes past `slots`
+            // read the last slot and are masked when the entry is consumed (slotmask).  Rounds 1-2 wrote `v = load; nn = level == 0
+            // ? v : load2; LDS store` inside a per-entry `if`: the generated code waited for every load (s_waitcnt vmcnt(0)) before
+            // issuing the next entry's — up to eight DEPENDENT round trips per round where the comment above promised one.
             {
-                u32 wv_[LA], wn_[LA];
                 const u32 slot_l = (u32)lane < slots ? (u32)lane : slots - 1u;
-                static_for<0, LA>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    const u32 nd = (u32)i < kwin ? pool.template peek_node<i>() : 0u;
-                    wv_[i] = lv.adj_vec[(u64)nd * M + slot_l];
-                    if (level != 0) wn_[i] = lv.adj_node[(u64)nd * M + slot_l];
-                });
-                static_for<0, LA>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    const bool live = (u32)i < kwin && (u32)lane < slots;
-                    const u32 v = live ? wv_[i] : ROW_EMPTY;
-                    sm.win_vec[i * 64 + lane] = v;
-                    sm.win_node[i * 64 + lane] = live ? (level == 0 ? v : wn_[i]) : ROW_EMPTY;
-                });
+                // two copies of the block (level 0 has no node indices of its own): merged into one, the compiler waited for the
+                // first group of loads before it issued the second
+                auto fetch_stage = [&](auto bothc) {
+                    constexpr bool BOTH = decltype(bothc)::value;
+                    u32 wv_[LA], wn_[LA];
+                    static_for<0, LA>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const u64 off = ((u64)pool.template peek_node<i>() << log2M) + slot_l;
+                        wv_[i] = lv.adj_vec[off];
+                        if constexpr (BOTH) wn_[i] = lv.adj_node[off];
+                    });
+                    static_for<0, LA>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        sm.win_vec[i * 64 + lane] = wv_[i];
+                        sm.win_node[i * 64 + lane] = BOTH ? wn_[i] : wv_[i];
+                    });
+                };
+                if (level != 0) fetch_stage(std::true_type{});
+                else fetch_stage(std::false_type{});
             }
             for (u32 wi = 0; wi < kwin; wi++) {
                 // the window entry being consumed IS the pool's head (that is what "still provably the next pop" means): the
@@ -335,16 +342,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                 pool.pop_head(lane);
                 npool--;
                 npop++;
-                n_exp++;
-                adj_bytes += (u64)M * 4;
                 const int limit = (int)wa.ef - (int)npop; // future pops still allowed
                 const int ahead = (int)kwin - 1 - (int)wi; // window entries still waiting at pool positions 0..ahead-1
-                bool window_ok = true;
+                u32 window_ok = 1;
 
                 // neighbour slots in slot order, one per lane (vector_store.rs:1161-1171)
                 const u32 nb_vec = sm.win_vec[wi * 64 + lane], nb_node = sm.win_node[wi * 64 + lane];
-                const bool valid = nb_vec != ROW_EMPTY;
-                bool win;
+                const u64 vmask = ballot64(nb_vec != ROW_EMPTY) & slotmask;
+                u64 wmask; // the expansion's winners: unvisited neighbours, as a lane set
                 if (!exact) {
                     // PerformantFixedSet: bucket=(id>>6)&(M-1), bit=id&63  <=> linear bit id & (64M-1)
                     u32 id = nb_vec;
@@ -357,42 +362,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                     const u32 word = bit >> 5, msk = 1u << (bit & 31);
                     u32 seen = sm.vis[word]; // unpredicated (an empty slot's word is in range too); the asm keeps the load out of an `if (valid)`
                     asm volatile("" : "+v"(seen));
-                    const bool cand = valid && !(seen & msk);
-                    if (!ballot64(cand)) continue; // nothing new: the next window entry is certainly the next pop
+                    const u64 cmask = vmask & ballot64((seen & msk) == 0u);
+                    if (!cmask) continue; // nothing new: the next window entry is certainly the next pop
                     u32 old = 0;
-                    if (cand) old = atomicOr(&sm.vis[word], msk);
-                    const bool lost = cand && (old & msk);
-                    win = cand && !lost;
-                    u64 lostmask = ballot64(lost);
+                    if (__builtin_amdgcn_inverse_ballot_w64(cmask)) old = atomicOr(&sm.vis[word], msk);
+                    u64 lostmask = cmask & ballot64((old & msk) != 0u);
+                    wmask = cmask & ~lostmask;
                     // two slots of this expansion alias the same residue: the LOWER slot wins (sequential scan order)
                     while (lostmask) {
                         const int l = __ffsll((long long)lostmask) - 1;
-                        const u32 b = readlane_u32(bit, l);
-                        const u64 g = ballot64(cand && bit == b);
-                        const int w = __ffsll((long long)g) - 1;
-                        if (cand && bit == b) win = (lane == w);
+                        const u64 g = cmask & ballot64(bit == readlane_u32(bit, l));
+                        wmask = (wmask & ~g) | (g & (0ull - g)); // of the slots that share the residue only the lowest stays
                         lostmask &= ~g;
                     }
                 } else {
-                    bool pre = false;
-                    if (valid) pre = (__hip_atomic_load(&vis[nb_node >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (nb_node & 31)) & 1u;
-                    win = valid && !pre;
-                    const u64 em = ballot64(win);
-                    if (!em) continue;
-                    if (win) {
-                        atomicOr(&vis[nb_node >> 5], 1u << (nb_node & 31));                    // fire and forget
-                        vlog[nlog + (u32)__popcll(em & ((1ull << lane) - 1ull))] = nb_node >> 5;   // undo log, in slot order
+                    u32 w = 0;
+                    if (__builtin_amdgcn_inverse_ballot_w64(vmask)) w = __hip_atomic_load(&vis[nb_node >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    wmask = vmask & ballot64(((w >> (nb_node & 31)) & 1u) == 0u);
+                    if (!wmask) continue;
+                    if (__builtin_amdgcn_inverse_ballot_w64(wmask)) {
+                        atomicOr(&vis[nb_node >> 5], 1u << (nb_node & 31));                          // fire and forget
+                        vlog[nlog + (u32)__popcll(wmask & ((1ull << lane) - 1ull))] = nb_node >> 5;  // undo log, in slot order
                     }
-                    nlog += (u32)__popcll(em);
+                    nlog += (u32)__popcll(wmask);
                 }
-
-                const u64 wmask = ballot64(win);
+                const bool win = __builtin_amdgcn_inverse_ballot_w64(wmask);
                 const int W = __popcll(wmask);
-                // Winners whose similarity sits in a lane (`lead`), key and node index beside it, go into the pool in lane = slot
+                lev_evals += (u32)W;
+                // Winners whose similarity sits in a lane of `leadmask`, key and node index beside it, go into the pool in lane = slot
                 // order.  One vector compare first screens them against the entry that closes the poppable part of the pool
                 // (position limit - 1): a key below it has at least `limit` entries above it, the loop would rank it only to
                 // reject it.  The bar can only rise while winners go in, so the screen is conservative and the loop's own test stays.
-                auto commit = [&](u64 leadmask, u32 keyv, u32 nodev) { // votes are ANDed as scalars: a bool that crossed a branch costs two VALU to vote on
+                auto commit = [&](u64 leadmask, u32 keyv, u32 nodev) {
                     const u64 bar = limit > 0 ? pool.peek_dyn((u32)(limit - 1)) : ~0ull;
                     u64 pm = leadmask & ballot64(pack_key(keyv, nodev) > bar);
                     while (pm) {
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                         if (pos < limit) {
                             pool.insert_at(kk, pos, lane);
                             if (npool < (u32)(64 * R)) npool++;
-                            if (pos < ahead) window_ok = false;
+                            if (pos < ahead) window_ok = 0;
                         }
                     }
                 };
@@ -412,11 +413,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                     // (level_table, kernels_flat.hip: exact integer dot on the i8 MFMA, the same conversion and division as
                     // below), so an expansion's winners cost ONE 4-byte gather and no code row is fetched or dotted.  u8 codes:
                     // |v| is the root of an integer, so a zero denominator is exactly a 0/0 = NaN in the table.
-                    n_evals += (u64)W;
-                    n_tab += (u64)W;
                     float simv = 0.0f;
                     if (win) simv = tabq[nb_node];
-                    if (metric == 0u && (wmask & ballot64(simv != simv))) { failed = true; break; }
+                    if (metric == 0u && (wmask & ballot64(simv != simv))) { failed = 1; break; }
                     commit(wmask, metric_key(metric, simv), nb_node);
                     if (!window_ok) break;
                     continue;
@@ -430,7 +429,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                     // select per row) and fetched |v| and the node index with one predicated scalar-indexed load per row: 24 VALU
                     // and 32 SALU per evaluation of the 38 + 36 the whole walk spent (profiles/r03_mid_round_pmc_sq_instruction_mix_rocprofv3.txt).
                     // Lanes past the row's last chunk re-read chunk 0 against a zero query register instead of being masked off.
-                    n_evals += (u64)W;
                     float magw = 1.0f; // |v| of every winner of the expansion: one vector load, in the winner's own lane
                     if (win) magw = ix.mags[nb_vec];
                     u64 m = wmask;
@@ -490,7 +488,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                         float sim = dotv;
                         if (metric == 0u) {
                             const float den = __fmul_rn(qmag, magv);
-                            if (leadmask & ballot64(den == 0.0f)) { failed = true; break; }
+                            if (leadmask & ballot64(den == 0.0f)) { failed = 1; break; }
                             sim = __fdiv_rn(dotv, den);
                         }
                         commit(leadmask, metric_key(metric, sim), nodev);
@@ -504,7 +502,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                     sm.wl_vec[rank] = nb_vec;
                     sm.wl_node[rank] = nb_node;
                 }
-                n_evals += (u64)W;
 
                 // evaluate winners: RP rows per pass, PB passes in flight
                 for (int base = 0; base < W; base += RP * PB) {
@@ -559,7 +556,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
                         float sim = dotf;
                         if (metric == 0u) {
                             const float den = __fmul_rn(qmag, pmag[p]);
-                            if (ballot64(mine < W && den == 0.0f)) { failed = true; break; }
+                            if (ballot64(mine < W && den == 0.0f)) { failed = 1; break; }
                             sim = __fdiv_rn(dotf, den);
                         }
                         const u32 mynode = leadg ? sm.wl_node[mine] : 0u;
@@ -571,6 +568,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 :
             }
             if (failed) break;
         }
+        n_exp += npop;
+        adj_bytes += (u64)npop * M * 4;
+        n_evals += lev_evals;
+        if (tab_level) n_tab += lev_evals;
         if (exact) {
             // undo: zero exactly the words this level set (whole words belong to this query), leaving the bitset all-zero
             // for the next level / launch.  One wave owns the filter and its vector-memory operations reach L2 in issue

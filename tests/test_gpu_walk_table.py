@@ -72,10 +72,10 @@ def test_table_with_locality_order_and_zero_query():
     Q = H.queries_from(X, B, noise=0.05, seed=9)
     Q[17] = oix.params.range_lo          # quantizes to the all-zero code: |q| = 0 -> 0/0 at the first evaluation (cosine.rs:228-232)
     Q[B - 1] = oix.params.range_lo
-    ids, sc, cnt, status = dix.batch_search(Q, 10, return_status=True)
+    ids, sc, cnt, rc, status = dix.batch_search(Q, 10, return_status=True)
     dix.set_walk_table(0, 0)
-    ids0, sc0, cnt0, status0 = dix.batch_search(Q, 10, return_status=True)
-    assert status[17] == 2 and status[B - 1] == 2 and np.count_nonzero(status) == 2
+    ids0, sc0, cnt0, rc0, status0 = dix.batch_search(Q, 10, return_status=True)
+    assert rc == 2 and rc0 == 2 and status[17] == 2 and status[B - 1] == 2 and np.count_nonzero(status) == 2
     assert np.array_equal(status, status0) and _same((ids, sc, cnt), (ids0, sc0, cnt0))
     ok = np.array([b for b in range(0, B, 53) if status[b] == 0])
     _check_against_oracle(oix, (ids, sc, cnt), Q, 10, ok)
