@@ -61,6 +61,7 @@ WORKLOADS = {
     "smoke": (50_000, 768, "mixture", 128, "reduced-size plumbing run (NOT a benchmark number)"),
 }
 ALL_CONFIGS = ["c2_uniform", "c5", "c3", "c4shard_ref", "c4shard_exact"]
+OPTIONAL_CONFIGS = ["c4shard_ref_m0_128", "c4shard_ref_m0_256"]   # --configs only: the reference filter with a larger level_0_neighbors_count
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -123,7 +124,7 @@ def resolve_configs(spec, world, workload):
             return []
         return list(ALL_CONFIGS) if world == 1 else ["c4shard_exact"]
     names = list(ALL_CONFIGS) if spec == "all" else [v for v in spec.split(",") if v]
-    bad = [v for v in names if v not in ALL_CONFIGS]
+    bad = [v for v in names if v not in ALL_CONFIGS + OPTIONAL_CONFIGS]
     if bad:
         raise SystemExit(f"bench.py: unknown --configs entries {bad}; known: {ALL_CONFIGS}")
     if world > 1:
@@ -333,7 +334,9 @@ class DenseWorkload:
                 gq = torch.Generator(device=dev)
                 gq.manual_seed(seed)
                 return self.X[torch.randint(0, n, (m,), generator=gq, device=dev)].contiguous()
-        self.n_qsets = max(self.S, 2)
+        # one fresh query set per step of the timed region (warm-up included) up to 32 sets: no launch re-walks a set an earlier one
+        # left in the caches (round 3 alternated over two sets)
+        self.n_qsets = max(self.S, 2, min(32, max(1, args.steps) + max(0, args.warmup)))
         self.Q = draw_q(self.B * self.n_qsets, 43)               # timed queries; identical on every rank
         self.Q_sel = draw_q(self.nrq, 44)                         # ef selection set
         self.Q_rep = draw_q(self.nrq, 45)                         # disjoint hold-out: the recall that is REPORTED
@@ -405,7 +408,7 @@ class DenseWorkload:
 
     # ---- one (build filter, search filter) mode -------------------------------------------------------------------
     def run_mode(self, build_visited, visited, ef_arg="auto", ef_sweep="", cpu_seconds=12.0, single_batch=False, host_api=False,
-                 hbm_probe=False, exchange="auto"):
+                 hbm_probe=False, exchange="auto", m0=64):
         env, ca, torch = self.env, self.ca, self.env.torch
         args = env.args
         dev, rank, world, local_rank, dist, dist_on = env.dev, env.rank, env.world, env.local_rank, env.dist, env.dist_on
@@ -418,7 +421,9 @@ class DenseWorkload:
         mode_of = lambda v: ca.VISITED_EXACT if v == "exact" else ca.VISITED_REF
 
         # index: reference defaults (config.toml:20-24,32)
-        hp = ca.HNSWHyperParams(num_layers=9, ef_construction=self.ef_construction, ef_search=ef, level_0_neighbors_count=64, neighbors_count=32)
+        # level_0_neighbors_count is a user hyper-parameter of the reference (indexes/hnsw/types.rs:10-17) and also the size of its
+        # visited filter, PerformantFixedSet::new(level_0_neighbors_count) (vector_store.rs:266-270): 64 = config.toml's default
+        hp = ca.HNSWHyperParams(num_layers=9, ef_construction=self.ef_construction, ef_search=ef, level_0_neighbors_count=m0, neighbors_count=32)
         ix = ca.HNSWIndex(d, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), self.values_range, shortlist_size=64,
                           device=local_rank, id_base=rank * n, seed=42 + rank, visited_mode=mode_of(build_visited))
         ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
@@ -516,7 +521,7 @@ class DenseWorkload:
             env.sync_all()
             ix.enable_timing(True)
             t = time.perf_counter()
-            for i in range(n_launch):
+            for i in range(n_warm, n_warm + n_launch):          # query set i % n_qsets: every step of a default run has its own
                 step(i)
             env.sync_all()
             el = time.perf_counter() - t
@@ -529,26 +534,50 @@ class DenseWorkload:
             row_bytes = d + 4  # u8 code row + f32 norm per distance evaluation
             walk_sum = prep_sum = fin_sum = 0.0
             walk_min, walk_max, nl = 1e30, 0.0, 0
-            cnts = []
+            cnts, splits = [], []
             for s in range(min(S, n_launch)):
                 ts = ix.timing_summary(streams[s].cuda_stream)
                 walk_sum += ts.walk_ms_sum; prep_sum += ts.prep_ms_sum; fin_sum += ts.finalize_ms_sum; nl += ts.launches
                 walk_min, walk_max = min(walk_min, ts.walk_ms_min), max(walk_max, ts.walk_ms_max)
                 stt = ix.last_stats(streams[s].cuda_stream)
                 cnts.append((stt.evals * row_bytes + stt.adj_bytes, stt.evals, stt.expansions, stt.reserved))
+                splits.append(ix.last_walk_split(streams[s].cuda_stream))   # the last launch of the stream, dispatch by dispatch
             ix.enable_timing(False)
+            mean = lambda f: float(np.mean([f(x) for x in splits]))
+            sp = {"table_level_min": int(splits[0].table_level_min), "table_cols": int(splits[0].table_cols), "cut_after_level": int(splits[0].cut_after_level),
+                  "table_ms": mean(lambda x: x.table_ms), "upper_ms": mean(lambda x: x.upper_ms), "sort_ms": mean(lambda x: x.sort_ms),
+                  "lower_ms": mean(lambda x: x.lower_ms), "table_int8_ops": mean(lambda x: x.table_int8_ops), "table_evals": mean(lambda x: x.table_evals),
+                  "upper_evals": mean(lambda x: x.upper_evals), "upper_expansions": mean(lambda x: x.upper_expansions),
+                  "upper_adj_bytes": mean(lambda x: x.upper_adj_bytes), "lower_evals": mean(lambda x: x.lower_evals),
+                  "lower_expansions": mean(lambda x: x.lower_expansions), "lower_adj_bytes": mean(lambda x: x.lower_adj_bytes),
+                  "launches_sampled": len(splits)}
             return {"elapsed": el, "walk_ms": walk_sum / nl, "prep_ms": prep_sum / nl, "finalize_ms": fin_sum / nl, "walk_ms_min": walk_min,
                     "walk_ms_max": walk_max, "timed_launches_sampled": nl, "bytes": float(np.mean([c[0] for c in cnts])),
                     "evals": float(np.mean([c[1] for c in cnts])), "expansions": float(np.mean([c[2] for c in cnts])),
-                    "rounds": float(np.mean([c[3] for c in cnts]))}
+                    "rounds": float(np.mean([c[3] for c in cnts])), "split": sp}
 
         tr = timed_run()
         # the locality order of big launches (cos_index_set_walk_order: from WALK_ORDER_DEFAULT_MIN_B queries, ef <= 256)
         cuts = ix.walk_order_cuts() if B >= ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B and ef <= 256 else []
         elapsed = tr["elapsed"]
         merged_qps = n_launch * B / elapsed        # answers over the global (world x n) corpus per second
-        avg_ms, avg_bytes = tr["walk_ms"], tr["bytes"]
-        kernel_gbps = avg_bytes / (avg_ms * 1e-3) / 1e9              # ONE walk launch: algorithmic bytes / its HIP-event duration
+        # Algorithmic bytes of one step's walk AS THIS DESIGN EVALUATES IT (SURVEY.md 8d's per-unit figures): an evaluation that gathers
+        # and dots a code row reads bytes_vec + 4; an evaluation served by the level table (cos_index_set_walk_table) reads the 4-byte
+        # similarity the table GEMM left — that GEMM is a dispatch of its own with its own (MFMA) roofline below; an expansion reads
+        # M_level x 4 of adjacency.  `reference_algorithmic_bytes` keeps SURVEY's figure for the same walk without a table (every
+        # evaluation a row): the number round 3 divided by the walk time and that came out above the HBM peak, because it charges to HBM
+        # rows that never leave the L2.
+        sp = tr["split"]
+        row_b = d + 4
+        ref_alg_bytes = tr["bytes"]
+        tab_upper = min(sp["table_evals"], sp["upper_evals"]) if sp["cut_after_level"] else 0.0   # the table's levels lie above the cut
+        tab_lower = sp["table_evals"] - tab_upper
+        upper_bytes = (sp["upper_evals"] - tab_upper) * row_b + tab_upper * 4.0 + sp["upper_adj_bytes"]
+        lower_bytes = (sp["lower_evals"] - tab_lower) * row_b + tab_lower * 4.0 + sp["lower_adj_bytes"]
+        avg_bytes = upper_bytes + lower_bytes
+        kern_ms = (sp["upper_ms"] + sp["lower_ms"]) or tr["walk_ms"]     # the walk kernel's own dispatches (the sort between them excluded)
+        avg_ms = tr["walk_ms"]
+        kernel_gbps = avg_bytes / (kern_ms * 1e-3) / 1e9              # ONE step's walk: algorithmic bytes / HIP-event time of its dispatches
         aggregate_gbps = avg_bytes * n_launch / elapsed / 1e9         # all launches / wall time (launches on different streams overlap)
         overlap = max(1.0, min(float(S), avg_ms * 1e-3 * n_launch / elapsed))
 
@@ -629,25 +658,91 @@ class DenseWorkload:
                     "note": "cos_search_batch on pageable host memory, PCIe-inclusive.  qps: %d concurrent synchronous callers (the launches in "
                             "flight `value` is measured with); single_caller: one call at a time, where the call itself runs as a chunk pipeline "
                             "(H2D of chunk i+1 and finalize of chunk i-1 under the walk of chunk i, engine.hip search_host_pipelined)" % S}
-            del qh
+            # ---- the reference's literal calling pattern (indexes/mod.rs:268-271, tests/rps-test.py:426-455): many concurrent callers of
+            # ONE 256-query batch each, fused by the library's dynamic batching (cos_index_set_coalescing) into launches of up to B
+            # queries; PCIe-inclusive.  Every caller's answer must be the answer of an un-coalesced call.
+            small = []
+            qsmall = Q[:B].cpu().numpy().reshape(self.C, Bc, d)
+            direct = ix.batch_search(qsmall[0], k)
+            for nc, maxq in ((self.C, B), (2 * self.C, B), (2 * self.C, B // 2)):
+                ix.set_coalescing(maxq, 300)
+                reps_s = 12
+                res0 = [None]
+                def small_caller(j):
+                    r = None
+                    for _ in range(reps_s):
+                        r = ix.batch_search(qsmall[j % self.C], k)
+                    if j == 0:
+                        res0[0] = r
+                th = [threading.Thread(target=small_caller, args=(j,)) for j in range(nc)]
+                t1 = time.perf_counter()
+                [t.start() for t in th]
+                [t.join() for t in th]
+                el_s = time.perf_counter() - t1
+                same = all(np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b_).view(np.uint32)) for a, b_ in zip(res0[0], direct))
+                small.append({"callers": nc, "queries_per_call": Bc, "coalescing_max_queries": maxq, "coalescing_window_us": 300, "calls_per_caller": reps_s,
+                              "qps": nc * reps_s * Bc / el_s, "identical_to_uncoalesced_call": bool(same)})
+            ix.set_coalescing(0, 0)
+            host["concurrent_256_query_callers"] = small
+            del qh, qsmall
 
         # ---- CPU baseline + parity: the oracle (C restatement of the Rust path) on this box's host cores, same graph ----------
         cpu = parity = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline and cpu_seconds > 0:
-            cpu, parity = self._cpu_baseline_and_parity(ix, ef, visited, cpu_seconds)
+            cpu, parity = self._cpu_baseline_and_parity(ix, ef, visited, cpu_seconds, m0)
 
         # HBM traffic of the walk kernel: PMC FETCH_SIZE cannot be read from inside the process; it is taken from the
         # committed rocprofv3 --pmc pass of this same command (profiles/pmc_traffic.json, written by
         # scripts/pmc_traffic.py) when the workload / ef / launch shape match, else null.
-        traffic = None
+        traffic, traffic_parts, traffic_k = None, {}, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 for ent in json.load(fh):
                     if (ent["workload"], ent["ef_search"], ent["queries_per_launch"]) == (self.name, ef, B) and self.standard_size \
                             and ent.get("visited", "ref") == visited:
                         traffic = ent["hbm_bytes_per_launch"]
+                        traffic_parts = {p: v["bytes"] for p, v in (ent.get("parts") or {}).items()}
+                        traffic_k = ent.get("fetch_factor_k")
         except (OSError, ValueError, KeyError):
             pass
+        issue = None
+        try:   # VALU / SALU issue of the walk kernel from the committed SQ pass of the same command (scripts/final_profile.sh)
+            with open(os.path.join(ROOT, "profiles", "pmc_issue.json")) as fh:
+                for ent in json.load(fh):
+                    if (ent["workload"], ent["ef_search"], ent["queries_per_launch"]) == (self.name, ef, B) and ent.get("visited", "ref") == visited:
+                        issue = {k: ent[k] for k in ("valu_per_step", "salu_per_step", "valu_per_eval", "salu_per_eval", "valu_busy", "salu_busy", "source") if k in ent}
+        except (OSError, ValueError, KeyError):
+            pass
+
+        def part(bound, alg, ms, traffic_b=None, **extra):
+            ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            r = {"bound": bound, "algorithmic_bytes": alg, "ms": ms, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS}
+            if traffic_b is not None and ms > 0:
+                r["traffic"] = traffic_b
+                r["traffic_GBps"] = traffic_b / (ms * 1e-3) / 1e9
+                r["traffic_frac_of_peak"] = r["traffic_GBps"] / HBM_PEAK_GBPS
+            r.update(extra)
+            return r
+        parts = None
+        if sp["cut_after_level"] or sp["table_level_min"]:
+            parts = {}
+            if sp["table_level_min"]:
+                tops = sp["table_int8_ops"] / (sp["table_ms"] * 1e-3) / 1e12 if sp["table_ms"] > 0 else 0.0
+                parts["level_table_gemm"] = {"bound": "mfma", "kernel": "flat_codes_gemm_i8<ENG_U8> (+ code sums)", "levels": f">= {sp['table_level_min']}",
+                                             "columns": sp["table_cols"], "int8_ops": sp["table_int8_ops"], "ms": sp["table_ms"], "achieved": tops,
+                                             "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_PEAK_TOPS,
+                                             "traffic": traffic_parts.get("table_gemm"), "table_bytes_written": float(B) * sp["table_cols"] * 4.0,
+                                             "note": "short-K (768) GEMM with an exact-quotient epilogue per output; it runs on the caller's stream under the "
+                                                     "previous step's walk"}
+            if sp["cut_after_level"]:
+                parts["walk_upper"] = part("hbm", upper_bytes, sp["upper_ms"], traffic_parts.get("upper"),
+                                           levels=f"{9}..{sp['cut_after_level']} in arrival order", evals=sp["upper_evals"], table_evals=sp["table_evals"],
+                                           expansions=sp["upper_expansions"])
+                parts["walk_lower"] = part("hbm", lower_bytes, sp["lower_ms"], traffic_parts.get("lower"),
+                                           levels=f"{sp['cut_after_level'] - 1}..0 in locality order", evals=sp["lower_evals"], expansions=sp["lower_expansions"],
+                                           note="neighbouring queries of the sorted launch share rows in the XCD's L2: the algorithmic rate of this dispatch "
+                                                "may exceed the HBM peak, its measured traffic cannot")
+                parts["order_sort_ms"] = sp["sort_ms"]
 
         # empirical HBM ceilings on THIS part: streaming read and the walk's own access pattern — random
         # gathers of d-byte rows over a buffer the size of the code array — measured after the timed region
@@ -657,7 +752,7 @@ class DenseWorkload:
             g = C_.c_double(0.0)
             empirical = {}
             for pname, kind, nbytes, rb in (("stream_read", 0, 4 << 30, 0), ("stream_copy", 1, 2 << 30, 0),
-                                            ("row_gather", 2, max(n * d, 1 << 20), d)):
+                                            ("row_gather", 2, max(n * d, 1 << 20), d), ("row_gather_64MB_table", 2, 64 << 20, d)):
                 ca._lib.check(lib.cos_hbm_probe(local_rank, kind, nbytes, rb, 3, C_.byref(g)))
                 empirical[pname + "_GBps"] = g.value
             empirical["row_gather_row_bytes"] = d
@@ -676,13 +771,16 @@ class DenseWorkload:
                        "query_batch": Bc, "batches_per_launch": self.C, "queries_per_step": B, "launches_in_flight": S, "top_k": k, "ef_search": ef,
                        "ef_policy": ("smallest ef whose recall@10 on the selection query set is >= %.2f with 95%% confidence; recall_at_10 is "
                                      "measured on a disjoint hold-out set" % args.recall_target) if ef_arg == "auto" else "fixed",
-                       "M": 32, "M0": 64, "num_layers": 9, "ef_construction": self.ef_construction, "build_visited": build_visited,
+                       "M": 32, "M0": m0, "num_layers": 9, "ef_construction": self.ef_construction, "build_visited": build_visited,
                        "storage": f"u8 (quantization {self.quantization}, values_range {self.values_range})",
                        "visited": "reference PerformantFixedSet (ID parity mode)" if visited == "ref" else "exact visited set (recall mode)",
                        "parallelism": f"id-range shards x{world}" + (" + RCCL all-gather top-k merge" if world > 1 else ""),
                        "exchange": exchange_kind, "corpus": self.corpus_desc},
             "roofline": {"bound": "hbm", "achieved": kernel_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": kernel_gbps / HBM_PEAK_GBPS,
-                         "traffic": traffic, "empirical": empirical,
+                         "traffic": traffic, "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac_of_peak": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "traffic_fetch_factor_k": traffic_k, "parts": parts, "issue": issue, "reference_algorithmic_bytes": ref_alg_bytes,
+                         "empirical": empirical,
                          "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64, %s>" % (1 if ef <= 64 else (4 if ef <= 256 else 8), visited),
                          "kernel_launches_per_step": 1 + len(cuts),
                          "walk_order": ({"cut_after_levels": cuts,
@@ -693,17 +791,19 @@ class DenseWorkload:
                          "aggregate": {"achieved": aggregate_gbps, "frac": aggregate_gbps / HBM_PEAK_GBPS, "in_flight": overlap,
                                        "note": "algorithmic bytes of ALL timed launches / timed wall time; exceeds the kernel-level figure "
                                                "only through launches overlapping on different streams"},
-                         "per_launch": {"algorithmic_bytes": avg_bytes, "avg_ms": avg_ms, "min_ms": tr["walk_ms_min"], "max_ms": tr["walk_ms_max"],
+                         "per_launch": {"algorithmic_bytes": avg_bytes, "kernel_ms": kern_ms, "avg_ms": avg_ms, "min_ms": tr["walk_ms_min"], "max_ms": tr["walk_ms_max"],
                                         "launches_sampled": tr["timed_launches_sampled"], "evals": tr["evals"], "expansions": tr["expansions"],
                                         "finalize_ms": tr["finalize_ms"], "prep_ms": tr["prep_ms"], "adjacency_rounds": tr["rounds"]},
-                         "note": "achieved = algorithmic bytes of one step's walk (evals x (dim+4) + expansions x M x 4, counted by the kernel) / "
-                                 "its average HIP-event duration on its own stream over the timed region (kernel_launches_per_step launches of the "
-                                 "kernel: a rocprofv3 trace shows that many dispatches per step, their durations add up to avg_ms)"},
+                         "note": "achieved = algorithmic bytes of one step's walk (row evaluations x (dim+4) + table evaluations x 4 + expansions x M x 4, "
+                                 "counted by the kernel) / the summed HIP-event durations of the walk kernel's dispatches of a step on their own stream "
+                                 "(kernel_ms; kernel_launches_per_step dispatches: a rocprofv3 trace shows them, their durations add up to kernel_ms); "
+                                 "traffic = fabric-side bytes of the same dispatches from the committed PMC pass (FETCH_SIZE x 1024 x k + WRITE_SIZE x 1024, k "
+                                 "calibrated on a gather with a known byte count: profiles/pmc_calibration.json); parts = the same per dispatch"},
         }
         del ix
         return rec
 
-    def _cpu_baseline_and_parity(self, ix, ef, visited, cpu_seconds):
+    def _cpu_baseline_and_parity(self, ix, ef, visited, cpu_seconds, m0=64):
         """the oracle on all usable host cores over a bounded sample of the SAME queries on the SAME graph; the same sample is the
         parity check (ids, score bits, counts).  The oracle's quantized corpus is made once per workload and takes each mode's graph."""
         from oracle import oracle as O
@@ -727,6 +827,8 @@ class DenseWorkload:
         Qh = self.Qh
         oix.set_visited_mode(O.VISITED_EXACT if visited == "exact" else O.VISITED_REF)
         oix.set_ef_search(ef)
+        if oix.params.level0_neighbors_count != m0:
+            oix.set_level0_neighbors(m0)
         oix.import_graph(ix.download_graph(), ix.download_root())
         t2 = time.perf_counter()
         pm = max(64, cores)
@@ -793,13 +895,16 @@ def compact_dense_record(rec, world):
 def _slim_roofline(r):
     if not r:
         return r
-    keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_launches_per_step") if k in r}
+    keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_GBps", "traffic_frac_of_peak", "traffic_fetch_factor_k",
+                                  "kernel", "kernel_launches_per_step", "reference_algorithmic_bytes", "issue") if k in r}
+    if r.get("parts"):
+        keep["parts"] = {pn: ({k: v for k, v in pv.items() if k not in ("note", "kernel")} if isinstance(pv, dict) else pv) for pn, pv in r["parts"].items()}
     if r.get("walk_order"):
         keep["walk_order_cut_after_levels"] = r["walk_order"]["cut_after_levels"]
     pl = r.get("per_launch") or {}
-    keep["per_launch"] = {k: pl[k] for k in ("algorithmic_bytes", "avg_ms", "gemm_ms_all_launches", "int8_ops", "launches_sampled", "finalize_ms") if k in pl}
+    keep["per_launch"] = {k: pl[k] for k in ("algorithmic_bytes", "kernel_ms", "avg_ms", "gemm_ms_all_launches", "int8_ops", "launches_sampled", "finalize_ms") if k in pl}
     if r.get("empirical"):
-        keep["empirical"] = {k: r["empirical"][k] for k in ("stream_read_GBps", "row_gather_GBps") if k in r["empirical"]}
+        keep["empirical"] = {k: r["empirical"][k] for k in ("stream_read_GBps", "row_gather_GBps", "row_gather_64MB_table_GBps") if k in r["empirical"]}
     return keep
 
 
@@ -1039,11 +1144,12 @@ def main():
                                                 "(bit-identical to the oracle) and what the exact visited set changes")
                 w2.close()
                 del w2
-            elif name in ("c4shard_ref", "c4shard_exact"):
-                if c4 is None:   # both modes share the 51 GB shard, its ground truth and the oracle's quantized copy
+            elif name.startswith("c4shard_"):
+                if c4 is None:   # every mode shares the 51 GB shard, its ground truth and the oracle's quantized copy
                     c4 = DenseWorkload(env, "c4shard", n_override=0 if scale == 1.0 else int(12_500_000 * scale))
-                v = "ref" if name == "c4shard_ref" else "exact"
-                r4 = c4.run_mode(v, v, cpu_seconds=args.config_cpu_seconds, exchange=args.exchange)
+                v = "exact" if name == "c4shard_exact" else "ref"
+                m0 = int(name.rsplit("_", 1)[1]) if "_m0_" in name else 64
+                r4 = c4.run_mode(v, v, cpu_seconds=args.config_cpu_seconds, exchange=args.exchange, m0=m0)
                 out["configs"][name] = compact_dense_record(r4, world)
             elif name == "c3":
                 from scripts import bench_c3

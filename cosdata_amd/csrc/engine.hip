@@ -224,6 +224,7 @@ static void reset_meta(cos_index *ix) {
 static void free_pipe(HostPipe *hp) {
     void *ptrs[] = {hp->d_q, hp->d_ids, hp->d_counts, hp->d_scores, hp->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (hp->pin) (void)hipHostFree(hp->pin);
     for (hipEvent_t e : hp->ev_in) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : hp->ev_walk) if (e) (void)hipEventDestroy(e);
     hipStream_t sts[] = {hp->s[0], hp->s[1], hp->sc, hp->sf};
@@ -1194,27 +1195,72 @@ struct CoalesceReq {
     int32_t rc = COS_OK;
     std::string err;
     bool done = false;
+    bool taken = false; // part of a group that has been formed (and may be running): it only waits for `done`
 };
 
+// One launch for a GROUP of host requests (cos_index_set_coalescing).  Round 3 gathered the group into one host vector first — a
+// single-threaded memcpy of 100 MB for 128 x 256 queries, three times what the launch itself takes.  Now every request's queries go
+// from the caller's own buffer straight into the launch's device buffer (one H2D per request, PCIe rate), the results come back in
+// three copies into the pipe's pinned staging buffer and are dealt to the callers' buffers from there (20 KB per request).
 static int32_t run_coalesced(cos_index *ix, std::vector<CoalesceReq *> &group) {
     const u32 top_k = group[0]->top_k, dim = ix->p.dim;
     u32 total = 0;
     for (auto *r : group) total += r->B;
-    std::vector<float> q((size_t)total * dim);
-    std::vector<u32> ids((size_t)total * top_k), counts(total);
-    std::vector<float> scores((size_t)total * top_k);
+    int32_t rc = COS_OK;
     std::vector<int32_t> status(total, 0);
+    std::string err;
+    {
+        PipeLease lease(ix);
+        rc = lease.acquire();
+        HostPipe *hp = lease.hp;
+        auto body = [&]() -> int32_t {
+            hipStream_t st = hp->s[0];
+            Workspace *w;
+            int32_t r0 = get_workspace(ix, (void *)st, st, total, top_k, true, &w);
+            if (r0) return r0;
+            const size_t need = (size_t)total * top_k * 8 + (size_t)total * 8;
+            if (need > hp->pin_cap) {
+                if (hp->pin) HIP_TRY(hipHostFree(hp->pin));
+                hp->pin = nullptr;
+                hp->pin_cap = 0;
+                HIP_TRY(hipHostMalloc(&hp->pin, need, hipHostMallocDefault));
+                hp->pin_cap = need;
+            }
+            size_t off = 0;
+            for (auto *r : group) {
+                HIP_TRY(hipMemcpyAsync(w->d_queries + off * dim, r->queries, (size_t)r->B * dim * 4, hipMemcpyHostToDevice, st));
+                off += r->B;
+            }
+            r0 = run_search(ix, w, w->d_queries, total, top_k, w->d_out_ids, w->d_out_scores, w->d_out_counts, w->d_out_status, true, st);
+            if (r0) { (void)hipStreamSynchronize(st); return r0; }
+            u32 *p_ids = (u32 *)hp->pin;
+            float *p_sc = (float *)(p_ids + (size_t)total * top_k);
+            u32 *p_cnt = (u32 *)(p_sc + (size_t)total * top_k);
+            int32_t *p_st = (int32_t *)(p_cnt + total);
+            hipError_t e = hipMemcpyAsync(p_ids, w->d_out_ids, (size_t)total * top_k * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(p_sc, w->d_out_scores, (size_t)total * top_k * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(p_cnt, w->d_out_counts, (size_t)total * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(p_st, w->d_out_status, (size_t)total * 4, hipMemcpyDeviceToHost, st);
+            const hipError_t es = hipStreamSynchronize(st);
+            HIP_TRY(e);
+            HIP_TRY(es);
+            off = 0;
+            for (auto *r : group) {
+                memcpy(r->out_ids, p_ids + off * top_k, (size_t)r->B * top_k * 4);
+                memcpy(r->out_scores, p_sc + off * top_k, (size_t)r->B * top_k * 4);
+                memcpy(r->out_counts, p_cnt + off, (size_t)r->B * 4);
+                off += r->B;
+            }
+            memcpy(status.data(), p_st, (size_t)total * 4);
+            return COS_OK;
+        };
+        if (rc == COS_OK) rc = body();
+    }
+    if (rc) err = cos_last_error_string();
+    const bool infra_failure = rc != COS_OK; // HIP errors etc. hit every request
     size_t off = 0;
-    for (auto *r : group) { memcpy(q.data() + off * dim, r->queries, (size_t)r->B * dim * 4); off += r->B; }
-    int32_t rc = search_host_once(ix, q.data(), total, top_k, ids.data(), scores.data(), counts.data(), status.data());
-    const std::string err = rc ? std::string(cos_last_error_string()) : std::string();
-    const bool infra_failure = rc != COS_OK && rc != COS_ERR_CALCULATION; // HIP errors etc. hit every request
-    off = 0;
     for (auto *r : group) {
-        memcpy(r->out_ids, ids.data() + off * top_k, (size_t)r->B * top_k * 4);
-        memcpy(r->out_scores, scores.data() + off * top_k, (size_t)r->B * top_k * 4);
-        memcpy(r->out_counts, counts.data() + off, (size_t)r->B * 4);
-        if (r->out_status) memcpy(r->out_status, status.data() + off, (size_t)r->B * 4);
+        if (!infra_failure && r->out_status) memcpy(r->out_status, status.data() + off, (size_t)r->B * 4);
         r->rc = infra_failure ? rc : COS_OK;
         r->err = infra_failure ? err : std::string();
         if (!infra_failure)
@@ -1253,7 +1299,7 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
     ix->co_pending.push_back(&me);
     ix->co_cv.notify_all();
     while (!me.done) {
-        if (!ix->co_leader_active) {
+        if (!me.taken && !ix->co_leader_active) {
             // become the leader: collect followers for up to `window` microseconds, then serve one group per round
             ix->co_leader_active = true;
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window);
@@ -1274,11 +1320,15 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
                 rest.erase(std::remove(rest.begin(), rest.end(), &me), rest.end());
             }
             ix->co_pending = rest;
+            for (auto *r : group) r->taken = true;
+            // the group is formed: the next one may form (and launch, on its own pipe) while this one runs — with one leader at a
+            // time until round 4 the copies of a group never overlapped the walk of another
+            ix->co_leader_active = false;
+            ix->co_cv.notify_all();
             lk.unlock();
             (void)run_coalesced(ix, group);
             lk.lock();
             for (auto *r : group) r->done = true;
-            ix->co_leader_active = false;
             ix->co_cv.notify_all();
         } else {
             ix->co_cv.wait(lk);

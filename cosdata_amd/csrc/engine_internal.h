@@ -157,6 +157,8 @@ struct HostPipe {
     float *d_scores = nullptr;
     int32_t *d_status = nullptr;
     size_t cap_q = 0, cap_ids = 0, cap_scores = 0, cap_counts = 0, cap_status = 0; // elements, one capacity per buffer
+    void *pin = nullptr;        // pinned host staging of a coalesced group's results (run_coalesced)
+    size_t pin_cap = 0;         // bytes
 };
 static constexpr u32 COS_MAX_HOST_PIPES = 32; // concurrent host-API calls served at once; further callers wait for a pipe
 

@@ -208,6 +208,15 @@ void coso_index_clear_graph(coso_index *ix) {
     if (!ix) return;
     for (uint32_t l = 0; l <= ix->p.num_layers; l++) level_free(&ix->lv[l]);
 }
+/* level_0_neighbors_count of the NEXT graph (indexes/hnsw/types.rs:10-17): also the size of the visited filter,
+ * PerformantFixedSet::new(level_0_neighbors_count) (vector_store.rs:266-270).  Drops the current graph; the vectors stay. */
+int coso_index_set_level0_neighbors(coso_index *ix, uint32_t m0) {
+    if (!ix || m0 == 0 || (m0 & (m0 - 1)) || m0 > 256) return COSO_ERR_INVALID;
+    coso_index_clear_graph(ix);
+    ix->p.level0_neighbors_count = m0;
+    ix->lv[0].M = m0;
+    return COSO_OK;
+}
 uint32_t coso_index_level_count(const coso_index *ix, uint32_t level) { return level <= ix->p.num_layers ? ix->lv[level].n : 0; }
 
 /* ------------------------------------------------------------------------------------------

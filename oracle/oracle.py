@@ -97,6 +97,7 @@ def lib():
         "coso_flat_search_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_int]),
         "coso_flat_candidates_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
         "coso_index_clear_graph": (None, [vp]),
+        "coso_index_set_level0_neighbors": (C.c_int, [vp, C.c_uint32]),
         "coso_bruteforce_topk": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
         "coso_meta_enable": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "coso_meta_set_nodes": (C.c_int, [vp, C.c_uint32, vp, vp]),
@@ -385,6 +386,14 @@ class OracleIndex:
 
     def mags(self):
         return np.ctypeslib.as_array(lib().coso_index_mags(self._h), shape=(self.n + 1,)).copy()
+
+    def set_level0_neighbors(self, m0):
+        """level_0_neighbors_count of the NEXT imported / built graph (drops the current one, keeps the quantized vectors)"""
+        rc = lib().coso_index_set_level0_neighbors(self._h, int(m0))
+        if rc != OK:
+            raise ValueError(f"set_level0_neighbors status {rc}")
+        self.params.level0_neighbors_count = int(m0)
+        return self
 
     def set_ef_search(self, ef):
         self.params.ef_search = ef

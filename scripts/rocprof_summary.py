@@ -58,6 +58,29 @@ def main(path):
         print("## PMC: kernel | grid | counter | dispatches | avg per dispatch | total")
         for name, grid, cn, calls, avg, tot in pm:
             print(f"{short(name):45s} | {grid:8d} | {cn} | {calls} | {avg:.1f} | {tot:.1f}")
+        # counters of a split walk by level range: under PMC the dispatches of the device run one at a time and the walk chain orders
+        # the big walks of different streams, so the big walk_kernel dispatches alternate upper range, lower range, upper, ...
+        try:
+            ccols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
+        except sqlite3.Error:
+            ccols = []
+        ocol = next((c for c in ("dispatch_id", "start", "id") if c in ccols), None)
+        if ocol and any("after deal_to_xcds" in k[2] for k in parts):
+            rows = cur.execute(f"select kernel_name, grid_size/workgroup_size, counter_name, value, {ocol} from counters_collection "
+                               f"where kernel_name like '%walk_kernel%' and grid_size/workgroup_size >= 4096 order by {ocol}").fetchall()
+            seen, acc = {}, {}
+            for name, grid, cn, val, oid in rows:
+                key = (short(name), grid, cn)
+                idx = seen.setdefault(key, {})
+                if oid not in idx:
+                    idx[oid] = len(idx)
+                part = "upper range (even dispatches)" if idx[oid] % 2 == 0 else "lower range (odd dispatches)"
+                a = acc.setdefault(key + (part,), [0, 0.0])
+                a[0] += 1
+                a[1] += val
+            print(f"## PMC of the split walk by level range (dispatch order = {ocol}): kernel | grid | counter | part | dispatches | avg per dispatch")
+            for (nm, grid, cn, part), (c, tot) in sorted(acc.items()):
+                print(f"{nm:45s} | {grid:8d} | {cn} | {part} | {c} | {tot / c:.1f}")
 
 
 if __name__ == "__main__":

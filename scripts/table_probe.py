@@ -70,11 +70,12 @@ for ef in EFS:
         ms1 = run(1)
         sp = ix.last_walk_split(streams[0].cuda_stream)
         ms2 = run(2)
+        ms3 = run(3) if os.environ.get("PROBE_3", "0") == "1" else 0.0
         ids = torch.cat([out[0][0], out[1][0]]).clone()
         same = True if ref is None else bool(torch.equal(ids, ref))
         ref = ids if ref is None else ref
         print(json.dumps({"ef": ef, "max_cols": cols, "table_level_min": info[0], "table_cols": info[1],
-                          "ms_per_launch_1_in_flight": round(ms1, 4), "ms_per_launch_2_in_flight": round(ms2, 4), "qps_2_in_flight": round(B / ms2 * 1e3),
+                          "ms_per_launch_1_in_flight": round(ms1, 4), "ms_per_launch_2_in_flight": round(ms2, 4), "qps_2_in_flight": round(B / ms2 * 1e3), "ms_per_launch_3_in_flight": round(ms3, 4),
                           "alone": {"table_ms": round(sp.table_ms, 4), "upper_ms": round(sp.upper_ms, 4), "sort_ms": round(sp.sort_ms, 4),
                                     "lower_ms": round(sp.lower_ms, 4), "table_evals": sp.table_evals, "upper_evals": sp.upper_evals,
                                     "lower_evals": sp.lower_evals, "upper_exp": sp.upper_expansions, "lower_exp": sp.lower_expansions,
