@@ -61,7 +61,7 @@ WORKLOADS = {
     "smoke": (50_000, 768, "mixture", 128, "reduced-size plumbing run (NOT a benchmark number)"),
 }
 ALL_CONFIGS = ["c2_uniform", "c5", "c3", "c4shard_ref", "c4shard_exact"]
-OPTIONAL_CONFIGS = ["c4shard_ref_m0_128", "c4shard_ref_m0_256"]   # --configs only: the reference filter with a larger level_0_neighbors_count
+OPTIONAL_CONFIGS = ["c4shard_ref_m0_128", "c4shard_ref_m0_256", "c4shard_ref_m0_256_m_64", "c4shard_ref_m0_256_m_128"]   # --configs only: the reference filter with a larger level_0_neighbors_count
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -133,6 +133,21 @@ def resolve_configs(spec, world, workload):
             print(f"bench.py: configs {dropped} are single-GPU configurations, skipped at N = {world}", file=sys.stderr)
         names = [v for v in names if v.startswith("c4shard")]
     return names
+
+
+def native_callers_harness():
+    """scripts/libcallers_bench.so (built from callers_bench.cpp with g++ on first use): N native threads calling cos_search_batch"""
+    import ctypes as C_
+    import subprocess
+    src = os.path.join(ROOT, "scripts", "callers_bench.cpp")
+    so = os.path.join(ROOT, "scripts", "libcallers_bench.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", so, src])
+    h = C_.CDLL(so)
+    vp, u32 = C_.c_void_p, C_.c_uint32
+    h.run_callers.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, u32, C_.POINTER(C_.c_double), vp, vp, vp]
+    h.run_callers.restype = C_.c_int32
+    return h
 
 
 def free_port():
@@ -408,7 +423,7 @@ class DenseWorkload:
 
     # ---- one (build filter, search filter) mode -------------------------------------------------------------------
     def run_mode(self, build_visited, visited, ef_arg="auto", ef_sweep="", cpu_seconds=12.0, single_batch=False, host_api=False,
-                 hbm_probe=False, exchange="auto", m0=64):
+                 hbm_probe=False, exchange="auto", m0=64, m=32):
         env, ca, torch = self.env, self.ca, self.env.torch
         args = env.args
         dev, rank, world, local_rank, dist, dist_on = env.dev, env.rank, env.world, env.local_rank, env.dist, env.dist_on
@@ -423,7 +438,7 @@ class DenseWorkload:
         # index: reference defaults (config.toml:20-24,32)
         # level_0_neighbors_count is a user hyper-parameter of the reference (indexes/hnsw/types.rs:10-17) and also the size of its
         # visited filter, PerformantFixedSet::new(level_0_neighbors_count) (vector_store.rs:266-270): 64 = config.toml's default
-        hp = ca.HNSWHyperParams(num_layers=9, ef_construction=self.ef_construction, ef_search=ef, level_0_neighbors_count=m0, neighbors_count=32)
+        hp = ca.HNSWHyperParams(num_layers=9, ef_construction=self.ef_construction, ef_search=ef, level_0_neighbors_count=m0, neighbors_count=m)
         ix = ca.HNSWIndex(d, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), self.values_range, shortlist_size=64,
                           device=local_rank, id_base=rank * n, seed=42 + rank, visited_mode=mode_of(build_visited))
         ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
@@ -557,6 +572,17 @@ class DenseWorkload:
                     "rounds": float(np.mean([c[3] for c in cnts])), "split": sp}
 
         tr = timed_run()
+        # the same step three more times, ONE launch at a time: the durations of its dispatches without a neighbouring launch's
+        # kernels on the chip (what a serialized rocprofv3 trace shows); the timed region's own events stretch a short kernel that
+        # shares the chip with another stream's walk (the level-table GEMM: 0.4 ms alone, ~3 ms under a walk)
+        ix.enable_timing(True)
+        alone = []
+        for i in range(3):
+            step(n_warm + n_launch + i)
+            env.sync_all()
+            alone.append(ix.last_walk_split(streams[(n_warm + n_launch + i) % S].cuda_stream))
+        ix.enable_timing(False)
+        sp_alone = {k_: float(np.mean([getattr(x, k_) for x in alone])) for k_ in ("table_ms", "upper_ms", "sort_ms", "lower_ms")}
         # the locality order of big launches (cos_index_set_walk_order: from WALK_ORDER_DEFAULT_MIN_B queries, ef <= 256)
         cuts = ix.walk_order_cuts() if B >= ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B and ef <= 256 else []
         elapsed = tr["elapsed"]
@@ -662,26 +688,21 @@ class DenseWorkload:
             # ONE 256-query batch each, fused by the library's dynamic batching (cos_index_set_coalescing) into launches of up to B
             # queries; PCIe-inclusive.  Every caller's answer must be the answer of an un-coalesced call.
             small = []
-            qsmall = Q[:B].cpu().numpy().reshape(self.C, Bc, d)
+            qsmall = np.ascontiguousarray(Q[:B].cpu().numpy().reshape(self.C, Bc, d))
             direct = ix.batch_search(qsmall[0], k)
-            for nc, maxq in ((self.C, B), (2 * self.C, B), (2 * self.C, B // 2)):
+            import ctypes as C_
+            harness = native_callers_harness()       # scripts/callers_bench.cpp: native threads (128 Python threads measure the GIL)
+            fn = C_.cast(lib.cos_search_batch, C_.c_void_p)
+            for nc, maxq in ((self.C, B), (2 * self.C, B), (2 * self.C, B // 2), (4 * self.C, B)):
                 ix.set_coalescing(maxq, 300)
-                reps_s = 12
-                res0 = [None]
-                def small_caller(j):
-                    r = None
-                    for _ in range(reps_s):
-                        r = ix.batch_search(qsmall[j % self.C], k)
-                    if j == 0:
-                        res0[0] = r
-                th = [threading.Thread(target=small_caller, args=(j,)) for j in range(nc)]
-                t1 = time.perf_counter()
-                [t.start() for t in th]
-                [t.join() for t in th]
-                el_s = time.perf_counter() - t1
-                same = all(np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b_).view(np.uint32)) for a, b_ in zip(res0[0], direct))
+                reps_s = 16
+                secs = C_.c_double(0.0)
+                i0 = np.zeros((Bc, k), np.uint32); s0 = np.zeros((Bc, k), np.float32); c0 = np.zeros(Bc, np.uint32)
+                nfail = harness.run_callers(fn, ix._h, qsmall.ctypes.data_as(C_.c_void_p), self.C, Bc, d, k, nc, reps_s, C_.byref(secs),
+                                            i0.ctypes.data_as(C_.c_void_p), s0.ctypes.data_as(C_.c_void_p), c0.ctypes.data_as(C_.c_void_p))
+                same = all(np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b_).view(np.uint32)) for a, b_ in zip((i0, s0, c0), direct))
                 small.append({"callers": nc, "queries_per_call": Bc, "coalescing_max_queries": maxq, "coalescing_window_us": 300, "calls_per_caller": reps_s,
-                              "qps": nc * reps_s * Bc / el_s, "identical_to_uncoalesced_call": bool(same)})
+                              "qps": nc * reps_s * Bc / secs.value, "failed_calls": int(nfail), "identical_to_uncoalesced_call": bool(same)})
             ix.set_coalescing(0, 0)
             host["concurrent_256_query_callers"] = small
             del qh, qsmall
@@ -689,7 +710,7 @@ class DenseWorkload:
         # ---- CPU baseline + parity: the oracle (C restatement of the Rust path) on this box's host cores, same graph ----------
         cpu = parity = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline and cpu_seconds > 0:
-            cpu, parity = self._cpu_baseline_and_parity(ix, ef, visited, cpu_seconds, m0)
+            cpu, parity = self._cpu_baseline_and_parity(ix, ef, visited, cpu_seconds, m0, m)
 
         # HBM traffic of the walk kernel: PMC FETCH_SIZE cannot be read from inside the process; it is taken from the
         # committed rocprofv3 --pmc pass of this same command (profiles/pmc_traffic.json, written by
@@ -727,22 +748,23 @@ class DenseWorkload:
         if sp["cut_after_level"] or sp["table_level_min"]:
             parts = {}
             if sp["table_level_min"]:
-                tops = sp["table_int8_ops"] / (sp["table_ms"] * 1e-3) / 1e12 if sp["table_ms"] > 0 else 0.0
+                tops = sp["table_int8_ops"] / (sp_alone["table_ms"] * 1e-3) / 1e12 if sp_alone["table_ms"] > 0 else 0.0
                 parts["level_table_gemm"] = {"bound": "mfma", "kernel": "flat_codes_gemm_i8<ENG_U8> (+ code sums)", "levels": f">= {sp['table_level_min']}",
-                                             "columns": sp["table_cols"], "int8_ops": sp["table_int8_ops"], "ms": sp["table_ms"], "achieved": tops,
+                                             "columns": sp["table_cols"], "int8_ops": sp["table_int8_ops"], "ms": sp_alone["table_ms"],
+                                             "ms_next_to_a_walk": sp["table_ms"], "achieved": tops,
                                              "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_PEAK_TOPS,
                                              "traffic": traffic_parts.get("table_gemm"), "table_bytes_written": float(B) * sp["table_cols"] * 4.0,
                                              "note": "short-K (768) GEMM with an exact-quotient epilogue per output; it runs on the caller's stream under the "
                                                      "previous step's walk"}
             if sp["cut_after_level"]:
-                parts["walk_upper"] = part("hbm", upper_bytes, sp["upper_ms"], traffic_parts.get("upper"),
+                parts["walk_upper"] = part("hbm", upper_bytes, sp["upper_ms"], traffic_parts.get("upper"), ms_alone=sp_alone["upper_ms"],
                                            levels=f"{9}..{sp['cut_after_level']} in arrival order", evals=sp["upper_evals"], table_evals=sp["table_evals"],
                                            expansions=sp["upper_expansions"])
-                parts["walk_lower"] = part("hbm", lower_bytes, sp["lower_ms"], traffic_parts.get("lower"),
+                parts["walk_lower"] = part("hbm", lower_bytes, sp["lower_ms"], traffic_parts.get("lower"), ms_alone=sp_alone["lower_ms"],
                                            levels=f"{sp['cut_after_level'] - 1}..0 in locality order", evals=sp["lower_evals"], expansions=sp["lower_expansions"],
                                            note="neighbouring queries of the sorted launch share rows in the XCD's L2: the algorithmic rate of this dispatch "
                                                 "may exceed the HBM peak, its measured traffic cannot")
-                parts["order_sort_ms"] = sp["sort_ms"]
+                parts["order_sort_ms"] = sp_alone["sort_ms"]
 
         # empirical HBM ceilings on THIS part: streaming read and the walk's own access pattern — random
         # gathers of d-byte rows over a buffer the size of the code array — measured after the timed region
@@ -771,7 +793,7 @@ class DenseWorkload:
                        "query_batch": Bc, "batches_per_launch": self.C, "queries_per_step": B, "launches_in_flight": S, "top_k": k, "ef_search": ef,
                        "ef_policy": ("smallest ef whose recall@10 on the selection query set is >= %.2f with 95%% confidence; recall_at_10 is "
                                      "measured on a disjoint hold-out set" % args.recall_target) if ef_arg == "auto" else "fixed",
-                       "M": 32, "M0": m0, "num_layers": 9, "ef_construction": self.ef_construction, "build_visited": build_visited,
+                       "M": m, "M0": m0, "num_layers": 9, "ef_construction": self.ef_construction, "build_visited": build_visited,
                        "storage": f"u8 (quantization {self.quantization}, values_range {self.values_range})",
                        "visited": "reference PerformantFixedSet (ID parity mode)" if visited == "ref" else "exact visited set (recall mode)",
                        "parallelism": f"id-range shards x{world}" + (" + RCCL all-gather top-k merge" if world > 1 else ""),
@@ -803,7 +825,7 @@ class DenseWorkload:
         del ix
         return rec
 
-    def _cpu_baseline_and_parity(self, ix, ef, visited, cpu_seconds, m0=64):
+    def _cpu_baseline_and_parity(self, ix, ef, visited, cpu_seconds, m0=64, m=32):
         """the oracle on all usable host cores over a bounded sample of the SAME queries on the SAME graph; the same sample is the
         parity check (ids, score bits, counts).  The oracle's quantized corpus is made once per workload and takes each mode's graph."""
         from oracle import oracle as O
@@ -829,6 +851,8 @@ class DenseWorkload:
         oix.set_ef_search(ef)
         if oix.params.level0_neighbors_count != m0:
             oix.set_level0_neighbors(m0)
+        if oix.params.neighbors_count != m:
+            oix.set_neighbors(m)
         oix.import_graph(ix.download_graph(), ix.download_root())
         t2 = time.perf_counter()
         pm = max(64, cores)
@@ -1148,8 +1172,10 @@ def main():
                 if c4 is None:   # every mode shares the 51 GB shard, its ground truth and the oracle's quantized copy
                     c4 = DenseWorkload(env, "c4shard", n_override=0 if scale == 1.0 else int(12_500_000 * scale))
                 v = "exact" if name == "c4shard_exact" else "ref"
-                m0 = int(name.rsplit("_", 1)[1]) if "_m0_" in name else 64
-                r4 = c4.run_mode(v, v, cpu_seconds=args.config_cpu_seconds, exchange=args.exchange, m0=m0)
+                toks = name.split("_")
+                m0 = int(toks[toks.index("m0") + 1]) if "m0" in toks else 64
+                mm = int(toks[toks.index("m") + 1]) if "m" in toks else 32
+                r4 = c4.run_mode(v, v, cpu_seconds=args.config_cpu_seconds, exchange=args.exchange, m0=m0, m=mm)
                 out["configs"][name] = compact_dense_record(r4, world)
             elif name == "c3":
                 from scripts import bench_c3

@@ -144,6 +144,7 @@ const float *coso_index_mags(const coso_index *ix);     /* [n+1] */
 void coso_index_set_ef_search(coso_index *ix, uint32_t ef);
 void coso_index_set_visited_mode(coso_index *ix, uint32_t mode);
 void coso_index_clear_graph(coso_index *ix); /* drop all levels, keep the vectors */
+int coso_index_set_neighbors(coso_index *ix, uint32_t m);          /* same for neighbors_count (levels >= 1) */
 int coso_index_set_level0_neighbors(coso_index *ix, uint32_t m0); /* clears the graph; the next one has M0 = m0 (power of two <= 256) */
 
 /* per-query device-comparable counters */

@@ -217,6 +217,14 @@ int coso_index_set_level0_neighbors(coso_index *ix, uint32_t m0) {
     ix->lv[0].M = m0;
     return COSO_OK;
 }
+/* neighbors_count (the upper levels' M and filter size) of the NEXT graph; drops the current graph, the vectors stay */
+int coso_index_set_neighbors(coso_index *ix, uint32_t m) {
+    if (!ix || m == 0 || (m & (m - 1)) || m > 256) return COSO_ERR_INVALID;
+    coso_index_clear_graph(ix);
+    ix->p.neighbors_count = m;
+    for (uint32_t l = 1; l <= ix->p.num_layers; l++) ix->lv[l].M = m;
+    return COSO_OK;
+}
 uint32_t coso_index_level_count(const coso_index *ix, uint32_t level) { return level <= ix->p.num_layers ? ix->lv[level].n : 0; }
 
 /* ------------------------------------------------------------------------------------------

@@ -98,6 +98,7 @@ def lib():
         "coso_flat_candidates_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
         "coso_index_clear_graph": (None, [vp]),
         "coso_index_set_level0_neighbors": (C.c_int, [vp, C.c_uint32]),
+        "coso_index_set_neighbors": (C.c_int, [vp, C.c_uint32]),
         "coso_bruteforce_topk": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int]),
         "coso_meta_enable": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "coso_meta_set_nodes": (C.c_int, [vp, C.c_uint32, vp, vp]),
@@ -393,6 +394,14 @@ class OracleIndex:
         if rc != OK:
             raise ValueError(f"set_level0_neighbors status {rc}")
         self.params.level0_neighbors_count = int(m0)
+        return self
+
+    def set_neighbors(self, m):
+        """neighbors_count of the NEXT imported / built graph (drops the current one, keeps the quantized vectors)"""
+        rc = lib().coso_index_set_neighbors(self._h, int(m))
+        if rc != OK:
+            raise ValueError(f"set_neighbors status {rc}")
+        self.params.neighbors_count = int(m)
         return self
 
     def set_ef_search(self, ef):
