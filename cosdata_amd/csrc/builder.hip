@@ -279,6 +279,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
         fprintf(stderr, "[cos_index_build] n=%u batches=%llu link rounds=%llu walk %.2fs link %.2fs\n", n, (unsigned long long)n_batches,
                 (unsigned long long)n_rounds, t_walk, t_link);
     guard.armed = false;
+    if (int32_t rc2 = cos_prepare_walk_plans(ix)) return rc2; // order ranks + level-table operand of the new graph, outside any search
     return COS_OK; // the id-format host copy is made on demand (cos_index_download_graph_level)
 }
 

@@ -155,6 +155,11 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
         delete ix;
         return cos_fail(COS_ERR_HIP, "cannot create stream on device %d", p->device);
     }
+    // the locality order deals sorted queries to the XCDs (kernels_order.hip): the count is the device's, not a constant; a part that
+    // does not report it (or reports one XCD) simply gets no dealing — the order then only sorts
+    int nx = 0;
+    if (hipDeviceGetAttribute(&nx, hipDeviceAttributeNumberOfXccs, p->device) == hipSuccess && nx >= 1 && nx <= 64) ix->num_xcd = (u32)nx;
+    else { (void)hipGetLastError(); ix->num_xcd = 1; }
     *out = ix;
     return COS_OK;
 }
@@ -192,7 +197,7 @@ static void free_level(LevelHost &l) {
     l.host_valid = false;
 }
 static void free_ws(Workspace *w) {
-    void *ptrs[] = {w->stats2, w->tab, w->qsums, w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
+    void *ptrs[] = {w->fin_flags, w->stats2, w->tab, w->qsums, w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
                     w->rerank_rows, w->vis.bits, w->vis.log, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     cosdev::walk_order_free(w->order);
@@ -415,6 +420,7 @@ extern "C" int32_t cos_index_upload_graph_level(cos_index *ix, uint32_t level, u
     if (rc) { free_level(L); return rc; }
     rc = resolve_children(ix, level);
     if (rc == COS_OK) rc = resolve_children(ix, level + 1);
+    if (rc == COS_OK && graph_ready(ix)) rc = cos_prepare_walk_plans(ix); // the last level of a graph: its order / level tables now, not under a search
     return rc;
 }
 
@@ -780,6 +786,19 @@ extern "C" int32_t cos_index_walk_table_info(cos_index *ix, uint32_t *out_level_
     return COS_OK;
 }
 
+// The per-graph tables of big launches (locality order ranks, level-table operand) built when a graph is committed — the end of
+// cos_index_build, the upload of a graph's last level, cos_index_load_reference_dir — instead of inside the first big search, where
+// the host-side DFS and the device synchronisations ran under ix->mu and held up every concurrent searcher.  The lazy calls in
+// get_workspace stay as a fall-back (knobs changed after the commit).
+int32_t cos_prepare_walk_plans(cos_index *ix) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->walk_order_min_B)
+        if (int32_t rc = ensure_order_rank(ix)) return rc;
+    if (walk_table_min_B(ix))
+        if (int32_t rc = ensure_level_table(ix)) return rc;
+    return COS_OK;
+}
+
 extern "C" int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t cap, uint32_t *out_n) {
     if (!ix || !out_n || (cap && !out_levels)) return cos_fail(COS_ERR_INVALID, "null argument");
     *out_n = 0;
@@ -813,6 +832,7 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         HIP_TRY(regrow(w->stats, (size_t)cap * 4));
         HIP_TRY(regrow(w->stats2, (size_t)cap * 4));
         HIP_TRY(regrow(w->qsums, cap));
+        HIP_TRY(regrow(w->fin_flags, cap));
         HIP_TRY(regrow(w->rerank_rows, cap));
         HIP_TRY(regrow(w->d_queries, (size_t)cap * ix->p.dim));
         HIP_TRY(regrow(w->d_out_counts, cap));
@@ -820,7 +840,7 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         w->capB = cap;
         w->cap_topk = 0;
     }
-    if (ix->walk_order_min_B && B >= ix->walk_order_min_B) {
+    if (ix->walk_order_min_B && B >= ix->walk_order_min_B && ix->p.ef_search <= 256u) { // wider beams keep the single launch (run_search)
         if (w->order.cap < w->capB) {
             HIP_TRY(hipStreamSynchronize(st));
             HIP_TRY(cosdev::walk_order_reserve(w->order, w->capB));
@@ -970,7 +990,7 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
             HIP_TRY(launch_walk(ix->eng, dev, wa, 0, 0, s));
             if (last) break;
             if (timed && i == 0) HIP_TRY(hipEventRecord(ev[6], s));
-            HIP_TRY(cosdev::launch_walk_order(w->order, B, key_n[i], s));
+            HIP_TRY(cosdev::launch_walk_order(w->order, B, key_n[i], ix->num_xcd, s));
             if (timed && i == 0) HIP_TRY(hipEventRecord(ev[7], s));
             wa.q_order = w->order.q_order;
             first = key_level[i] - 1;
@@ -997,7 +1017,7 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     }
     if (do_finalize) {
         HIP_TRY(launch_finalize(dev, d_queries, ix->p.dim, w->q_raw_mags, w->walk_ids, w->walk_sims, w->walk_counts, w->walk_status, B, top_k,
-                                d_out_ids, d_out_scores, d_out_counts, d_out_status, w->rerank_rows, sf, ordered ? w->order.q_order : nullptr));
+                                d_out_ids, d_out_scores, d_out_counts, d_out_status, w->rerank_rows, sf, ordered ? w->order.q_order : nullptr, w->fin_flags));
     }
     if (timed) { HIP_TRY(hipEventRecord(ev[3], sf)); w->ev_count++; }
     w->lastB = B;
@@ -1090,7 +1110,7 @@ static int32_t search_host_simple(cos_index *ix, HostPipe *hp, const float *quer
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(w->d_queries, queries, (size_t)B * ix->p.dim * 4, hipMemcpyHostToDevice, st));
     rc = run_search(ix, w, w->d_queries, B, top_k, w->d_out_ids, w->d_out_scores, w->d_out_counts, w->d_out_status, true, st);
-    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    if (rc) { (void)hipDeviceSynchronize(); return rc; } // the walk may be running on the workspace's side stream
     std::vector<int32_t> status(B);
     hipError_t e = hipMemcpyAsync(out_ids, w->d_out_ids, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, w->d_out_scores, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
@@ -1132,7 +1152,14 @@ static int32_t search_host_pipelined(cos_index *ix, HostPipe *hp, const float *q
     HIP_TRY(grow_elems(hp->d_status, hp->cap_status, (size_t)B));
     struct Drain { // whatever happens, nothing of this call is still running when its buffers are handed back
         HostPipe *hp;
-        ~Drain() { hipStream_t sts[] = {hp->sc, hp->s[0], hp->s[1], hp->sf}; for (hipStream_t st : sts) if (st) (void)hipStreamSynchronize(st); }
+        bool ok = false;
+        ~Drain() {
+            hipStream_t sts[] = {hp->sc, hp->s[0], hp->s[1], hp->sf};
+            for (hipStream_t st : sts) if (st) (void)hipStreamSynchronize(st);
+            // big chunks walk on their workspace's own low-priority stream: on an error return that walk may have been launched
+            // without `sf` ever waiting for it, so the error path drains the device before the pipe's buffers are handed back
+            if (!ok) (void)hipDeviceSynchronize();
+        }
     } drain{hp};
     for (u32 i = 0; i < nch; i++) {
         const u32 c0 = i * chunk, cb = std::min(chunk, B - c0);
@@ -1156,6 +1183,7 @@ static int32_t search_host_pipelined(cos_index *ix, HostPipe *hp, const float *q
     const hipError_t es = hipStreamSynchronize(hp->sf);
     HIP_TRY(e);
     HIP_TRY(es);
+    drain.ok = true;
     if (out_status) memcpy(out_status, status.data(), (size_t)B * 4);
     return report_status(status.data(), B);
 }
@@ -1232,7 +1260,7 @@ static int32_t run_coalesced(cos_index *ix, std::vector<CoalesceReq *> &group) {
                 off += r->B;
             }
             r0 = run_search(ix, w, w->d_queries, total, top_k, w->d_out_ids, w->d_out_scores, w->d_out_counts, w->d_out_status, true, st);
-            if (r0) { (void)hipStreamSynchronize(st); return r0; }
+            if (r0) { (void)hipDeviceSynchronize(); return r0; } // the walk may be running on the workspace's side stream
             u32 *p_ids = (u32 *)hp->pin;
             float *p_sc = (float *)(p_ids + (size_t)total * top_k);
             u32 *p_cnt = (u32 *)(p_sc + (size_t)total * top_k);

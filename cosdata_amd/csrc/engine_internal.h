@@ -26,7 +26,7 @@ hipError_t launch_walk_meta_index(int eng, const IndexDev &ix, const WalkArgs &w
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
                            u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
-                           hipStream_t st, const u32 *q_order = nullptr);
+                           hipStream_t st, const u32 *q_order = nullptr, u32 *slow_flags = nullptr);
 // buffers of the locality order of one workspace's big launches (kernels_order.hip)
 struct WalkOrder {
     u32 cap = 0;
@@ -39,7 +39,7 @@ struct WalkOrder {
 };
 hipError_t walk_order_reserve(WalkOrder &o, u32 B); // synchronous (re)allocation
 void walk_order_free(WalkOrder &o);
-hipError_t launch_walk_order(WalkOrder &o, u32 B, u32 key_max, hipStream_t st);
+hipError_t launch_walk_order(WalkOrder &o, u32 B, u32 key_max, u32 num_xcd, hipStream_t st);
 // level table of the walk (kernels_flat.hip; WalkArgs::tab)
 hipError_t launch_level_table_gather(const uint8_t *codes, const float *mags, u64 row_stride, const u32 *node_vec, u32 n, u32 col0,
                                      uint8_t *tcodes, float *tmags, hipStream_t st);
@@ -109,6 +109,7 @@ struct Workspace {
     float *tab = nullptr;       // level table of this workspace's big launches [capB][tab_stride] (WalkArgs::tab), grown on demand
     size_t tab_cap = 0;         // floats
     u32 *qsums = nullptr;       // [capB] code sums of the queries (the table GEMM's recentring term)
+    u32 *fin_flags = nullptr;   // [capB] finalize_fast_kernel -> finalize_kernel hand-over (kernels_walk.hip)
     u64 *rerank_rows = nullptr; // [B]
     VisTab vis; // EXACT mode visited filters
     cosdev::WalkOrder order; // locality order of big launches (cos_index::walk_order_min_B)
@@ -204,6 +205,7 @@ struct cos_index {
     // launches of at least this many queries split their walk in two (upper levels | level 0) and run level 0 in locality order
     // (kernels_order.hip); 0 = never.  Env COS_WALK_ORDER_MIN_B.
     u32 walk_order_min_B = COS_WALK_ORDER_DEFAULT_MIN_B;
+    u32 num_xcd = 8; // hipDeviceAttributeNumberOfXccs of the handle's device (workgroup b of a grid runs on XCD b % num_xcd)
     // the order keys' tables: position of every node of a key level in a depth-first order of that level's graph, and the key
     // levels themselves, descending (ensure_order_rank, engine.hip); rebuilt after the graph changes
     u32 *d_order_rank[cosdev::MAX_LEVELS] = {};
@@ -235,4 +237,5 @@ void cos_flat_ws_release(cos_index *ix);
 cosdev::IndexDev cos_make_index_dev(const cos_index *ix);
 cosdev::IndexDev cos_make_meta_dev(const cos_index *ix);
 int32_t cos_set_device(const cos_index *ix);
+int32_t cos_prepare_walk_plans(cos_index *ix); // order ranks + level-table operand of a freshly committed graph (engine.hip)
 void cos_meta_free_levels(cos_index *ix); // device arrays + host lists of every level of the pseudo-root component

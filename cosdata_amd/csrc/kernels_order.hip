@@ -14,14 +14,13 @@
 
 namespace cosdev {
 
-constexpr u32 NUM_XCD = 8; // MI355X: 8 XCDs x 32 CUs
-
-__global__ void deal_to_xcds_kernel(const u32 *__restrict__ sorted, u32 B, u32 *__restrict__ q_order) {
+// num_xcd: the device's XCD count (hipDeviceAttributeNumberOfXccs, read at cos_index_create; MI355X: 8 XCDs x 32 CUs)
+__global__ void deal_to_xcds_kernel(const u32 *__restrict__ sorted, u32 B, u32 num_xcd, u32 *__restrict__ q_order) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    // XCD x receives workgroups x, x + 8, ...: B / 8 of them, one more for x < B % 8.  Its run of the sorted order starts after
-    // the runs of the XCDs before it.
-    const u32 q = B / NUM_XCD, r = B % NUM_XCD, x = b % NUM_XCD, j = b / NUM_XCD;
+    // XCD x receives workgroups x, x + num_xcd, ...: B / num_xcd of them, one more for x < B % num_xcd.  Its run of the sorted order
+    // starts after the runs of the XCDs before it.
+    const u32 q = B / num_xcd, r = B % num_xcd, x = b % num_xcd, j = b / num_xcd;
     q_order[b] = sorted[x * q + (x < r ? x : r) + j];
 }
 
@@ -51,7 +50,7 @@ void walk_order_free(WalkOrder &o) {
 }
 
 // order_key[0..B) / iota[0..B) (both written by the upper-level phase; keys <= key_max) -> q_order[0..B), all on `st`
-hipError_t launch_walk_order(WalkOrder &o, u32 B, u32 key_max, hipStream_t st) {
+hipError_t launch_walk_order(WalkOrder &o, u32 B, u32 key_max, u32 num_xcd, hipStream_t st) {
     if (B > o.cap) return hipErrorInvalidValue;
     int end_bit = 1;
     while (end_bit < 32 && (key_max >> end_bit)) end_bit++; // radix passes over the bits the keys have
@@ -62,7 +61,7 @@ hipError_t launch_walk_order(WalkOrder &o, u32 B, u32 key_max, hipStream_t st) {
     bytes = o.tmp_bytes;
     e = hipcub::DeviceRadixSort::SortPairs(o.tmp, bytes, o.order_key, o.keys_sorted, o.iota, o.vals_sorted, (int)B, 0, end_bit, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(deal_to_xcds_kernel, dim3((B + 255) / 256), dim3(256), 0, st, o.vals_sorted, B, o.q_order);
+    hipLaunchKernelGGL(deal_to_xcds_kernel, dim3((B + 255) / 256), dim3(256), 0, st, o.vals_sorted, B, num_xcd ? num_xcd : 1u, o.q_order);
     return hipGetLastError();
 }
 

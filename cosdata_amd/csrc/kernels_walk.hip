@@ -672,6 +672,7 @@ struct FinalizeArgs {
     u64 *out_rerank_rows; // [B]
     const u32 *q_order;   // optional [B]: workgroup -> query, the locality order the walk of this launch ended with (engine_types.h):
                           // neighbouring queries rerank many of the same raw rows
+    u32 *slow_flags;      // optional [B]: finalize_fast_kernel writes 1 for the queries it leaves to finalize_kernel, which then skips the others
 };
 
 template <int FR>
@@ -680,6 +681,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
     const int lane = threadIdx.x;
     if (blockIdx.x >= fa.B) return;
     const u32 qi = fa.q_order ? fa.q_order[blockIdx.x] : blockIdx.x;
+    if (fa.slow_flags && fa.slow_flags[qi] == 0u) return; // answered by finalize_fast_kernel
     const u32 L = ix.num_layers;
     const u32 metric = ix.metric;
     float *qf = (float *)smem_raw;                                   // dim floats (padded to 16 B)
@@ -815,6 +817,136 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// finalize_fast: the same result for the usual shape of a search (5 * top_k <= 64), at a fraction of the work.
+// finalize_kernel sorts the first 5k + 1 entries of EVERY level list — 510 keys at ten levels, a 512-key bitonic network in 121
+// VGPRs (4 waves per SIMD) — to keep the best 5k distinct ones.  But level 0's own list already holds 5k + 1 distinct nodes (at most
+// one of them the root): an entry of any list below level 0's (5k + 1)-th key has 5k distinct non-root entries above it and can never
+// be kept.  So: T = that key; the entries >= T of all lists — level 0's 5k + 1 and the few upper-level entries that are among the
+// query's nearest (the same nodes at the same scores: duplicates) — are compacted into LDS, typically ~70 of them; up to 128 are sorted
+// by a 128-key network (two keys per lane), deduplicated and reranked exactly as below.  More than 128 survivors (small graphs, tiny
+// ef: level 0 has no (5k + 1)-th entry and nothing is screened) leave the query to finalize_kernel through slow_flags.
+// ------------------------------------------------------------------------------------------------
+constexpr int FAST_CAP = 128;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void finalize_fast_kernel(const IndexDev ix, const FinalizeArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= fa.B) return;
+    const u32 qi = fa.q_order ? fa.q_order[blockIdx.x] : blockIdx.x;
+    const u32 L = ix.num_layers;
+    const u32 metric = ix.metric;
+    float *qf = (float *)smem_raw;                                                       // dim floats (padded to 16 B)
+    u64 *surv = (u64 *)(smem_raw + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));           // FAST_CAP survivor keys
+    u32 *cand = (u32 *)(surv + FAST_CAP);                                                // 64 candidate ids
+
+    const int32_t wst = fa.walk_status[qi];
+    if (wst != COS_OK) {
+        if (lane == 0) { fa.out_status[qi] = wst; fa.out_counts[qi] = 0; if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = 0; fa.slow_flags[qi] = 0u; }
+        return;
+    }
+    const float *q = fa.queries + (u64)qi * fa.q_stride;
+    for (u32 i = lane; i < ix.dim; i += 64) qf[i] = q[i];
+
+    const u32 want = 5u * fa.top_k, per = want + 1u; // truncate(5k) (common.rs:409); entries of a level that can matter
+    // counts of every level in one load; the threshold from level 0's list (slot L)
+    const u32 cnt_l = (u32)lane <= L ? fa.walk_counts[(u64)qi * (L + 1) + lane] : 0u;
+    const u32 c0 = readlane_u32(cnt_l, (int)L);
+    const u64 b0 = ((u64)qi * (L + 1) + L) * KEEP_SEARCH;
+    u64 T = 0ull;
+    if (c0 >= per) T = pack_key(metric_key(metric, uniform_f32(fa.walk_sims[b0 + want])), uniform_u32(fa.walk_ids[b0 + want]));
+    // every level's first min(count, 5k + 1) entries, one per lane (5k + 1 <= 64): loads of all levels first, then the screen
+    u32 n = 0;
+    bool overflow = false;
+    for (u32 s0 = 0; s0 <= L; s0 += 4) { // four levels' loads in flight
+        u32 idv[4];
+        float smv[4];
+        u32 cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32 s = s0 + (u32)u;
+            u32 c = s <= L ? readlane_u32(cnt_l, (int)(s <= L ? s : L)) : 0u;
+            c = c > per ? per : c;
+            cc[u] = c;
+            const u64 b = ((u64)qi * (L + 1) + (s <= L ? s : L)) * KEEP_SEARCH;
+            const u32 j = (u32)lane < c ? (u32)lane : 0u;
+            idv[u] = fa.walk_ids[b + j];
+            smv[u] = fa.walk_sims[b + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32 id = idv[u];
+            // root filtered (common.rs:397); so are the pseudo nodes of a metadata collection (common.rs:400-402)
+            const bool drop = id == COS_ROOT_ID || (ix.mdim != 0u && id >= 0xFFFFFEFEu && id <= 0xFFFFFFFDu);
+            const u64 key = pack_key(metric_key(metric, smv[u]), id);
+            const u64 keep = ballot64((u32)lane < cc[u] && !drop && key >= T);
+            const u32 nk = (u32)__popcll(keep);
+            if (n + nk > (u32)FAST_CAP) { overflow = true; break; }
+            if (__builtin_amdgcn_inverse_ballot_w64(keep)) surv[n + (u32)__popcll(keep & ((1ull << lane) - 1ull))] = key;
+            n += nk;
+        }
+        if (overflow) break;
+    }
+    if (overflow) {
+        if (lane == 0) fa.slow_flags[qi] = 1u;
+        return;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    u64 k[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const u32 e = (u32)lane * 2u + (u32)r;
+        k[r] = e < n ? surv[e] : 0ull;
+    }
+    bitonic_sort_desc<2>(k, lane);
+    // duplicates of a node carry identical (score, id) keys and are adjacent after the sort: keep the first
+    const u64 prev_last = shfl_up1_u64(k[1]);
+    const bool keep0 = k[0] != 0ull && (lane == 0 || k[0] != prev_last), keep1 = k[1] != 0ull && k[1] != k[0];
+    const u32 mine = (keep0 ? 1u : 0u) + (keep1 ? 1u : 0u);
+    u32 incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = (u32)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    u32 pos = incl - mine;
+    const u32 total = readlane_u32(incl, 63);
+    const u32 ncand = total < want ? total : want;
+    if (keep0) { if (pos < ncand) cand[pos] = (u32)k[0]; pos++; }
+    if (keep1) { if (pos < ncand) cand[pos] = (u32)k[1]; }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    // exact rerank on raw f32 (vector_store.rs:404-445); 32 candidates per pass (one lane pair each); survivor j ends in lane j and
+    // one 64-key sort finishes the job (5k <= 64)
+    const float mag_query = fa.q_raw_mags[qi];
+    const u32 nout = ncand < fa.top_k ? ncand : fa.top_k;
+    const int pair = lane >> 1;
+    u64 res[1] = {0ull};
+    for (u32 base = 0; base < ncand; base += 32) {
+        const u32 my = base + (u32)pair;
+        const u32 id = my < ncand ? cand[my] : 0u;
+        const u32 rrow = id / ix.id_stride; // raw embedding of an id = its base id (collection.rs:368-384)
+        const float dp = f32_pair_dot(ix.raw + (u64)rrow * ix.raw_stride, qf, ix.dim, lane & 1);
+        const float cs = x86_div(dp, __fmul_rn(mag_query, ix.raw_mags[rrow])); // 0/0 (zero raw vector or query) -> x86's -NaN
+        const u64 key = my < ncand ? pack_key(simkey(cs), id) : 0ull; // total_cmp desc; larger id first on ties
+        const int from = (2 * (lane - (int)base)) & 63;
+        const u32 klo = (u32)__shfl((int)(u32)key, from, 64), khi = (u32)__shfl((int)(u32)(key >> 32), from, 64);
+        if ((u32)lane >= base && (u32)lane < base + 32) res[0] = ((u64)khi << 32) | klo;
+    }
+    bitonic_sort_desc<1>(res, lane);
+    if ((u32)lane < nout) {
+        fa.out_ids[(u64)qi * fa.top_k + lane] = (u32)res[0] + ix.id_base;
+        fa.out_scores[(u64)qi * fa.top_k + lane] = simkey_inv((u32)(res[0] >> 32));
+    }
+    if (lane == 0) {
+        fa.out_counts[qi] = nout;
+        fa.out_status[qi] = COS_OK;
+        if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = ncand;
+        fa.slow_flags[qi] = 0u;
+    }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -928,13 +1060,23 @@ hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
                            u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
-                           hipStream_t st, const u32 *q_order) {
+                           hipStream_t st, const u32 *q_order, u32 *slow_flags) {
     if (B == 0) return hipSuccess;
     FinalizeArgs fa{queries, q_stride, q_raw_mags, walk_ids, walk_sims, walk_counts, walk_status, B, top_k,
-                    out_ids, out_scores, out_counts, out_status, out_rerank_rows, q_order};
+                    out_ids, out_scores, out_counts, out_status, out_rerank_rows, q_order, nullptr};
     const u32 per_level = std::min<u32>(KEEP_SEARCH, 5u * top_k + 1u);
     const u32 total = (ix.num_layers + 1) * per_level;
     dim3 grid(B), block(64);
+    // the screened kernel first (5k + 1 <= 64 entries per level list, a flag word per query to hand the rest over); COS_FINALIZE_FAST=0
+    // keeps the general kernel alone (experiments)
+    static const bool fast_on = [] { const char *e = getenv("COS_FINALIZE_FAST"); return !e || atoi(e) != 0; }();
+    if (fast_on && slow_flags && ix.mdim == 0u && 5u * top_k + 1u <= 64u && KEEP_SEARCH >= 5u * top_k + 1u) { // base collections: only the root is ever dropped
+        fa.slow_flags = slow_flags;
+        const size_t smem_f = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + (size_t)FAST_CAP * 8 + 64 * 4;
+        hipLaunchKernelGGL(finalize_fast_kernel, grid, block, smem_f, st, ix, fa);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     if (total <= 64 * 4) {
         size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 4 * 4;
         hipLaunchKernelGGL(finalize_kernel<4>, grid, block, smem, st, ix, fa);

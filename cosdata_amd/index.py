@@ -149,12 +149,14 @@ class HNSWIndex:
             raise CosdataError(_lib.ERR_INVALID, f"vectors must be [n][{self.dim}] f32, got shape {tuple(raw.shape)}")
         check(_lib.lib().cos_index_upload_vectors(self._h, _p(raw), raw.shape[0], 0))
         self.n = raw.shape[0]
+        self.mdim = 0  # a re-upload drops the metadata schema with the graph (cosdata_hip.h): enable_metadata again before filtering
         return self
 
     def upload_vectors_device(self, dev_ptr: int, n: int, keepalive=None):
         """raw f32 [n][dim] already in HBM (e.g. a torch tensor's data_ptr()); borrowed, not copied."""
         check(_lib.lib().cos_index_upload_vectors(self._h, C.c_void_p(dev_ptr), n, 1))
         self.n = n
+        self.mdim = 0  # see upload_vectors
         self._keepalive = keepalive
         return self
 

@@ -113,6 +113,9 @@ int32_t cos_hbm_probe(int32_t device, uint32_t kind, uint64_t buffer_bytes, uint
  * internal ids [0,n).  The library quantizes them on the device with the index's StorageType
  * (ScalarQuantization::quantize, quantization/scalar.rs:10-52) and keeps raw for the exact rerank. */
 int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uint32_t n, uint32_t flags);
+/* Re-uploading vectors starts a new collection snapshot: the graph, the pseudo-root component AND the metadata schema
+ * (cos_index_enable_metadata: mdim, max_replicas_per_node, the node table) are dropped — ids go back to id = vector row — so a host
+ * that filters must call cos_index_enable_metadata again before cos_index_upload_meta_nodes / cos_index_build_meta. */
 /* create_root_node's random vector (vector_store.rs:30-36), id u32::MAX. */
 int32_t cos_index_set_root(cos_index *ix, const float *root_raw);
 /* One HNSW level as flat arrays exported from ProbNode (prob_node.rs:97-109):
@@ -235,7 +238,10 @@ typedef struct {
     uint64_t lower_evals, lower_expansions, lower_adj_bytes; /* levels below the cut (or the whole walk) */
 } cos_walk_split;
 int32_t cos_index_last_walk_split(cos_index *ix, void *stream, cos_walk_split *out);
-/* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream) */
+/* counters + kernel times of the last completed batch on `stream` (NULL = the host API's stream).  A lone big cos_search_batch call
+ * runs as up to four chunk launches (each with its own workspace): with stream == NULL the figures then describe the LAST chunk only
+ * (about a quarter of the call's queries; cos_walk_split.queries says how many) — whether a call is chunked depends on what else is
+ * in flight on the handle, so callers that want whole-batch counters use cos_search_batch_device on their own stream. */
 int32_t cos_index_enable_timing(cos_index *ix, int32_t on);
 int32_t cos_index_last_stats(cos_index *ix, void *stream, cos_search_stats *out);
 /* HIP-event times of the (up to 128 most recent) launches enqueued on `stream` since cos_index_enable_timing(1):

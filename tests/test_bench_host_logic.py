@@ -43,10 +43,11 @@ def test_effective_cores_is_bounded_by_affinity():
 def test_resolve_configs_auto_all_none_and_world_rules():
     import bench
     assert bench.resolve_configs("auto", 1, "c2") == bench.ALL_CONFIGS                  # every BASELINE config at N = 1
-    assert bench.resolve_configs("auto", 8, "c2") == ["c4shard_exact"]                  # N > 1: configs[3] itself
+    assert bench.resolve_configs("auto", 8, "c2") == ["c4shard_ref_m0_256_m_64"]        # N > 1: configs[3] itself, in the Rust path's semantics
     assert bench.resolve_configs("auto", 1, "smoke") == [] and bench.resolve_configs("none", 1, "c2") == []
     assert bench.resolve_configs("c3,c5", 1, "c2") == ["c3", "c5"]
-    assert bench.resolve_configs("all", 2, "c2") == ["c4shard_ref", "c4shard_exact"]    # single-GPU configs are dropped at N > 1
+    assert bench.resolve_configs("all", 2, "c2") == ["c4shard_ref", "c4shard_ref_m0_256_m_64"]    # single-GPU configs are dropped at N > 1
+    assert bench.resolve_configs("c4shard_exact,c4shard_ref_m0_128", 1, "c2") == ["c4shard_exact", "c4shard_ref_m0_128"]   # optional records
     import pytest
     with pytest.raises(SystemExit):
         bench.resolve_configs("c9", 1, "c2")
