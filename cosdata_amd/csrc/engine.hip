@@ -229,7 +229,6 @@ static void reset_meta(cos_index *ix) {
 static void free_pipe(HostPipe *hp) {
     void *ptrs[] = {hp->d_q, hp->d_ids, hp->d_counts, hp->d_scores, hp->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (hp->pin) (void)hipHostFree(hp->pin);
     for (hipEvent_t e : hp->ev_in) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : hp->ev_walk) if (e) (void)hipEventDestroy(e);
     hipStream_t sts[] = {hp->s[0], hp->s[1], hp->sc, hp->sf};
@@ -244,6 +243,7 @@ extern "C" int32_t cos_index_destroy(cos_index *ix) {
     for (auto &kv : ix->ws) free_ws(kv.second);
     cos_flat_ws_release(ix);
     for (HostPipe *hp : ix->pipes_all) free_pipe(hp);
+    cos_coalesce_release(ix);
     for (auto &l : ix->lv) free_level(l);
     for (auto &l : ix->meta.lv) free_level(l);
     if (ix->meta.d_mbits) (void)hipFree(ix->meta.d_mbits);
@@ -832,7 +832,7 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         HIP_TRY(regrow(w->stats, (size_t)cap * 4));
         HIP_TRY(regrow(w->stats2, (size_t)cap * 4));
         HIP_TRY(regrow(w->qsums, cap));
-        HIP_TRY(regrow(w->fin_flags, cap));
+        HIP_TRY(regrow(w->fin_flags, (size_t)cap + 1));
         HIP_TRY(regrow(w->rerank_rows, cap));
         HIP_TRY(regrow(w->d_queries, (size_t)cap * ix->p.dim));
         HIP_TRY(regrow(w->d_out_counts, cap));
@@ -1213,96 +1213,94 @@ static int32_t search_host_once(cos_index *ix, const float *queries, uint32_t B,
 // are pending), runs ONE launch for all of them and hands every caller its own slice.  Results are
 // identical to un-coalesced calls (queries are independent); errors stay per request.
 // ------------------------------------------------------------------------------------------------
-struct CoalesceReq {
-    const float *queries;
-    u32 B, top_k;
-    u32 *out_ids;
-    float *out_scores;
-    u32 *out_counts;
-    int32_t *out_status;
+// A slot = one launch being assembled: pinned staging for up to `cap` queries and their results.  Callers reserve a range under
+// co_mu, copy their own queries into the slot's pinned buffer IN PARALLEL (128 callers x 786 KB: the copies of a group used to be
+// issued one after the other by the leader, each a pageable H2D of its own with its pinning overhead), and copy their own results out
+// the same way; the leader — the request that opened the slot — only waits for the window, issues ONE H2D / launch / D2H and wakes the
+// others.  Slots are pooled per handle; a slot is recycled when its last request has copied its results out.
+struct CoSlot {
+    float *pin_q = nullptr;     // [cap][dim]
+    unsigned char *pin_out = nullptr; // ids [cap][k] | scores [cap][k] | counts [cap] | status [cap]
+    u32 cap = 0, cap_k = 0;
+    u32 top_k = 0;
+    u32 reserved = 0, n_req = 0, left = 0; // queries reserved, requests in the slot, requests that have not left yet
+    std::atomic<u32> copied{0};            // requests whose queries are in pin_q
+    bool closed = false, done = false;
     int32_t rc = COS_OK;
     std::string err;
-    bool done = false;
-    bool taken = false; // part of a group that has been formed (and may be running): it only waits for `done`
+    std::condition_variable cv;            // with co_mu: `reserved` grew (leader) / `done` (followers)
 };
 
-// One launch for a GROUP of host requests (cos_index_set_coalescing).  Round 3 gathered the group into one host vector first — a
-// single-threaded memcpy of 100 MB for 128 x 256 queries, three times what the launch itself takes.  Now every request's queries go
-// from the caller's own buffer straight into the launch's device buffer (one H2D per request, PCIe rate), the results come back in
-// three copies into the pipe's pinned staging buffer and are dealt to the callers' buffers from there (20 KB per request).
-static int32_t run_coalesced(cos_index *ix, std::vector<CoalesceReq *> &group) {
-    const u32 top_k = group[0]->top_k, dim = ix->p.dim;
-    u32 total = 0;
-    for (auto *r : group) total += r->B;
-    int32_t rc = COS_OK;
-    std::vector<int32_t> status(total, 0);
-    std::string err;
-    {
-        PipeLease lease(ix);
-        rc = lease.acquire();
-        HostPipe *hp = lease.hp;
-        auto body = [&]() -> int32_t {
-            hipStream_t st = hp->s[0];
-            Workspace *w;
-            int32_t r0 = get_workspace(ix, (void *)st, st, total, top_k, true, &w);
-            if (r0) return r0;
-            const size_t need = (size_t)total * top_k * 8 + (size_t)total * 8;
-            if (need > hp->pin_cap) {
-                if (hp->pin) HIP_TRY(hipHostFree(hp->pin));
-                hp->pin = nullptr;
-                hp->pin_cap = 0;
-                HIP_TRY(hipHostMalloc(&hp->pin, need, hipHostMallocDefault));
-                hp->pin_cap = need;
-            }
-            size_t off = 0;
-            for (auto *r : group) {
-                HIP_TRY(hipMemcpyAsync(w->d_queries + off * dim, r->queries, (size_t)r->B * dim * 4, hipMemcpyHostToDevice, st));
-                off += r->B;
-            }
-            r0 = run_search(ix, w, w->d_queries, total, top_k, w->d_out_ids, w->d_out_scores, w->d_out_counts, w->d_out_status, true, st);
-            if (r0) { (void)hipDeviceSynchronize(); return r0; } // the walk may be running on the workspace's side stream
-            u32 *p_ids = (u32 *)hp->pin;
-            float *p_sc = (float *)(p_ids + (size_t)total * top_k);
-            u32 *p_cnt = (u32 *)(p_sc + (size_t)total * top_k);
-            int32_t *p_st = (int32_t *)(p_cnt + total);
-            hipError_t e = hipMemcpyAsync(p_ids, w->d_out_ids, (size_t)total * top_k * 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(p_sc, w->d_out_scores, (size_t)total * top_k * 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(p_cnt, w->d_out_counts, (size_t)total * 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(p_st, w->d_out_status, (size_t)total * 4, hipMemcpyDeviceToHost, st);
-            const hipError_t es = hipStreamSynchronize(st);
-            HIP_TRY(e);
-            HIP_TRY(es);
-            off = 0;
-            for (auto *r : group) {
-                memcpy(r->out_ids, p_ids + off * top_k, (size_t)r->B * top_k * 4);
-                memcpy(r->out_scores, p_sc + off * top_k, (size_t)r->B * top_k * 4);
-                memcpy(r->out_counts, p_cnt + off, (size_t)r->B * 4);
-                off += r->B;
-            }
-            memcpy(status.data(), p_st, (size_t)total * 4);
-            return COS_OK;
-        };
-        if (rc == COS_OK) rc = body();
+static void co_slot_free(CoSlot *sl) {
+    if (sl->pin_q) (void)hipHostFree(sl->pin_q);
+    if (sl->pin_out) (void)hipHostFree(sl->pin_out);
+    delete sl;
+}
+void cos_coalesce_release(cos_index *ix) { // cos_index_destroy
+    for (CoSlot *sl : ix->co_slots) co_slot_free(sl);
+    ix->co_slots.clear();
+    ix->co_open = nullptr;
+}
+
+// an idle slot with room for max_q queries of top_k results (caller holds co_mu)
+static CoSlot *co_slot_get(cos_index *ix, u32 max_q, u32 top_k) {
+    CoSlot *sl = nullptr;
+    for (CoSlot *c : ix->co_slots)
+        if (c->left == 0 && !c->closed && c->n_req == 0) { sl = c; break; }
+    if (!sl) {
+        if (ix->co_slots.size() >= 8) return nullptr; // every slot is in flight: the caller launches on its own
+        sl = new CoSlot();
+        ix->co_slots.push_back(sl);
     }
-    if (rc) err = cos_last_error_string();
-    const bool infra_failure = rc != COS_OK; // HIP errors etc. hit every request
-    size_t off = 0;
-    for (auto *r : group) {
-        if (!infra_failure && r->out_status) memcpy(r->out_status, status.data() + off, (size_t)r->B * 4);
-        r->rc = infra_failure ? rc : COS_OK;
-        r->err = infra_failure ? err : std::string();
-        if (!infra_failure)
-            for (u32 b = 0; b < r->B; b++)
-                if (status[off + b] != COS_OK) { // the reference fails the whole request of THIS caller (collect::<Result<_>>)
-                    r->rc = status[off + b];
-                    char buf[160];
-                    snprintf(buf, sizeof(buf), "query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", b, status[off + b]);
-                    r->err = buf;
-                    break;
-                }
-        off += r->B;
+    if (sl->cap < max_q) {
+        if (sl->pin_q) (void)hipHostFree(sl->pin_q);
+        sl->pin_q = nullptr;
+        sl->cap = 0;
+        if (hipHostMalloc((void **)&sl->pin_q, (size_t)max_q * ix->p.dim * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        sl->cap = max_q;
+        sl->cap_k = 0;
     }
-    return rc;
+    if (sl->cap_k < top_k) {
+        if (sl->pin_out) (void)hipHostFree(sl->pin_out);
+        sl->pin_out = nullptr;
+        sl->cap_k = 0;
+        if (hipHostMalloc((void **)&sl->pin_out, (size_t)sl->cap * top_k * 8 + (size_t)sl->cap * 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        sl->cap_k = top_k;
+    }
+    sl->top_k = top_k;
+    sl->reserved = sl->n_req = sl->left = 0;
+    sl->copied.store(0);
+    sl->closed = sl->done = false;
+    sl->rc = COS_OK;
+    sl->err.clear();
+    return sl;
+}
+
+// the leader's launch: pinned queries -> device, search, results -> pinned
+static int32_t co_slot_run(cos_index *ix, CoSlot *sl) {
+    const u32 total = sl->reserved, top_k = sl->top_k;
+    PipeLease lease(ix);
+    int32_t rc = lease.acquire();
+    if (rc) return rc;
+    hipStream_t st = lease.hp->s[0];
+    Workspace *w;
+    rc = get_workspace(ix, (void *)st, st, total, top_k, true, &w);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(w->d_queries, sl->pin_q, (size_t)total * ix->p.dim * 4, hipMemcpyHostToDevice, st));
+    rc = run_search(ix, w, w->d_queries, total, top_k, w->d_out_ids, w->d_out_scores, w->d_out_counts, w->d_out_status, true, st);
+    if (rc) { (void)hipDeviceSynchronize(); return rc; } // the walk may be running on the workspace's side stream
+    u32 *p_ids = (u32 *)sl->pin_out;
+    float *p_sc = (float *)(p_ids + (size_t)sl->cap * top_k);
+    u32 *p_cnt = (u32 *)(p_sc + (size_t)sl->cap * top_k);
+    int32_t *p_st = (int32_t *)(p_cnt + sl->cap);
+    hipError_t e = hipMemcpyAsync(p_ids, w->d_out_ids, (size_t)total * top_k * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(p_sc, w->d_out_scores, (size_t)total * top_k * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(p_cnt, w->d_out_counts, (size_t)total * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(p_st, w->d_out_status, (size_t)total * 4, hipMemcpyDeviceToHost, st);
+    const hipError_t es = hipStreamSynchronize(st);
+    HIP_TRY(e);
+    HIP_TRY(es);
+    return COS_OK;
 }
 
 extern "C" int32_t cos_index_set_coalescing(cos_index *ix, uint32_t max_queries, uint32_t window_us) {
@@ -1318,52 +1316,87 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
     int32_t rc = check_search_args(ix, queries, B, top_k);
     if (rc) return rc;
     if (!out_ids || !out_scores || !out_counts) return cos_fail(COS_ERR_INVALID, "null output");
-    u32 max_q, window;
-    { std::lock_guard<std::mutex> g(ix->co_mu); max_q = ix->co_max_queries; window = ix->co_window_us; }
-    if (max_q == 0 || B >= max_q) return search_host_once(ix, queries, B, top_k, out_ids, out_scores, out_counts, out_status);
-
-    CoalesceReq me{queries, B, top_k, out_ids, out_scores, out_counts, out_status};
-    std::unique_lock<std::mutex> lk(ix->co_mu);
-    ix->co_pending.push_back(&me);
-    ix->co_cv.notify_all();
-    while (!me.done) {
-        if (!me.taken && !ix->co_leader_active) {
-            // become the leader: collect followers for up to `window` microseconds, then serve one group per round
-            ix->co_leader_active = true;
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window);
-            for (;;) {
-                u32 pend = 0;
-                for (auto *r : ix->co_pending) pend += r->B;
-                if (pend >= max_q || ix->co_cv.wait_until(lk, deadline) == std::cv_status::timeout) break;
+    const size_t dim = ix->p.dim;
+    CoSlot *sl = nullptr;
+    u32 off = 0, max_q = 0, window = 0;
+    bool leader = false;
+    {
+        std::unique_lock<std::mutex> lk(ix->co_mu);
+        max_q = ix->co_max_queries;
+        window = ix->co_window_us;
+        if (max_q != 0 && B < max_q) {
+            sl = ix->co_open;
+            if (sl && (sl->closed || sl->top_k != top_k || sl->reserved + B > max_q || sl->reserved + B > sl->cap)) {
+                sl->closed = true; // full (or another top_k): its leader launches it as it is; a new slot opens
+                sl->cv.notify_all();
+                sl = nullptr;
             }
-            std::vector<CoalesceReq *> group, rest;
-            u32 taken = 0;
-            for (auto *r : ix->co_pending) {
-                if (r->top_k == me.top_k && (taken == 0 || taken + r->B <= max_q)) { group.push_back(r); taken += r->B; }
-                else rest.push_back(r);
+            if (!sl) {
+                sl = co_slot_get(ix, max_q, top_k);
+                ix->co_open = sl;
+                leader = sl != nullptr;
             }
-            if (std::find(group.begin(), group.end(), &me) == group.end()) { // never starve the leader itself
-                rest.insert(rest.end(), group.begin(), group.end());
-                group.assign(1, &me);
-                rest.erase(std::remove(rest.begin(), rest.end(), &me), rest.end());
+            if (sl) {
+                off = sl->reserved;
+                sl->reserved += B;
+                sl->n_req++;
+                sl->left++;
+                if (sl->reserved >= max_q) { sl->closed = true; ix->co_open = nullptr; }
+                sl->cv.notify_all();
             }
-            ix->co_pending = rest;
-            for (auto *r : group) r->taken = true;
-            // the group is formed: the next one may form (and launch, on its own pipe) while this one runs — with one leader at a
-            // time until round 4 the copies of a group never overlapped the walk of another
-            ix->co_leader_active = false;
-            ix->co_cv.notify_all();
-            lk.unlock();
-            (void)run_coalesced(ix, group);
-            lk.lock();
-            for (auto *r : group) r->done = true;
-            ix->co_cv.notify_all();
-        } else {
-            ix->co_cv.wait(lk);
         }
     }
-    lk.unlock();
-    if (me.rc != COS_OK) return cos_fail(me.rc, "%s", me.err.c_str());
+    if (!sl) return search_host_once(ix, queries, B, top_k, out_ids, out_scores, out_counts, out_status);
+
+    memcpy(sl->pin_q + (size_t)off * dim, queries, (size_t)B * dim * 4); // every caller stages its own queries, in parallel
+    sl->copied.fetch_add(1, std::memory_order_release);
+    if (leader) {
+        u32 n_req;
+        {
+            std::unique_lock<std::mutex> lk(ix->co_mu);
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window);
+            while (!sl->closed && sl->cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
+            sl->closed = true;
+            if (ix->co_open == sl) ix->co_open = nullptr;
+            n_req = sl->n_req;
+        }
+        while (sl->copied.load(std::memory_order_acquire) < n_req) std::this_thread::yield(); // followers still copying (microseconds)
+        const int32_t r = co_slot_run(ix, sl);
+        const std::string e = r ? std::string(cos_last_error_string()) : std::string();
+        {
+            std::lock_guard<std::mutex> lk(ix->co_mu);
+            sl->rc = r;
+            sl->err = e;
+            sl->done = true;
+        }
+        sl->cv.notify_all();
+    } else {
+        std::unique_lock<std::mutex> lk(ix->co_mu);
+        while (!sl->done) sl->cv.wait(lk);
+    }
+    // every request takes its own slice out of the pinned result buffer and judges its own queries
+    const int32_t slot_rc = sl->rc;
+    std::string slot_err = sl->err;
+    int32_t my_rc = COS_OK;
+    u32 bad_q = 0;
+    if (slot_rc == COS_OK) {
+        const u32 *p_ids = (const u32 *)sl->pin_out;
+        const float *p_sc = (const float *)(p_ids + (size_t)sl->cap * top_k);
+        const u32 *p_cnt = (const u32 *)(p_sc + (size_t)sl->cap * top_k);
+        const int32_t *p_st = (const int32_t *)(p_cnt + sl->cap);
+        memcpy(out_ids, p_ids + (size_t)off * top_k, (size_t)B * top_k * 4);
+        memcpy(out_scores, p_sc + (size_t)off * top_k, (size_t)B * top_k * 4);
+        memcpy(out_counts, p_cnt + off, (size_t)B * 4);
+        if (out_status) memcpy(out_status, p_st + off, (size_t)B * 4);
+        for (u32 b = 0; b < B; b++)
+            if (p_st[off + b] != COS_OK) { my_rc = p_st[off + b]; bad_q = b; break; } // the reference fails the whole request of THIS caller (collect::<Result<_>>)
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->co_mu);
+        if (--sl->left == 0) { sl->n_req = 0; sl->closed = false; } // back in the pool
+    }
+    if (slot_rc != COS_OK) return cos_fail(slot_rc, "%s", slot_err.c_str()); // HIP errors etc. hit every request of the launch
+    if (my_rc != COS_OK) return cos_fail(my_rc, "query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", bad_q, my_rc);
     return COS_OK;
 }
 

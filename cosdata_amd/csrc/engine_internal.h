@@ -26,7 +26,7 @@ hipError_t launch_walk_meta_index(int eng, const IndexDev &ix, const WalkArgs &w
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
                            u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
-                           hipStream_t st, const u32 *q_order = nullptr, u32 *slow_flags = nullptr);
+                           hipStream_t st, const u32 *q_order = nullptr, u32 *slow_list = nullptr);
 // buffers of the locality order of one workspace's big launches (kernels_order.hip)
 struct WalkOrder {
     u32 cap = 0;
@@ -109,7 +109,7 @@ struct Workspace {
     float *tab = nullptr;       // level table of this workspace's big launches [capB][tab_stride] (WalkArgs::tab), grown on demand
     size_t tab_cap = 0;         // floats
     u32 *qsums = nullptr;       // [capB] code sums of the queries (the table GEMM's recentring term)
-    u32 *fin_flags = nullptr;   // [capB] finalize_fast_kernel -> finalize_kernel hand-over (kernels_walk.hip)
+    u32 *fin_flags = nullptr;   // [capB + 1] finalize_fast_kernel -> finalize_list_kernel hand-over: count, then the queries (kernels_walk.hip)
     u64 *rerank_rows = nullptr; // [B]
     VisTab vis; // EXACT mode visited filters
     cosdev::WalkOrder order; // locality order of big launches (cos_index::walk_order_min_B)
@@ -158,8 +158,6 @@ struct HostPipe {
     float *d_scores = nullptr;
     int32_t *d_status = nullptr;
     size_t cap_q = 0, cap_ids = 0, cap_scores = 0, cap_counts = 0, cap_status = 0; // elements, one capacity per buffer
-    void *pin = nullptr;        // pinned host staging of a coalesced group's results (run_coalesced)
-    size_t pin_cap = 0;         // bytes
 };
 static constexpr u32 COS_MAX_HOST_PIPES = 32; // concurrent host-API calls served at once; further callers wait for a pipe
 
@@ -191,8 +189,8 @@ struct cos_index {
     // host-API request coalescing (cos_index_set_coalescing)
     std::mutex co_mu;
     std::condition_variable co_cv;
-    std::vector<struct CoalesceReq *> co_pending;
-    bool co_leader_active = false;
+    std::vector<struct CoSlot *> co_slots; // pooled launches-in-assembly (engine.hip, CoSlot)
+    struct CoSlot *co_open = nullptr;      // the slot new requests join
     u32 co_max_queries = 0, co_window_us = 0;
     bool timing = false;
     // Walk chain: a launch big enough to fill the chip several times over (>= chain_min_B queries) gains nothing from sharing
@@ -234,6 +232,7 @@ struct cos_index {
 
 struct FlatWs;
 void cos_flat_ws_release(cos_index *ix);
+void cos_coalesce_release(cos_index *ix);
 cosdev::IndexDev cos_make_index_dev(const cos_index *ix);
 cosdev::IndexDev cos_make_meta_dev(const cos_index *ix);
 int32_t cos_set_device(const cos_index *ix);

@@ -672,16 +672,13 @@ struct FinalizeArgs {
     u64 *out_rerank_rows; // [B]
     const u32 *q_order;   // optional [B]: workgroup -> query, the locality order the walk of this launch ended with (engine_types.h):
                           // neighbouring queries rerank many of the same raw rows
-    u32 *slow_flags;      // optional [B]: finalize_fast_kernel writes 1 for the queries it leaves to finalize_kernel, which then skips the others
+    u32 *slow_list;       // finalize_fast_kernel: [B] queries it leaves to finalize_list_kernel (more than FAST_CAP survivors) ...
+    u32 *slow_count;      // ... and how many (zeroed before the launch)
 };
 
 template <int FR>
-__global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const FinalizeArgs fa) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void finalize_one(const IndexDev &ix, const FinalizeArgs &fa, const u32 qi, unsigned char *smem_raw) {
     const int lane = threadIdx.x;
-    if (blockIdx.x >= fa.B) return;
-    const u32 qi = fa.q_order ? fa.q_order[blockIdx.x] : blockIdx.x;
-    if (fa.slow_flags && fa.slow_flags[qi] == 0u) return; // answered by finalize_fast_kernel
     const u32 L = ix.num_layers;
     const u32 metric = ix.metric;
     float *qf = (float *)smem_raw;                                   // dim floats (padded to 16 B)
@@ -817,6 +814,26 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
     }
 }
 
+// grid = B: one wave per query (q_order: the launch's locality order)
+template <int FR>
+__global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const FinalizeArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (blockIdx.x >= fa.B) return;
+    finalize_one<FR>(ix, fa, fa.q_order ? fa.q_order[blockIdx.x] : blockIdx.x, smem_raw);
+}
+// the queries finalize_fast_kernel left over (slow_list / slow_count): a small fixed grid walks the list — nothing to do costs a
+// launch of a few workgroups instead of B that look at a flag and leave (60 us per 32768-query launch)
+template <int FR>
+__global__ __launch_bounds__(64) void finalize_list_kernel(const IndexDev ix, const FinalizeArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const u32 n = *fa.slow_count;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        finalize_one<FR>(ix, fa, fa.slow_list[i], smem_raw);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier(); // the next query rewrites the LDS buffers
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // finalize_fast: the same result for the usual shape of a search (5 * top_k <= 64), at a fraction of the work.
 // finalize_kernel sorts the first 5k + 1 entries of EVERY level list — 510 keys at ten levels, a 512-key bitonic network in 121
@@ -825,7 +842,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
 // be kept.  So: T = that key; the entries >= T of all lists — level 0's 5k + 1 and the few upper-level entries that are among the
 // query's nearest (the same nodes at the same scores: duplicates) — are compacted into LDS, typically ~70 of them; up to 128 are sorted
 // by a 128-key network (two keys per lane), deduplicated and reranked exactly as below.  More than 128 survivors (small graphs, tiny
-// ef: level 0 has no (5k + 1)-th entry and nothing is screened) leave the query to finalize_kernel through slow_flags.
+// ef: level 0 has no (5k + 1)-th entry and nothing is screened) leave the query to finalize_list_kernel through slow_list.
 // ------------------------------------------------------------------------------------------------
 constexpr int FAST_CAP = 128;
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void finalize_fast_kernel(const IndexDev ix, const FinalizeArgs fa) {
@@ -841,7 +858,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
 
     const int32_t wst = fa.walk_status[qi];
     if (wst != COS_OK) {
-        if (lane == 0) { fa.out_status[qi] = wst; fa.out_counts[qi] = 0; if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = 0; fa.slow_flags[qi] = 0u; }
+        if (lane == 0) { fa.out_status[qi] = wst; fa.out_counts[qi] = 0; if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = 0; }
         return;
     }
     const float *q = fa.queries + (u64)qi * fa.q_stride;
@@ -887,7 +904,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
         if (overflow) break;
     }
     if (overflow) {
-        if (lane == 0) fa.slow_flags[qi] = 1u;
+        if (lane == 0) fa.slow_list[atomicAdd(fa.slow_count, 1u)] = qi;
         return;
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -943,7 +960,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
         fa.out_counts[qi] = nout;
         fa.out_status[qi] = COS_OK;
         if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = ncand;
-        fa.slow_flags[qi] = 0u;
     }
 }
 
@@ -1060,37 +1076,41 @@ hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_
 hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_stride, const float *q_raw_mags, const u32 *walk_ids,
                            const float *walk_sims, const u32 *walk_counts, const int32_t *walk_status, u32 B, u32 top_k,
                            u32 *out_ids, float *out_scores, u32 *out_counts, int32_t *out_status, u64 *out_rerank_rows,
-                           hipStream_t st, const u32 *q_order, u32 *slow_flags) {
+                           hipStream_t st, const u32 *q_order, u32 *slow_list /* [B + 1] scratch: count, then the list */) {
     if (B == 0) return hipSuccess;
     FinalizeArgs fa{queries, q_stride, q_raw_mags, walk_ids, walk_sims, walk_counts, walk_status, B, top_k,
-                    out_ids, out_scores, out_counts, out_status, out_rerank_rows, q_order, nullptr};
+                    out_ids, out_scores, out_counts, out_status, out_rerank_rows, q_order, nullptr, nullptr};
     const u32 per_level = std::min<u32>(KEEP_SEARCH, 5u * top_k + 1u);
     const u32 total = (ix.num_layers + 1) * per_level;
     dim3 grid(B), block(64);
-    // the screened kernel first (5k + 1 <= 64 entries per level list, a flag word per query to hand the rest over); COS_FINALIZE_FAST=0
-    // keeps the general kernel alone (experiments)
+    // the screened kernel first (5k + 1 <= 64 entries per level list), then the general kernel over the list of queries it left;
+    // COS_FINALIZE_FAST=0 keeps the general kernel alone (experiments)
     static const bool fast_on = [] { const char *e = getenv("COS_FINALIZE_FAST"); return !e || atoi(e) != 0; }();
-    if (fast_on && slow_flags && ix.mdim == 0u && 5u * top_k + 1u <= 64u && KEEP_SEARCH >= 5u * top_k + 1u) { // base collections: only the root is ever dropped
-        fa.slow_flags = slow_flags;
+    bool listed = false;
+    if (fast_on && slow_list && ix.mdim == 0u && 5u * top_k + 1u <= 64u && KEEP_SEARCH >= 5u * top_k + 1u) { // base collections: only the root is ever dropped
+        fa.slow_list = slow_list + 1;
+        fa.slow_count = slow_list;
+        hipError_t e = hipMemsetAsync(slow_list, 0, 4, st);
+        if (e != hipSuccess) return e;
         const size_t smem_f = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + (size_t)FAST_CAP * 8 + 64 * 4;
         hipLaunchKernelGGL(finalize_fast_kernel, grid, block, smem_f, st, ix, fa);
-        hipError_t e = hipGetLastError();
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
+        listed = true;
+        grid = dim3(std::min<u32>(B, 2048u));
     }
-    if (total <= 64 * 4) {
-        size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 4 * 4;
-        hipLaunchKernelGGL(finalize_kernel<4>, grid, block, smem, st, ix, fa);
-    } else if (total <= 64 * 8) {
-        size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 8 * 4;
-        hipLaunchKernelGGL(finalize_kernel<8>, grid, block, smem, st, ix, fa);
-    } else if (total <= 64 * 16) {
-        size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 16 * 4;
-        hipLaunchKernelGGL(finalize_kernel<16>, grid, block, smem, st, ix, fa);
-    } else if (total <= 64 * 32) {
-        size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * 32 * 4;
-        hipLaunchKernelGGL(finalize_kernel<32>, grid, block, smem, st, ix, fa);
-    } else
-        return hipErrorInvalidValue;
+#define FIN(FR_)                                                                                                   \
+    do {                                                                                                           \
+        const size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * (FR_) * 4;                            \
+        if (listed) hipLaunchKernelGGL(finalize_list_kernel<FR_>, grid, block, smem, st, ix, fa);                 \
+        else hipLaunchKernelGGL(finalize_kernel<FR_>, grid, block, smem, st, ix, fa);                             \
+    } while (0)
+    if (total <= 64 * 4) FIN(4);
+    else if (total <= 64 * 8) FIN(8);
+    else if (total <= 64 * 16) FIN(16);
+    else if (total <= 64 * 32) FIN(32);
+    else return hipErrorInvalidValue;
+#undef FIN
     return hipGetLastError();
 }
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
         acc = readlane_u32(acc, 0);
         const float dotf = (float)acc; // integer dot `as f32` (RNE)
         if (metric == 0u) {            // cosine_similarity_from_dot_product (cosine.rs:223-235)
-            const float den = __fmul_rn(qmag, ix.mags[row]);
+            const float den = uniform_f32(__fmul_rn(qmag, ix.mags[row]));
             if (den == 0.0f) return false;
             sim_out = __fdiv_rn(dotf, den);
         } else {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
         __syncthreads();
         u32 npool = 0, npop = 0;
         if (wave == 0) { // start node (vector_store.rs:1144-1148)
-            const u32 erow = lv.node_vec ? lv.node_vec[entry] : entry;
+            const u32 erow = uniform_u32(lv.node_vec ? lv.node_vec[entry] : entry);
             float s0 = 0.0f;
             const bool ok = single_distance(erow, s0);
             if (lane == 0) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
         }
         n_evals++;
         __syncthreads();
-        if (s_misc[1]) { status = COS_ERR_CALCULATION; break; }
+        if (uniform_u32(s_misc[1])) { status = COS_ERR_CALCULATION; break; } // the same word in every lane: a scalar branch
         npool = 1;
 
         bool failed = false;
@@ -156,18 +156,19 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
             u64 *pool_nx = s_pool + (size_t)(cur ^ 1u) * CAP;
 
             // ---- A. this wave's window entries: adjacency rows (all loads first, none predicated), candidates, claims, similarities ----
-            u32 av[E], an[E];
+            u32 av[E], an[E], wnode[E];
             u64 wkey[E];
             const u32 slot_l = (u32)lane < slots ? (u32)lane : slots - 1u;
 #pragma unroll
             for (int i = 0; i < E; i++) {
                 const u32 e = (u32)(i * NW + wave);
                 wkey[i] = pool[e < kwin ? e : 0u];
-                av[i] = lv.adj_vec[(u64)(u32)wkey[i] * M + slot_l];
+                wnode[i] = uniform_u32((u32)wkey[i]); // the same LDS word in every lane: a scalar row base for the adjacency loads
+                av[i] = lv.adj_vec[(u64)wnode[i] * M + slot_l];
             }
             if (level != 0) {
 #pragma unroll
-                for (int i = 0; i < E; i++) an[i] = lv.adj_node[(u64)(u32)wkey[i] * M + slot_l];
+                for (int i = 0; i < E; i++) an[i] = lv.adj_node[(u64)wnode[i] * M + slot_l];
             }
             const u64 last_key = pool[kwin - 1u];
             bool cnd[E];
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
                 const u32 vword = s_vis[bitv[i] >> 5];
                 cnd[i] = av[i] != ROW_EMPTY && !(vword & (1u << (bitv[i] & 31u)));
                 if (cnd[i]) atomicMin(&s_first[bitv[i]], e * 64u + (u32)lane);
-                const u64 cm = __ballot(cnd[i]);
+                const u64 cm = ballot64(cnd[i]);
                 if (cnd[i]) my_cl[T + (u32)__popcll(cm & lt_mask)] = (u64)av[i] | ((u64)(u32)(i * 64 + lane) << 32);
                 T += (u32)__popcll(cm);
             }
@@ -251,10 +252,10 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
                 win[i] = cnd[i] && s_first[bitv[i]] == e * 64u + (u32)lane;
                 const u64 sp = win[i] ? my_spec[i * 64 + lane] : 0ull;
                 key[i] = pack_key((u32)sp, an[i]);
-                wmask[i] = __ballot(win[i]);
+                wmask[i] = ballot64(win[i]);
                 if (e < kwin) { // wave-uniform
-                    const bool stale = e + 1u < kwin && __any(win[i] && key[i] > last_key);
-                    const bool bad = __any(win[i] && (sp >> 32) != 0ull);
+                    const bool stale = e + 1u < kwin && (wmask[i] & ballot64(key[i] > last_key)) != 0ull;
+                    const bool bad = (wmask[i] & ballot64((sp >> 32) != 0ull)) != 0ull;
                     if (lane == 0) s_flag[e] = (stale ? 1u : 0u) | (bad ? 2u : 0u) | ((u32)__popcll(wmask[i]) << 8);
                 }
             }
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
                         const u64 kw = readlane_u64(kw_l, (int)w);
                         pos_p += kw > pk ? 1u : 0u;                              // a pool entry moves up by the winners above it
                         pos_w += kw > kw_l ? 1u : 0u;                            // a winner lands behind the winners above it ...
-                        const u32 above = (u32)__popcll(__ballot(live_p && pk > kw));
+                        const u32 above = (u32)__popcll(ballot64(live_p && pk > kw));
                         if ((u32)lane == w) pos_w += above;                      // ... and behind the pool entries above it
                     }
                     if (live_p && pos_p < CAP) pool_nx[pos_p] = pk;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
                 if ((u32)(r * 64) < n_valid && wave == (r & (NW - 1))) { // wave-uniform: winners' registers are spread over the waves
                     u32 lo = j + 1u, hi = npool; // pool entries (descending) greater than the winner: [j + 1, lo)
                     const u64 kw = wreg[r];
-                    while (__any(lo < hi)) {
+                    while (ballot64(lo < hi)) {
                         const u32 mid = (lo + hi) >> 1;
                         const bool go = lo < hi;
                         const u64 pm = pool[go ? mid : j + 1u];
@@ -416,8 +417,8 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
             }
         }
         __syncthreads();
-        if (s_misc[1]) { status = COS_ERR_CALCULATION; break; }
-        if (level > 0) entry = s_misc[0];
+        if (uniform_u32(s_misc[1])) { status = COS_ERR_CALCULATION; break; }
+        if (level > 0) entry = uniform_u32(s_misc[0]);
         __syncthreads(); // s_misc is rewritten by the next level's start node
     }
 
