@@ -700,7 +700,7 @@ class DenseWorkload:
             import ctypes as C_
             harness = native_callers_harness()       # scripts/callers_bench.cpp: native threads (128 Python threads measure the GIL)
             fn = C_.cast(lib.cos_search_batch, C_.c_void_p)
-            for nc, maxq in ((self.C, B), (2 * self.C, B), (2 * self.C, B // 2), (4 * self.C, B)):
+            for nc, maxq in ((self.C, B), (self.C, B // 2), (self.C // 2, B // 2), (2 * self.C, B)):
                 ix.set_coalescing(maxq, 300)
                 reps_s = 16
                 secs = C_.c_double(0.0)

@@ -847,7 +847,7 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         }
         if (int32_t rc = ensure_order_rank(ix)) return rc;
     }
-    if (const u32 tmin = walk_table_min_B(ix); tmin && B >= tmin) {
+    if (const u32 tmin = walk_table_min_B(ix); tmin && (B >= tmin || B <= ix->lat4_max_B)) { // big launches and the four-wave latency kernel's
         if (int32_t rc = ensure_level_table(ix)) return rc;
         const size_t need = (size_t)w->capB * ix->table_stride;
         if (need > w->tab_cap) {
@@ -884,7 +884,7 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     bool timed;
     u32 ef, lat_max_B, lat4_max_B, order_min_B, n_keys = 0, key_level[cosdev::MAX_LEVELS], key_n[cosdev::MAX_LEVELS];
     const u32 *order_rank[cosdev::MAX_LEVELS];
-    u32 tab_level_min = 0, tab_cols = 0, tab_col0[cosdev::MAX_LEVELS] = {};
+    u32 tab_level_min = 0, tab_cols = 0, tab_col0[cosdev::MAX_LEVELS] = {}, tab_min_B = 0;
     u64 tab_stride = 0;
     const uint8_t *tcodes = nullptr;
     const float *tmags = nullptr;
@@ -897,8 +897,8 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
             key_n[n_keys] = ix->order_rank_n[l];
             order_rank[n_keys++] = ix->d_order_rank[l];
         }
-        if (const u32 tmin = walk_table_min_B(ix); tmin && B >= tmin && ix->level_table_valid && ix->table_level_min &&
-                                                    w->tab && (size_t)B * ix->table_stride <= w->tab_cap) {
+        tab_min_B = walk_table_min_B(ix);
+        if (tab_min_B && ix->level_table_valid && ix->table_level_min && w->tab && (size_t)B * ix->table_stride <= w->tab_cap) {
             tab_level_min = ix->table_level_min;
             tab_cols = ix->table_cols;
             tab_stride = ix->table_stride;
@@ -918,6 +918,17 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     if (dev.visited_mode == COS_VISITED_EXACT) {
         int32_t rc = vis_tab_prepare(w->vis, ix, B, ef, st, wa);
         if (rc) return rc;
+    }
+    // which kernel walks this launch decides whether the level table is worth its GEMM: the throughput kernel (big launches, from
+    // walk_table_min_B queries) and the four-wave latency kernel (one client batch) read it, the one-wave latency kernel does not
+    const bool ordered = order_min_B && B >= order_min_B && n_keys > 0 && w->order.cap >= B && ef <= 256u;
+    if (tab_level_min) {
+        WalkArgs probe;
+        memset(&probe, 0, sizeof(probe));
+        probe.B = B;
+        probe.ef = ef;
+        const int kind = ordered ? 0 : cosdev::walk_kernel_kind(ix->eng, dev, probe, lat_max_B, lat4_max_B);
+        if (!(kind == 4 || (kind == 0 && B >= tab_min_B))) tab_level_min = 0;
     }
     hipEvent_t *ev = &w->ev[(size_t)(w->ev_count % Workspace::EV_RING) * Workspace::EV_PER];
     if (timed) HIP_TRY(hipEventRecord(ev[0], st));
@@ -973,7 +984,6 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     // the ef, while what the order saves shrinks as the walk turns from memory-bound to bound by its own serial work (c2: +16 % at
     // ef 64, +3.6 % at 128, +2.6 % at 256, +1 % at 512; nothing measurable at ef 512 on the uniform corpus or on a 12.5M shard:
     // profiles/r03_order_probe_*.jsonl and the two r03_final_bench_default_* lines, taken with and without this rule).
-    const bool ordered = order_min_B && B >= order_min_B && n_keys > 0 && w->order.cap >= B && ef <= 256u;
     auto walk = [&](hipStream_t s) -> int32_t {
         if (!ordered) { HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, lat4_max_B, s)); return COS_OK; }
         wa.phase = 1;

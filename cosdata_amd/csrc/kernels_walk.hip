@@ -1042,12 +1042,26 @@ hipError_t launch_walk_lat4(int eng, const IndexDev &ix, const WalkArgs &wa, hip
 // lat_max_B: launches of at most this many queries take the latency kernel where it applies (cos_index_set_latency_mode; 0 = never);
 // lat4_max_B: the smallest of them give every query four waves (cos_index_set_latency_waves; 0 = never).
 // COS_WALK_LAT=<n> / COS_WALK_LAT4=<n> override the handle's values (experiments: 0 = off, 4294967295 = always)
-hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, hipStream_t st) {
-    if (wa.B == 0) return hipSuccess;
+// does the kernel launch_walk would pick for this launch read WalkArgs::tab?  (the throughput kernel and the four-wave latency
+// kernel do; the one-wave latency kernel does not: engine.hip then skips the table GEMM)
+static void walk_env_overrides(u32 &lat_max_B, u32 &lat4_max_B) {
     static const long long lat_env = [] { const char *e = getenv("COS_WALK_LAT"); return e ? atoll(e) : -1ll; }();
     static const long long lat4_env = [] { const char *e = getenv("COS_WALK_LAT4"); return e ? atoll(e) : -1ll; }();
     if (lat_env >= 0) lat_max_B = lat_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat_env;
     if (lat4_env >= 0) lat4_max_B = lat4_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat4_env;
+}
+int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B) { // 0 throughput, 1 one-wave latency, 4 four-wave latency
+    walk_env_overrides(lat_max_B, lat4_max_B);
+    if (wa.phase == 0u) {
+        if (walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return 4;
+        if (walk_lat_applicable(eng, ix, wa, lat_max_B)) return 1;
+    }
+    return 0;
+}
+
+hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, hipStream_t st) {
+    if (wa.B == 0) return hipSuccess;
+    walk_env_overrides(lat_max_B, lat4_max_B);
     if (wa.phase == 0u) { // the split (locality-ordered) walk exists in the throughput kernel only
         if (walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return launch_walk_lat4(eng, ix, wa, st);
         if (walk_lat_applicable(eng, ix, wa, lat_max_B)) return launch_walk_lat(eng, ix, wa, st);

@@ -123,6 +123,9 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
         const u32 bitmask = 64u * M - 1u;
         const u32 out_slot = L - (u32)level;
         u32 cur = 0; // pool buffer in use
+        // table level (WalkArgs::tab, u8 codes): similarity(query, node) of every node of this level was computed ahead of the walk
+        const bool tab_level = ENG == ENG_U8 && wa.tab != nullptr && (u32)level >= wa.tab_level_min;
+        const float *tabq = wa.tab + (u64)qi * wa.tab_stride + wa.tab_col0[level];
 
         // fresh visited filter, pre-seeded with the query / new-node id (vector_store.rs:266-271, :807)
         for (u32 w = tid; w < 2 * M; w += 256) s_vis[w] = 0;
@@ -131,7 +134,12 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
         if (wave == 0) { // start node (vector_store.rs:1144-1148)
             const u32 erow = uniform_u32(lv.node_vec ? lv.node_vec[entry] : entry);
             float s0 = 0.0f;
-            const bool ok = single_distance(erow, s0);
+            bool ok;
+            if (tab_level) {
+                s0 = uniform_f32(tabq[entry]);
+                ok = !(metric == 0u && s0 != s0); // u8 codes: a zero denominator is exactly a 0/0 = NaN in the table
+            } else
+                ok = single_distance(erow, s0);
             if (lane == 0) {
                 const u32 b = self_id & bitmask;
                 s_vis[b >> 5] |= 1u << (b & 31);
@@ -191,6 +199,17 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
                 T += (u32)__popcll(cm);
             }
             __builtin_amdgcn_wave_barrier();
+            if (tab_level) {
+                // table level: every candidate's similarity is ONE 4-byte gather by the lane that holds the slot (no code row, no dot)
+#pragma unroll
+                for (int i = 0; i < E; i++) {
+                    float sim = 0.0f;
+                    if (cnd[i]) sim = tabq[an[i]];
+                    const bool bad = metric == 0u && sim != sim;
+                    if (cnd[i]) my_spec[i * 64 + lane] = (u64)metric_key(metric, sim) | (bad ? (1ull << 32) : 0ull);
+                }
+                T = 0; // nothing left for the row loop below
+            }
             // similarities of this wave's candidates: 4 rows per pass, PBL4 passes in flight; no lane is ever masked off (see
             // kernels_walk_lat.hip: a lane group without a candidate re-reads the block's first row, a lane past the row's last
             // chunk re-reads that chunk against a zero query chunk)

@@ -96,3 +96,28 @@ def test_table_follows_the_graph():
     r2 = dix.batch_search(Q, 5)
     assert dix.last_walk_split().table_evals > 0
     _check_against_oracle(o2, r2, Q, 5, np.arange(0, B, 61))
+
+
+@pytest.mark.parametrize("dim,metric", [(768, O.METRIC_COSINE), (96, O.METRIC_DOT)])
+def test_one_client_batch_reads_the_table_too(dim, metric):
+    """a 256-query batch takes the four-wave latency kernel, which reads the level table as well (kernels_walk_lat4.hip): same bits
+    as without the table and as the throughput kernel"""
+    X = H.clustered_corpus(4000, dim, n_centers=16, seed=dim)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=48, ef_search=48, metric=metric)
+    dix = H.device_index_from_oracle(oix, X)
+    Q = H.queries_from(X, 256, noise=0.05, seed=2)
+    Q[5] = oix.params.range_lo                                # |q| = 0: CalculationError at the entry node's table entry (cosine only)
+    assert dix.walk_table_info()[0] == 1
+    res_tab = dix.batch_search(Q, 10, return_status=True)
+    walk_tab = dix.ann_search_batch(np.delete(Q, 5, axis=0))
+    dix.set_walk_table(0, 0)
+    res_plain = dix.batch_search(Q, 10, return_status=True)
+    walk_plain = dix.ann_search_batch(np.delete(Q, 5, axis=0))
+    dix.set_latency_mode(0)                                   # throughput kernel, no table
+    res_tk = dix.batch_search(Q, 10, return_status=True)
+    for a, b in ((res_tab, res_plain), (res_tab, res_tk)):
+        assert a[3] == b[3] and np.array_equal(a[4], b[4]) and _same(a[:3], b[:3])
+    assert _same(walk_tab, walk_plain)
+    assert (res_tab[4][5] == 2) == (metric == O.METRIC_COSINE)
+    ok = np.array([b for b in range(0, 256, 7) if res_tab[4][b] == 0])
+    _check_against_oracle(oix, res_tab[:3], Q, 10, ok)
