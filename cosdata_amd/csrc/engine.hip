@@ -927,8 +927,8 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
         memset(&probe, 0, sizeof(probe));
         probe.B = B;
         probe.ef = ef;
-        const int kind = ordered ? 0 : cosdev::walk_kernel_kind(ix->eng, dev, probe, lat_max_B, lat4_max_B);
-        if (!(kind == 4 || (kind == 0 && B >= tab_min_B))) tab_level_min = 0;
+        const int kind = ordered ? 0 : cosdev::walk_kernel_kind(ix->eng, dev, probe, lat_max_B, lat4_max_B, true);
+        if (!(kind == 4 || (kind == 0 && (B >= tab_min_B || B <= lat4_max_B)))) tab_level_min = 0;
     }
     hipEvent_t *ev = &w->ev[(size_t)(w->ev_count % Workspace::EV_RING) * Workspace::EV_PER];
     if (timed) HIP_TRY(hipEventRecord(ev[0], st));

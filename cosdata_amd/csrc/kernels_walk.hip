@@ -1050,8 +1050,13 @@ static void walk_env_overrides(u32 &lat_max_B, u32 &lat4_max_B) {
     if (lat_env >= 0) lat_max_B = lat_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat_env;
     if (lat4_env >= 0) lat4_max_B = lat4_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat4_env;
 }
-int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B) { // 0 throughput, 1 one-wave latency, 4 four-wave latency
+// table_available: the launch can have a level table.  Up to ef 64 the throughput kernel WITH the table beats both latency kernels
+// on one client batch (1M x 768: 0.77 ms per 256 queries against 0.82 for four waves with the table, 0.88 without, 0.99 for the
+// one-wave kernel; profiles/r04_single_batch_probe.jsonl); above, the four-wave kernel with the table stays ahead.
+int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, bool table_available) { // 0 throughput, 1 one-wave latency, 4 four-wave latency
     walk_env_overrides(lat_max_B, lat4_max_B);
+    static const bool tk_small = [] { const char *e = getenv("COS_WALK_SMALL_TABLE_TK"); return !e || atoi(e) != 0; }();
+    if (table_available && tk_small && eng == ENG_U8 && wa.ef <= 64u && wa.B <= lat4_max_B) return 0;
     if (wa.phase == 0u) {
         if (walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return 4;
         if (walk_lat_applicable(eng, ix, wa, lat_max_B)) return 1;
@@ -1061,11 +1066,9 @@ int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_ma
 
 hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, hipStream_t st) {
     if (wa.B == 0) return hipSuccess;
-    walk_env_overrides(lat_max_B, lat4_max_B);
-    if (wa.phase == 0u) { // the split (locality-ordered) walk exists in the throughput kernel only
-        if (walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return launch_walk_lat4(eng, ix, wa, st);
-        if (walk_lat_applicable(eng, ix, wa, lat_max_B)) return launch_walk_lat(eng, ix, wa, st);
-    }
+    const int kind = walk_kernel_kind(eng, ix, wa, lat_max_B, lat4_max_B, wa.tab != nullptr); // the split (locality-ordered) walk exists in the throughput kernel only
+    if (kind == 4) return launch_walk_lat4(eng, ix, wa, st);
+    if (kind == 1) return launch_walk_lat(eng, ix, wa, st);
     const u32 ch = (eng == ENG_F32 || eng == ENG_F16) ? 1 : (ix.nchunks + ix.G - 1) / ix.G;
     switch (eng) {
     case ENG_U8:
