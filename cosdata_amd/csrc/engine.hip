@@ -1364,8 +1364,16 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
         u32 n_req;
         {
             std::unique_lock<std::mutex> lk(ix->co_mu);
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window);
-            while (!sl->closed && sl->cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
+            // the window restarts with every arrival (a quiet period), up to eight windows in all: callers that outnumber the host's
+            // cores arrive in a trickle, and a launch that leaves when the FIRST window ends carries a fraction of them
+            const auto t0 = std::chrono::steady_clock::now();
+            const auto hard = t0 + std::chrono::microseconds(8ull * window);
+            auto deadline = t0 + std::chrono::microseconds(window);
+            u32 seen = sl->reserved;
+            while (!sl->closed) {
+                if (sl->cv.wait_until(lk, std::min(deadline, hard)) == std::cv_status::timeout) break;
+                if (sl->reserved != seen) { seen = sl->reserved; deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window); }
+            }
             sl->closed = true;
             if (ix->co_open == sl) ix->co_open = nullptr;
             n_req = sl->n_req;
