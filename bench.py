@@ -705,10 +705,14 @@ class DenseWorkload:
                 reps_s = 16
                 secs = C_.c_double(0.0)
                 i0 = np.zeros((Bc, k), np.uint32); s0 = np.zeros((Bc, k), np.float32); c0 = np.zeros(Bc, np.uint32)
-                nfail = harness.run_callers(fn, ix._h, qsmall.ctypes.data_as(C_.c_void_p), self.C, Bc, d, k, nc, reps_s, C_.byref(secs),
-                                            i0.ctypes.data_as(C_.c_void_p), s0.ctypes.data_as(C_.c_void_p), c0.ctypes.data_as(C_.c_void_p))
+                nfail, best = 0, 1e30
+                for _ in range(3):      # best of three: with more native threads than host cores a run's rate follows the scheduler's mood
+                    nfail += harness.run_callers(fn, ix._h, qsmall.ctypes.data_as(C_.c_void_p), self.C, Bc, d, k, nc, reps_s, C_.byref(secs),
+                                                 i0.ctypes.data_as(C_.c_void_p), s0.ctypes.data_as(C_.c_void_p), c0.ctypes.data_as(C_.c_void_p))
+                    best = min(best, secs.value)
+                secs.value = best
                 same = all(np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b_).view(np.uint32)) for a, b_ in zip((i0, s0, c0), direct))
-                small.append({"callers": nc, "queries_per_call": Bc, "coalescing_max_queries": maxq, "coalescing_window_us": 300, "calls_per_caller": reps_s,
+                small.append({"callers": nc, "queries_per_call": Bc, "coalescing_max_queries": maxq, "coalescing_window_us": 300, "calls_per_caller": reps_s, "runs": 3,
                               "qps": nc * reps_s * Bc / secs.value, "failed_calls": int(nfail), "identical_to_uncoalesced_call": bool(same)})
             ix.set_coalescing(0, 0)
             host["concurrent_256_query_callers"] = small
@@ -743,12 +747,18 @@ class DenseWorkload:
             pass
 
         def part(bound, alg, ms, traffic_b=None, **extra):
-            ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            r = {"bound": bound, "algorithmic_bytes": alg, "ms": ms, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS}
+            """one dispatch of the walk: `achieved` is the MEASURED fabric-side rate when the committed PMC pass has this dispatch (it cannot
+            exceed the roof), else the algorithmic one; both are given"""
+            alg_gbps = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            r = {"bound": bound, "algorithmic_bytes": alg, "ms": ms, "algorithmic_GBps": alg_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
             if traffic_b is not None and ms > 0:
                 r["traffic"] = traffic_b
-                r["traffic_GBps"] = traffic_b / (ms * 1e-3) / 1e9
-                r["traffic_frac_of_peak"] = r["traffic_GBps"] / HBM_PEAK_GBPS
+                r["achieved"] = traffic_b / (ms * 1e-3) / 1e9
+                r["achieved_basis"] = "fabric-side traffic (PMC FETCH_SIZE x k + WRITE_SIZE of the committed pass) / HIP-event time"
+            else:
+                r["achieved"] = alg_gbps
+                r["achieved_basis"] = "algorithmic bytes / HIP-event time (no PMC pass for this launch shape)"
+            r["frac"] = r["achieved"] / HBM_PEAK_GBPS
             r.update(extra)
             return r
         parts = None
@@ -769,8 +779,8 @@ class DenseWorkload:
                                            expansions=sp["upper_expansions"])
                 parts["walk_lower"] = part("hbm", lower_bytes, sp["lower_ms"], traffic_parts.get("lower"), ms_alone=sp_alone["lower_ms"],
                                            levels=f"{sp['cut_after_level'] - 1}..0 in locality order", evals=sp["lower_evals"], expansions=sp["lower_expansions"],
-                                           note="neighbouring queries of the sorted launch share rows in the XCD's L2: the algorithmic rate of this dispatch "
-                                                "may exceed the HBM peak, its measured traffic cannot")
+                                           note="neighbouring queries of the sorted launch share rows in the XCD's L2: algorithmic_GBps of this dispatch exceeds "
+                                                "the HBM peak, its measured traffic (achieved) cannot")
                 parts["order_sort_ms"] = sp_alone["sort_ms"]
 
         # empirical HBM ceilings on THIS part: streaming read and the walk's own access pattern — random
@@ -978,6 +988,11 @@ def slim_line(out):
             e["roofline_dense_half"] = {k: c["roofline_dense_half"][k] for k in ("achieved", "frac", "kernel")}
         e["cpu_baseline"] = _slim_cpu(c.get("cpu_baseline"))
         e["parity_vs_oracle"] = {k: v for k, v in (c.get("parity_vs_oracle") or {}).items() if k not in ("oracle_mode", "checked", "collection")} or None
+        if c.get("hnsw_walk_quaternary"):
+            w = c["hnsw_walk_quaternary"]
+            e["hnsw_walk_quaternary"] = {k: w[k] for k in ("n", "build_s", "qps", "ms_per_launch", "recall_at_10_vs_f32_bruteforce", "parity_vs_oracle") if k in w}
+            e["hnsw_walk_quaternary"]["roofline"] = _slim_roofline(w.get("roofline"))
+            e["hnsw_walk_quaternary"]["cpu_baseline"] = _slim_cpu(w.get("cpu_baseline"))
         if c.get("same_graph_exact_visited_set"):
             e["same_graph_exact_visited_set"] = [{k: x[k] for k in ("ef_search", "qps", "recall_at_10")} for x in c["same_graph_exact_visited_set"]]
         cfgs[name] = e

@@ -59,11 +59,12 @@ for part, (nd, kb) in f.items():
     parts[part] = {"dispatches": nd, "fetch_size_kb_raw": kb, "write_size_kb_raw": wkb, "bytes": kb * 1024.0 * k_fetch + wkb * 1024.0}
 # the level-table GEMM of the same steps (grid = column tiles x row tiles: match by name only)
 cur = sqlite3.connect(db_fetch).cursor()
-g = cur.execute("select count(*), avg(value) from counters_collection where kernel_name like '%flat_codes_gemm_i8%' and counter_name = 'FETCH_SIZE'").fetchone()
+GEMM_Q = ("select count(*), avg(value) from counters_collection where kernel_name like '%flat_codes_gemm_i8%' and counter_name = ? and "
+          "grid_size = (select max(grid_size) from counters_collection where kernel_name like '%flat_codes_gemm_i8%')")   # the big launches' GEMM only
+g = cur.execute(GEMM_Q, ("FETCH_SIZE",)).fetchone()
 gw = (0, 0.0)
 if db_write:
-    gw = sqlite3.connect(db_write).cursor().execute(
-        "select count(*), avg(value) from counters_collection where kernel_name like '%flat_codes_gemm_i8%' and counter_name = 'WRITE_SIZE'").fetchone()
+    gw = sqlite3.connect(db_write).cursor().execute(GEMM_Q, ("WRITE_SIZE",)).fetchone()
 if g and g[0]:
     parts["table_gemm"] = {"dispatches": g[0], "fetch_size_kb_raw": g[1], "write_size_kb_raw": gw[1] or 0.0,
                            "bytes": g[1] * 1024.0 * k_fetch + (gw[1] or 0.0) * 1024.0}
