@@ -657,6 +657,34 @@ class DenseWorkload:
         ix.set_ef_search(ef)
         ix.set_visited_mode(main_mode)
 
+        # ---- launch size: the same index at half and twice the step's queries per launch (dynamic batching depth).  A bigger launch
+        # puts more queries into every region of the graph, so neighbouring queries find more of each other's rows in the XCD's L2: the
+        # rate keeps rising with the launch size (and so does the time a query waits for its launch) — `value` stays at the step this
+        # bench has used since round 1 (128 client batches).
+        size_sweep = []
+        if single_batch and not dist_on:
+            for mult_num, mult_den in ((1, 2), (2, 1)):
+                Bx = B * mult_num // mult_den
+                Qx = Q[:Bx] if Bx <= Q.shape[0] else None
+                if Qx is None:
+                    continue
+                outs = [(torch.zeros(Bx, k, dtype=torch.int32, device=dev), torch.zeros(Bx, k, dtype=torch.float32, device=dev),
+                         torch.zeros(Bx, dtype=torch.int32, device=dev), torch.zeros(Bx, dtype=torch.int32, device=dev)) for _ in range(2)]
+                def lx(i):
+                    q = Q[((i % max(1, Q.shape[0] // Bx)) * Bx):((i % max(1, Q.shape[0] // Bx)) + 1) * Bx]
+                    o = outs[i % 2]
+                    ix.batch_search_device(q.data_ptr(), Bx, k, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), streams[i % 2].cuda_stream)
+                for i in range(4):
+                    lx(i)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                nx = 10
+                for i in range(nx):
+                    lx(i)
+                torch.cuda.synchronize(dev)
+                size_sweep.append({"queries_per_launch": Bx, "launches_in_flight": 2, "qps": nx * Bx / (time.perf_counter() - t1)})
+                del outs
+
         # ---- the boundary as the Rust host would call it: host buffers in, host buffers out (cos_search_batch: H2D of the queries,
         # the same kernels, D2H of ids / scores / counts).  PCIe-inclusive, reported next to `value`, never it.
         host = None
@@ -803,7 +831,7 @@ class DenseWorkload:
             shardset.close()
         rec = {
             "value": merged_qps, "elapsed": elapsed, "steps": n_launch, "warmup": n_warm, "ef": ef, "ef_table": ef_table,
-            "recall": (recall, recall_se, recall_lo), "status_bad": status_bad, "props": props, "sweep": sweep, "serial": serial,
+            "recall": (recall, recall_se, recall_lo), "status_bad": status_bad, "props": props, "sweep": sweep, "size_sweep": size_sweep, "serial": serial,
             "host_api": host, "cpu": cpu, "parity": parity, "build_s": build_s, "seconds": time.time() - t_setup, "exchange_kind": exchange_kind,
             "config": {"workload": self.name + ": " + self.desc, "standard_size": self.standard_size, "vectors_per_gpu": n, "dim": d,
                        "step": f"one coalesced launch = {self.C} client batches x {Bc} queries = {B} queries through quantize -> walk -> rerank -> top-k",
@@ -1165,7 +1193,8 @@ def main():
         "single_batch_qps": rec["serial"]["qps"], "single_batch_qps_one_wave_latency_kernel": rec["serial"]["qps_one_wave_latency_kernel"],
         "single_batch_qps_throughput_kernel": rec["serial"]["qps_throughput_kernel"],
         "single_batch_latency_walk_identical_to_throughput_walk": rec["serial"]["identical"],
-        "ef_selection": rec["ef_table"], "ef_sweep": rec["sweep"], "build_seconds": rec["build_s"], "setup_seconds": time.time() - t_setup,
+        "ef_selection": rec["ef_table"], "ef_sweep": rec["sweep"], "launch_size_sweep": rec["size_sweep"], "build_seconds": rec["build_s"],
+        "setup_seconds": time.time() - t_setup,
         "roofline": rec["roofline"],
         "flat_scan_ground_truth": flat, "result_properties": rec["props"], "cpu_baseline": rec["cpu"], "parity_vs_oracle": rec["parity"],
         "host_api_pcie_inclusive": rec["host_api"],
