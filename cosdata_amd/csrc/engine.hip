@@ -851,12 +851,20 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         if (int32_t rc = ensure_level_table(ix)) return rc;
         const size_t need = (size_t)w->capB * ix->table_stride;
         if (need > w->tab_cap) {
+            // every workspace (one per caller stream, up to five per leased host pipe) holds the table of its own launch in flight:
+            // a handle's tables together stay under a budget (COS_WALK_TABLE_MAX_BYTES, default 16 GiB) — a workspace that would
+            // exceed it simply walks without a table (same results)
+            static const size_t budget = [] { const char *e = getenv("COS_WALK_TABLE_MAX_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)16 << 30); }();
             HIP_TRY(hipStreamSynchronize(st));
             if (w->tab) HIP_TRY(hipFree(w->tab));
+            ix->table_bytes_total -= w->tab_cap * 4;
             w->tab = nullptr;
             w->tab_cap = 0;
-            HIP_TRY(hipMalloc((void **)&w->tab, need * 4));
-            w->tab_cap = need;
+            if (ix->table_bytes_total + need * 4 <= budget) {
+                HIP_TRY(hipMalloc((void **)&w->tab, need * 4));
+                w->tab_cap = need;
+                ix->table_bytes_total += need * 4;
+            }
         }
     }
     if (host_api && (size_t)top_k * w->capB > (size_t)w->cap_topk * w->capB) {

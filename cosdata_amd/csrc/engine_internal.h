@@ -215,6 +215,7 @@ struct cos_index {
     // node of the levels >= table_level_min with one i8 MFMA GEMM; table_level_min = the lowest level such that the levels from it
     // to the top hold at most walk_table_max_cols nodes together (0 = no table).  Env COS_WALK_TABLE_COLS / COS_WALK_TABLE_MIN_B.
     u32 walk_table_max_cols = COS_WALK_TABLE_DEFAULT_MAX_COLS, walk_table_min_B = COS_WALK_TABLE_DEFAULT_MIN_B;
+    size_t table_bytes_total = 0;    // tables held by this handle's workspaces (budget: get_workspace)
     bool level_table_valid = false;  // the arrays below follow the graph and walk_table_max_cols
     u32 table_level_min = 0, table_cols = 0, table_built_for_cols = 0;
     u64 table_stride = 0;            // floats per query row (cols padded to 32)

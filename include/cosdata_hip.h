@@ -213,7 +213,12 @@ int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t 
  * one exact-integer i8 MFMA GEMM (dot_product_u8's integer, the same `as f32` and the same division by |q| * |v|, cosine.rs:223-235),
  * and the walk of those levels reads the similarity (4 bytes) where it would have gathered and dotted a code row.  Which nodes a
  * walk visits, the lossy visited filter and every result are bit for bit what they are without the table; a launch holds
- * queries x columns x 4 bytes of it (32 768 x 5 312: 0.7 GB per stream in flight). */
+ * queries x columns x 4 bytes of it (32 768 x 5 312: 0.7 GB per stream in flight); a handle's tables together stay under 16 GiB
+ * (COS_WALK_TABLE_MAX_BYTES): a launch whose workspace would exceed that walks without a table.
+ * Device memory of the search side in general: every caller stream (cos_search_batch_device) and every host call in flight
+ * (cos_search_batch: up to 32 leased pipes, a lone big call uses up to five workspaces) owns a workspace sized for its largest launch
+ * — query codes, per-level result lists ((num_layers + 1) x 100 x 8 B per query: 8 KB at ten levels), statistics, the level table —
+ * and keeps it until the handle is destroyed. */
 #define COS_WALK_TABLE_DEFAULT_MIN_B 4096u
 #define COS_WALK_TABLE_DEFAULT_MAX_COLS 8192u
 int32_t cos_index_set_walk_table(cos_index *ix, uint32_t max_cols, uint32_t min_queries);

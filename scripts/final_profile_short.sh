@@ -1,0 +1,19 @@
+#!/bin/bash
+# A shorter round-end pass when only host code / bench.py changed since scripts/final_profile.sh ran (the kernel trace and the SQ pass of
+# that run stay valid): GPU tests, the two PMC traffic passes, then the default bench, which reads profiles/pmc_traffic.json.
+R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
+timeout 900 python -m pytest tests -m gpu -q > $OUT/final_pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/final_pytest.log
+cd /tmp; export TMPDIR=/tmp
+export COS_BENCH_FULL_RECORD=bench_full_record_of_a_profiler_pass.json
+PM="--steps 8 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --ef-sweep 256 --recall-queries 2048"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- python $R/bench.py $PM > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- python $R/bench.py $PM > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+cd $R
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" /tmp/p_w/w_results.db ref > $OUT/pmc_traffic_ef64.json
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "walk_kernel<0, 1, 4, true, false, 8>" /tmp/p_w/w_results.db ref > $OUT/pmc_traffic_ef256.json
+python scripts/rocprof_summary.py /tmp/p_f/f_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_fetch_size.txt
+python scripts/rocprof_summary.py /tmp/p_w/w_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_write_size.txt
+cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
+unset COS_BENCH_FULL_RECORD
+COS_BENCH_FULL_RECORD=final_bench_all_configs_full_record.json timeout 1500 python bench.py > $OUT/final_bench_all_configs.json 2> $OUT/final_bench_all_configs.err; echo "bench rc=$?"
+head -c 400 $OUT/final_bench_all_configs.json; echo; cat $OUT/pmc_traffic_ef64.json | head -c 1200
