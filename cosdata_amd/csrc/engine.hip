@@ -253,9 +253,11 @@ extern "C" int32_t cos_index_destroy(cos_index *ix) {
     if (ix->d_codes) (void)hipFree(ix->d_codes);
     if (ix->d_mags) (void)hipFree(ix->d_mags);
     for (u32 *p : ix->d_order_rank) if (p) (void)hipFree(p);
-    if (ix->d_tcodes) (void)hipFree(ix->d_tcodes);
-    if (ix->d_tmags) (void)hipFree(ix->d_tmags);
-    if (ix->d_tcsums) (void)hipFree(ix->d_tcsums);
+    for (auto &t : ix->table_sets) { // level-table operands (the current one is among them)
+        if (t.tcodes) (void)hipFree(t.tcodes);
+        if (t.tmags) (void)hipFree(t.tmags);
+        if (t.tcsums) (void)hipFree(t.tcsums);
+    }
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
     return COS_OK;
@@ -710,10 +712,7 @@ static int32_t ensure_order_rank(cos_index *ix) {
 
 // The level table's per-graph operand (WalkArgs::tab, cosdata_hip.h cos_index_set_walk_table): which levels it covers and the code
 // rows, norms and code sums of their nodes, level by level from the top, gathered on the device.  Caller holds ix->mu.
-static void free_level_table(cos_index *ix) {
-    if (ix->d_tcodes) (void)hipFree(ix->d_tcodes);
-    if (ix->d_tmags) (void)hipFree(ix->d_tmags);
-    if (ix->d_tcsums) (void)hipFree(ix->d_tcsums);
+static void clear_current_table(cos_index *ix) {
     ix->d_tcodes = nullptr;
     ix->d_tmags = nullptr;
     ix->d_tcsums = nullptr;
@@ -721,7 +720,17 @@ static void free_level_table(cos_index *ix) {
     ix->table_level_min = 0;
     ix->table_stride = 0;
 }
-static u32 walk_table_max_cols(const cos_index *ix) {
+// every operand of the handle (the graph changed, or the handle dies): exclusive entry points only
+static void free_level_tables(cos_index *ix) {
+    for (auto &t : ix->table_sets) {
+        if (t.tcodes) (void)hipFree(t.tcodes);
+        if (t.tmags) (void)hipFree(t.tmags);
+        if (t.tcsums) (void)hipFree(t.tcsums);
+    }
+    ix->table_sets.clear();
+    clear_current_table(ix);
+}
+static u32 walk_table_max_cols(const cos_index *ix) { // COS_WALK_TABLE_AUTO = sized from ef_search and neighbors_count (ensure_level_table)
     static const long long env = [] { const char *e = getenv("COS_WALK_TABLE_COLS"); return e ? atoll(e) : -1ll; }();
     return env >= 0 ? (u32)std::min<long long>(env, 1ll << 20) : ix->walk_table_max_cols;
 }
@@ -731,15 +740,40 @@ static u32 walk_table_min_B(const cos_index *ix) {
 }
 static int32_t ensure_level_table(cos_index *ix) {
     const u32 max_cols = walk_table_max_cols(ix);
-    if (ix->level_table_valid && ix->table_built_for_cols == max_cols) return COS_OK;
-    free_level_table(ix);
+    // Which levels pay.  A table column costs one GEMM column per launch (~2.6 ps per query and column at K = 1024), a level walked
+    // from rows costs ~0.11 ns per evaluation, and a level's walk evaluates 0.2-0.4 x ef x M rows per query: a level of n nodes pays
+    // while n < ~40 x that.  Measured on both ends — 1M x 768 at ef 64, M 32: level 4 (3 917 nodes) pays, level 3 (15 570) does not;
+    // one 12.5M x 1024 shard at ef 128, M 64: level 5 (12 225) +24 % QPS, level 4 (48 870) another +17 %, both far above a fixed
+    // 8 192 columns (profiles/r04_c4_table_cols_probe.jsonl) — the automatic rule is n_level <= 6 x ef_search x neighbors_count, level
+    // by level from the top; an explicit max_cols caps the columns of all table levels together instead.
+    const bool automatic = max_cols == COS_WALK_TABLE_AUTO;
+    const u64 per_level = automatic ? std::min<u64>((u64)6 * ix->p.ef_search * ix->p.neighbors_count, 1u << 20) : (u64)(1u << 20);
+    const u64 total_cap = automatic ? (u64)(1u << 20) : (u64)max_cols;
+    const u64 key = automatic ? (0x8000000000000000ull | per_level) : (u64)max_cols;
+    if (ix->level_table_valid && ix->table_built_for_key == key) return COS_OK;
+    if (!ix->level_table_valid) { // a new graph: the old graph's operands go (graph changes are exclusive: no search is in flight)
+        HIP_TRY(hipDeviceSynchronize());
+        free_level_tables(ix);
+    }
     ix->level_table_valid = true;
-    ix->table_built_for_cols = max_cols;
+    ix->table_built_for_key = key;
+    clear_current_table(ix);
+    for (const auto &t : ix->table_sets)
+        if (t.key == key) { // built before for this graph (ef_search went back and forth)
+            ix->table_level_min = t.level_min;
+            ix->table_cols = t.cols;
+            ix->table_stride = t.stride;
+            memcpy(ix->table_col0, t.col0, sizeof(t.col0));
+            ix->d_tcodes = t.tcodes;
+            ix->d_tmags = t.tmags;
+            ix->d_tcsums = t.tcsums;
+            return COS_OK;
+        }
     if (ix->eng != ENG_U8 || max_cols == 0) return COS_OK; // u8 codes only
     const u32 Ltop = ix->p.num_layers;
     u32 cols = 0, lmin = 0;
     for (u32 l = Ltop; l >= 1; l--) { // level 0 (every vector) never takes part
-        if (!ix->lv[l].d_node_vec || ix->lv[l].n == 0 || cols + ix->lv[l].n > max_cols) break;
+        if (!ix->lv[l].d_node_vec || ix->lv[l].n == 0 || ix->lv[l].n > per_level || (u64)cols + ix->lv[l].n > total_cap) break;
         cols += ix->lv[l].n;
         lmin = l;
     }
@@ -760,12 +794,22 @@ static int32_t ensure_level_table(cos_index *ix) {
     ix->table_cols = cols;
     ix->table_level_min = lmin;
     ix->table_stride = ((u64)cols + 31) / 32 * 32;
+    cos_index::TableSet t;
+    t.key = key;
+    t.level_min = lmin;
+    t.cols = cols;
+    t.stride = ix->table_stride;
+    memcpy(t.col0, ix->table_col0, sizeof(t.col0));
+    t.tcodes = ix->d_tcodes;
+    t.tmags = ix->d_tmags;
+    t.tcsums = ix->d_tcsums;
+    ix->table_sets.push_back(t);
     return COS_OK;
 }
 
 extern "C" int32_t cos_index_set_walk_table(cos_index *ix, uint32_t max_cols, uint32_t min_queries) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null argument");
-    if (max_cols > (1u << 20)) return cos_fail(COS_ERR_INVALID, "max_cols must be <= 2^20");
+    if (max_cols > (1u << 20) && max_cols != COS_WALK_TABLE_AUTO) return cos_fail(COS_ERR_INVALID, "max_cols must be <= 2^20 (or COS_WALK_TABLE_AUTO)");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->walk_table_max_cols = max_cols;
     ix->walk_table_min_B = min_queries;
@@ -852,9 +896,9 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         const size_t need = (size_t)w->capB * ix->table_stride;
         if (need > w->tab_cap) {
             // every workspace (one per caller stream, up to five per leased host pipe) holds the table of its own launch in flight:
-            // a handle's tables together stay under a budget (COS_WALK_TABLE_MAX_BYTES, default 16 GiB) — a workspace that would
+            // a handle's tables together stay under a budget (COS_WALK_TABLE_MAX_BYTES, default 48 GiB) — a workspace that would
             // exceed it simply walks without a table (same results)
-            static const size_t budget = [] { const char *e = getenv("COS_WALK_TABLE_MAX_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)16 << 30); }();
+            static const size_t budget = [] { const char *e = getenv("COS_WALK_TABLE_MAX_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)48 << 30); }();
             HIP_TRY(hipStreamSynchronize(st));
             if (w->tab) HIP_TRY(hipFree(w->tab));
             ix->table_bytes_total -= w->tab_cap * 4;

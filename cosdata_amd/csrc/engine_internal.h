@@ -214,15 +214,20 @@ struct cos_index {
     // Level table (WalkArgs::tab): launches of at least walk_table_min_B queries over u8 codes precompute the similarities to every
     // node of the levels >= table_level_min with one i8 MFMA GEMM; table_level_min = the lowest level such that the levels from it
     // to the top hold at most walk_table_max_cols nodes together (0 = no table).  Env COS_WALK_TABLE_COLS / COS_WALK_TABLE_MIN_B.
-    u32 walk_table_max_cols = COS_WALK_TABLE_DEFAULT_MAX_COLS, walk_table_min_B = COS_WALK_TABLE_DEFAULT_MIN_B;
+    u32 walk_table_max_cols = COS_WALK_TABLE_AUTO, walk_table_min_B = COS_WALK_TABLE_DEFAULT_MIN_B;
     size_t table_bytes_total = 0;    // tables held by this handle's workspaces (budget: get_workspace)
     bool level_table_valid = false;  // the arrays below follow the graph and walk_table_max_cols
-    u32 table_level_min = 0, table_cols = 0, table_built_for_cols = 0;
+    u32 table_level_min = 0, table_cols = 0;
+    u64 table_built_for_key = 0;    // max_cols, or the automatic rule's per-level bound: a change rebuilds the operand
     u64 table_stride = 0;            // floats per query row (cols padded to 32)
     u32 table_col0[cosdev::MAX_LEVELS] = {};
     uint8_t *d_tcodes = nullptr;     // [table_cols][row_stride] code rows of the table's nodes, level by level from the top
     float *d_tmags = nullptr;        // [table_cols]
     u32 *d_tcsums = nullptr;         // [table_cols]
+    // operands built for other keys of the SAME graph (ef_search changes re-select the table's levels while searches of the previous
+    // ef may still be in flight: nothing a launch may be reading is freed before the graph itself is replaced)
+    struct TableSet { u64 key; u32 level_min, cols; u64 stride; u32 col0[cosdev::MAX_LEVELS]; uint8_t *tcodes; float *tmags; u32 *tcsums; };
+    std::vector<TableSet> table_sets;
     u32 walk_side_min_B = 4096; // launches of at least this many queries walk on the workspace's low-priority stream; 0 = never
     // launches of at most this many queries run the latency variant of the walk (kernels_walk_lat.hip) where it applies; 0 = never
     u32 lat_max_B = COS_LATENCY_MODE_DEFAULT_MAX_B;

@@ -208,19 +208,24 @@ int32_t cos_index_set_walk_order(cos_index *ix, uint32_t min_queries);
 int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t cap, uint32_t *out_n);
 /* Level table of big launches — at least min_queries queries over u8 codes (default COS_WALK_TABLE_DEFAULT_MIN_B; 0 = never).  Not a
  * reference interface.  The graph's top levels are small and walked by every query (1M vectors: levels >= 4 hold 5 300 nodes), so
- * for the levels >= L_t — the lowest level such that the levels from it to the top hold at most max_cols nodes together (default
- * COS_WALK_TABLE_DEFAULT_MAX_COLS; 0 = no table) — the launch first computes similarity(query, node) for EVERY node of those levels as
- * one exact-integer i8 MFMA GEMM (dot_product_u8's integer, the same `as f32` and the same division by |q| * |v|, cosine.rs:223-235),
- * and the walk of those levels reads the similarity (4 bytes) where it would have gathered and dotted a code row.  Which nodes a
- * walk visits, the lossy visited filter and every result are bit for bit what they are without the table; a launch holds
- * queries x columns x 4 bytes of it (32 768 x 5 312: 0.7 GB per stream in flight); a handle's tables together stay under 16 GiB
- * (COS_WALK_TABLE_MAX_BYTES): a launch whose workspace would exceed that walks without a table.
+ * for the levels >= L_t the launch first computes similarity(query, node) for EVERY node of those levels as one exact-integer i8 MFMA
+ * GEMM (dot_product_u8's integer, the same `as f32` and the same division by |q| * |v|, cosine.rs:223-235), and the walk of those
+ * levels reads the similarity (4 bytes) where it would have gathered and dotted a code row.  Which nodes a walk visits, the lossy
+ * visited filter and every result are bit for bit what they are without the table.
+ * L_t: with max_cols = COS_WALK_TABLE_AUTO (the default) a level takes part while it holds at most 6 x ef_search x neighbors_count
+ * nodes, level by level from the top (a level's walk evaluates a multiple of ef x M rows per query; the table costs one GEMM column
+ * per node): 1M x 768 at ef 64 / M 32 -> levels >= 4 (5 333 columns); a 12.5M x 1024 shard at ef 128 / M 64 -> levels >= 4 (65 161
+ * columns, +45 % QPS over a fixed 8 192).  An explicit max_cols caps the columns of all table levels together; 0 = no table.  The
+ * operand follows ef_search (cos_index_set_ef_search rebuilds it on the next big launch).
+ * A launch holds queries x columns x 4 bytes of table (32 768 x 5 344: 0.7 GB; 32 768 x 65 184: 8.5 GB); a handle's tables together
+ * stay under 48 GiB (COS_WALK_TABLE_MAX_BYTES): a launch whose workspace would exceed that walks without a table.
  * Device memory of the search side in general: every caller stream (cos_search_batch_device) and every host call in flight
  * (cos_search_batch: up to 32 leased pipes, a lone big call uses up to five workspaces) owns a workspace sized for its largest launch
  * — query codes, per-level result lists ((num_layers + 1) x 100 x 8 B per query: 8 KB at ten levels), statistics, the level table —
  * and keeps it until the handle is destroyed. */
 #define COS_WALK_TABLE_DEFAULT_MIN_B 4096u
-#define COS_WALK_TABLE_DEFAULT_MAX_COLS 8192u
+#define COS_WALK_TABLE_DEFAULT_MAX_COLS 8192u /* kept for callers that want the round-4 mid-round default */
+#define COS_WALK_TABLE_AUTO 0xFFFFFFFFu
 int32_t cos_index_set_walk_table(cos_index *ix, uint32_t max_cols, uint32_t min_queries);
 /* the table the next big launch would use: its lowest level and its columns (0, 0 = none).  Diagnostic: bench.py reports it. */
 int32_t cos_index_walk_table_info(cos_index *ix, uint32_t *out_level_min, uint32_t *out_cols);

@@ -30,7 +30,8 @@ X = bench.mixture(torch, N, D, 42, dev, centers)
 Q = bench.mixture(torch, 2 * B, D, 43, dev, centers)
 vr = ca.sample_values_range(X[:1000].cpu().numpy(), 1.0)
 mode = ca.VISITED_EXACT if EXACT else ca.VISITED_REF
-hp = ca.HNSWHyperParams(num_layers=9, ef_construction=EFC, ef_search=EFS[0], level_0_neighbors_count=64, neighbors_count=32)
+hp = ca.HNSWHyperParams(num_layers=9, ef_construction=EFC, ef_search=EFS[0], level_0_neighbors_count=int(os.environ.get("PROBE_M0", 64)),
+                        neighbors_count=int(os.environ.get("PROBE_M", 32)))
 ix = ca.HNSWIndex(D, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), vr, shortlist_size=64, device=0, seed=42, visited_mode=mode)
 ix.upload_vectors_device(X.data_ptr(), N, keepalive=X)
 t0 = time.time()
