@@ -508,6 +508,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         return;
     }
+    // Unfused epilogue (score matrix out: the unfused flat scan and the walk's level table, where it is most of the kernel — K = 768
+    // is short and every output needs an exact quotient).  The per-row terms (|q| and the query's share of the u8 recentring) are
+    // staged in LDS once per workgroup (the operand panels are dead: the k loop ended with a barrier) instead of two global loads per
+    // output; the output pointer of a 32 x 32 block advances by a constant stride; tiles inside the matrix skip the bounds tests.
+    float *rqm = (float *)As;             // [CM] |q|
+    int *rqs = (int *)(As + CM * 4);      // [CM] 128 * sum(q) - 16384 * kdims (u8), 0 otherwise
+    for (int idx = tid; idx < CM; idx += 512) {
+        const u32 row = row0 + idx;
+        rqm[idx] = row < B ? qmags[row] : 1.0f;
+        rqs[idx] = (ENG == ENG_U8 && row < B) ? 128 * (int)qsums[row] - 16384 * (int)kdims : 0;
+    }
+    __syncthreads();
+    const bool inside = row0 + CM <= B && col0 + CN <= n_chunk; // workgroup-uniform
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -515,17 +528,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const u32 col = col0 + wc * 64 + j * 32 + (lane & 31);
             const bool cv = col < n_chunk;
             const float xm = cv ? mags[n0 + col] : 1.0f;
-            const int cs = (ENG == ENG_U8 && cv) ? (int)csums[n0 + col] : 0;
+            const int cs = (ENG == ENG_U8 && cv) ? 128 * (int)csums[n0 + col] : 0;
+            const int rl0 = wr * 64 + i * 32 + 4 * (lane >> 5);
+            float *out = scores + (u64)(row0 + rl0) * s_stride + col;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const u32 row = row0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < B && cv) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                const int rl = rl0 + dr;
+                if (inside || (row0 + (u32)rl < B && cv)) {
                     int dot = acc[i][j][r];
-                    if constexpr (ENG == ENG_U8) dot += 128 * (int)qsums[row] + 128 * cs - 16384 * (int)kdims;
+                    if constexpr (ENG == ENG_U8) dot += rqs[rl] + cs;
                     const float dotf = (float)(u32)dot; // exact integer -> f32 RNE, like `as f32` on the u64 dot
                     float sc = dotf;
-                    if (metric == 0u) sc = __fdiv_rn(dotf, __fmul_rn(qmags[row], xm)); // zero norms are screened on the host side
-                    scores[(u64)row * s_stride + col] = sc;
+                    if (metric == 0u) sc = __fdiv_rn(dotf, __fmul_rn(rqm[rl], xm)); // zero norms are screened on the host side
+                    out[(u64)dr * s_stride] = sc;
                 }
             }
         }
@@ -943,8 +959,13 @@ hipError_t launch_level_table(const uint8_t *qcodes, const float *qmags, u32 *qs
     const u32 kdims = (u32)((row_stride + 63) / 64 * 64);
     dim3 grid((ncols + CN - 1) / CN, (B + CM - 1) / CM);
     FusedOut fo{nullptr, nullptr, nullptr, 0u, nullptr};
-    hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, false, 2>), grid, dim3(512), 0, st, qcodes, qmags, (const u32 *)qsums, B, tcodes, tmags, tcsums,
-                       row_stride, 0u, ncols, kdims, metric, tab, tab_stride, fo);
+    static const int pf = [] { const char *e = getenv("COS_TABLE_GEMM_PF"); return e ? atoi(e) : 2; }(); // k panels in flight (experiments)
+#define TAB_GEMM(P) hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, false, P>), grid, dim3(512), 0, st, qcodes, qmags, (const u32 *)qsums, B, tcodes, tmags, \
+                                       tcsums, row_stride, 0u, ncols, kdims, metric, tab, tab_stride, fo)
+    if (pf == 3) TAB_GEMM(3);
+    else if (pf == 1) TAB_GEMM(1);
+    else TAB_GEMM(2);
+#undef TAB_GEMM
     return hipGetLastError();
 }
 

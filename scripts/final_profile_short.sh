@@ -1,10 +1,13 @@
 #!/bin/bash
-# A shorter round-end pass when only host code / bench.py changed since scripts/final_profile.sh ran (the kernel trace and the SQ pass of
-# that run stay valid): GPU tests, the two PMC traffic passes, then the default bench, which reads profiles/pmc_traffic.json.
+# A shorter round-end pass when the walk kernels have not changed since scripts/final_profile.sh ran (its SQ pass and its c3 / c5 traces
+# stay valid): GPU tests, the c2 kernel trace, the two PMC traffic passes, then the default bench, which reads profiles/pmc_traffic.json.
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
 timeout 900 python -m pytest tests -m gpu -q > $OUT/final_pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/final_pytest.log
 cd /tmp; export TMPDIR=/tmp
 export COS_BENCH_FULL_RECORD=bench_full_record_of_a_profiler_pass.json
+MAIN="--steps 20 --warmup 5 --configs none --no-cpu-baseline --no-hbm-probe --ef-sweep 256"
+rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python $R/bench.py $MAIN > $OUT/final_bench_c2_under_rocprofv3.json 2> $OUT/final_kt.err
+python $R/scripts/rocprof_summary.py /tmp/p_kt/kt_results.db > $OUT/final_kernel_trace_c2.txt
 PM="--steps 8 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --ef-sweep 256 --recall-queries 2048"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- python $R/bench.py $PM > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- python $R/bench.py $PM > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
