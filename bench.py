@@ -1128,6 +1128,8 @@ def main():
     ap.add_argument("--build-batch", type=int, default=4096)
     ap.add_argument("--recall-queries", type=int, default=8192, help="size of EACH of the two disjoint recall query sets (selection / report)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer API legs (cos_search_batch from 1-256 host threads); the profiler "
+                                                                "passes of scripts/final_profile*.sh use it: rocprofv3 does not survive a few thousand short-lived native threads")
     ap.add_argument("--no-hbm-probe", action="store_true", help="skip the empirical HBM ceiling probes (cos_hbm_probe)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--config-cpu-seconds", type=float, default=5.0, help="CPU-baseline sample of each extra config")
@@ -1171,7 +1173,7 @@ def main():
     wl = DenseWorkload(env, args.workload, n_override=args.n, ef_construction=args.ef_construction, quantization=args.quantization,
                        build_batch=args.build_batch)
     rec = wl.run_mode(args.build_visited, args.visited, ef_arg=args.ef, ef_sweep=args.ef_sweep, cpu_seconds=args.cpu_seconds,
-                      single_batch=True, host_api=True, hbm_probe=not args.no_hbm_probe, exchange=args.exchange)
+                      single_batch=True, host_api=not args.no_host_api, hbm_probe=not args.no_hbm_probe, exchange=args.exchange)
     flat = wl.flat
     n = wl.n
     wl.close()

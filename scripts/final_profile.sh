@@ -12,10 +12,10 @@ R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
 timeout 900 python -m pytest tests -m gpu -q > $OUT/final_pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/final_pytest.log
 cd /tmp; export TMPDIR=/tmp
 export COS_BENCH_FULL_RECORD=bench_full_record_of_a_profiler_pass.json
-MAIN="--steps 20 --warmup 5 --configs none --no-cpu-baseline --no-hbm-probe --ef-sweep 256"
+MAIN="--steps 20 --warmup 5 --configs none --no-cpu-baseline --no-hbm-probe --no-host-api --ef-sweep 256"
 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python $R/bench.py $MAIN > $OUT/final_bench_c2_under_rocprofv3.json 2> $OUT/final_kt.err
 python $R/scripts/rocprof_summary.py /tmp/p_kt/kt_results.db > $OUT/final_kernel_trace_c2.txt
-PM="--steps 8 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --ef-sweep 256 --recall-queries 2048"
+PM="--steps 8 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --no-host-api --ef-sweep 256 --recall-queries 2048"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- python $R/bench.py $PM > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- python $R/bench.py $PM > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d /tmp/p_s2 -o s2 -- python $R/bench.py $PM > $OUT/pmc_sq2_bench.json 2> $OUT/pmc_sq2.err

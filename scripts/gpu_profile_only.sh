@@ -1,8 +1,6 @@
 #!/bin/bash
-# A shorter round-end pass when the walk kernels have not changed since scripts/final_profile.sh ran (its SQ pass and its c3 / c5 traces
-# stay valid): GPU tests, the c2 kernel trace, the two PMC traffic passes, then the default bench, which reads profiles/pmc_traffic.json.
+# the profiler passes of scripts/final_profile_short.sh alone (c2 kernel trace, FETCH_SIZE, WRITE_SIZE)
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
-timeout 900 python -m pytest tests -m gpu -q > $OUT/final_pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/final_pytest.log
 cd /tmp; export TMPDIR=/tmp
 export COS_BENCH_FULL_RECORD=bench_full_record_of_a_profiler_pass.json
 MAIN="--steps 20 --warmup 5 --configs none --no-cpu-baseline --no-hbm-probe --no-host-api --ef-sweep 256"
@@ -17,6 +15,4 @@ python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "walk_kernel<0,
 python scripts/rocprof_summary.py /tmp/p_f/f_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_fetch_size.txt
 python scripts/rocprof_summary.py /tmp/p_w/w_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_write_size.txt
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
-unset COS_BENCH_FULL_RECORD
-COS_BENCH_FULL_RECORD=final_bench_all_configs_full_record.json timeout 1500 python bench.py > $OUT/final_bench_all_configs.json 2> $OUT/final_bench_all_configs.err; echo "bench rc=$?"
-head -c 400 $OUT/final_bench_all_configs.json; echo; cat $OUT/pmc_traffic_ef64.json | head -c 1200
+head -12 $OUT/final_kernel_trace_c2.txt; cat $OUT/pmc_traffic_ef64.json | head -c 1300; echo; tail -2 $OUT/pmc_fetch.err
