@@ -608,8 +608,8 @@ class DenseWorkload:
         upper_bytes = (sp["upper_evals"] - tab_upper) * row_b + tab_upper * 4.0 + sp["upper_adj_bytes"]
         lower_bytes = (sp["lower_evals"] - tab_lower) * row_b + tab_lower * 4.0 + sp["lower_adj_bytes"]
         avg_bytes = upper_bytes + lower_bytes
-        kern_ms = (sp["upper_ms"] + sp["lower_ms"]) or tr["walk_ms"]     # the walk kernel's own dispatches (the sort between them excluded)
-        avg_ms = tr["walk_ms"]
+        avg_ms = tr["walk_ms"]                                           # ring average over every timed launch: upper range | sort | lower range
+        kern_ms = avg_ms - (sp_alone["sort_ms"] if sp["cut_after_level"] else 0.0)   # the walk kernel's own dispatches (sp[...]: the last launch of each stream only)
         kernel_gbps = avg_bytes / (kern_ms * 1e-3) / 1e9              # ONE step's walk: algorithmic bytes / HIP-event time of its dispatches
         aggregate_gbps = avg_bytes * n_launch / elapsed / 1e9         # all launches / wall time (launches on different streams overlap)
         overlap = max(1.0, min(float(S), avg_ms * 1e-3 * n_launch / elapsed))

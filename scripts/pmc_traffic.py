@@ -5,7 +5,7 @@ range below it, and the level-table GEMM.  bytes = FETCH_SIZE x 1024 x k + WRITE
 (scripts/pmc_calibrate.py: the factor measured on this part's own row-gather pattern with a known byte count; 2.0 on gfx950, which is
 also what MI355X_MICROARCH.md prescribes for wide coalesced reads).
 
-usage: pmc_traffic.py <fetch.db> <queries_per_launch> <workload> <ef> <walk kernel pattern> [<write.db>|-] [<visited>]
+usage: pmc_traffic.py <fetch.db> <queries_per_launch> <workload> <ef> <walk kernel pattern> [<write.db>|-] [<visited>] [<GEMM workgroups>]
 Under PMC the device runs one dispatch at a time and the walk chain orders the big walks of different streams, so the big dispatches
 of the walk kernel alternate upper range, lower range, upper range, ... (an unsplit walk: every dispatch is "lower")."""
 import json
@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 db_fetch, grid, workload, ef, pattern = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
 db_write = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] != "-" else None
 visited = sys.argv[7] if len(sys.argv) > 7 else "ref"
+gemm_grid = int(sys.argv[8]) if len(sys.argv) > 8 else 0   # workgroups of this launch shape's level-table GEMM (column tiles x row tiles); 0 = the largest seen
 
 try:
     cal = json.load(open(os.path.join(ROOT, "profiles", "pmc_calibration.json")))
@@ -59,8 +60,9 @@ for part, (nd, kb) in f.items():
     parts[part] = {"dispatches": nd, "fetch_size_kb_raw": kb, "write_size_kb_raw": wkb, "bytes": kb * 1024.0 * k_fetch + wkb * 1024.0}
 # the level-table GEMM of the same steps (grid = column tiles x row tiles: match by name only)
 cur = sqlite3.connect(db_fetch).cursor()
-GEMM_Q = ("select count(*), avg(value) from counters_collection where kernel_name like '%flat_codes_gemm_i8%' and counter_name = ? and "
-          "grid_size = (select max(grid_size) from counters_collection where kernel_name like '%flat_codes_gemm_i8%')")   # the big launches' GEMM only
+GEMM_Q = ("select count(*), avg(value) from counters_collection where kernel_name like '%flat_codes_gemm_i8%' and counter_name = ? and " +
+          (f"grid_size/workgroup_size = {gemm_grid}" if gemm_grid else
+           "grid_size = (select max(grid_size) from counters_collection where kernel_name like '%flat_codes_gemm_i8%')"))   # this launch shape's GEMM only
 g = cur.execute(GEMM_Q, ("FETCH_SIZE",)).fetchone()
 gw = (0, 0.0)
 if db_write:
