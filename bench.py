@@ -631,13 +631,15 @@ class DenseWorkload:
                 rate = 8 * Bc / (time.perf_counter() - t1)
                 return rate, (o_ids[0][:Bc].clone(), o_sc[0][:Bc].clone().view(torch.int32), o_cnt[0][:Bc].clone(), o_st[0][:Bc].clone())
             torch.cuda.synchronize(dev)
-            serial_qps, serial_out = serial_rate()              # default: four waves per query (walk_lat4_kernel)
+            serial_qps, serial_out = serial_rate()              # default policy: throughput kernel + level table up to ef 64, four waves + table above
+            ix.set_walk_table(0, 0)                             # without a table the named kernels are selectable
             ix.set_latency_waves(0)
             serial_qps_1w, serial_out_1w = serial_rate()        # one-wave latency kernel
             ix.set_latency_mode(0)
-            serial_qps_tk, serial_out_tk = serial_rate()        # throughput kernel
+            serial_qps_tk, serial_out_tk = serial_rate()        # throughput kernel, no table
             ix.set_latency_mode(ca.HNSWIndex.LATENCY_MODE_DEFAULT_MAX_B)
             ix.set_latency_waves(ca.HNSWIndex.LATENCY_WAVES_DEFAULT_MAX_B)
+            ix.set_walk_table(ca.HNSWIndex.WALK_TABLE_AUTO, ca.HNSWIndex.WALK_TABLE_DEFAULT_MIN_B)
             serial = {"qps": serial_qps, "qps_one_wave_latency_kernel": serial_qps_1w, "qps_throughput_kernel": serial_qps_tk,
                       "identical": all(bool(torch.equal(a, b_)) and bool(torch.equal(a, c_)) for a, b_, c_ in zip(serial_out, serial_out_tk, serial_out_1w))}
 

@@ -891,7 +891,7 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         }
         if (int32_t rc = ensure_order_rank(ix)) return rc;
     }
-    if (const u32 tmin = walk_table_min_B(ix); tmin && (B >= tmin || B <= ix->lat4_max_B)) { // big launches and the four-wave latency kernel's
+    if (const u32 tmin = walk_table_min_B(ix); tmin && (B >= tmin || B <= ix->lat4_max_B)) { // from min_queries on, and the four-wave latency kernel's launches
         if (int32_t rc = ensure_level_table(ix)) return rc;
         const size_t need = (size_t)w->capB * ix->table_stride;
         if (need > w->tab_cap) {

@@ -1050,13 +1050,18 @@ static void walk_env_overrides(u32 &lat_max_B, u32 &lat4_max_B) {
     if (lat_env >= 0) lat_max_B = lat_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat_env;
     if (lat4_env >= 0) lat4_max_B = lat4_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat4_env;
 }
-// table_available: the launch can have a level table.  Up to ef 64 the throughput kernel WITH the table beats both latency kernels
-// on one client batch (1M x 768: 0.77 ms per 256 queries against 0.82 for four waves with the table, 0.88 without, 0.99 for the
-// one-wave kernel; profiles/r04_single_batch_probe.jsonl); above, the four-wave kernel with the table stays ahead.
+// table_available: the launch can have a level table (u8 codes).  With the table the throughput kernel beats the one-wave latency
+// kernel at every launch size (1M x 768, ms per launch at ef 64 / 256: 256 queries 0.77 / 2.20 against 0.99 / 2.37; 1 024 queries
+// 0.84 / 2.33 against 1.13 / 2.57; 2 048 queries 0.95 / 2.58 against 1.50 / 2.91) and the four-wave kernel up to ef 64 (0.77
+// against 0.82 with the table, 0.88 without); above ef 64 the four-wave kernel with the table stays ahead on one client batch
+// (1.73 against 2.20 at ef 256).  profiles/r04_single_batch_probe.jsonl, r04_mid_size_probe.jsonl.
 int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, bool table_available) { // 0 throughput, 1 one-wave latency, 4 four-wave latency
     walk_env_overrides(lat_max_B, lat4_max_B);
     static const bool tk_small = [] { const char *e = getenv("COS_WALK_SMALL_TABLE_TK"); return !e || atoi(e) != 0; }();
-    if (table_available && tk_small && eng == ENG_U8 && wa.ef <= 64u && wa.B <= lat4_max_B) return 0;
+    if (table_available && tk_small && eng == ENG_U8) {
+        if (wa.phase == 0u && wa.ef > 64u && walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return 4;
+        return 0;
+    }
     if (wa.phase == 0u) {
         if (walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return 4;
         if (walk_lat_applicable(eng, ix, wa, lat_max_B)) return 1;

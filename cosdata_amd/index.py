@@ -265,7 +265,7 @@ class HNSWIndex:
         check(_lib.lib().cos_index_walk_order_cuts(self._h, lv, 16, C.byref(n)))
         return [int(lv[i]) for i in range(min(n.value, 16))]
 
-    WALK_TABLE_DEFAULT_MIN_B = 4096      # COS_WALK_TABLE_DEFAULT_MIN_B (include/cosdata_hip.h)
+    WALK_TABLE_DEFAULT_MIN_B = 1         # COS_WALK_TABLE_DEFAULT_MIN_B (include/cosdata_hip.h): every launch
     WALK_TABLE_DEFAULT_MAX_COLS = 8192   # COS_WALK_TABLE_DEFAULT_MAX_COLS
     WALK_TABLE_AUTO = 0xFFFFFFFF         # COS_WALK_TABLE_AUTO: levels of at most 6 x ef_search x neighbors_count nodes
 

@@ -206,8 +206,10 @@ int32_t cos_index_set_walk_order(cos_index *ix, uint32_t min_queries);
 /* The levels after which such a launch is cut (descending; the launch is re-sorted after each): by default ONE, the lowest level whose
  * code rows take at most 64 MB; none (*out_n = 0) if the graph has no level the order can use.  Diagnostic: bench.py reports it. */
 int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t cap, uint32_t *out_n);
-/* Level table of big launches — at least min_queries queries over u8 codes (default COS_WALK_TABLE_DEFAULT_MIN_B; 0 = never).  Not a
- * reference interface.  The graph's top levels are small and walked by every query (1M vectors: levels >= 4 hold 5 300 nodes), so
+/* Level table — launches of at least min_queries queries over u8 codes (default COS_WALK_TABLE_DEFAULT_MIN_B = every launch; 0 =
+ * never).  With a table a launch takes the throughput kernel, except one client batch above ef_search 64, which takes the four-wave
+ * latency kernel (it reads the table too); the one-wave latency kernel then only serves storages without a table.  Not a reference
+ * interface.  The graph's top levels are small and walked by every query (1M vectors: levels >= 4 hold 5 300 nodes), so
  * for the levels >= L_t the launch first computes similarity(query, node) for EVERY node of those levels as one exact-integer i8 MFMA
  * GEMM (dot_product_u8's integer, the same `as f32` and the same division by |q| * |v|, cosine.rs:223-235), and the walk of those
  * levels reads the similarity (4 bytes) where it would have gathered and dotted a code row.  Which nodes a walk visits, the lossy
@@ -223,7 +225,7 @@ int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t 
  * (cos_search_batch: up to 32 leased pipes, a lone big call uses up to five workspaces) owns a workspace sized for its largest launch
  * — query codes, per-level result lists ((num_layers + 1) x 100 x 8 B per query: 8 KB at ten levels), statistics, the level table —
  * and keeps it until the handle is destroyed. */
-#define COS_WALK_TABLE_DEFAULT_MIN_B 4096u
+#define COS_WALK_TABLE_DEFAULT_MIN_B 1u
 #define COS_WALK_TABLE_DEFAULT_MAX_COLS 8192u /* kept for callers that want the round-4 mid-round default */
 #define COS_WALK_TABLE_AUTO 0xFFFFFFFFu
 int32_t cos_index_set_walk_table(cos_index *ix, uint32_t max_cols, uint32_t min_queries);

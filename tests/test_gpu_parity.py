@@ -44,16 +44,21 @@ def test_resident_codes_match_oracle(name, storage, res, dim):
     assert np.array_equal(np.asarray(mags).view(np.uint32), omags.view(np.uint32))
 
 
-# (name, cos_index_set_latency_mode, cos_index_set_latency_waves, cos_index_set_walk_order)
-WALK_VARIANTS = [("throughput kernel", 0, 0, 0), ("one-wave latency kernel where it applies", 0xFFFFFFFF, 0, 0),
-                 ("four-wave latency kernel where it applies", 0xFFFFFFFF, 0xFFFFFFFF, 0),
-                 ("throughput kernel, split walk in locality order", 0, 0, 1)]
+# (name, cos_index_set_latency_mode, cos_index_set_latency_waves, cos_index_set_walk_order, level table on).  With a level table
+# (u8 codes) the library picks the kernel itself (walk_kernel_kind), so the variants that name a kernel switch the table off.
+WALK_VARIANTS = [("throughput kernel", 0, 0, 0, False), ("one-wave latency kernel where it applies", 0xFFFFFFFF, 0, 0, False),
+                 ("four-wave latency kernel where it applies", 0xFFFFFFFF, 0xFFFFFFFF, 0, False),
+                 ("throughput kernel, split walk in locality order", 0, 0, 1, False),
+                 ("default policy with the level table (throughput kernel, or four waves above ef 64)", 0xFFFFFFFF, 0xFFFFFFFF, 0, True),
+                 ("level table + split walk in locality order", 0, 0, 1, True)]
 
 
-def _set_variant(dix, max_b, max_b4, order_min=0):
+def _set_variant(dix, max_b, max_b4, order_min=0, table=False):
+    import cosdata_amd as ca
     dix.set_latency_mode(max_b)
     dix.set_latency_waves(max_b4)
     dix.set_walk_order(order_min)
+    dix.set_walk_table(ca.HNSWIndex.WALK_TABLE_AUTO if table else 0, 1 if table else 0)
 
 
 def _reset_variant(dix):
@@ -61,13 +66,14 @@ def _reset_variant(dix):
     dix.set_latency_mode(ca.HNSWIndex.LATENCY_MODE_DEFAULT_MAX_B)
     dix.set_latency_waves(ca.HNSWIndex.LATENCY_WAVES_DEFAULT_MAX_B)
     dix.set_walk_order(ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B)
+    dix.set_walk_table(ca.HNSWIndex.WALK_TABLE_AUTO, ca.HNSWIndex.WALK_TABLE_DEFAULT_MIN_B)
 
 
 def _assert_same_search(oix, dix, Q, top_k):
     """every variant of the walk (cos_index_set_latency_mode / _waves: walk_kernel / walk_lat_kernel / walk_lat4_kernel) must give the oracle's answer"""
     oids, osc, ocnt = oix.search_batch(Q, top_k, threads=4)[:3]
-    for vname, max_b, max_b4, order_min in WALK_VARIANTS:
-        _set_variant(dix, max_b, max_b4, order_min)
+    for vname, max_b, max_b4, order_min, table in WALK_VARIANTS:
+        _set_variant(dix, max_b, max_b4, order_min, table)
         ids, sc, cnt = dix.batch_search(Q, top_k)
         assert np.array_equal(cnt, ocnt), vname
         for b in range(Q.shape[0]):
@@ -84,8 +90,8 @@ def ca_default_latency():
 
 def _assert_same_walk(oix, dix, Q):
     ow = [oix.ann_search(Q[b]) for b in range(Q.shape[0])]
-    for vname, max_b, max_b4, order_min in WALK_VARIANTS:
-        _set_variant(dix, max_b, max_b4, order_min)
+    for vname, max_b, max_b4, order_min, table in WALK_VARIANTS:
+        _set_variant(dix, max_b, max_b4, order_min, table)
         ids, sims, counts = dix.ann_search_batch(Q)
         for b in range(Q.shape[0]):
             oi, osim, olc = ow[b]
@@ -129,8 +135,8 @@ def test_zero_norm_query_is_calculation_error():
     Q = H.queries_from(X, 4)
     Q[2, :] = -1.0  # quantizes to all-zero bytes -> |q| = 0 -> DistanceError::CalculationError (cosine.rs:228-232)
     o = oix.search_batch(Q, 5, raise_on_error=False)
-    for _, max_b, max_b4, order_min in WALK_VARIANTS:
-        _set_variant(dix, max_b, max_b4, order_min)
+    for _, max_b, max_b4, order_min, table in WALK_VARIANTS:
+        _set_variant(dix, max_b, max_b4, order_min, table)
         with pytest.raises(ca.CosdataError) as ei:
             dix.batch_search(Q, 5)
         assert ei.value.status == 2
