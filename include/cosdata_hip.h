@@ -181,6 +181,9 @@ int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode);
  * entry of the lookahead window are fetched speculatively in one go and committed in pop order.  Same results bit for bit;
  * it trades bandwidth (idle on a small launch) for dependent round trips.  The reference's caller submits one 256-query batch
  * at a time per worker (indexes/mod.rs:260-272); bigger launches (coalesced batches) keep the throughput kernel. */
+/* Since round 4 a launch over u8 codes has a level table (cos_index_set_walk_table, on by default) and then takes the throughput kernel
+ * at every size — with the table it is faster than the one-wave latency kernel from 256 to 2048 queries per launch — so this knob
+ * now selects the kernel only for quaternary storage, or with the table switched off. */
 #define COS_LATENCY_MODE_DEFAULT_MAX_B 2048u
 int32_t cos_index_set_latency_mode(cos_index *ix, uint32_t max_queries);
 /* Four waves per query (kernels_walk_lat4.hip) for the smallest launches — at most max_queries queries (default
@@ -189,6 +192,8 @@ int32_t cos_index_set_latency_mode(cos_index *ix, uint32_t max_queries);
  * and same results, bit for bit, as the one-wave latency variant; it exists for the reference's literal unit of work, one
  * `query-batch = 256` per worker (indexes/mod.rs:260-272): 0.94 vs 1.05 ms per batch at ef 64, 1.87 vs 2.35 ms at ef 256 (1M x 768 u8);
  * from 1024 queries per launch on the one-wave kernel is faster (two of these workgroups fill a CU's registers). */
+/* With a level table (u8, the default) the four-wave kernel is taken above ef_search 64 only (it reads the table too: 1.73 vs 2.20 ms
+ * per batch at ef 256); up to ef 64 the throughput kernel with the table is faster (0.77 vs 0.82 ms). */
 #define COS_LATENCY_WAVES_DEFAULT_MAX_B 512u
 int32_t cos_index_set_latency_waves(cos_index *ix, uint32_t max_queries);
 /* Locality order of big launches — at least min_queries queries (default COS_WALK_ORDER_DEFAULT_MIN_B; 0 = never).  Not a reference
