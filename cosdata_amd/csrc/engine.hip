@@ -744,10 +744,14 @@ static int32_t ensure_level_table(cos_index *ix) {
     // from rows costs ~0.11 ns per evaluation, and a level's walk evaluates 0.2-0.4 x ef x M rows per query: a level of n nodes pays
     // while n < ~40 x that.  Measured on both ends — 1M x 768 at ef 64, M 32: level 4 (3 917 nodes) pays, level 3 (15 570) does not;
     // one 12.5M x 1024 shard at ef 128, M 64: level 5 (12 225) +24 % QPS, level 4 (48 870) another +17 %, both far above a fixed
-    // 8 192 columns (profiles/r04_c4_table_cols_probe.jsonl) — the automatic rule is n_level <= 6 x ef_search x neighbors_count, level
-    // by level from the top; an explicit max_cols caps the columns of all table levels together instead.
+    // 8 192 columns (profiles/r04_c4_table_cols_probe.jsonl) — the automatic rule is n_level <= c x ef_search x neighbors_count, level
+    // by level from the top; an explicit max_cols caps the columns of all table levels together instead.  c = 8 up to ef 64 and 6
+    // above: the wider pools of ef > 64 make a walk spend its time ranking and inserting, so a row it does not fetch saves less
+    // (1M x 768, M 32: at ef 64 level 3 = 7.6 x ef x M pays, 7.53 -> 7.13 ms per 32 768 queries; at ef 256 level 2 = 7.7 x ef x M
+    // costs 5.4 ms of GEMM and saves nothing, level 3 = 1.9 x pays; profiles/r04_table_level_rule_probe.jsonl).
     const bool automatic = max_cols == COS_WALK_TABLE_AUTO;
-    const u64 per_level = automatic ? std::min<u64>((u64)6 * ix->p.ef_search * ix->p.neighbors_count, 1u << 20) : (u64)(1u << 20);
+    const u64 c_rule = ix->p.ef_search <= 64u ? 8u : 6u;
+    const u64 per_level = automatic ? std::min<u64>(c_rule * ix->p.ef_search * ix->p.neighbors_count, 1u << 20) : (u64)(1u << 20);
     const u64 total_cap = automatic ? (u64)(1u << 20) : (u64)max_cols;
     const u64 key = automatic ? (0x8000000000000000ull | per_level) : (u64)max_cols;
     if (ix->level_table_valid && ix->table_built_for_key == key) return COS_OK;

@@ -219,12 +219,12 @@ int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t 
  * GEMM (dot_product_u8's integer, the same `as f32` and the same division by |q| * |v|, cosine.rs:223-235), and the walk of those
  * levels reads the similarity (4 bytes) where it would have gathered and dotted a code row.  Which nodes a walk visits, the lossy
  * visited filter and every result are bit for bit what they are without the table.
- * L_t: with max_cols = COS_WALK_TABLE_AUTO (the default) a level takes part while it holds at most 6 x ef_search x neighbors_count
- * nodes, level by level from the top (a level's walk evaluates a multiple of ef x M rows per query; the table costs one GEMM column
- * per node): 1M x 768 at ef 64 / M 32 -> levels >= 4 (5 333 columns); a 12.5M x 1024 shard at ef 128 / M 64 -> levels >= 4 (65 161
+ * L_t: with max_cols = COS_WALK_TABLE_AUTO (the default) a level takes part while it holds at most c x ef_search x neighbors_count
+ * nodes (c = 8 up to ef_search 64, 6 above), level by level from the top (a level's walk evaluates a multiple of ef x M rows per
+ * query; the table costs one GEMM column per node): 1M x 768 at ef 64 / M 32 -> levels >= 3 (20 903 columns); a 12.5M x 1024 shard at ef 128 / M 64 -> levels >= 4 (65 161
  * columns, +45 % QPS over a fixed 8 192).  An explicit max_cols caps the columns of all table levels together; 0 = no table.  The
  * operand follows ef_search (cos_index_set_ef_search rebuilds it on the next big launch).
- * A launch holds queries x columns x 4 bytes of table (32 768 x 5 344: 0.7 GB; 32 768 x 65 184: 8.5 GB); a handle's tables together
+ * A launch holds queries x columns x 4 bytes of table (32 768 x 20 928: 2.7 GB; 32 768 x 65 184: 8.5 GB); a handle's tables together
  * stay under 48 GiB (COS_WALK_TABLE_MAX_BYTES): a launch whose workspace would exceed that walks without a table.
  * Device memory of the search side in general: every caller stream (cos_search_batch_device) and every host call in flight
  * (cos_search_batch: up to 32 leased pipes, a lone big call uses up to five workspaces) owns a workspace sized for its largest launch

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the profiler passes of scripts/final_profile_short.sh alone (c2 kernel trace, FETCH_SIZE, WRITE_SIZE)
+# the profiler passes of scripts/final_profile.sh alone (c2 kernel trace, FETCH_SIZE, WRITE_SIZE, SQ instruction mix)
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 export COS_BENCH_FULL_RECORD=bench_full_record_of_a_profiler_pass.json
@@ -9,8 +9,17 @@ python $R/scripts/rocprof_summary.py /tmp/p_kt/kt_results.db > $OUT/final_kernel
 PM="--steps 8 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --no-host-api --ef-sweep 256 --recall-queries 2048"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- python $R/bench.py $PM > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- python $R/bench.py $PM > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d /tmp/p_s2 -o s2 -- python $R/bench.py $PM > $OUT/pmc_sq2_bench.json 2> $OUT/pmc_sq2.err
 cd $R
-python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" /tmp/p_w/w_results.db ref 5376 > $OUT/pmc_traffic_ef64.json
+EVALS=$(python - <<'PY'
+import json
+r = json.load(open("gpurun_out/pmc_fetch_bench.json")); p = r["roofline"]["parts"]; print(int(p["walk_upper"]["evals"] + p["walk_lower"]["evals"]))
+PY
+)
+python scripts/pmc_issue.py /tmp/p_s2/s2_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" $EVALS ref > $OUT/pmc_issue_ef64.json
+python scripts/rocprof_summary.py /tmp/p_s2/s2_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_sq_instruction_mix.txt
+cp profiles/pmc_issue.json $OUT/pmc_issue.json
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef64.json
 python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "walk_kernel<0, 1, 4, true, false, 8>" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef256.json
 python scripts/rocprof_summary.py /tmp/p_f/f_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_fetch_size.txt
 python scripts/rocprof_summary.py /tmp/p_w/w_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_write_size.txt
