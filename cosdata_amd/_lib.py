@@ -99,7 +99,7 @@ ABI_SYMBOLS = [
     "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_coalescing", "cos_index_set_ef_search",
     "cos_index_set_visited_mode", "cos_index_set_latency_mode", "cos_index_set_latency_waves", "cos_index_set_walk_order", "cos_index_walk_order_cuts", "cos_index_set_walk_table", "cos_index_walk_table_info", "cos_index_last_walk_split", "cos_index_enable_timing", "cos_index_last_stats", "cos_index_timing_summary", "cos_quantize_batch",
     "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
-    "cos_bm25_search_batch", "cos_bm25_search_batch_device", "cos_rrf_fuse_batch", "cos_hybrid_search_batch", "cos_text_process", "cos_text_count_tokens", "cos_bm25_term_frequency", "cos_xxhash32", "cos_stem_english", "cos_sparse_create", "cos_sparse_build_csr", "cos_sparse_create_from_vectors", "cos_sparse_destroy", "cos_sparse_search_batch", "cos_sparse_last_stats", "cos_merge_topk_device", "cos_merge_topk_packed_device", "cos_hbm_probe",
+    "cos_bm25_search_batch", "cos_bm25_search_batch_device", "cos_rrf_fuse_batch", "cos_hybrid_search_batch", "cos_text_process", "cos_text_count_tokens", "cos_bm25_term_frequency", "cos_xxhash32", "cos_stem_english", "cos_sparse_create", "cos_sparse_build_csr", "cos_sparse_create_from_vectors", "cos_sparse_destroy", "cos_sparse_search_batch", "cos_sparse_last_stats", "cos_sparse_layout", "cos_merge_topk_device", "cos_merge_topk_packed_device", "cos_hbm_probe",
     "cos_shardset_unique_id", "cos_shardset_create", "cos_shardset_destroy", "cos_shardset_search_batch", "cos_shardset_exchange_device",
 ]
 
@@ -176,6 +176,7 @@ def lib():
         "cos_sparse_destroy": [vp],
         "cos_sparse_search_batch": [vp, vp, vp, vp, u32, u32, f32, u32, vp, vp, vp],
         "cos_sparse_last_stats": [vp, vp],
+        "cos_sparse_layout": [vp, C.POINTER(u32)],
         "cos_merge_topk_device": [vp, vp, vp, u32, u32, u32, vp, vp, vp, i32, vp],
         "cos_merge_topk_packed_device": [vp, u32, u32, u32, vp, vp, vp, i32, vp],
         "cos_hbm_probe": [i32, u32, C.c_uint64, u32, u32, C.POINTER(C.c_double)],

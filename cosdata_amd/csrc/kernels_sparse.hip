@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -378,6 +379,260 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
     }
 }
 
+// ---- packed layout (cos_sparse::packed; COS_SPARSE_PACKED=1 at cos_sparse_create) -------------------------------------------
+// One u32 per posting, key << 24 | (vector id + 1), instead of a u32 id + a u8 key: 4 B instead of 5 B of HBM traffic per posting,
+// one load instead of two, and the apply step of a posting shrinks from ~19 to ~9 instructions:
+//   * a step's postings are fetched through a buffer descriptor whose num_records is the step's own length — a lane past the step's
+//     end reads 0 = "vector id -1", which is outside every tile — so there is no `lane + 64 u < len` mask;
+//   * slot = min((p - (d0 + 1)) & 0xFFFFFF, STILE + lane): postings of other tiles (a short list is scanned whole per tile) and the
+//     out-of-range zeros wrap to a huge value and land on a dummy slot behind the tile; no compare, no select;
+//   * COUNTED blocks (the usual case): a posting adds qq * key + 2^22, so a slot's high 10 bits count the postings that reached the
+//     vector and the low 22 bits hold the similarity — "visited with similarity 0" needs no flag word and no second pass.  The
+//     host checks per query that neither field can overflow (sum over its terms of multiplicity x qq x (Q - 1) < 2^22, at most
+//     1023 touches; `multiplicity` = how often one vector id occurs in the dimension's list, 1 unless the caller's CSR repeats ids);
+//     other queries run the same steps with the flag words of the unpacked kernel.
+// Vector ids need 24 bits: n_vectors <= SPK_MAX_N, larger collections keep the unpacked layout.  Queries of more than 64 terms are
+// walked in groups of 64 terms (the step directory is one lane per term); slices the LDS table does not hold are looked up on the way.
+constexpr u32 SPK_CNT = 1u << 22;
+constexpr u32 SPK_SUM = SPK_CNT - 1u;
+constexpr u32 SPK_MAX_N = (1u << 24) - 2u * STILE;
+constexpr u32 SPK_COUNTED = 0x80000000u; // bit of order[]: this query's blocks may count touches in the accumulator
+
+template <bool COUNTED>
+__device__ __forceinline__ void sparse_packed_body(const u32 *__restrict__ m_pk, const STerm *__restrict__ qt, const u32 nt, const u32 n_tiles,
+                                                   const u32 *__restrict__ tile_dir, const u32 split, const u32 splits, u64 *__restrict__ out, u32 *acc,
+                                                   u32 *zflag, u64 (*wpool)[SEL], u64 *sl_b, u32 *sl_n, u32 *sl_w, u32 *st_pre, u32 *st_ctr) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr u32 STEP = 64u * SPU;
+    for (u32 i = threadIdx.x; i < STILE / 4; i += blockDim.x) reinterpret_cast<uint4 *>(acc)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (!COUNTED)
+        for (u32 i = threadIdx.x; i < STILE / 32; i += blockDim.x) zflag[i] = 0u;
+    Pool<1> pool;
+    pool.clear();
+    u64 thr = 0ull;
+    auto insert_keys = [&](u64 key) { // the keys of a wave's lanes that beat the pool's last entry
+        u64 m = ballot64(key > thr);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const u64 kk = readlane_u64(key, l);
+            if (kk > thr) {
+                pool.insert_at(kk, pool.rank_of(kk), lane);
+                thr = readlane_u64(pool.e[0], SEL - 1);
+            }
+        }
+    };
+    // The (tile, term) slices are resolved into the LDS table a WINDOW at a time, all lookups of a window in flight together: TB tiles
+    // x all nt terms when nt <= SLICES (one window for the whole block in the usual case), one tile x SLICES terms otherwise.
+    const u32 my_tiles = (n_tiles - split + splits - 1) / splits;
+    const u32 TW = nt < SLICES ? nt : SLICES;
+    const u32 TB = nt < SLICES ? (SLICES / nt < my_tiles ? SLICES / nt : my_tiles) : 1u;
+    const u32 dummy4 = (STILE + (u32)lane) * 4u; // byte address of the lane's dummy slot
+    char *accb = reinterpret_cast<char *>(acc);
+    for (u32 ti0 = 0; ti0 < my_tiles; ti0 += TB) {
+        const u32 tbn = my_tiles - ti0 < TB ? my_tiles - ti0 : TB;
+        for (u32 tw0 = 0; tw0 < nt; tw0 += TW) {
+            const u32 twn = nt - tw0 < TW ? nt - tw0 : TW;
+            __syncthreads(); // the previous window is done with the table
+            for (u32 p = threadIdx.x; p < tbn * twn; p += blockDim.x) {
+                const u32 tile = split + (ti0 + p / twn) * splits, t = tw0 + p % twn;
+                const u32 dr = qt[t].dir;
+                u64 b = qt[t].begin, e = qt[t].end;
+                if (dr != SNO_DIR) {
+                    const u32 *row = tile_dir + (u64)dr * (n_tiles + 1);
+                    e = b + row[tile + 1];
+                    b = b + row[tile];
+                }
+                sl_b[p] = b;
+                sl_n[p] = (u32)(e - b);
+                if (p < twn) sl_w[p] = qt[t].qq_k0;
+            }
+            const u32 groups = (twn + 63u) >> 6;
+            for (u32 tj = 0; tj < tbn; tj++) {
+                const u32 tile = split + (ti0 + tj) * splits, d0 = tile * STILE;
+                const u32 d1 = d0 + 1u; // a posting holds vector id + 1 in its low 24 bits
+                for (u32 g = 0; g < groups; g++) {
+                    const u32 tb = g << 6, ng = twn - tb < 64u ? twn - tb : 64u;
+                    const u32 row0 = tj * twn + tb; // table row of the group's first term
+                    __syncthreads(); // the table; the previous group's directory is no longer read; the previous tile's flush
+                    if (wave == 0) { // step counts of this group's slices of the tile -> exclusive prefix (one lane per term)
+                        u32 ns = 0;
+                        if ((u32)lane < ng) ns = (sl_n[row0 + lane] + STEP - 1u) / STEP;
+                        u32 incl = ns;
+#pragma unroll
+                        for (int dd = 1; dd < 64; dd <<= 1) {
+                            const u32 o = (u32)__shfl_up((int)incl, dd, 64);
+                            if (lane >= dd) incl += o;
+                        }
+                        if ((u32)lane < ng) st_pre[lane] = incl - ns;
+                        if ((u32)lane == ng - 1u) st_pre[ng] = incl;
+                        if (lane == 0) *st_ctr = 0u;
+                    }
+                    __syncthreads();
+                    const u32 total = uniform_u32(st_pre[ng]);
+                    const u32 my_lo = (u32)lane < ng ? st_pre[lane] : 0xFFFFFFFFu, my_hi = (u32)lane < ng ? st_pre[lane + 1] : 0u;
+                    auto pull = [&]() -> u32 {
+                        u32 k = 0;
+                        if (lane == 0) k = atomicAdd(st_ctr, 1u);
+                        return readlane_u32(k, 0);
+                    };
+                    struct Step { u32 base_lo, base_hi, len, w; bool valid; };
+                    auto locate = [&](u32 k) -> Step {
+                        Step sp;
+                        sp.valid = k < total;
+                        sp.base_lo = 0; sp.base_hi = 0; sp.len = 0; sp.w = 0;
+                        if (sp.valid) {
+                            const u64 m = ballot64(k >= my_lo && k < my_hi);
+                            const u32 tl = (u32)(__ffsll((long long)m) - 1);
+                            const u32 done = (k - readlane_u32(my_lo, (int)tl)) * STEP, left = sl_n[row0 + tl] - done;
+                            const u64 b = sl_b[row0 + tl] + done;
+                            // wave-uniform by construction; say so (values that arrive through a vector load count as divergent)
+                            sp.base_lo = uniform_u32((u32)b);
+                            sp.base_hi = uniform_u32((u32)(b >> 32));
+                            sp.len = uniform_u32(left < STEP ? left : STEP);
+                            sp.w = uniform_u32(sl_w[tb + tl]);
+                        }
+                        return sp;
+                    };
+                    auto fetch_p = [&](const Step &sp, u32 (&pv)[SPU]) {
+                        const u32 *bp = m_pk + ((u64)sp.base_hi << 32 | sp.base_lo);
+                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)bp, (short)0, (int)(sp.len * 4u), 0x00020000);
+#pragma unroll
+                        for (int u = 0; u < SPU; u++) pv[u] = (u32)__builtin_amdgcn_raw_buffer_load_b32(rsrc, ((u32)lane + (u32)u * 64u) * 4u, 0, 0);
+                    };
+                    // a posting: slot = its id relative to the tile (other tiles' postings and the zeros past the step's end wrap to >=
+                    // STILE and fall on the lane's dummy slot behind the tile through the min), weight = qq * key
+                    auto apply_p = [&](const Step &sp, const u32 (&pv)[SPU]) {
+                        const u32 qq = sp.w & 255u, k0 = sp.w >> 8;
+                        if (COUNTED) {
+                            auto one = [&](u32 p, bool keyed) {
+                                const u32 rel = p - d1;
+                                // (rel & 0xFFFFFF) * 4, the slot's byte address, and qq * (rel >> 24) as ONE full-rate instruction each
+                                // (left alone the compiler shifts and masks for the first and picks the quarter-rate v_mul_lo_u32 for the second)
+                                u32 at, w;
+                                asm("v_mul_u32_u24 %0, %1, 4" : "=v"(at) : "v"(rel));
+                                asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(w) : "v"(rel), "s"(qq));
+                                if (keyed) at = (rel >> 24) >= k0 ? at : dummy4;
+                                at = min(at, dummy4);
+                                atomicAdd(reinterpret_cast<u32 *>(accb + at), w | SPK_CNT);
+                            };
+                            if (sp.len == STEP) { // a full step: no tests at all
+                                if (k0 == 0u) {
+#pragma unroll
+                                    for (int u = 0; u < SPU; u++) one(pv[u], false);
+                                } else {
+#pragma unroll
+                                    for (int u = 0; u < SPU; u++) one(pv[u], true);
+                                }
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < SPU; u++)
+                                    if ((u32)u * 64u < sp.len) one(pv[u], true);
+                                // every path consumes the whole register set: a load still in flight into a register the next
+                                // iteration reuses would make the loop head wait for ALL loads, the prefetched step's included
+                                asm volatile("" ::"v"(pv[SPU - 1]));
+                            }
+                        } else {
+                            bool zero_any = false;
+#pragma unroll
+                            for (int u = 0; u < SPU; u++) {
+                                const u32 rel = pv[u] - d1, key = rel >> 24, slot = rel & 0xFFFFFFu;
+                                const bool ok = slot < STILE && key >= k0;
+                                const u32 w = __umul24(qq, key);
+                                atomicAdd(reinterpret_cast<u32 *>(accb + (ok ? slot * 4u : dummy4)), ok ? w : 0u);
+                                zero_any |= ok && w == 0u;
+                            }
+                            if (__any(zero_any)) {
+#pragma unroll
+                                for (int u = 0; u < SPU; u++) {
+                                    const u32 rel = pv[u] - d1, key = rel >> 24, slot = rel & 0xFFFFFFu;
+                                    if (slot < STILE && key >= k0 && qq * key == 0u) atomicOr(&zflag[slot >> 5], 1u << (slot & 31u));
+                                }
+                            }
+                        }
+                    };
+                    // Two steps per iteration, no exit in the middle: a step behind the last one has length 0 — eight out-of-range loads,
+                    // no memory traffic, nothing applied.  Every fetch is issued and every register set consumed on every path, so the
+                    // wait for the older step's postings always leaves exactly the newer step's eight loads in flight (a load that
+                    // some path leaves pending makes the loop head wait for ALL loads, the prefetched step's included).
+                    u32 pa[SPU], pb[SPU];
+                    Step sa = locate(pull()), sb;
+                    fetch_p(sa, pa);
+                    while (sa.valid) { // ping-pong between the two register sets
+                        sb = locate(pull());
+                        fetch_p(sb, pb);
+                        apply_p(sa, pa);
+                        sa = locate(pull());
+                        fetch_p(sa, pa);
+                        apply_p(sb, pb);
+                    }
+                }
+                if (tw0 + TW < nt) continue; // more term windows of this tile to come (TB == 1 then)
+                __syncthreads();             // every wave's adds to the tile are done
+                // flush: wave w scans slots [w * 2048, (w + 1) * 2048) of the tile into its pool and clears them
+                if (COUNTED) {
+                    for (u32 s0 = (u32)wave * (STILE / 4); s0 < (u32)(wave + 1) * (STILE / 4); s0 += 256) {
+                        const u32 slot = s0 + (u32)lane * 4u;
+                        const uint4 a4 = *reinterpret_cast<const uint4 *>(&acc[slot]);
+                        *reinterpret_cast<uint4 *>(&acc[slot]) = make_uint4(0u, 0u, 0u, 0u);
+                        const u32 thr_hi = (u32)(thr >> 32);
+                        const u32 a[4] = {a4.x, a4.y, a4.z, a4.w};
+                        bool c[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) c[j] = a[j] != 0u && (a[j] & SPK_SUM) + 1u >= thr_hi;
+                        if (__any(c[0] | c[1] | c[2] | c[3])) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) insert_keys(c[j] ? ((u64)((a[j] & SPK_SUM) + 1u) << 32 | (u64)(d0 + slot + (u32)j)) : 0ull);
+                        }
+                    }
+                } else {
+                    for (u32 s0 = (u32)wave * (STILE / 4); s0 < (u32)(wave + 1) * (STILE / 4); s0 += 64) {
+                        const u32 slot = s0 + (u32)lane;
+                        const u32 a = acc[slot];
+                        const u32 fw = zflag[slot >> 5];
+                        acc[slot] = 0u;
+                        const bool reached = a != 0u || ((fw >> (slot & 31u)) & 1u);
+                        insert_keys(reached ? (((u64)a + 1ull) << 32 | (u64)(d0 + slot)) : 0ull);
+                    }
+                    zflag[(u32)wave * (STILE / 128) + (u32)lane] = 0u; // the flag words of this wave's own slots (nobody else reads them)
+                }
+                // (the next group's barrier orders the cleared slots before the next tile's first add)
+            }
+        }
+    }
+    wpool[wave][lane] = pool.e[0];
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 4; w++) insert_keys(wpool[w][lane]);
+        out[lane] = pool.e[0];
+    }
+}
+
+// grid / blocks / pools as sparse_tile_kernel; order[i] = query | SPK_COUNTED
+__global__ __launch_bounds__(256) void sparse_packed_kernel(const u32 *__restrict__ m_pk, const STerm *__restrict__ terms, const u32 *__restrict__ qt_off, u32 n,
+                                                            const u32 *__restrict__ tile_dir, const u32 *__restrict__ order, u32 splits,
+                                                            u64 *__restrict__ part /*[B][splits][64]*/) {
+    __shared__ __attribute__((aligned(16))) u32 acc[STILE + 64];
+    __shared__ u32 zflag[STILE / 32];
+    __shared__ u64 wpool[4][SEL];
+    __shared__ u64 sl_b[SLICES];
+    __shared__ u32 sl_n[SLICES], sl_w[SLICES];
+    __shared__ u32 st_pre[65];
+    __shared__ u32 st_ctr;
+    const u32 oq = order[blockIdx.x / splits];
+    const u32 q = oq & ~SPK_COUNTED;
+    const u32 split = blockIdx.x % splits;
+    const u32 t0 = qt_off[q], nt = qt_off[q + 1] - t0;
+    const u32 n_tiles = (n + STILE - 1) / STILE;
+    u64 *out = part + ((u64)q * splits + split) * SEL;
+    if (nt == 0 || split >= n_tiles) { // nothing to visit: an empty pool (the finish kernel reads every split)
+        if (threadIdx.x < SEL) out[threadIdx.x] = 0ull;
+        return;
+    }
+    if (oq & SPK_COUNTED) sparse_packed_body<true>(m_pk, terms + t0, nt, n_tiles, tile_dir, split, splits, out, acc, zflag, wpool, sl_b, sl_n, sl_w, st_pre, &st_ctr);
+    else sparse_packed_body<false>(m_pk, terms + t0, nt, n_tiles, tile_dir, split, splits, out, acc, zflag, wpool, sl_b, sl_n, sl_w, st_pre, &st_ctr);
+}
+
 // one wave per query: merge the segment pools, optional raw-value rerank, write the top k
 __global__ __launch_bounds__(64) void sparse_finish_kernel(const SparseDev ix, const u64 *__restrict__ part, u32 S, const u32 *__restrict__ q_dims,
                                                            const float *__restrict__ q_vals, const u32 *__restrict__ q_off, u32 top_k, u32 k_with_reranking,
@@ -446,9 +701,12 @@ struct cos_sparse {
     std::vector<u32> h_dims;    // [T] ascending
     std::vector<u64> h_key_off; // [T][Q + 1] (the caller's CSR offsets: list begin/end and the postings a term visits from key k0 on)
     std::vector<u32> h_dir;     // [T] row in the tile directory or SNO_DIR
+    std::vector<u32> h_mult;    // [T] how often one vector id occurs in the dimension's list at most (1 unless the caller's CSR repeats ids)
+    bool packed = false;        // device layout: one u32 per posting (d_pk) instead of d_ids + d_keys
     // device: one id-sorted list per dimension (same offsets as the caller's CSR: list t = [key_off[t][0], key_off[t][Q]))
     u32 *d_ids = nullptr;
     uint8_t *d_keys = nullptr;
+    u32 *d_pk = nullptr; // packed layout: key << 24 | (vector id + 1)
     u32 *d_tile_dir = nullptr; // [rows][n_tiles + 1], offsets relative to the list's begin
     u32 *d_raw_dims = nullptr;
     u64 *d_row_off = nullptr;
@@ -475,7 +733,7 @@ static hipError_t sparse_grow(cos_sparse::Buf &b, size_t need) {
 extern "C" int32_t cos_sparse_destroy(cos_sparse *s) {
     if (!s) return COS_OK;
     (void)hipSetDevice(s->device);
-    void *ptrs[] = {s->d_ids, s->d_keys, s->d_tile_dir, s->d_raw_dims, s->d_row_off, s->d_raw_vals, s->w_qd.p, s->w_qv.p, s->w_qo.p,
+    void *ptrs[] = {s->d_ids, s->d_keys, s->d_pk, s->d_tile_dir, s->d_raw_dims, s->d_row_off, s->d_raw_vals, s->w_qd.p, s->w_qv.p, s->w_qo.p,
                     s->w_terms.p, s->w_qt_off.p, s->w_order.p, s->w_part.p, s->w_oi.p, s->w_os.p, s->w_oc.p};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -517,6 +775,10 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
     std::vector<uint8_t> m_keys((size_t)nnz + PAD, 0);
     std::vector<u32> tile_dir;
     s->h_dir.assign(n_dims, SNO_DIR);
+    s->h_mult.assign(n_dims, 1u);
+    // COS_SPARSE_PACKED=1: the one-word-per-posting layout and its kernel (sparse_packed_kernel); vector ids must fit 24 bits
+    const char *pk_env = getenv("COS_SPARSE_PACKED");
+    s->packed = pk_env && atoi(pk_env) != 0 && n_vectors <= SPK_MAX_N;
     std::vector<u64> tmp;
     u32 rows = 0;
     const u32 nt1 = s->n_tiles + 1;
@@ -528,6 +790,12 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
             for (u64 p = ko[k]; p < ko[k + 1]; p++) tmp.push_back((u64)vec_ids[p] << 8 | k);
         std::sort(tmp.begin(), tmp.end());
         for (u64 p = b; p < e; p++) { m_ids[p] = (u32)(tmp[p - b] >> 8); m_keys[p] = (uint8_t)(tmp[p - b] & 255u); }
+        u32 run = 0, mult = 1;
+        for (u64 p = b; p < e; p++) {
+            run = p > b && m_ids[p] == m_ids[p - 1] ? run + 1 : 1;
+            mult = std::max(mult, run);
+        }
+        s->h_mult[t] = mult;
         if (e - b > SDIR_MIN) {
             if (e - b > 0xFFFFFFFFull) { cos_sparse_destroy(s); return cos_fail(COS_ERR_UNIMPLEMENTED, "dimension %u holds more than 2^32 postings", dims[t]); }
             s->h_dir[t] = rows++;
@@ -545,8 +813,15 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
         hipError_t e = hipMalloc(dst, bytes ? bytes : 1);
         return e == hipSuccess && bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : e;
     };
-    hipError_t e = up((void **)&s->d_ids, m_ids.data(), m_ids.size() * 4);
-    if (e == hipSuccess) e = up((void **)&s->d_keys, m_keys.data(), m_keys.size());
+    hipError_t e = hipSuccess;
+    if (s->packed) {
+        std::vector<u32> m_pk((size_t)nnz + 1, 0u);
+        for (u64 p = 0; p < nnz; p++) m_pk[p] = (u32)m_keys[p] << 24 | (m_ids[p] + 1u);
+        e = up((void **)&s->d_pk, m_pk.data(), m_pk.size() * 4);
+    } else {
+        e = up((void **)&s->d_ids, m_ids.data(), m_ids.size() * 4);
+        if (e == hipSuccess) e = up((void **)&s->d_keys, m_keys.data(), m_keys.size());
+    }
     if (e == hipSuccess) e = up((void **)&s->d_tile_dir, tile_dir.data(), tile_dir.size() * 4);
     if (e == hipSuccess && row_offsets) {
         const u64 rnnz = row_offsets[n_vectors];
@@ -644,6 +919,7 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
                                            float early_terminate_threshold, uint32_t reranking_factor, uint32_t *out_ids, float *out_scores,
                                            uint32_t *out_counts) {
     if (!s || !q_dims || !q_vals || !q_offsets || !out_ids || !out_scores || !out_counts || B == 0 || top_k == 0) return cos_fail(COS_ERR_INVALID, "bad argument");
+    if (B >= SPK_COUNTED) return cos_fail(COS_ERR_INVALID, "batch of %u queries", B);
     const bool rerank = reranking_factor != 0;
     if (rerank && !s->have_raw) return cos_fail(COS_ERR_NOT_READY, "raw-value rerank needs the raw sparse vectors (cos_sparse_create row_offsets / raw_dims / raw_vals)");
     const u32 kwr = top_k * (rerank ? reranking_factor : 1u);
@@ -661,8 +937,10 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     terms.reserve(nq);
     std::vector<u32> qt_off(B + 1, 0), order(B);
     std::vector<u64> weight(B, 0);
+    std::vector<uint8_t> counted(B, 0);
     u64 visited = 0;
     for (u32 b = 0; b < B; b++) {
+        u64 sum_bound = 0, touch_bound = 0; // packed layout: may this query's blocks count touches next to the sum (sparse_packed_body)?
         for (u32 i = q_offsets[b]; i < q_offsets[b + 1]; i++) {
             auto it = std::lower_bound(s->h_dims.begin(), s->h_dims.end(), q_dims[i]);
             if (it == s->h_dims.end() || *it != q_dims[i]) continue;
@@ -675,11 +953,17 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
             terms.push_back(STerm{ko[0], ko[Q], s->h_dir[t], qq | k0 << 8});
             weight[b] += ko[Q] - ko[0];
             visited += ko[Q] - ko[k0];
+            sum_bound += (u64)s->h_mult[t] * qq * (Q - 1u);
+            touch_bound += s->h_mult[t];
         }
+        counted[b] = sum_bound < SPK_CNT && touch_bound <= 1023u;
         qt_off[b + 1] = (u32)terms.size();
     }
     for (u32 b = 0; b < B; b++) order[b] = b;
     std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 c) { return weight[a] > weight[c]; }); // heaviest query first
+    if (s->packed)
+        for (u32 b = 0; b < B; b++)
+            if (counted[order[b]]) order[b] |= SPK_COUNTED;
     // blocks: enough to fill the chip several times over, at most one per tile
     const u32 splits = std::max<u32>(1u, std::min<u32>(s->n_tiles, (4096u + B - 1) / B));
     std::lock_guard<std::mutex> guard(s->mu);
@@ -703,8 +987,12 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     HIP_TRY(hipMemcpy(d_order.p, order.data(), (size_t)B * 4, hipMemcpyHostToDevice));
     SparseDev dev{nullptr, nullptr, nullptr, s->d_row_off, s->d_raw_dims, s->d_raw_vals, s->T, Q, s->n, s->bits, s->upper};
     HIP_TRY(hipEventRecord(s->ev0, 0));
-    hipLaunchKernelGGL(sparse_tile_kernel, dim3(B * splits), dim3(256), 0, 0, s->d_ids, s->d_keys, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,
-                       d_order.as<u32>(), splits, d_part.as<u64>());
+    if (s->packed)
+        hipLaunchKernelGGL(sparse_packed_kernel, dim3(B * splits), dim3(256), 0, 0, s->d_pk, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,
+                           d_order.as<u32>(), splits, d_part.as<u64>());
+    else
+        hipLaunchKernelGGL(sparse_tile_kernel, dim3(B * splits), dim3(256), 0, 0, s->d_ids, s->d_keys, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,
+                           d_order.as<u32>(), splits, d_part.as<u64>());
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(sparse_finish_kernel, dim3(B), dim3(64), 0, 0, dev, d_part.as<u64>(), splits, d_qd.as<u32>(), d_qv.as<float>(), d_qo.as<u32>(), top_k, kwr,
                        rerank ? 1 : 0, d_oi.as<u32>(), d_os.as<float>(), d_oc.as<u32>());
@@ -719,6 +1007,12 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     s->last.postings_visited = visited;
     s->last.posting_bytes = visited * 4;
     s->last.blocks = B * splits;
+    return COS_OK;
+}
+
+extern "C" int32_t cos_sparse_layout(cos_sparse *s, uint32_t *packed) {
+    if (!s || !packed) return cos_fail(COS_ERR_INVALID, "null argument");
+    *packed = s->packed ? 1u : 0u;
     return COS_OK;
 }
 

@@ -154,6 +154,16 @@ def _sparse_last_stats(self):
 InvertedIndex.last_stats = _sparse_last_stats
 
 
+def _sparse_packed(self) -> bool:
+    """True when the handle keeps one packed u32 per posting (cos_sparse_layout; COS_SPARSE_PACKED=1 at creation)"""
+    v = C.c_uint32(0)
+    check(_lib.lib().cos_sparse_layout(self._h, C.byref(v)))
+    return bool(v.value)
+
+
+InvertedIndex.packed = property(_sparse_packed)
+
+
 def sparse_build_csr(quantization_bits: int, values_upper_bound: float, row_offsets, raw_dims, raw_vals):
     """cos_sparse_build_csr (host code, no device): raw sparse vectors in id order -> (dims, key_offsets, vec_ids)"""
     ro, rd, rv = _c(row_offsets, np.uint64), _c(raw_dims, np.uint32), _c(raw_vals, np.float32)

@@ -436,6 +436,10 @@ typedef struct cos_sparse_stats {
     uint64_t posting_bytes;
 } cos_sparse_stats;
 int32_t cos_sparse_last_stats(cos_sparse *s, cos_sparse_stats *out);
+/* Device layout of the handle's postings: 0 = a u32 id + a u8 key per posting (5 B), 1 = one packed u32 per posting
+ * (key << 24 | id + 1; chosen at cos_sparse_create when COS_SPARSE_PACKED=1 is set in the environment and the collection holds
+ * fewer than 2^24 - 16384 vectors).  Same results either way; a tuning choice, not a reference interface. */
+int32_t cos_sparse_layout(cos_sparse *s, uint32_t *packed);
 
 /* ---- multi-GPU helper ----------------------------------------------------------------------- */
 /* S-way merge of per-shard top-k lists gathered by the caller's RCCL all-gather

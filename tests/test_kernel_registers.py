@@ -52,3 +52,46 @@ def test_walk_and_finalize_kernels_keep_their_occupancy(tmp_path):
     assert exact["vgpr_count"] <= 80
     fin = _find(ks, "finalize_fast_kernel")
     assert fin["vgpr_count"] <= 72 and fin["private_segment_fixed_size"] == 0        # 7 waves per SIMD (the general kernel: 121 VGPRs = 4)
+
+
+def _disassembly(obj, tmp_path, symbol_part):
+    src = os.path.join(ROOT, "cosdata_amd", "csrc", obj)
+    if not os.path.exists(src) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("built objects / llvm tools not present")
+    work = str(tmp_path)
+    shutil.copy(src, work)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", obj], cwd=work, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dev = [f for f in os.listdir(work) if "amdgcn" in f and "gfx950" in f]
+    text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", dev[0]], cwd=work, check=True, capture_output=True, text=True).stdout
+    body, on = [], False
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            on = symbol_part in m.group(1)
+            continue
+        if on:
+            ins = line.split("//")[0].strip()
+            if ins:
+                body.append(ins)
+    assert body, symbol_part
+    return body
+
+
+def test_packed_sparse_kernel_instruction_budget(tmp_path):
+    """the packed posting layout exists to cut the instructions a posting costs: 60 VGPRs, nothing in scratch, and a
+    full step's eight postings apply with at most six vector instructions between two LDS adds (subtract, two 24-bit multiplies,
+    min, or — plus a compare and a select in the variant with a first visited key), none of them the quarter-rate 32-bit multiply"""
+    ks = _kernels("kernels_sparse.o", tmp_path)
+    pk = _find(ks, "sparse_packed_kernel")
+    assert pk["vgpr_count"] <= 64 and pk["private_segment_fixed_size"] == 0
+    body = _disassembly("kernels_sparse.o", tmp_path, "sparse_packed_kernel")
+    adds = [i for i, ins in enumerate(body) if ins.startswith("ds_add_u32")]
+    best = None
+    for a in range(len(adds) - 7):                               # eight consecutive adds with no branch in between = one full step
+        seg = body[adds[a]:adds[a + 7] + 1]
+        if any(x.startswith(("s_cbranch", "s_branch")) for x in seg):
+            continue
+        valu = sum(1 for x in seg if x.startswith("v_"))
+        best = valu if best is None else min(best, valu)
+        assert not any(x.startswith("v_mul_lo_u32") for x in seg)
+    assert best is not None and best <= 7 * 6, best               # seven gaps between eight adds
