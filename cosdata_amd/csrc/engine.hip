@@ -783,18 +783,33 @@ static int32_t ensure_level_table(cos_index *ix) {
     }
     if (lmin == 0) return COS_OK;
     HIP_TRY(hipDeviceSynchronize()); // a build or an upload on another stream may still be writing the levels
-    HIP_TRY(hipMalloc((void **)&ix->d_tcodes, (size_t)cols * ix->row_stride));
-    HIP_TRY(hipMalloc((void **)&ix->d_tmags, (size_t)cols * 4));
-    HIP_TRY(hipMalloc((void **)&ix->d_tcsums, (size_t)cols * 4));
-    u32 c0 = 0;
-    for (u32 l = Ltop; l >= lmin; l--) {
-        ix->table_col0[l] = c0;
-        HIP_TRY(cosdev::launch_level_table_gather(ix->d_codes, ix->d_mags, ix->row_stride, ix->lv[l].d_node_vec, ix->lv[l].n, c0, ix->d_tcodes,
-                                                  ix->d_tmags, nullptr));
-        c0 += ix->lv[l].n;
+    uint8_t *tcodes = nullptr;
+    float *tmags = nullptr;
+    u32 *tcsums = nullptr;
+    auto build = [&]() -> hipError_t { // (a failure leaves the handle without a table for this key — same results — and frees what it had allocated)
+        hipError_t e = hipMalloc((void **)&tcodes, (size_t)cols * ix->row_stride);
+        if (e == hipSuccess) e = hipMalloc((void **)&tmags, (size_t)cols * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&tcsums, (size_t)cols * 4);
+        u32 c0 = 0;
+        for (u32 l = Ltop; l >= lmin && e == hipSuccess; l--) {
+            ix->table_col0[l] = c0;
+            e = cosdev::launch_level_table_gather(ix->d_codes, ix->d_mags, ix->row_stride, ix->lv[l].d_node_vec, ix->lv[l].n, c0, tcodes, tmags, nullptr);
+            c0 += ix->lv[l].n;
+        }
+        if (e == hipSuccess) e = cosdev::launch_code_sums(tcodes, ix->row_stride, cols, tcsums, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        return e;
+    };
+    if (const hipError_t e = build(); e != hipSuccess) {
+        (void)hipDeviceSynchronize();
+        if (tcodes) (void)hipFree(tcodes);
+        if (tmags) (void)hipFree(tmags);
+        if (tcsums) (void)hipFree(tcsums);
+        HIP_TRY(e);
     }
-    HIP_TRY(cosdev::launch_code_sums(ix->d_tcodes, ix->row_stride, cols, ix->d_tcsums, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
+    ix->d_tcodes = tcodes;
+    ix->d_tmags = tmags;
+    ix->d_tcsums = tcsums;
     ix->table_cols = cols;
     ix->table_level_min = lmin;
     ix->table_stride = ((u64)cols + 31) / 32 * 32;

@@ -398,12 +398,12 @@ constexpr u32 SPK_SUM = SPK_CNT - 1u;
 constexpr u32 SPK_MAX_N = (1u << 24) - 2u * STILE;
 constexpr u32 SPK_COUNTED = 0x80000000u; // bit of order[]: this query's blocks may count touches in the accumulator
 
-template <bool COUNTED>
+template <bool COUNTED, int PU /* postings per lane per step */>
 __device__ __forceinline__ void sparse_packed_body(const u32 *__restrict__ m_pk, const STerm *__restrict__ qt, const u32 nt, const u32 n_tiles,
                                                    const u32 *__restrict__ tile_dir, const u32 split, const u32 splits, u64 *__restrict__ out, u32 *acc,
                                                    u32 *zflag, u64 (*wpool)[SEL], u64 *sl_b, u32 *sl_n, u32 *sl_w, u32 *st_pre, u32 *st_ctr) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    constexpr u32 STEP = 64u * SPU;
+    constexpr u32 STEP = 64u * PU;
     for (u32 i = threadIdx.x; i < STILE / 4; i += blockDim.x) reinterpret_cast<uint4 *>(acc)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (!COUNTED)
         for (u32 i = threadIdx.x; i < STILE / 32; i += blockDim.x) zflag[i] = 0u;
@@ -494,15 +494,15 @@ __device__ __forceinline__ void sparse_packed_body(const u32 *__restrict__ m_pk,
                         }
                         return sp;
                     };
-                    auto fetch_p = [&](const Step &sp, u32 (&pv)[SPU]) {
+                    auto fetch_p = [&](const Step &sp, u32 (&pv)[PU]) {
                         const u32 *bp = m_pk + ((u64)sp.base_hi << 32 | sp.base_lo);
                         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)bp, (short)0, (int)(sp.len * 4u), 0x00020000);
 #pragma unroll
-                        for (int u = 0; u < SPU; u++) pv[u] = (u32)__builtin_amdgcn_raw_buffer_load_b32(rsrc, ((u32)lane + (u32)u * 64u) * 4u, 0, 0);
+                        for (int u = 0; u < PU; u++) pv[u] = (u32)__builtin_amdgcn_raw_buffer_load_b32(rsrc, ((u32)lane + (u32)u * 64u) * 4u, 0, 0);
                     };
                     // a posting: slot = its id relative to the tile (other tiles' postings and the zeros past the step's end wrap to >=
                     // STILE and fall on the lane's dummy slot behind the tile through the min), weight = qq * key
-                    auto apply_p = [&](const Step &sp, const u32 (&pv)[SPU]) {
+                    auto apply_p = [&](const Step &sp, const u32 (&pv)[PU]) {
                         const u32 qq = sp.w & 255u, k0 = sp.w >> 8;
                         if (COUNTED) {
                             auto one = [&](u32 p, bool keyed) {
@@ -519,23 +519,23 @@ __device__ __forceinline__ void sparse_packed_body(const u32 *__restrict__ m_pk,
                             if (sp.len == STEP) { // a full step: no tests at all
                                 if (k0 == 0u) {
 #pragma unroll
-                                    for (int u = 0; u < SPU; u++) one(pv[u], false);
+                                    for (int u = 0; u < PU; u++) one(pv[u], false);
                                 } else {
 #pragma unroll
-                                    for (int u = 0; u < SPU; u++) one(pv[u], true);
+                                    for (int u = 0; u < PU; u++) one(pv[u], true);
                                 }
                             } else {
 #pragma unroll
-                                for (int u = 0; u < SPU; u++)
+                                for (int u = 0; u < PU; u++)
                                     if ((u32)u * 64u < sp.len) one(pv[u], true);
                                 // every path consumes the whole register set: a load still in flight into a register the next
                                 // iteration reuses would make the loop head wait for ALL loads, the prefetched step's included
-                                asm volatile("" ::"v"(pv[SPU - 1]));
+                                asm volatile("" ::"v"(pv[PU - 1]));
                             }
                         } else {
                             bool zero_any = false;
 #pragma unroll
-                            for (int u = 0; u < SPU; u++) {
+                            for (int u = 0; u < PU; u++) {
                                 const u32 rel = pv[u] - d1, key = rel >> 24, slot = rel & 0xFFFFFFu;
                                 const bool ok = slot < STILE && key >= k0;
                                 const u32 w = __umul24(qq, key);
@@ -544,7 +544,7 @@ __device__ __forceinline__ void sparse_packed_body(const u32 *__restrict__ m_pk,
                             }
                             if (__any(zero_any)) {
 #pragma unroll
-                                for (int u = 0; u < SPU; u++) {
+                                for (int u = 0; u < PU; u++) {
                                     const u32 rel = pv[u] - d1, key = rel >> 24, slot = rel & 0xFFFFFFu;
                                     if (slot < STILE && key >= k0 && qq * key == 0u) atomicOr(&zflag[slot >> 5], 1u << (slot & 31u));
                                 }
@@ -555,7 +555,7 @@ __device__ __forceinline__ void sparse_packed_body(const u32 *__restrict__ m_pk,
                     // no memory traffic, nothing applied.  Every fetch is issued and every register set consumed on every path, so the
                     // wait for the older step's postings always leaves exactly the newer step's eight loads in flight (a load that
                     // some path leaves pending makes the loop head wait for ALL loads, the prefetched step's included).
-                    u32 pa[SPU], pb[SPU];
+                    u32 pa[PU], pb[PU];
                     Step sa = locate(pull()), sb;
                     fetch_p(sa, pa);
                     while (sa.valid) { // ping-pong between the two register sets
@@ -609,6 +609,7 @@ __device__ __forceinline__ void sparse_packed_body(const u32 *__restrict__ m_pk,
 }
 
 // grid / blocks / pools as sparse_tile_kernel; order[i] = query | SPK_COUNTED
+template <int PU>
 __global__ __launch_bounds__(256) void sparse_packed_kernel(const u32 *__restrict__ m_pk, const STerm *__restrict__ terms, const u32 *__restrict__ qt_off, u32 n,
                                                             const u32 *__restrict__ tile_dir, const u32 *__restrict__ order, u32 splits,
                                                             u64 *__restrict__ part /*[B][splits][64]*/) {
@@ -629,8 +630,8 @@ __global__ __launch_bounds__(256) void sparse_packed_kernel(const u32 *__restric
         if (threadIdx.x < SEL) out[threadIdx.x] = 0ull;
         return;
     }
-    if (oq & SPK_COUNTED) sparse_packed_body<true>(m_pk, terms + t0, nt, n_tiles, tile_dir, split, splits, out, acc, zflag, wpool, sl_b, sl_n, sl_w, st_pre, &st_ctr);
-    else sparse_packed_body<false>(m_pk, terms + t0, nt, n_tiles, tile_dir, split, splits, out, acc, zflag, wpool, sl_b, sl_n, sl_w, st_pre, &st_ctr);
+    if (oq & SPK_COUNTED) sparse_packed_body<true, PU>(m_pk, terms + t0, nt, n_tiles, tile_dir, split, splits, out, acc, zflag, wpool, sl_b, sl_n, sl_w, st_pre, &st_ctr);
+    else sparse_packed_body<false, PU>(m_pk, terms + t0, nt, n_tiles, tile_dir, split, splits, out, acc, zflag, wpool, sl_b, sl_n, sl_w, st_pre, &st_ctr);
 }
 
 // one wave per query: merge the segment pools, optional raw-value rerank, write the top k
@@ -987,8 +988,12 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     HIP_TRY(hipMemcpy(d_order.p, order.data(), (size_t)B * 4, hipMemcpyHostToDevice));
     SparseDev dev{nullptr, nullptr, nullptr, s->d_row_off, s->d_raw_dims, s->d_raw_vals, s->T, Q, s->n, s->bits, s->upper};
     HIP_TRY(hipEventRecord(s->ev0, 0));
-    if (s->packed)
-        hipLaunchKernelGGL(sparse_packed_kernel, dim3(B * splits), dim3(256), 0, 0, s->d_pk, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,
+    static const int packed_pu = [] { const char *e = getenv("COS_SPARSE_SPU"); return e && atoi(e) == 16 ? 16 : 8; }(); // postings per lane per step
+    if (s->packed && packed_pu == 16)
+        hipLaunchKernelGGL(sparse_packed_kernel<16>, dim3(B * splits), dim3(256), 0, 0, s->d_pk, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,
+                           d_order.as<u32>(), splits, d_part.as<u64>());
+    else if (s->packed)
+        hipLaunchKernelGGL(sparse_packed_kernel<8>, dim3(B * splits), dim3(256), 0, 0, s->d_pk, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,
                            d_order.as<u32>(), splits, d_part.as<u64>());
     else
         hipLaunchKernelGGL(sparse_tile_kernel, dim3(B * splits), dim3(256), 0, 0, s->d_ids, s->d_keys, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,

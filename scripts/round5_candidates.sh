@@ -1,0 +1,24 @@
+#!/bin/bash
+# First GPU call of the next round: the candidates written at the end of round 4 without a device at hand (each is OFF by default,
+# each has its parity tests behind COS_CANDIDATES=1).  Run from the repo root; results land in gpurun_out/.
+#   1. learned-sparse index, packed posting layout (kernels_sparse.hip sparse_packed_kernel):
+#      parity tests, then scripts/bench_sparse.py with the unpacked layout, the packed one, and the packed one with 16 postings per
+#      lane and step — kernel time, fraction of the HBM roof, parity 256 / 256 each.
+# If the packed layout is green and faster: make it the default in cos_sparse_create (COS_SPARSE_PACKED unset -> packed when the
+# collection fits 24-bit ids), drop the `candidates` mark from tests/test_sparse.py, re-run scripts/bench_sparse.py under
+# rocprofv3 (kernel trace + SQ_INSTS_VALU) for profiles/.
+R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
+COS_CANDIDATES=1 timeout 600 python -m pytest tests/test_sparse.py -m gpu -q > $OUT/cand_sparse_pytest.log 2>&1; echo "sparse candidates pytest rc=$?"; tail -3 $OUT/cand_sparse_pytest.log
+timeout 300 python scripts/bench_sparse.py > $OUT/cand_sparse_unpacked.json 2> $OUT/cand_sparse_unpacked.err; echo "unpacked rc=$?"
+COS_SPARSE_PACKED=1 timeout 300 python scripts/bench_sparse.py > $OUT/cand_sparse_packed.json 2> $OUT/cand_sparse_packed.err; echo "packed rc=$?"
+COS_SPARSE_PACKED=1 COS_SPARSE_SPU=16 timeout 300 python scripts/bench_sparse.py > $OUT/cand_sparse_packed_spu16.json 2> $OUT/cand_sparse_packed_spu16.err; echo "packed spu16 rc=$?"
+python - <<'PY'
+import json
+for f in ("unpacked", "packed", "packed_spu16"):
+    try:
+        r = json.load(open(f"gpurun_out/cand_sparse_{f}.json"))
+        print(f, "kernel_ms", round(r["roofline"]["per_launch"]["avg_ms"], 3), "frac", round(r["roofline"]["frac"], 3), "host_ms", round(r["ms_per_batch_host_api"], 3),
+              "parity", r["parity_vs_oracle"])
+    except Exception as e:
+        print(f, "failed:", e)
+PY

@@ -82,9 +82,11 @@ def test_packed_sparse_kernel_instruction_budget(tmp_path):
     full step's eight postings apply with at most six vector instructions between two LDS adds (subtract, two 24-bit multiplies,
     min, or — plus a compare and a select in the variant with a first visited key), none of them the quarter-rate 32-bit multiply"""
     ks = _kernels("kernels_sparse.o", tmp_path)
-    pk = _find(ks, "sparse_packed_kernel")
+    pk = _find(ks, "sparse_packed_kernel<8>")
     assert pk["vgpr_count"] <= 64 and pk["private_segment_fixed_size"] == 0
-    body = _disassembly("kernels_sparse.o", tmp_path, "sparse_packed_kernel")
+    pk16 = _find(ks, "sparse_packed_kernel<16>")                 # sixteen postings per lane and step (COS_SPARSE_SPU=16): LDS already limits a SIMD to 4 waves
+    assert pk16["vgpr_count"] <= 128 and pk16["private_segment_fixed_size"] == 0
+    body = _disassembly("kernels_sparse.o", tmp_path, "sparse_packed_kernelILi8E")
     adds = [i for i, ins in enumerate(body) if ins.startswith("ds_add_u32")]
     best = None
     for a in range(len(adds) - 7):                               # eight consecutive adds with no branch in between = one full step
