@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "host_stage.h"
 
 using namespace cosdev;
 
@@ -229,6 +230,7 @@ static void reset_meta(cos_index *ix) {
 static void free_pipe(HostPipe *hp) {
     void *ptrs[] = {hp->d_q, hp->d_ids, hp->d_counts, hp->d_scores, hp->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (hp->pin_q) (void)hipHostFree(hp->pin_q);
     for (hipEvent_t e : hp->ev_in) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : hp->ev_walk) if (e) (void)hipEventDestroy(e);
     hipStream_t sts[] = {hp->s[0], hp->s[1], hp->sc, hp->sf};
@@ -1214,9 +1216,29 @@ static int32_t search_host_simple(cos_index *ix, HostPipe *hp, const float *quer
 // next one fills the wave slots the previous one drains; they are not put in the walk chain).  Results are those of one
 // launch: queries are independent.  When other host calls are in flight the same overlap already happens ACROSS calls (their
 // copies hide under this call's chained walk), and whole-batch launches are the better shape — then the simple path is used.
+// COS_HOST_STAGE_THREADS=n (n >= 1; unset or 0 = off, the default until it has been measured): the chunks of a pipelined host call are
+// copied into the pipe's pinned buffer by n helper threads + the caller (host_stage.h) and travel from there, instead of one pageable
+// hipMemcpyAsync per chunk staged by the runtime on the calling thread.  One pool per process, started on first use.
+static cosdev::StagePool *stage_pool() {
+    static cosdev::StagePool *pool = []() -> cosdev::StagePool * {
+        const char *e = getenv("COS_HOST_STAGE_THREADS");
+        const long n = e ? strtol(e, nullptr, 10) : 0;
+        return n >= 1 ? new cosdev::StagePool((unsigned)std::min<long>(n, 32)) : nullptr; // lives as long as the process
+    }();
+    return pool;
+}
+
 static int32_t search_host_pipelined(cos_index *ix, HostPipe *hp, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
                                      float *out_scores, uint32_t *out_counts, int32_t *out_status) {
     const size_t dim = ix->p.dim;
+    cosdev::StagePool *stage = stage_pool();
+    if (stage && hp->cap_pin < (size_t)B * dim) { // (the pipe is leased: nothing of an earlier call still reads the old buffer)
+        if (hp->pin_q) (void)hipHostFree(hp->pin_q);
+        hp->pin_q = nullptr;
+        hp->cap_pin = 0;
+        if (hipHostMalloc((void **)&hp->pin_q, (size_t)B * dim * 4, hipHostMallocDefault) == hipSuccess) hp->cap_pin = (size_t)B * dim;
+        else { (void)hipGetLastError(); hp->pin_q = nullptr; stage = nullptr; } // no pinned memory to be had: the plain path
+    }
     const u32 chunk = (((B + HostPipe::MAX_CHUNKS - 1) / HostPipe::MAX_CHUNKS) + 255u) & ~255u;
     const u32 nch = (B + chunk - 1) / chunk;
     if (!hp->s[1]) HIP_TRY(hipStreamCreateWithFlags(&hp->s[1], hipStreamNonBlocking));
@@ -1249,7 +1271,12 @@ static int32_t search_host_pipelined(cos_index *ix, HostPipe *hp, const float *q
         int32_t rc = get_workspace(ix, (void *)&hp->wkey[i], st, cb, top_k, false, &w);
         if (rc) return rc;
         float *dq = hp->d_q + (size_t)c0 * dim;
-        HIP_TRY(hipMemcpyAsync(dq, queries + (size_t)c0 * dim, (size_t)cb * dim * 4, hipMemcpyHostToDevice, hp->sc));
+        const float *src = queries + (size_t)c0 * dim;
+        if (stage) { // chunk i is staged while chunk i-1 travels and walks
+            stage->copy(hp->pin_q + (size_t)c0 * dim, src, (size_t)cb * dim * 4);
+            src = hp->pin_q + (size_t)c0 * dim;
+        }
+        HIP_TRY(hipMemcpyAsync(dq, src, (size_t)cb * dim * 4, hipMemcpyHostToDevice, hp->sc));
         HIP_TRY(hipEventRecord(hp->ev_in[i], hp->sc));
         HIP_TRY(hipStreamWaitEvent(st, hp->ev_in[i], 0));
         rc = run_search(ix, w, dq, cb, top_k, hp->d_ids + (size_t)c0 * top_k, hp->d_scores + (size_t)c0 * top_k, hp->d_counts + c0, hp->d_status + c0,

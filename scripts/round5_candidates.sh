@@ -22,3 +22,10 @@ for f in ("unpacked", "packed", "packed_spu16"):
     except Exception as e:
         print(f, "failed:", e)
 PY
+#   2. host-buffer API, one synchronous caller of 32 768 queries: COS_HOST_STAGE_THREADS = helper threads that stage the call's chunks
+#      into pinned memory (engine.hip search_host_pipelined, host_stage.h).  Parity test, then scripts/host_api_sweep.py per setting.
+#      If >= 0.9 x the resident rate with some n: make that n the default (stage_pool()), rerun bench.py for host_api_pcie_inclusive.
+COS_CANDIDATES=1 timeout 900 python -m pytest tests/test_gpu_host_stage.py -m gpu -q > $OUT/cand_host_stage_pytest.log 2>&1; echo "host stage pytest rc=$?"; tail -3 $OUT/cand_host_stage_pytest.log
+for T in 0 2 4 8; do
+  COS_HOST_STAGE_THREADS=$T timeout 400 python scripts/host_api_sweep.py > $OUT/cand_host_stage_threads_$T.json 2> $OUT/cand_host_stage_threads_$T.err; echo "threads $T rc=$?"; head -c 700 $OUT/cand_host_stage_threads_$T.json; echo
+done
