@@ -1107,6 +1107,7 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     w->timed = timed;
     w->last_tab = tab_level_min != 0;
     w->last_tab_cols = tab_cols;
+    w->last_tab_level_min = tab_level_min;
     w->last_split = ordered;
     w->last_cut_level = ordered ? key_level[0] : 0u;
     { std::lock_guard<std::mutex> g(ix->mu); ix->last_ws = w; }
@@ -1600,7 +1601,7 @@ extern "C" int32_t cos_index_last_walk_split(cos_index *ix, void *stream, cos_wa
     }
     if (!w || w->lastB == 0) return cos_fail(COS_ERR_NOT_READY, "no batch has run on this stream");
     out->queries = w->lastB;
-    out->table_level_min = w->last_tab ? ix->table_level_min : 0u;
+    out->table_level_min = w->last_tab ? w->last_tab_level_min : 0u; // of THAT launch (the handle's may have moved on with ef_search)
     out->table_cols = w->last_tab ? w->last_tab_cols : 0u;
     out->cut_after_level = w->last_cut_level;
     if (w->timed && w->ev_count) {

@@ -133,7 +133,7 @@ struct Workspace {
     u32 lastB = 0;
     bool timed = false;
     bool last_tab = false, last_split = false; // the last launch used the level table / was cut into two level ranges
-    u32 last_tab_cols = 0, last_cut_level = 0;
+    u32 last_tab_cols = 0, last_tab_level_min = 0, last_cut_level = 0;
 };
 
 // The pseudo-root component of a collection with a metadata schema: pseudo nodes + Metadata replicas, a graph of
