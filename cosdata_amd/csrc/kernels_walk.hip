@@ -998,8 +998,13 @@ size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
 // rows in flight per wave on the G = 64 u8 path (see PB64 above); COS_WALK_PB=4|8 overrides the default (experiments).
 // The widest pool (ef > 256: 16 VGPRs of pool) with eight row buffers needs 110 VGPRs = 4 waves per SIMD; with four it fits 5 waves
 // without spills and measured 3.3 % faster (c2 at ef 512: 50.9 vs 52.6 ms per 32768 queries, profiles/r03_order_probe_c2_ef512_pb4.jsonl).
-static int walk_pb_policy(u32 B, u32 ef) {
+// COS_WALK_PB_UPPER=4|8 (experiments, unset = no effect): the variant of the UPPER range of a split walk only.  With the level table
+// that range is almost all table levels — a latency chain that fetches no rows (c2: 91 M table evaluations against 2 M row evaluations) —
+// and the four-buffer variant needs 53 VGPRs at ef <= 64 = 8 waves per SIMD where the eight-buffer one has 69 = 7.
+static int walk_pb_policy(u32 B, u32 ef, bool upper_range_of_a_split_walk) {
     static const int forced = [] { const char *e = getenv("COS_WALK_PB"); return e ? atoi(e) : 0; }();
+    static const int forced_upper = [] { const char *e = getenv("COS_WALK_PB_UPPER"); return e ? atoi(e) : 0; }();
+    if (upper_range_of_a_split_walk && (forced_upper == 4 || forced_upper == 8)) return forced_upper;
     if (forced == 4 || forced == 8) return forced;
     return ef > 256u ? 4 : 8;
 }
@@ -1010,7 +1015,7 @@ static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStrea
     dim3 grid(wa.B), block(64);
     const bool exact = ix.visited_mode != 0;
     constexpr bool HAS_PB8 = ENG == ENG_U8 && G64 && CH == 1; // the headline path (u8, 513..1024 dims)
-    const bool pb8 = HAS_PB8 && walk_pb_policy(wa.B, wa.ef) == 8;
+    const bool pb8 = HAS_PB8 && walk_pb_policy(wa.B, wa.ef, wa.phase != 0u && wa.level_last >= 1u) == 8;
 #define WALK(R_)                                                                                                          \
     do {                                                                                                                  \
         if constexpr (HAS_PB8) {                                                                                          \

@@ -29,3 +29,9 @@ COS_CANDIDATES=1 timeout 900 python -m pytest tests/test_gpu_host_stage.py -m gp
 for T in 0 2 4 8; do
   COS_HOST_STAGE_THREADS=$T timeout 400 python scripts/host_api_sweep.py > $OUT/cand_host_stage_threads_$T.json 2> $OUT/cand_host_stage_threads_$T.err; echo "threads $T rc=$?"; head -c 700 $OUT/cand_host_stage_threads_$T.json; echo
 done
+#   3. walk, upper range of the split launch with the four-row-buffer variant (53 VGPRs = 8 waves per SIMD instead of 69 = 7; the range
+#      is a latency chain over table levels since level 3 joined the table): COS_WALK_PB_UPPER=4 against the default, ef 64 and 256.
+#      PROBE_COLS=4294967295 = the automatic table rule.  If faster: make it walk_pb_policy's default for that range.
+for PBU in 0 4; do
+  COS_WALK_PB_UPPER=$PBU PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_pb_upper_$PBU.jsonl 2> $OUT/cand_walk_pb_upper_$PBU.err; echo "pb_upper $PBU rc=$?"; cut -c1-400 $OUT/cand_walk_pb_upper_$PBU.jsonl
+done
