@@ -111,545 +111,8 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
     }
 }
 
-constexpr int PB = 4; // code rows in flight per lane group before the dots are consumed
-constexpr int LA = 4; // lookahead window: adjacency rows prefetched per round
-// G = 64 path: code rows in flight per wave = template parameter PB64.  An expansion discovers ~7 new neighbours on average:
-// with 4 rows in flight that is two dependent HBM round trips per pop, with 8 it is one.  Measured on c2 (profiles/
-// r02_c2_launch_shape_sweep_pb8.jsonl): 8 is faster at every launch size (+6 % at ef 64, +2 % at ef 256), so 8 is the default where
-// the variant exists and the registers allow it: round 3's evaluation block holds the kernel at 80 VGPRs = 6 waves per SIMD for ef <= 64
-// (amdgpu_waves_per_eu below; 7 waves spill inside the loops and measured 7 % slower), 96 = 5 waves up to ef 256, and above that the
-// widest pool takes the 4-row variant (walk_pb_policy).
-
-// ------------------------------------------------------------------------------------------------
-// walk kernel
-// ------------------------------------------------------------------------------------------------
-struct WalkSmem {
-    u32 *vis;     // visited filter words (REF mode)
-    u64 *res;     // popped (key, node) list, ef entries
-    u32 *wl_vec;  // winners of the current expansion: vector rows
-    u32 *wl_node; //                                     node indices
-    u32 *win_vec; // lookahead window: prefetched adjacency rows [LA][64]
-    u32 *win_node;
-    float *qf;    // F32 engine: the query vector
-};
-
-template <int ENG, int CH, int R, bool G64, bool EXACT, int PB64 = 4>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 : (R <= 4 ? 5 : 4), 8))) void walk_kernel(const IndexDev ix, const WalkArgs wa) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x;
-    if (blockIdx.x >= wa.B) return;
-    const u32 qi = wa.q_order ? wa.q_order[blockIdx.x] : blockIdx.x; // split walk: locality order (engine_types.h)
-    const bool resume = wa.phase != 0u && wa.level_first < ix.num_layers; // a level range below the top: entry node from the range above
-    if (resume && wa.out_status[qi] != COS_OK) return;                   // failed in the levels above: nothing below is read
-
-    const u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
-    WalkSmem sm;
-    {
-        unsigned char *p = smem_raw;
-        sm.vis = (u32 *)p;      p += (size_t)Mmax * 8;
-        sm.res = (u64 *)p;      p += (size_t)wa.ef * 8;
-        sm.wl_vec = (u32 *)p;   p += 64 * 4;
-        sm.wl_node = (u32 *)p;  p += 64 * 4;
-        sm.win_vec = (u32 *)p;  p += LA * 64 * 4;
-        sm.win_node = (u32 *)p; p += LA * 64 * 4;
-        p = (unsigned char *)(((size_t)p + 15) & ~(size_t)15);
-        sm.qf = (float *)p;
-    }
-
-    const u32 qrow = wa.q_rows ? wa.q_rows[qi] : qi;
-    const u32 self_id = wa.self_ids ? wa.self_ids[qi] * ix.id_stride : COS_QUERY_ID; // self_ids are vector rows
-    const uint8_t *qcode = wa.qcodes + (u64)qrow * ix.row_stride;
-    const float qmag = wa.qmags[qrow];
-    const u32 N = ix.n;
-    const u32 L = ix.num_layers;
-    const u32 metric = ix.metric;
-    constexpr bool exact = EXACT; // compile-time: the REF kernels carry none of the hash-set code
-    // EXACT mode: this query's bitset (one bit per node of the level being walked; all-zero between levels) and the undo log
-    // of the words it set, so the filter is cleared by touching only what the level touched (no per-launch memset)
-    u32 *vis = exact ? wa.vis_bits + (u64)qi * wa.vis_words_per_query : sm.vis;
-    u32 *vlog = exact ? wa.vis_log + (u64)qi * wa.vis_log_cap : nullptr;
-
-    // ---- engine set-up -------------------------------------------------------------------------
-    constexpr bool FLOAT_ENG = ENG == ENG_F32 || ENG == ENG_F16; // ordered f32 chains instead of integer chunk dots
-    constexpr bool TABLE_OK = ENG == ENG_U8; // level tables exist for u8 codes (engine.hip, ensure_level_table)
-    const int G = (ENG == ENG_F32) ? 8 : (ENG == ENG_F16 ? 1 : (int)ix.G); // f32: eight lanes per row, one per accumulator chain
-    const int lig = lane & (G - 1);  // lane in group
-    const int grp = lane / G;        // group index
-    const int RP = 64 / G;           // rows per pass
-    uint4 qreg[CH];
-    if constexpr (!FLOAT_ENG) {
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-            u32 chunk = (u32)lig + (u32)c * (u32)G;
-            qreg[c] = chunk < ix.nchunks ? *(const uint4 *)(qcode + (u64)chunk * 16) : make_uint4(0, 0, 0, 0);
-        }
-    } else if constexpr (ENG == ENG_F16) {
-        const __half *qh = (const __half *)qcode;
-        for (u32 i = lane; i < ix.dim; i += 64) sm.qf[i] = __half2float(qh[i]);
-        __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll
-        for (int c = 0; c < CH; c++) qreg[c] = make_uint4(0, 0, 0, 0);
-    } else {
-        const float *qg = (const float *)qcode;
-        for (u32 i = lane; i < (u32)(ix.row_stride / 4); i += 64) sm.qf[i] = qg[i];
-        __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll
-        for (int c = 0; c < CH; c++) qreg[c] = make_uint4(0, 0, 0, 0);
-    }
-
-    // G = 64 evaluation block: byte offset of this lane's 16-byte chunk inside a code row, per chunk pass; lanes past the last
-    // chunk point at chunk 0 (their query register is zero, so what they read does not matter)
-    u32 loff64[CH];
-#pragma unroll
-    for (int c = 0; c < CH; c++) {
-        const u32 chunk = (u32)lane + (u32)c * 64u;
-        loff64[c] = (chunk < ix.nchunks ? chunk : 0u) * 16u;
-    }
-
-    u64 n_evals = 0, n_exp = 0, adj_bytes = 0, n_rounds = 0, n_tab = 0;
-    int32_t status = COS_OK;
-    u32 entry = uniform_u32(resume ? wa.entry0[qi] : ix.lv[L].root_idx);
-    const int level_first = wa.phase ? (int)wa.level_first : (int)L, level_last = wa.phase ? (int)wa.level_last : 0;
-    u32 order_key = wa.key_n; // split walk: depth-first position of the best node of level_last
-
-    // distance of ONE row computed by group 0 (entry node); result valid in every lane
-    auto single_distance = [&](u32 row, float &sim_out) -> bool {
-        float dotf;
-        if constexpr (!FLOAT_ENG) {
-            u32 acc = 0;
-            if (grp == 0) {
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    u32 chunk = (u32)lig + (u32)c * (u32)G;
-                    if (chunk < ix.nchunks) acc = chunk_dot<ENG>(qreg[c], *(const uint4 *)(ix.codes + (u64)row * ix.row_stride + (u64)chunk * 16), acc);
-                }
-            }
-            acc = group_reduce_add_u32(acc, G);
-            acc = readlane_u32(acc, 0);
-            dotf = (float)acc; // integer dot `as f32` (RNE)
-        } else if constexpr (ENG == ENG_F16) {
-            float d = f16_lane_dot(ix.codes + (u64)row * ix.row_stride, sm.qf, ix.dim);
-            dotf = __uint_as_float(readlane_u32(__float_as_uint(d), 0));
-        } else {
-            float d = f32_oct_dot((const float *)(ix.codes + (u64)row * ix.row_stride), sm.qf, ix.dim, lane & 7);
-            dotf = __uint_as_float(readlane_u32(__float_as_uint(d), 0));
-        }
-        if (metric == 0u) { // cosine_similarity_from_dot_product (cosine.rs:223-235)
-            const float den = uniform_f32(__fmul_rn(qmag, ix.mags[row]));
-            if (den == 0.0f) return false;
-            sim_out = __fdiv_rn(dotf, den);
-        } else {
-            sim_out = dotf; // DotProductDistance (dotproduct.rs:14-64)
-        }
-        return true;
-    };
-
-    for (int level = level_first; level >= level_last; level--) {
-        const LevelDev lv = ix.lv[level];
-        const u32 M = lv.M;
-        const u32 slots = M < ix.shortlist ? M : ix.shortlist;
-        const u32 bitmask = 64u * M - 1u;
-        const u32 out_slot = L - (u32)level;
-        u32 nlog = 0; // EXACT mode: entries of the undo log (wave-uniform)
-        // table level (WalkArgs::tab): this query's row of precomputed similarities, columns of this level
-        const bool tab_level = TABLE_OK && wa.tab != nullptr && (u32)level >= wa.tab_level_min;
-        const float *tabq = wa.tab + (u64)qi * wa.tab_stride + wa.tab_col0[level];
-
-        // fresh visited filter, pre-seeded with the query / new-node id (vector_store.rs:266-271, :807)
-        if (!exact) {
-            for (u32 w = lane; w < 2 * M; w += 64) sm.vis[w] = 0;
-            if (lane == 0) {
-                u32 b = self_id & bitmask;
-                sm.vis[b >> 5] |= 1u << (b & 31);
-            }
-        }
-
-        Pool<R> pool;
-        pool.clear();
-        u32 npool = 0, npop = 0;
-        u32 res_lo = 0, res_hi = 0; // R == 1: the popped (key, node) list, entry i in lane i
-
-        // start node (vector_store.rs:1144-1148)
-        {
-            const u32 erow = uniform_u32(lv.node_vec ? lv.node_vec[entry] : entry);
-            float s0;
-            if (tab_level) {
-                s0 = uniform_f32(tabq[entry]);
-                if (metric == 0u && s0 != s0) { status = COS_ERR_CALCULATION; break; }
-            } else if (!single_distance(erow, s0)) { status = COS_ERR_CALCULATION; break; }
-            const u32 eid = erow == N ? COS_ROOT_ID : erow * ix.id_stride;
-            if (lane == 0) {
-                if (!exact) { u32 b = eid & bitmask; sm.vis[b >> 5] |= 1u << (b & 31); }
-                else {
-                    atomicOr(&vis[entry >> 5], 1u << (entry & 31));
-                    vlog[0] = entry >> 5;
-                }
-            }
-            pool.insert_at(pack_key(metric_key(metric, s0), entry), 0, lane);
-            npool = 1;
-            if (exact) nlog = 1;
-        }
-
-        u32 failed = 0; // wave-uniform flags are u32 and lane sets u64 ballots: a bool that crosses a branch is kept as a lane mask
-                        // and merged with exec-mask arithmetic at every join, a bool that is voted on is first turned into 0 / 1
-        u32 lev_evals = 1; // distance evaluations of this level, the entry node's included
-        const u32 log2M = (u32)__ffs((int)M) - 1u; // M is a power of two (cos_params)
-        const u64 slotmask = slots >= 64u ? ~0ull : ((1ull << slots) - 1ull); // lanes that hold a scanned slot
-        // Lookahead window: the adjacency rows of the next LA pool entries are fetched together (independent
-        // loads, one latency); entry i+1 of the window is consumed only while it is still provably the next pop,
-        // i.e. while no candidate has been inserted ahead of it.  Most pops of a walk discover nothing new
-        // (3-4 evaluations per pop on average), so this collapses chains of dependent HBM round trips.
-        while (npool > 0 && npop < wa.ef) {
-            n_rounds++;
-            u32 kwin = npool < (u32)LA ? npool : (u32)LA;
-            if (kwin > wa.ef - npop) kwin = wa.ef - npop;
-            // the window lives in LDS so the consume loop below is a runtime loop (small code, no extra VGPRs)
-            // All loads of the window are issued before the first value is looked at, and none is predicated: a pool position past
-            // the window holds a real node or the empty key (node 0) — its row is fetched and never looked at; lanes past `slots`
-            // read the last slot and are masked when the entry is consumed (slotmask).  Rounds 1-2 wrote `v = load; nn = level == 0
-            // ? v : load2; LDS store` inside a per-entry `if`: the generated code waited for every load (s_waitcnt vmcnt(0)) before
-            // issuing the next entry's — up to eight DEPENDENT round trips per round where the comment above promised one.
-            {
-                const u32 slot_l = (u32)lane < slots ? (u32)lane : slots - 1u;
-                // two copies of the block (level 0 has no node indices of its own): merged into one, the compiler waited for the
-                // first group of loads before it issued the second
-                auto fetch_stage = [&](auto bothc) {
-                    constexpr bool BOTH = decltype(bothc)::value;
-                    u32 wv_[LA], wn_[LA];
-                    static_for<0, LA>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        const u64 off = ((u64)pool.template peek_node<i>() << log2M) + slot_l;
-                        wv_[i] = lv.adj_vec[off];
-                        if constexpr (BOTH) wn_[i] = lv.adj_node[off];
-                    });
-                    static_for<0, LA>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        sm.win_vec[i * 64 + lane] = wv_[i];
-                        sm.win_node[i * 64 + lane] = BOTH ? wn_[i] : wv_[i];
-                    });
-                };
-                if (level != 0) fetch_stage(std::true_type{});
-                else fetch_stage(std::false_type{});
-            }
-            for (u32 wi = 0; wi < kwin; wi++) {
-                // the window entry being consumed IS the pool's head (that is what "still provably the next pop" means): the
-                // popped list takes it from lane 0's register — until round 4 the window's keys made a detour through LDS
-                if constexpr (R == 1) { // ef <= 64: the popped list is one entry per lane, lane npop takes the head by v_writelane
-                    const u64 hd = pool.head();
-                    res_lo = writelane_dyn(res_lo, (u32)hd, (int)npop);
-                    res_hi = writelane_dyn(res_hi, (u32)(hd >> 32), (int)npop);
-                } else if (lane == 0) sm.res[npop] = pool.e[0];
-                pool.pop_head(lane);
-                npool--;
-                npop++;
-                const int limit = (int)wa.ef - (int)npop; // future pops still allowed
-                const int ahead = (int)kwin - 1 - (int)wi; // window entries still waiting at pool positions 0..ahead-1
-                u32 window_ok = 1;
-
-                // neighbour slots in slot order, one per lane (vector_store.rs:1161-1171)
-                const u32 nb_vec = sm.win_vec[wi * 64 + lane], nb_node = sm.win_node[wi * 64 + lane];
-                const u64 vmask = ballot64(nb_vec != ROW_EMPTY) & slotmask;
-                u64 wmask; // the expansion's winners: unvisited neighbours, as a lane set
-                if (!exact) {
-                    // PerformantFixedSet: bucket=(id>>6)&(M-1), bit=id&63  <=> linear bit id & (64M-1)
-                    u32 id = nb_vec;
-                    if (ix.id_stride != 1u) { // wave-uniform branch (the empty asm keeps it one): v_mul_lo_u32 is a quarter-rate instruction
-                        asm volatile("");
-                        id = nb_vec * ix.id_stride;
-                    }
-                    id = nb_vec == N ? COS_ROOT_ID : id;
-                    const u32 bit = id & bitmask;
-                    const u32 word = bit >> 5, msk = 1u << (bit & 31);
-                    u32 seen = sm.vis[word]; // unpredicated (an empty slot's word is in range too); the asm keeps the load out of an `if (valid)`
-                    asm volatile("" : "+v"(seen));
-                    const u64 cmask = vmask & ballot64((seen & msk) == 0u);
-                    if (!cmask) continue; // nothing new: the next window entry is certainly the next pop
-                    u32 old = 0;
-                    if (__builtin_amdgcn_inverse_ballot_w64(cmask)) old = atomicOr(&sm.vis[word], msk);
-                    u64 lostmask = cmask & ballot64((old & msk) != 0u);
-                    wmask = cmask & ~lostmask;
-                    // two slots of this expansion alias the same residue: the LOWER slot wins (sequential scan order)
-                    while (lostmask) {
-                        const int l = __ffsll((long long)lostmask) - 1;
-                        const u64 g = cmask & ballot64(bit == readlane_u32(bit, l));
-                        wmask = (wmask & ~g) | (g & (0ull - g)); // of the slots that share the residue only the lowest stays
-                        lostmask &= ~g;
-                    }
-                } else {
-                    u32 w = 0;
-                    if (__builtin_amdgcn_inverse_ballot_w64(vmask)) w = __hip_atomic_load(&vis[nb_node >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    wmask = vmask & ballot64(((w >> (nb_node & 31)) & 1u) == 0u);
-                    if (!wmask) continue;
-                    if (__builtin_amdgcn_inverse_ballot_w64(wmask)) {
-                        atomicOr(&vis[nb_node >> 5], 1u << (nb_node & 31));                          // fire and forget
-                        vlog[nlog + (u32)__popcll(wmask & ((1ull << lane) - 1ull))] = nb_node >> 5;  // undo log, in slot order
-                    }
-                    nlog += (u32)__popcll(wmask);
-                }
-                const bool win = __builtin_amdgcn_inverse_ballot_w64(wmask);
-                const int W = __popcll(wmask);
-                lev_evals += (u32)W;
-                // Winners whose similarity sits in a lane of `leadmask`, key and node index beside it, go into the pool in lane = slot
-                // order.  One vector compare first screens them against the entry that closes the poppable part of the pool
-                // (position limit - 1): a key below it has at least `limit` entries above it, the loop would rank it only to
-                // reject it.  The bar can only rise while winners go in, so the screen is conservative and the loop's own test stays.
-                auto commit = [&](u64 leadmask, u32 keyv, u32 nodev) {
-                    const u64 bar = limit > 0 ? pool.peek_dyn((u32)(limit - 1)) : ~0ull;
-                    u64 pm = leadmask & ballot64(pack_key(keyv, nodev) > bar);
-                    while (pm) {
-                        const int p = __ffsll((long long)pm) - 1;
-                        pm &= pm - 1;
-                        const u64 kk = pack_key(readlane_u32(keyv, p), readlane_u32(nodev, p));
-                        const int pos = pool.rank_of(kk);
-                        if (pos < limit) {
-                            pool.insert_at(kk, pos, lane);
-                            if (npool < (u32)(64 * R)) npool++;
-                            if (pos < ahead) window_ok = 0;
-                        }
-                    }
-                };
-                if (tab_level) {
-                    // Table level: the similarity of (query, node) was computed ahead of the walk for every node of the level
-                    // (level_table, kernels_flat.hip: exact integer dot on the i8 MFMA, the same conversion and division as
-                    // below), so an expansion's winners cost ONE 4-byte gather and no code row is fetched or dotted.  u8 codes:
-                    // |v| is the root of an integer, so a zero denominator is exactly a 0/0 = NaN in the table.
-                    float simv = 0.0f;
-                    if (win) simv = tabq[nb_node];
-                    if (metric == 0u && (wmask & ballot64(simv != simv))) { failed = 1; break; }
-                    commit(wmask, metric_key(metric, simv), nb_node);
-                    if (!window_ok) break;
-                    continue;
-                }
-                if constexpr (G64 && !FLOAT_ENG) {
-                    // One code row per wave pass (64 lanes x 16 B cover the row): the winner's row index is wave-uniform, so it
-                    // is taken straight from the owning lane with v_readlane and the row base lives in SGPRs (the load is the
-                    // saddr + 32-bit lane offset form: no vector address arithmetic).  PB64 rows are in flight before the dots;
-                    // their PB64 dot vectors are summed TOGETHER (wave_reduce_rows: 18 VALU for 8 rows), row p of the block
-                    // landing in the lanes of group p — until late in round 3 the block reduced row by row (4 dependent DPP adds + 4 v_readlane + a
-                    // select per row) and fetched |v| and the node index with one predicated scalar-indexed load per row: 24 VALU
-                    // and 32 SALU per evaluation of the 38 + 36 the whole walk spent (profiles/r03_mid_round_pmc_sq_instruction_mix_rocprofv3.txt).
-                    // Lanes past the row's last chunk re-read chunk 0 against a zero query register instead of being masked off.
-                    float magw = 1.0f; // |v| of every winner of the expansion: one vector load, in the winner's own lane
-                    if (win) magw = ix.mags[nb_vec];
-                    u64 m = wmask;
-                    while (m && !failed) {
-                        u32 lsel = 0;  // landing lane of winner p of this block <- 4 * (the lane that owns the winner): a ds_bpermute address
-                        u32 tot = 0;   // landing lanes: the winner's integer dot
-                        u64 leadmask = 0; // first lane of the landing group of every winner of this block
-                        // A block of up to NP winners, row p landing in lanes p*(64/NP)...: the rows are fetched together, dotted,
-                        // and the NP partial-sum vectors reduced at once.  The dots of rows a short block does not have are
-                        // skipped by real branches (the empty asm keeps the compiler from turning them into 5 VALU + a select each).
-                        auto eval_block = [&](auto npc) {
-                            constexpr int NP = decltype(npc)::value;
-                            constexpr int LS = 64 / NP;
-                            uint4 buf[NP][CH];
-                            int cnt = 0;
-                            static_for<0, NP>([&](auto pc) {
-                                constexpr int p = decltype(pc)::value;
-                                if (m) {
-                                    const int l = __ffsll((long long)m) - 1;
-                                    m = clear_bit_u64(m, l);
-                                    const uint8_t *rp = row_ptr_scalar(ix.codes, readlane_u32(nb_vec, l), (u32)ix.row_stride);
-                                    lsel = writelane_u32<p * LS>(lsel, (u32)l << 2);
-#pragma unroll
-                                    for (int c = 0; c < CH; c++) {
-                                        u32 lo = loff64[c];
-                                        asm("" : "+v"(lo)); // keeps the zero-extension in this block: saddr + 32-bit voffset addressing
-                                        buf[p][c] = *(const uint4 *)(rp + lo);
-                                    }
-                                    cnt++;
-                                }
-                            });
-                            u32 acc[NP];
-                            static_for<0, NP>([&](auto pc) {
-                                constexpr int p = decltype(pc)::value;
-                                acc[p] = 0;
-                                if (p < cnt) {
-                                    asm volatile("");
-#pragma unroll
-                                    for (int c = 0; c < CH; c++) acc[p] = chunk_dot<ENG>(qreg[c], buf[p][c], acc[p]);
-                                }
-                            });
-                            tot = wave_reduce_rows<NP>(acc);
-                            constexpr u64 firsts = NP == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
-                            leadmask = cnt == NP ? firsts : firsts & ((1ull << (cnt * LS)) - 1ull);
-                        };
-                        if constexpr (PB64 == 8) {
-                            if (__popcll(m) > 4) eval_block(std::integral_constant<int, 8>{});
-                            else eval_block(std::integral_constant<int, 4>{});
-                        } else {
-                            eval_block(std::integral_constant<int, 4>{});
-                        }
-                        // |v| and node index of the block's winners move to the landing lanes (two ds_bpermute)
-                        const float magv = __uint_as_float((u32)__builtin_amdgcn_ds_bpermute((int)lsel, (int)__float_as_uint(magw)));
-                        const u32 nodev = (u32)__builtin_amdgcn_ds_bpermute((int)lsel, (int)nb_node);
-                        const float dotv = (float)tot; // integer dot `as f32` (RNE)
-                        // one vector epilogue for the whole block: cosine_similarity_from_dot_product (cosine.rs:223-235)
-                        float sim = dotv;
-                        if (metric == 0u) {
-                            const float den = __fmul_rn(qmag, magv);
-                            if (leadmask & ballot64(den == 0.0f)) { failed = 1; break; }
-                            sim = __fdiv_rn(dotv, den);
-                        }
-                        commit(leadmask, metric_key(metric, sim), nodev);
-                    }
-                    if (failed || !window_ok) break;
-                    continue;
-                }
-                // compact winners (slot order) into LDS
-                if (win) {
-                    const int rank = __popcll(wmask & ((1ull << lane) - 1ull));
-                    sm.wl_vec[rank] = nb_vec;
-                    sm.wl_node[rank] = nb_node;
-                }
-
-                // evaluate winners: RP rows per pass, PB passes in flight
-                for (int base = 0; base < W; base += RP * PB) {
-                    u32 prow[PB];
-                    float pmag[PB];
-                    uint4 buf[PB][CH];
-                    float fdot[PB];
-#pragma unroll
-                    for (int p = 0; p < PB; p++) {
-                        if (base + p * RP >= W) break; // wave-uniform
-                        const int my = base + p * RP + grp;
-                        const bool v = my < W;
-                        prow[p] = v ? sm.wl_vec[my] : 0u;
-                        pmag[p] = 1.0f;
-                        if (v) pmag[p] = ix.mags[prow[p]];
-                        if constexpr (!FLOAT_ENG) {
-#pragma unroll
-                            for (int c = 0; c < CH; c++) {
-                                u32 chunk = (u32)lig + (u32)c * (u32)G;
-                                buf[p][c] = make_uint4(0, 0, 0, 0);
-                                if (v && chunk < ix.nchunks) buf[p][c] = *(const uint4 *)(ix.codes + (u64)prow[p] * ix.row_stride + (u64)chunk * 16);
-                            }
-                        }
-                    }
-                    if constexpr (FLOAT_ENG) {
-                        // every lane group runs the uniform-trip-count dot; groups without a winner read row 0 and are ignored
-#pragma unroll
-                        for (int p = 0; p < PB; p++) {
-                            if (base + p * RP >= W) break;
-                            if constexpr (ENG == ENG_F32)
-                                fdot[p] = f32_oct_dot((const float *)(ix.codes + (u64)prow[p] * ix.row_stride), sm.qf, ix.dim, lane & 7);
-                            else
-                                fdot[p] = f16_lane_dot(ix.codes + (u64)prow[p] * ix.row_stride, sm.qf, ix.dim);
-                        }
-                    }
-#pragma unroll
-                    for (int p = 0; p < PB; p++) {
-                        if (base + p * RP >= W) break; // wave-uniform
-                        float dotf;
-                        if constexpr (!FLOAT_ENG) {
-                            u32 acc = 0;
-#pragma unroll
-                            for (int c = 0; c < CH; c++) acc = chunk_dot<ENG>(qreg[c], buf[p][c], acc);
-                            acc = group_reduce_add_u32(acc, G);
-                            dotf = (float)acc;
-                        } else {
-                            dotf = fdot[p];
-                        }
-                        // this pass's rows in winner order: the first lane of every group holds its row's key
-                        const int mine = base + p * RP + grp;
-                        const bool leadg = lig == 0 && mine < W;
-                        float sim = dotf;
-                        if (metric == 0u) {
-                            const float den = __fmul_rn(qmag, pmag[p]);
-                            if (ballot64(mine < W && den == 0.0f)) { failed = 1; break; }
-                            sim = __fdiv_rn(dotf, den);
-                        }
-                        const u32 mynode = leadg ? sm.wl_node[mine] : 0u;
-                        commit(ballot64(leadg), metric_key(metric, sim), mynode);
-                    }
-                    if (failed) break;
-                }
-                if (failed || !window_ok) break;
-            }
-            if (failed) break;
-        }
-        n_exp += npop;
-        adj_bytes += (u64)npop * M * 4;
-        n_evals += lev_evals;
-        if (tab_level) n_tab += lev_evals;
-        if (exact) {
-            // undo: zero exactly the words this level set (whole words belong to this query), leaving the bitset all-zero
-            // for the next level / launch.  One wave owns the filter and its vector-memory operations reach L2 in issue
-            // order, so waiting for the outstanding ones (no cache write-back fence) orders set -> clear -> next test.
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            __builtin_amdgcn_s_waitcnt(0);
-            for (u32 i = lane; i < nlog; i += 64) {
-                const u32 w = __hip_atomic_load(&vlog[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&vis[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            __builtin_amdgcn_s_waitcnt(0);
-        }
-        if (failed) { status = COS_ERR_CALCULATION; break; }
-
-        // keep the best `keep`, sorted descending (vector_store.rs:1194-1201)
-        u64 rk[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const u32 e = (u32)lane * R + r;
-            if constexpr (R == 1) rk[r] = e < npop ? pack_key(res_hi, res_lo) : 0ull;
-            else rk[r] = e < npop ? sm.res[e] : 0ull;
-        }
-        bitonic_sort_desc<R>(rk, lane);
-        u32 cnt = npop < wa.keep ? npop : wa.keep;
-        // npop == 0 only if ef == 0: fall back to the entry node's own distance (vector_store.rs:329-380)
-        if (npop == 0) {
-            const u32 erow = uniform_u32(lv.node_vec ? lv.node_vec[entry] : entry);
-            float s0;
-            if (!single_distance(erow, s0)) { status = COS_ERR_CALCULATION; break; }
-            rk[0] = lane == 0 ? pack_key(metric_key(metric, s0), entry) : 0ull;
-            cnt = 1;
-        }
-        const u64 obase = ((u64)qi * (L + 1) + out_slot) * wa.keep;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const u32 e = (u32)lane * R + r;
-            if (e < cnt) {
-                const u32 nd = (u32)rk[r];
-                const u32 vrow = lv.node_vec ? lv.node_vec[nd] : nd;
-                wa.out_ids[obase + e] = vrow == N ? COS_ROOT_ID : vrow * ix.id_stride;
-                wa.out_sims[obase + e] = metric_key_inv(metric, (u32)(rk[r] >> 32));
-                if (wa.out_nodes) wa.out_nodes[obase + e] = nd;
-            }
-        }
-        if (lane == 0) wa.out_counts[(u64)qi * (L + 1) + out_slot] = cnt;
-        // descend through the best hit's child link (vector_store.rs:382-385)
-        if (level > 0) {
-            const u32 best = (u32)readlane_u64(rk[0], 0);
-            entry = uniform_u32(lv.child[best]);
-            if (wa.phase != 0u && level == level_last) order_key = uniform_u32(wa.order_rank[best]);
-        }
-    }
-
-    if (lane == 0) {
-        wa.out_status[qi] = status;
-        if (wa.phase != 0u && level_last > 0) {
-            wa.entry0[qi] = entry;
-            wa.order_key[qi] = status == COS_OK ? order_key : wa.key_n;
-            wa.order_iota[qi] = qi;
-        }
-        if (wa.out_stats) {
-            const bool add = resume; // the counters of the levels above are already there
-            wa.out_stats[(u64)qi * 4 + 0] = n_evals + (add ? wa.out_stats[(u64)qi * 4 + 0] : 0ull);
-            wa.out_stats[(u64)qi * 4 + 1] = n_exp + (add ? wa.out_stats[(u64)qi * 4 + 1] : 0ull);
-            wa.out_stats[(u64)qi * 4 + 2] = adj_bytes + (add ? wa.out_stats[(u64)qi * 4 + 2] : 0ull);
-            wa.out_stats[(u64)qi * 4 + 3] = n_rounds + (add ? wa.out_stats[(u64)qi * 4 + 3] : 0ull);
-        }
-        if (wa.out_stats2) { // the split of a launch's counters the roofline report wants: the last level range on its own, table evaluations
-            if (resume || wa.phase == 0u) {
-                wa.out_stats2[(u64)qi * 4 + 0] = n_evals;
-                wa.out_stats2[(u64)qi * 4 + 1] = n_exp;
-                wa.out_stats2[(u64)qi * 4 + 2] = adj_bytes;
-            }
-            wa.out_stats2[(u64)qi * 4 + 3] = n_tab + (resume ? wa.out_stats2[(u64)qi * 4 + 3] : 0ull);
-        }
-    }
-}
+#define COS_WALK_KERNEL_NAME walk_kernel
+#include "walk_kernel.inc"
 
 // ------------------------------------------------------------------------------------------------
 // finalize: one wave per query.
@@ -1009,6 +472,10 @@ static int walk_pb_policy(u32 B, u32 ef, bool upper_range_of_a_split_walk) {
     return ef > 256u ? 4 : 8;
 }
 
+// kernels_walk_spec.hip: the candidate kernel that gathers table values ahead (COS_WALK_SPEC_TABLE=1; off by default)
+size_t walk_spec_extra_smem();
+hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa, int row_buffers, size_t smem, hipStream_t st);
+
 template <int ENG, int CH, bool G64>
 static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     const size_t smem = walk_smem_bytes(ix, wa.ef, ENG);
@@ -1016,6 +483,10 @@ static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStrea
     const bool exact = ix.visited_mode != 0;
     constexpr bool HAS_PB8 = ENG == ENG_U8 && G64 && CH == 1; // the headline path (u8, 513..1024 dims)
     const bool pb8 = HAS_PB8 && walk_pb_policy(wa.B, wa.ef, wa.phase != 0u && wa.level_last >= 1u) == 8;
+    if constexpr (HAS_PB8) {
+        static const bool spec_env = [] { const char *e = getenv("COS_WALK_SPEC_TABLE"); return e && atoi(e) != 0; }();
+        if (spec_env && !exact && wa.tab != nullptr) return launch_walk_spec(ix, wa, pb8 ? 8 : 4, smem + walk_spec_extra_smem(), st);
+    }
 #define WALK(R_)                                                                                                          \
     do {                                                                                                                  \
         if constexpr (HAS_PB8) {                                                                                          \

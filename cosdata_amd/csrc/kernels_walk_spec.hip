@@ -1,0 +1,46 @@
+// kernels_walk_spec.hip — the walk kernel with table values gathered ahead (walk_kernel.inc, COS_WALK_SPEC): a CANDIDATE, launched
+// only when COS_WALK_SPEC_TABLE=1 is set (kernels_walk.hip launch_walk_r), for the launches the headline path takes: u8 codes of
+// 513..1024 dimensions, reference visited filter, a level table present.  Its own translation unit and its own
+// kernel name so that the shipped kernels of kernels_walk.hip stay byte for byte what was measured.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "engine_types.h"
+#include "dot_engines.h"
+
+using namespace cosdev;
+
+#define COS_OK 0
+#define COS_ERR_CALCULATION 2
+#define COS_QUERY_ID 0xFFFFFFFEu
+#define COS_ROOT_ID 0xFFFFFFFFu
+
+namespace {
+#define COS_WALK_SPEC 1
+#define COS_WALK_KERNEL_NAME walk_spec_kernel
+#include "walk_kernel.inc"
+} // namespace
+
+namespace cosdev {
+
+size_t walk_spec_extra_smem() { return (size_t)SPEC_N * 64 * 4; }
+
+// smem = walk_smem_bytes of the launch + walk_spec_extra_smem(); row_buffers = 8 | 4 (walk_pb_policy)
+hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa, int row_buffers, size_t smem, hipStream_t st) {
+    dim3 grid(wa.B), block(64);
+#define SPEC_WALK(R_)                                                                                                              \
+    do {                                                                                                                           \
+        if (row_buffers == 8) hipLaunchKernelGGL((walk_spec_kernel<ENG_U8, 1, R_, true, false, 8>), grid, block, smem, st, ix, wa); \
+        else hipLaunchKernelGGL((walk_spec_kernel<ENG_U8, 1, R_, true, false, 4>), grid, block, smem, st, ix, wa);                 \
+    } while (0)
+    if (wa.ef <= 64) SPEC_WALK(1);
+    else if (wa.ef <= 256) SPEC_WALK(4);
+    else if (wa.ef <= 512) SPEC_WALK(8);
+    else return hipErrorInvalidValue;
+#undef SPEC_WALK
+    return hipGetLastError();
+}
+
+} // namespace cosdev
