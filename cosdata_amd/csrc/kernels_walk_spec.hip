@@ -17,23 +17,41 @@ using namespace cosdev;
 #define COS_QUERY_ID 0xFFFFFFFEu
 #define COS_ROOT_ID 0xFFFFFFFFu
 
-namespace {
-#define COS_WALK_SPEC 1
+// two instances of the kernel source: table values of the first 2 / of all 4 window entries gathered ahead (COS_WALK_SPEC_TABLE=2|4;
+// 1 = 2).  Each in its own namespace: the include file defines the kernel's constants and its LDS layout too.
+namespace spec2 {
+#define COS_WALK_SPEC 2
 #define COS_WALK_KERNEL_NAME walk_spec_kernel
 #include "walk_kernel.inc"
-} // namespace
+#undef COS_WALK_SPEC
+} // namespace spec2
+namespace spec4 {
+#define COS_WALK_SPEC 4
+#include "walk_kernel.inc"
+#undef COS_WALK_SPEC
+} // namespace spec4
 
 namespace cosdev {
 
-size_t walk_spec_extra_smem() { return (size_t)SPEC_N * 64 * 4; }
+static int walk_spec_entries() { // COS_WALK_SPEC_TABLE: 0 / unset = off (kernels_walk.hip does not come here), 4 = four entries, anything else = two
+    static const int n = [] { const char *e = getenv("COS_WALK_SPEC_TABLE"); return e && atoi(e) == 4 ? 4 : 2; }();
+    return n;
+}
+size_t walk_spec_extra_smem() { return (size_t)walk_spec_entries() * 64 * 4; }
 
 // smem = walk_smem_bytes of the launch + walk_spec_extra_smem(); row_buffers = 8 | 4 (walk_pb_policy)
 hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa, int row_buffers, size_t smem, hipStream_t st) {
     dim3 grid(wa.B), block(64);
-#define SPEC_WALK(R_)                                                                                                              \
-    do {                                                                                                                           \
-        if (row_buffers == 8) hipLaunchKernelGGL((walk_spec_kernel<ENG_U8, 1, R_, true, false, 8>), grid, block, smem, st, ix, wa); \
-        else hipLaunchKernelGGL((walk_spec_kernel<ENG_U8, 1, R_, true, false, 4>), grid, block, smem, st, ix, wa);                 \
+    const bool four = walk_spec_entries() == 4;
+#define SPEC_WALK(R_)                                                                                                                         \
+    do {                                                                                                                                      \
+        if (four) {                                                                                                                           \
+            if (row_buffers == 8) hipLaunchKernelGGL((spec4::walk_spec_kernel<ENG_U8, 1, R_, true, false, 8>), grid, block, smem, st, ix, wa); \
+            else hipLaunchKernelGGL((spec4::walk_spec_kernel<ENG_U8, 1, R_, true, false, 4>), grid, block, smem, st, ix, wa);                 \
+        } else {                                                                                                                              \
+            if (row_buffers == 8) hipLaunchKernelGGL((spec2::walk_spec_kernel<ENG_U8, 1, R_, true, false, 8>), grid, block, smem, st, ix, wa); \
+            else hipLaunchKernelGGL((spec2::walk_spec_kernel<ENG_U8, 1, R_, true, false, 4>), grid, block, smem, st, ix, wa);                 \
+        }                                                                                                                                     \
     } while (0)
     if (wa.ef <= 64) SPEC_WALK(1);
     else if (wa.ef <= 256) SPEC_WALK(4);

@@ -36,8 +36,10 @@ for PBU in 0 4; do
   COS_WALK_PB_UPPER=$PBU PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_pb_upper_$PBU.jsonl 2> $OUT/cand_walk_pb_upper_$PBU.err; echo "pb_upper $PBU rc=$?"; cut -c1-400 $OUT/cand_walk_pb_upper_$PBU.jsonl
 done
 #   4. walk with table values gathered ahead (kernels_walk_spec.hip, walk_kernel.inc COS_WALK_SPEC): the parity
-#      suites of the walk under COS_WALK_SPEC_TABLE=1 (the variable is read once per process), then the same probe as in 3.
+#      suites of the walk under COS_WALK_SPEC_TABLE=1 (two window entries gathered ahead; =4: all four; read once per process), then
+#      the same probe as in 3.
 #      If green and faster: launch it by default for the launches it covers (launch_walk_r), add its register guard, profile it.
 COS_WALK_SPEC_TABLE=1 timeout 900 python -m pytest tests/test_gpu_walk_table.py tests/test_gpu_walk_order.py tests/test_gpu_parity.py -m gpu -q -x > $OUT/cand_walk_spec_pytest.log 2>&1; echo "walk spec pytest rc=$?"; tail -3 $OUT/cand_walk_spec_pytest.log
 COS_WALK_SPEC_TABLE=1 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec.jsonl 2> $OUT/cand_walk_spec.err; echo "walk spec probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec.jsonl
+COS_WALK_SPEC_TABLE=4 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec4.jsonl 2> $OUT/cand_walk_spec4.err; echo "walk spec (4 entries ahead) probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec4.jsonl
 COS_WALK_SPEC_TABLE=1 COS_WALK_PB_UPPER=4 PROBE_EFS=64 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec_pbu4.jsonl 2> $OUT/cand_walk_spec_pbu4.err; echo "walk spec + pb_upper 4 rc=$?"; cut -c1-400 $OUT/cand_walk_spec_pbu4.jsonl
