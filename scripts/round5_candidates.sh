@@ -43,3 +43,7 @@ COS_WALK_SPEC_TABLE=1 timeout 900 python -m pytest tests/test_gpu_walk_table.py 
 COS_WALK_SPEC_TABLE=1 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec.jsonl 2> $OUT/cand_walk_spec.err; echo "walk spec probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec.jsonl
 COS_WALK_SPEC_TABLE=4 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec4.jsonl 2> $OUT/cand_walk_spec4.err; echo "walk spec (4 entries ahead) probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec4.jsonl
 COS_WALK_SPEC_TABLE=1 COS_WALK_PB_UPPER=4 PROBE_EFS=64 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec_pbu4.jsonl 2> $OUT/cand_walk_spec_pbu4.err; echo "walk spec + pb_upper 4 rc=$?"; cut -c1-400 $OUT/cand_walk_spec_pbu4.jsonl
+# one 256-query batch is the same chain with nothing to hide it behind (~400 table-level expansions per query): the candidate there
+for SP in 0 2 4; do
+  COS_WALK_SPEC_TABLE=$SP timeout 300 python scripts/single_batch_probe.py > $OUT/cand_single_batch_spec_$SP.jsonl 2> $OUT/cand_single_batch_spec_$SP.err; echo "single batch, spec $SP rc=$?"; cut -c1-500 $OUT/cand_single_batch_spec_$SP.jsonl
+done
