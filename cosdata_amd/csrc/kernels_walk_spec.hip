@@ -40,8 +40,11 @@ static int walk_spec_entries() { // COS_WALK_SPEC_TABLE: 0 / unset = off (kernel
 size_t walk_spec_extra_smem() { return (size_t)walk_spec_entries() * 64 * 4; }
 
 // smem = walk_smem_bytes of the launch + walk_spec_extra_smem(); row_buffers = 8 | 4 (walk_pb_policy)
-hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa, int row_buffers, size_t smem, hipStream_t st) {
-    dim3 grid(wa.B), block(64);
+hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa_in, int row_buffers, size_t smem, hipStream_t st) {
+    dim3 grid(wa_in.B), block(64);
+    static const bool warm = [] { const char *e = getenv("COS_WALK_SPEC_WARM"); return e && atoi(e) != 0; }();
+    WalkArgs wa = wa_in;
+    if (warm) wa.tab_level_min |= 0x80000000u; // walk_kernel.inc: fetch the top of the query's table row before the first level
     const bool four = walk_spec_entries() == 4;
 #define SPEC_WALK(R_)                                                                                                                         \
     do {                                                                                                                                      \

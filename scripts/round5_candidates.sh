@@ -47,3 +47,6 @@ COS_WALK_SPEC_TABLE=1 COS_WALK_PB_UPPER=4 PROBE_EFS=64 PROBE_COLS=4294967295 tim
 for SP in 0 2 4; do
   COS_WALK_SPEC_TABLE=$SP timeout 300 python scripts/single_batch_probe.py > $OUT/cand_single_batch_spec_$SP.jsonl 2> $OUT/cand_single_batch_spec_$SP.err; echo "single batch, spec $SP rc=$?"; cut -c1-500 $OUT/cand_single_batch_spec_$SP.jsonl
 done
+# + the top of every query's table row fetched in one instruction before the first level (COS_WALK_SPEC_WARM=1)
+COS_WALK_SPEC_TABLE=2 COS_WALK_SPEC_WARM=1 PROBE_EFS=64 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec_warm.jsonl 2> $OUT/cand_walk_spec_warm.err; echo "walk spec + warm rc=$?"; cut -c1-400 $OUT/cand_walk_spec_warm.jsonl
+COS_WALK_SPEC_TABLE=2 COS_WALK_SPEC_WARM=1 PROBE_EFS=64 timeout 300 python scripts/single_batch_probe.py > $OUT/cand_single_batch_spec_warm.jsonl 2> $OUT/cand_single_batch_spec_warm.err; echo "single batch, spec + warm rc=$?"; cut -c1-500 $OUT/cand_single_batch_spec_warm.jsonl
