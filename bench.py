@@ -1202,6 +1202,8 @@ def main():
         "roofline": rec["roofline"],
         "flat_scan_ground_truth": flat, "result_properties": rec["props"], "cpu_baseline": rec["cpu"], "parity_vs_oracle": rec["parity"],
         "host_api_pcie_inclusive": rec["host_api"],
+        # every COS_* variable of the process: the library's experiment switches must be visible in the record they shaped
+        "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("COS_") and k != "COS_BENCH_FULL_RECORD"},
         "configs": {},
     }
     emitter.out = out
