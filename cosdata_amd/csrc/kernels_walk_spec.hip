@@ -30,14 +30,29 @@ namespace spec4 {
 #include "walk_kernel.inc"
 #undef COS_WALK_SPEC
 } // namespace spec4
+// a window of EIGHT adjacency rows per round, all eight with their table values gathered ahead (COS_WALK_SPEC_TABLE=8): the walk
+// consumes ~3 entries of its four-entry window per round on average (17.5 M expansions in 5.9 M rounds at c2), i.e. the window
+// is often the limit; on a table level a consumed entry costs nothing but LDS reads once its values are there
+namespace spec8 {
+#define COS_WALK_SPEC 8
+#define COS_WALK_LA 8
+#include "walk_kernel.inc"
+#undef COS_WALK_SPEC
+#undef COS_WALK_LA
+} // namespace spec8
 
 namespace cosdev {
 
-static int walk_spec_entries() { // COS_WALK_SPEC_TABLE: 0 / unset = off (kernels_walk.hip does not come here), 4 = four entries, anything else = two
-    static const int n = [] { const char *e = getenv("COS_WALK_SPEC_TABLE"); return e && atoi(e) == 4 ? 4 : 2; }();
+static int walk_spec_entries() { // COS_WALK_SPEC_TABLE: 0 / unset = off (kernels_walk.hip does not come here), 4 / 8 = that many entries, anything else = two
+    static const int n = [] { const char *e = getenv("COS_WALK_SPEC_TABLE"); const int v = e ? atoi(e) : 0; return v == 4 || v == 8 ? v : 2; }();
     return n;
 }
-size_t walk_spec_extra_smem() { return (size_t)walk_spec_entries() * 64 * 4; }
+// bytes on top of walk_smem_bytes (which sizes the four-entry window of the shipped kernels): the gathered values, and the second half
+// of an eight-entry window
+size_t walk_spec_extra_smem() {
+    const int n = walk_spec_entries();
+    return (size_t)n * 64 * 4 + (n == 8 ? (size_t)4 * 64 * 4 * 2 : 0);
+}
 
 // smem = walk_smem_bytes of the launch + walk_spec_extra_smem(); row_buffers = 8 | 4 (walk_pb_policy)
 hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa_in, int row_buffers, size_t smem, hipStream_t st) {
@@ -45,22 +60,24 @@ hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa_in, int row_b
     static const bool warm = [] { const char *e = getenv("COS_WALK_SPEC_WARM"); return e && atoi(e) != 0; }();
     WalkArgs wa = wa_in;
     if (warm) wa.tab_level_min |= 0x80000000u; // walk_kernel.inc: fetch the top of the query's table row before the first level
-    const bool four = walk_spec_entries() == 4;
-#define SPEC_WALK(R_)                                                                                                                         \
-    do {                                                                                                                                      \
-        if (four) {                                                                                                                           \
-            if (row_buffers == 8) hipLaunchKernelGGL((spec4::walk_spec_kernel<ENG_U8, 1, R_, true, false, 8>), grid, block, smem, st, ix, wa); \
-            else hipLaunchKernelGGL((spec4::walk_spec_kernel<ENG_U8, 1, R_, true, false, 4>), grid, block, smem, st, ix, wa);                 \
-        } else {                                                                                                                              \
-            if (row_buffers == 8) hipLaunchKernelGGL((spec2::walk_spec_kernel<ENG_U8, 1, R_, true, false, 8>), grid, block, smem, st, ix, wa); \
-            else hipLaunchKernelGGL((spec2::walk_spec_kernel<ENG_U8, 1, R_, true, false, 4>), grid, block, smem, st, ix, wa);                 \
-        }                                                                                                                                     \
+    const int n = walk_spec_entries();
+#define SPEC_LAUNCH(NS, R_)                                                                                                                \
+    do {                                                                                                                                   \
+        if (row_buffers == 8) hipLaunchKernelGGL((NS::walk_spec_kernel<ENG_U8, 1, R_, true, false, 8>), grid, block, smem, st, ix, wa);     \
+        else hipLaunchKernelGGL((NS::walk_spec_kernel<ENG_U8, 1, R_, true, false, 4>), grid, block, smem, st, ix, wa);                     \
+    } while (0)
+#define SPEC_WALK(R_)                                                                                                                      \
+    do {                                                                                                                                   \
+        if (n == 8) SPEC_LAUNCH(spec8, R_);                                                                                                \
+        else if (n == 4) SPEC_LAUNCH(spec4, R_);                                                                                           \
+        else SPEC_LAUNCH(spec2, R_);                                                                                                       \
     } while (0)
     if (wa.ef <= 64) SPEC_WALK(1);
     else if (wa.ef <= 256) SPEC_WALK(4);
     else if (wa.ef <= 512) SPEC_WALK(8);
     else return hipErrorInvalidValue;
 #undef SPEC_WALK
+#undef SPEC_LAUNCH
     return hipGetLastError();
 }
 

@@ -102,7 +102,7 @@ def test_packed_sparse_kernel_instruction_budget(tmp_path):
 def test_gather_ahead_walk_candidate_keeps_the_default_kernels_occupancy(tmp_path):
     """kernels_walk_spec.hip (COS_WALK_SPEC_TABLE=1): the candidate must not cost waves per SIMD against the kernel it would replace"""
     ks = _kernels("kernels_walk_spec.o", tmp_path)
-    for ns in ("spec2", "spec4"):                                     # table values of 2 / 4 window entries gathered ahead
+    for ns in ("spec2", "spec4", "spec8"):                            # table values of 2 / 4 / 8 (eight-entry window) entries gathered ahead
         head = _find(ks, ns + "::walk_spec_kernel<0, 1, 1, true, false, 8>")
         assert head["vgpr_count"] <= 72 and head["private_segment_fixed_size"] == 0      # 7 waves per SIMD, like walk_kernel<0, 1, 1, true, false, 8>
         upper = _find(ks, ns + "::walk_spec_kernel<0, 1, 1, true, false, 4>")
