@@ -39,7 +39,10 @@ done
 #      suites of the walk under COS_WALK_SPEC_TABLE=1 (two window entries gathered ahead; =4: all four; read once per process), then
 #      the same probe as in 3.
 #      If green and faster: launch it by default for the launches it covers (launch_walk_r), add its register guard, profile it.
-COS_WALK_SPEC_TABLE=1 timeout 900 python -m pytest tests/test_gpu_walk_table.py tests/test_gpu_walk_order.py tests/test_gpu_parity.py -m gpu -q -x > $OUT/cand_walk_spec_pytest.log 2>&1; echo "walk spec pytest rc=$?"; tail -3 $OUT/cand_walk_spec_pytest.log
+for SP in 2 4 8; do
+  COS_WALK_SPEC_TABLE=$SP COS_WALK_SPEC_WARM=1 timeout 600 python -m pytest tests/test_gpu_walk_table.py tests/test_gpu_walk_order.py tests/test_gpu_dim1024.py -m gpu -q -x > $OUT/cand_walk_spec_pytest_$SP.log 2>&1; echo "walk spec $SP (+ warm) pytest rc=$?"; tail -2 $OUT/cand_walk_spec_pytest_$SP.log
+done
+COS_WALK_SPEC_TABLE=4 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_builder.py -m gpu -q -x > $OUT/cand_walk_spec_pytest_parity.log 2>&1; echo "walk spec 4, parity / edges / builder suites rc=$?"; tail -2 $OUT/cand_walk_spec_pytest_parity.log
 COS_WALK_SPEC_TABLE=1 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec.jsonl 2> $OUT/cand_walk_spec.err; echo "walk spec probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec.jsonl
 COS_WALK_SPEC_TABLE=4 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec4.jsonl 2> $OUT/cand_walk_spec4.err; echo "walk spec (4 entries ahead) probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec4.jsonl
 COS_WALK_SPEC_TABLE=8 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec8.jsonl 2> $OUT/cand_walk_spec8.err; echo "walk spec (eight-entry window, all ahead; 7.7 KB of LDS per wave = 5 waves per SIMD) probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec8.jsonl
