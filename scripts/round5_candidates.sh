@@ -7,7 +7,10 @@
 # If the packed layout is green and faster: make it the default in cos_sparse_create (COS_SPARSE_PACKED unset -> packed when the
 # collection fits 24-bit ids), drop the `candidates` mark from tests/test_sparse.py, re-run scripts/bench_sparse.py under
 # rocprofv3 (kernel trace + SQ_INSTS_VALU) for profiles/.
+# usage: bash scripts/round5_candidates.sh [sparse] [host] [walk]   (no argument = all three, ~30 GPU-minutes; one part = 5-15)
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
+WHAT="${*:-sparse host walk}"
+part_sparse() {
 COS_CANDIDATES=1 timeout 600 python -m pytest tests/test_sparse.py -m gpu -q > $OUT/cand_sparse_pytest.log 2>&1; echo "sparse candidates pytest rc=$?"; tail -3 $OUT/cand_sparse_pytest.log
 timeout 300 python scripts/bench_sparse.py > $OUT/cand_sparse_unpacked.json 2> $OUT/cand_sparse_unpacked.err; echo "unpacked rc=$?"
 COS_SPARSE_PACKED=1 timeout 300 python scripts/bench_sparse.py > $OUT/cand_sparse_packed.json 2> $OUT/cand_sparse_packed.err; echo "packed rc=$?"
@@ -22,6 +25,8 @@ for f in ("unpacked", "packed", "packed_spu16"):
     except Exception as e:
         print(f, "failed:", e)
 PY
+}
+part_host() {
 #   2. host-buffer API, one synchronous caller of 32 768 queries: COS_HOST_STAGE_THREADS = helper threads that stage the call's chunks
 #      into pinned memory (engine.hip search_host_pipelined, host_stage.h).  Parity test, then scripts/host_api_sweep.py per setting.
 #      If >= 0.9 x the resident rate with some n: make that n the default (stage_pool()), rerun bench.py for host_api_pcie_inclusive.
@@ -29,6 +34,8 @@ COS_CANDIDATES=1 timeout 900 python -m pytest tests/test_gpu_host_stage.py -m gp
 for T in 0 2 4 8; do
   COS_HOST_STAGE_THREADS=$T timeout 400 python scripts/host_api_sweep.py > $OUT/cand_host_stage_threads_$T.json 2> $OUT/cand_host_stage_threads_$T.err; echo "threads $T rc=$?"; head -c 700 $OUT/cand_host_stage_threads_$T.json; echo
 done
+}
+part_walk() {
 #   3. walk, upper range of the split launch with the four-row-buffer variant (53 VGPRs = 8 waves per SIMD instead of 69 = 7; the range
 #      is a latency chain over table levels since level 3 joined the table): COS_WALK_PB_UPPER=4 against the default, ef 64 and 256.
 #      PROBE_COLS=4294967295 = the automatic table rule.  If faster: make it walk_pb_policy's default for that range.
@@ -54,3 +61,5 @@ done
 # + the top of every query's table row fetched in one instruction before the first level (COS_WALK_SPEC_WARM=1)
 COS_WALK_SPEC_TABLE=2 COS_WALK_SPEC_WARM=1 PROBE_EFS=64 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec_warm.jsonl 2> $OUT/cand_walk_spec_warm.err; echo "walk spec + warm rc=$?"; cut -c1-400 $OUT/cand_walk_spec_warm.jsonl
 COS_WALK_SPEC_TABLE=2 COS_WALK_SPEC_WARM=1 PROBE_EFS=64 timeout 300 python scripts/single_batch_probe.py > $OUT/cand_single_batch_spec_warm.jsonl 2> $OUT/cand_single_batch_spec_warm.err; echo "single batch, spec + warm rc=$?"; cut -c1-500 $OUT/cand_single_batch_spec_warm.jsonl
+}
+for P in $WHAT; do part_$P; done
