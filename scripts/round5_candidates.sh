@@ -45,7 +45,8 @@ done
 #   4. walk with table values gathered ahead (kernels_walk_spec.hip, walk_kernel.inc COS_WALK_SPEC): the parity
 #      suites of the walk under COS_WALK_SPEC_TABLE=1 (two window entries gathered ahead; =4: all four; read once per process), then
 #      the same probe as in 3.
-#      If green and faster: launch it by default for the launches it covers (launch_walk_r), add its register guard, profile it.
+#      If green and faster: launch it by default for the launches it covers (launch_walk_r), and give the profile scripts its kernel
+#      name (scripts/final_profile.sh, gpu_profile_only.sh, bench.py's roofline.kernel: they look for "walk_kernel<0, 1, 1, true, false, 8>").
 for SP in 2 4 8; do
   COS_WALK_SPEC_TABLE=$SP COS_WALK_SPEC_WARM=1 timeout 600 python -m pytest tests/test_gpu_walk_table.py tests/test_gpu_walk_order.py tests/test_gpu_dim1024.py -m gpu -q -x > $OUT/cand_walk_spec_pytest_$SP.log 2>&1; echo "walk spec $SP (+ warm) pytest rc=$?"; tail -2 $OUT/cand_walk_spec_pytest_$SP.log
 done
