@@ -30,28 +30,20 @@ namespace spec4 {
 #include "walk_kernel.inc"
 #undef COS_WALK_SPEC
 } // namespace spec4
-// a window of EIGHT adjacency rows per round, all eight with their table values gathered ahead (COS_WALK_SPEC_TABLE=8): the walk
-// consumes ~3 entries of its four-entry window per round on average (17.5 M expansions in 5.9 M rounds at c2), i.e. the window
-// is often the limit; on a table level a consumed entry costs nothing but LDS reads once its values are there
-namespace spec8 {
-#define COS_WALK_SPEC 8
-#define COS_WALK_LA 8
-#include "walk_kernel.inc"
-#undef COS_WALK_SPEC
-#undef COS_WALK_LA
-} // namespace spec8
-
 namespace cosdev {
 
-static int walk_spec_entries() { // COS_WALK_SPEC_TABLE: 0 / unset = off (kernels_walk.hip does not come here), 4 / 8 = that many entries, anything else = two
-    static const int n = [] { const char *e = getenv("COS_WALK_SPEC_TABLE"); const int v = e ? atoi(e) : 0; return v == 4 || v == 8 ? v : 2; }();
+// kernels_walk_spec_wide.hip: windows of six / eight entries, all gathered ahead
+hipError_t launch_walk_spec_wide(const IndexDev &ix, const WalkArgs &wa, int entries, int row_buffers, size_t smem, hipStream_t st);
+
+static int walk_spec_entries() { // COS_WALK_SPEC_TABLE: 0 / unset = off (kernels_walk.hip does not come here), 4 / 6 / 8 = that many entries, anything else = two
+    static const int n = [] { const char *e = getenv("COS_WALK_SPEC_TABLE"); const int v = e ? atoi(e) : 0; return v == 4 || v == 6 || v == 8 ? v : 2; }();
     return n;
 }
 // bytes on top of walk_smem_bytes (which sizes the four-entry window of the shipped kernels): the gathered values, and the second half
-// of an eight-entry window
+// of a six- or eight-entry window
 size_t walk_spec_extra_smem() {
     const int n = walk_spec_entries();
-    return (size_t)n * 64 * 4 + (n == 8 ? (size_t)4 * 64 * 4 * 2 : 0);
+    return (size_t)n * 64 * 4 + (n > 4 ? (size_t)(n - 4) * 64 * 4 * 2 : 0);
 }
 
 // smem = walk_smem_bytes of the launch + walk_spec_extra_smem(); row_buffers = 8 | 4 (walk_pb_policy)
@@ -61,6 +53,7 @@ hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa_in, int row_b
     WalkArgs wa = wa_in;
     if (warm) wa.tab_level_min |= 0x80000000u; // walk_kernel.inc: fetch the top of the query's table row before the first level
     const int n = walk_spec_entries();
+    if (n > 4) return launch_walk_spec_wide(ix, wa, n, row_buffers, smem, st);
 #define SPEC_LAUNCH(NS, R_)                                                                                                                \
     do {                                                                                                                                   \
         if (row_buffers == 8) hipLaunchKernelGGL((NS::walk_spec_kernel<ENG_U8, 1, R_, true, false, 8>), grid, block, smem, st, ix, wa);     \
@@ -68,8 +61,7 @@ hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa_in, int row_b
     } while (0)
 #define SPEC_WALK(R_)                                                                                                                      \
     do {                                                                                                                                   \
-        if (n == 8) SPEC_LAUNCH(spec8, R_);                                                                                                \
-        else if (n == 4) SPEC_LAUNCH(spec4, R_);                                                                                           \
+        if (n == 4) SPEC_LAUNCH(spec4, R_);                                                                                                \
         else SPEC_LAUNCH(spec2, R_);                                                                                                       \
     } while (0)
     if (wa.ef <= 64) SPEC_WALK(1);

@@ -47,16 +47,17 @@ done
 #      the same probe as in 3.
 #      If green and faster: launch it by default for the launches it covers (launch_walk_r), and give the profile scripts its kernel
 #      name (scripts/final_profile.sh, gpu_profile_only.sh, bench.py's roofline.kernel: they look for "walk_kernel<0, 1, 1, true, false, 8>").
-for SP in 2 4 8; do
+for SP in 2 4 6 8; do
   COS_WALK_SPEC_TABLE=$SP COS_WALK_SPEC_WARM=1 timeout 600 python -m pytest tests/test_gpu_walk_table.py tests/test_gpu_walk_order.py tests/test_gpu_dim1024.py -m gpu -q -x > $OUT/cand_walk_spec_pytest_$SP.log 2>&1; echo "walk spec $SP (+ warm) pytest rc=$?"; tail -2 $OUT/cand_walk_spec_pytest_$SP.log
 done
 COS_WALK_SPEC_TABLE=4 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_builder.py -m gpu -q -x > $OUT/cand_walk_spec_pytest_parity.log 2>&1; echo "walk spec 4, parity / edges / builder suites rc=$?"; tail -2 $OUT/cand_walk_spec_pytest_parity.log
 COS_WALK_SPEC_TABLE=1 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec.jsonl 2> $OUT/cand_walk_spec.err; echo "walk spec probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec.jsonl
 COS_WALK_SPEC_TABLE=4 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec4.jsonl 2> $OUT/cand_walk_spec4.err; echo "walk spec (4 entries ahead) probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec4.jsonl
+COS_WALK_SPEC_TABLE=6 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec6.jsonl 2> $OUT/cand_walk_spec6.err; echo "walk spec (six-entry window, all ahead; 6.1 KB of LDS per wave = 6 waves per SIMD) probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec6.jsonl
 COS_WALK_SPEC_TABLE=8 PROBE_EFS=64,256 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec8.jsonl 2> $OUT/cand_walk_spec8.err; echo "walk spec (eight-entry window, all ahead; 7.7 KB of LDS per wave = 5 waves per SIMD) probe rc=$?"; cut -c1-400 $OUT/cand_walk_spec8.jsonl
 COS_WALK_SPEC_TABLE=1 COS_WALK_PB_UPPER=4 PROBE_EFS=64 PROBE_COLS=4294967295 timeout 400 python scripts/table_probe.py > $OUT/cand_walk_spec_pbu4.jsonl 2> $OUT/cand_walk_spec_pbu4.err; echo "walk spec + pb_upper 4 rc=$?"; cut -c1-400 $OUT/cand_walk_spec_pbu4.jsonl
 # one 256-query batch is the same chain with nothing to hide it behind (~400 table-level expansions per query): the candidate there
-for SP in 0 2 4 8; do
+for SP in 0 2 4 6 8; do
   COS_WALK_SPEC_TABLE=$SP timeout 300 python scripts/single_batch_probe.py > $OUT/cand_single_batch_spec_$SP.jsonl 2> $OUT/cand_single_batch_spec_$SP.err; echo "single batch, spec $SP rc=$?"; cut -c1-500 $OUT/cand_single_batch_spec_$SP.jsonl
 done
 # + the top of every query's table row fetched in one instruction before the first level (COS_WALK_SPEC_WARM=1)

@@ -100,12 +100,16 @@ def test_packed_sparse_kernel_instruction_budget(tmp_path):
 
 
 def test_gather_ahead_walk_candidate_keeps_the_default_kernels_occupancy(tmp_path):
-    """kernels_walk_spec.hip (COS_WALK_SPEC_TABLE=1): the candidate must not cost waves per SIMD against the kernel it would replace"""
-    ks = _kernels("kernels_walk_spec.o", tmp_path)
-    for ns in ("spec2", "spec4", "spec8"):                            # table values of 2 / 4 / 8 (eight-entry window) entries gathered ahead
-        head = _find(ks, ns + "::walk_spec_kernel<0, 1, 1, true, false, 8>")
-        assert head["vgpr_count"] <= 72 and head["private_segment_fixed_size"] == 0      # 7 waves per SIMD, like walk_kernel<0, 1, 1, true, false, 8>
-        upper = _find(ks, ns + "::walk_spec_kernel<0, 1, 1, true, false, 4>")
-        assert upper["vgpr_count"] <= 64 and upper["private_segment_fixed_size"] == 0    # 8 waves per SIMD (COS_WALK_PB_UPPER=4)
-        ef256 = _find(ks, ns + "::walk_spec_kernel<0, 1, 4, true, false, 8>")
-        assert ef256["vgpr_count"] <= 96 and ef256["private_segment_fixed_size"] == 0
+    """kernels_walk_spec*.hip (COS_WALK_SPEC_TABLE=2|4|6|8): the candidates must not cost waves per SIMD in REGISTERS against the kernel they
+    would replace (the wider windows pay in LDS instead: kernels_walk_spec_wide.hip)"""
+    for obj, spaces in (("kernels_walk_spec.o", ("spec2", "spec4")), ("kernels_walk_spec_wide.o", ("spec6", "spec8"))):
+        work = tmp_path / obj
+        work.mkdir()
+        ks = _kernels(obj, work)
+        for ns in spaces:                                                  # table values of 2 / 4 / 6 / 8 window entries gathered ahead
+            head = _find(ks, ns + "::walk_spec_kernel<0, 1, 1, true, false, 8>")
+            assert head["vgpr_count"] <= 72 and head["private_segment_fixed_size"] == 0      # 7 waves per SIMD, like walk_kernel<0, 1, 1, true, false, 8>
+            upper = _find(ks, ns + "::walk_spec_kernel<0, 1, 1, true, false, 4>")
+            assert upper["vgpr_count"] <= 64 and upper["private_segment_fixed_size"] == 0    # 8 waves per SIMD (COS_WALK_PB_UPPER=4)
+            ef256 = _find(ks, ns + "::walk_spec_kernel<0, 1, 4, true, false, 8>")
+            assert ef256["vgpr_count"] <= 96 and ef256["private_segment_fixed_size"] == 0
