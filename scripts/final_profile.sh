@@ -9,6 +9,8 @@
 #      step 2, so the traffic / issue figures in it belong to the same build;
 #   4. kernel traces of c5 and c3 (small scripts).
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
+# the walk kernel of the c2 launches at ef 64 / 256 as rocprofv3 names it (another kernel became the default? export these)
+K64=${WALK_KERNEL_EF64:-"walk_kernel<0, 1, 1, true, false, 8>"}; K256=${WALK_KERNEL_EF256:-"walk_kernel<0, 1, 4, true, false, 8>"}
 timeout 900 python -m pytest tests -m gpu -q > $OUT/final_pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/final_pytest.log
 cd /tmp; export TMPDIR=/tmp
 export COS_BENCH_FULL_RECORD=bench_full_record_of_a_profiler_pass.json
@@ -25,9 +27,9 @@ import json
 r = json.load(open("gpurun_out/pmc_fetch_bench.json")); p = r["roofline"]["parts"]; print(int(p["walk_upper"]["evals"] + p["walk_lower"]["evals"]))
 PY
 )
-python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef64.json
-python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "walk_kernel<0, 1, 4, true, false, 8>" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef256.json
-python scripts/pmc_issue.py /tmp/p_s2/s2_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" $EVALS ref > $OUT/pmc_issue_ef64.json
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "$K64" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef64.json
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "$K256" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef256.json
+python scripts/pmc_issue.py /tmp/p_s2/s2_results.db 32768 c2 64 "$K64" $EVALS ref > $OUT/pmc_issue_ef64.json
 python scripts/rocprof_summary.py /tmp/p_f/f_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_fetch_size.txt
 python scripts/rocprof_summary.py /tmp/p_w/w_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_write_size.txt
 python scripts/rocprof_summary.py /tmp/p_s2/s2_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_sq_instruction_mix.txt 2>> $OUT/pmc_sq2.err

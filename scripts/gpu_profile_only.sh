@@ -1,6 +1,8 @@
 #!/bin/bash
 # the profiler passes of scripts/final_profile.sh alone (c2 kernel trace, FETCH_SIZE, WRITE_SIZE, SQ instruction mix)
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
+# the walk kernel of the c2 launches at ef 64 / 256 as rocprofv3 names it (another kernel became the default? export these)
+K64=${WALK_KERNEL_EF64:-"walk_kernel<0, 1, 1, true, false, 8>"}; K256=${WALK_KERNEL_EF256:-"walk_kernel<0, 1, 4, true, false, 8>"}
 cd /tmp; export TMPDIR=/tmp
 export COS_BENCH_FULL_RECORD=bench_full_record_of_a_profiler_pass.json
 MAIN="--steps 20 --warmup 5 --configs none --no-cpu-baseline --no-hbm-probe --no-host-api --ef-sweep 256"
@@ -16,11 +18,11 @@ import json
 r = json.load(open("gpurun_out/pmc_fetch_bench.json")); p = r["roofline"]["parts"]; print(int(p["walk_upper"]["evals"] + p["walk_lower"]["evals"]))
 PY
 )
-python scripts/pmc_issue.py /tmp/p_s2/s2_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" $EVALS ref > $OUT/pmc_issue_ef64.json
+python scripts/pmc_issue.py /tmp/p_s2/s2_results.db 32768 c2 64 "$K64" $EVALS ref > $OUT/pmc_issue_ef64.json
 python scripts/rocprof_summary.py /tmp/p_s2/s2_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_sq_instruction_mix.txt
 cp profiles/pmc_issue.json $OUT/pmc_issue.json
-python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "walk_kernel<0, 1, 1, true, false, 8>" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef64.json
-python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "walk_kernel<0, 1, 4, true, false, 8>" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef256.json
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "$K64" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef64.json
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "$K256" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef256.json
 python scripts/rocprof_summary.py /tmp/p_f/f_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_fetch_size.txt
 python scripts/rocprof_summary.py /tmp/p_w/w_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_write_size.txt
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json

@@ -5,7 +5,7 @@ import sys
 
 
 def short(name):
-    for key in ("walk_lat4_kernel", "walk_lat_kernel", "walk_meta_kernel", "walk_kernel", "finalize_kernel", "quantize_rows_kernel", "scatter_rows_kernel",
+    for key in ("walk_lat4_kernel", "walk_lat_kernel", "walk_meta_kernel", "walk_spec_kernel", "walk_kernel", "finalize_kernel", "quantize_rows_kernel", "scatter_rows_kernel",
                 "merge_topk_kernel", "deal_to_xcds_kernel", "flat_", "bm25_", "rrf_kernel", "sparse_tile_kernel", "sparse_finish_kernel", "link_kernel", "claim_kernel", "evict_kernel"):
         if key in name:
             i = name.index(key)
@@ -38,7 +38,7 @@ def main(path):
     parts = {}
     prev = {}
     for name, grid, dur, lane in seq:
-        if "walk_kernel" in name and grid >= 4096:
+        if ("walk_kernel" in name or "walk_spec_kernel" in name) and grid >= 4096:
             after_deal = "deal_to_xcds" in prev.get(lane, "")
             part = "lower levels, after deal_to_xcds (locality order)" if after_deal else "upper levels (arrival order) or unsplit walk"
             parts.setdefault((short(name), grid, part), []).append(dur)
@@ -67,7 +67,7 @@ def main(path):
         ocol = next((c for c in ("dispatch_id", "start", "id") if c in ccols), None)
         if ocol and any("after deal_to_xcds" in k[2] for k in parts):
             rows = cur.execute(f"select kernel_name, grid_size/workgroup_size, counter_name, value, {ocol} from counters_collection "
-                               f"where kernel_name like '%walk_kernel%' and grid_size/workgroup_size >= 4096 order by {ocol}").fetchall()
+                               f"where (kernel_name like '%walk_kernel%' or kernel_name like '%walk_spec_kernel%') and grid_size/workgroup_size >= 4096 order by {ocol}").fetchall()
             seen, acc = {}, {}
             for name, grid, cn, val, oid in rows:
                 key = (short(name), grid, cn)
