@@ -9,6 +9,8 @@ def short(name):
                 "merge_topk_kernel", "deal_to_xcds_kernel", "flat_", "bm25_", "rrf_kernel", "sparse_tile_kernel", "sparse_finish_kernel", "link_kernel", "claim_kernel", "evict_kernel"):
         if key in name:
             i = name.index(key)
+            if key == "walk_spec_kernel" and name[max(0, i - 7):i].startswith("spec") and name[i - 2:i] == "::":
+                i -= 7  # keep the variant's namespace (spec2:: .. spec8::)
             j = name.find("(", i)
             return name[i:j if j > 0 else None]
     return name[:60]
