@@ -101,6 +101,7 @@ ABI_SYMBOLS = [
     "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
     "cos_bm25_search_batch", "cos_bm25_search_batch_device", "cos_rrf_fuse_batch", "cos_hybrid_search_batch", "cos_text_process", "cos_text_count_tokens", "cos_bm25_term_frequency", "cos_xxhash32", "cos_stem_english", "cos_sparse_create", "cos_sparse_build_csr", "cos_sparse_create_from_vectors", "cos_sparse_destroy", "cos_sparse_search_batch", "cos_sparse_last_stats", "cos_sparse_layout", "cos_merge_topk_device", "cos_merge_topk_packed_device", "cos_hbm_probe",
     "cos_shardset_unique_id", "cos_shardset_create", "cos_shardset_destroy", "cos_shardset_search_batch", "cos_shardset_exchange_device",
+    "cos_tuning_set", "cos_tuning_clear", "cos_tuning_get",
 ]
 
 
@@ -185,6 +186,9 @@ def lib():
         "cos_shardset_destroy": [vp],
         "cos_shardset_search_batch": [vp, vp, u32, u32, vp, vp, vp],
         "cos_shardset_exchange_device": [vp, vp, u32, u32, vp, vp, vp, vp, vp],
+        "cos_tuning_set": [C.c_char_p, C.c_int64],
+        "cos_tuning_clear": [C.c_char_p],
+        "cos_tuning_get": [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(i32)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -211,3 +215,42 @@ def lib():
 def check(rc: int):
     if rc != OK:
         raise CosdataError(rc, lib().cos_last_error_string().decode("utf-8", "replace"))
+
+
+def tuning_set(name: str, value: int):
+    """cos_tuning_set: an experiment knob of the library (cosdata_amd/csrc/tuning.h); never changes a result."""
+    check(lib().cos_tuning_set(name.encode(), int(value)))
+
+
+def tuning_clear(name: str | None = None):
+    """cos_tuning_clear: one knob (or, with None, every knob) back to its built-in default."""
+    check(lib().cos_tuning_clear(name.encode() if name is not None else None))
+
+
+def tuning_get(name: str):
+    """-> the knob's value, or None when nobody set it."""
+    v, isset = C.c_int64(), C.c_int32()
+    check(lib().cos_tuning_get(name.encode(), C.byref(v), C.byref(isset)))
+    return int(v.value) if isset.value else None
+
+
+class tuning:
+    """with tuning(flat_tile_kernel=1): ...  — knobs set for the block, restored afterwards."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            self.old[k] = tuning_get(k)
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                tuning_clear(k)
+            else:
+                tuning_set(k, v)
+        return False

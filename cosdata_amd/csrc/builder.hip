@@ -201,7 +201,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     std::vector<u32> cursor(L1, 0); // first node of each level not yet inserted (nodes are in id order)
     u32 inserted = 0, round = 0;
     u64 n_rounds = 0, n_batches = 0;
-    const bool prof = getenv("COS_BUILD_PROFILE") != nullptr;
+    const bool prof = cosdev::tune_or(cosdev::TUNE_BUILD_PROFILE, 0) != 0;
     double t_walk = 0, t_link = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     u32 *cnt = d_cnt.as<u32>();

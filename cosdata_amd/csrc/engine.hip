@@ -17,7 +17,6 @@
 #include <vector>
 
 #include "engine_internal.h"
-#include "host_stage.h"
 
 using namespace cosdev;
 
@@ -142,9 +141,10 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return cos_fail(COS_ERR_NO_DEVICE, "no HIP device visible; the GPU path has no CPU fallback");
     if (p->device < 0 || p->device >= ndev) return cos_fail(COS_ERR_INVALID, "device %d out of range (%d visible)", p->device, ndev);
     cos_index *ix = new cos_index();
-    if (const char *e = getenv("COS_WALK_CHAIN_MIN_B")) ix->chain_min_B = (u32)strtoul(e, nullptr, 10); // experiments: 0 = always, 4294967295 = never
-    if (const char *e = getenv("COS_WALK_ORDER_MIN_B")) ix->walk_order_min_B = (u32)strtoul(e, nullptr, 10); // 0 = one launch, arrival order
-    if (const char *e = getenv("COS_WALK_SIDE_MIN_B")) ix->walk_side_min_B = (u32)strtoul(e, nullptr, 10); // 0 = walks stay on the caller's stream
+    // experiments (tuning.h): 0 = always / 4294967295 = never; 0 = one launch, arrival order; 0 = walks stay on the caller's stream
+    ix->chain_min_B = (u32)cosdev::tune_or(cosdev::TUNE_WALK_CHAIN_MIN_B, ix->chain_min_B);
+    ix->walk_order_min_B = (u32)cosdev::tune_or(cosdev::TUNE_WALK_ORDER_MIN_B, ix->walk_order_min_B);
+    ix->walk_side_min_B = (u32)cosdev::tune_or(cosdev::TUNE_WALK_SIDE_MIN_B, ix->walk_side_min_B);
     ix->p = *p;
     ix->eng = eng;
     ix->row_stride = row_stride;
@@ -230,7 +230,6 @@ static void reset_meta(cos_index *ix) {
 static void free_pipe(HostPipe *hp) {
     void *ptrs[] = {hp->d_q, hp->d_ids, hp->d_counts, hp->d_scores, hp->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (hp->pin_q) (void)hipHostFree(hp->pin_q);
     for (hipEvent_t e : hp->ev_in) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : hp->ev_walk) if (e) (void)hipEventDestroy(e);
     hipStream_t sts[] = {hp->s[0], hp->s[1], hp->sc, hp->sf};
@@ -340,6 +339,9 @@ extern "C" int32_t cos_index_set_root(cos_index *ix, const float *root_raw) {
                                  ix->d_codes + (size_t)ix->n * ix->row_stride, ix->row_stride, ix->d_mags + ix->n, d_dummy, ix->own_stream));
     HIP_TRY(hipStreamSynchronize(ix->own_stream));
     ix->have_root = true;
+    // the root is a node of every level: the level-table operand holds a gathered COPY of its code row, norm and code sum, which a
+    // second set_root on a live graph would leave stale (the row levels would use the new row) — the next search regathers
+    ix->level_table_valid = false;
     return COS_OK;
 }
 
@@ -548,11 +550,20 @@ extern "C" int32_t cos_index_download_root(const cos_index *ix, float *root_raw)
     return COS_OK;
 }
 
+static int32_t ensure_level_table(cos_index *ix);
+static u32 walk_table_min_B(const cos_index *ix);
 extern "C" int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
     if (ef > 512) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
+    const bool live = graph_ready(ix);
+    if (live)
+        if (int32_t rc = cos_set_device(ix)) return rc;
     std::lock_guard<std::mutex> g(ix->mu); // searches snapshot ef / visited mode under the same lock (run_search)
     ix->p.ef_search = ef;
+    // the automatic level-table rule depends on ef: the operand of the new rule is gathered HERE, by the caller that changes the
+    // knob, not inside the next search (where the gather and its device synchronisation ran under ix->mu in front of every
+    // concurrent searcher); operands are cached per (graph, rule), so going back and forth costs nothing the second time
+    if (live && walk_table_min_B(ix)) return ensure_level_table(ix);
     return COS_OK;
 }
 extern "C" int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode) {
@@ -661,14 +672,9 @@ static int32_t ensure_order_rank(cos_index *ix) {
     const u32 Ltop = ix->p.num_layers;
     auto usable = [&](u32 l) { return l >= 1 && l <= Ltop && ix->lv[l].n > 1 && ix->lv[l].n <= (1u << 20) && ix->lv[l].d_adj_node; };
     std::vector<u32> want;
-    if (const char *e = getenv("COS_WALK_SPLIT")) {
-        for (const char *p = e; *p;) {
-            char *q;
-            const unsigned long v = strtoul(p, &q, 10);
-            if (q == p) break;
-            want.push_back((u32)v);
-            p = *q == ',' ? q + 1 : q;
-        }
+    if (const long long mask = cosdev::tune(cosdev::TUNE_WALK_SPLIT_LEVELS); mask != cosdev::TUNE_UNSET) { // experiments: bit l = cut after level l
+        for (u32 l = Ltop; l >= 1; l--)
+            if ((mask >> l) & 1) want.push_back(l);
     } else {
         for (u32 l = 1; l <= Ltop; l++)
             if (usable(l) && (size_t)ix->lv[l].n * ix->row_stride <= ((size_t)64 << 20)) { want.push_back(l); break; }
@@ -733,11 +739,11 @@ static void free_level_tables(cos_index *ix) {
     clear_current_table(ix);
 }
 static u32 walk_table_max_cols(const cos_index *ix) { // COS_WALK_TABLE_AUTO = sized from ef_search and neighbors_count (ensure_level_table)
-    static const long long env = [] { const char *e = getenv("COS_WALK_TABLE_COLS"); return e ? atoll(e) : -1ll; }();
+    const long long env = cosdev::tune_or(cosdev::TUNE_WALK_TABLE_COLS, -1);
     return env >= 0 ? (u32)std::min<long long>(env, 1ll << 20) : ix->walk_table_max_cols;
 }
 static u32 walk_table_min_B(const cos_index *ix) {
-    static const long long env = [] { const char *e = getenv("COS_WALK_TABLE_MIN_B"); return e ? atoll(e) : -1ll; }();
+    const long long env = cosdev::tune_or(cosdev::TUNE_WALK_TABLE_MIN_B, -1);
     return env >= 0 ? (u32)std::min<long long>(env, 0xFFFFFFFFll) : ix->walk_table_min_B;
 }
 static int32_t ensure_level_table(cos_index *ix) {
@@ -761,6 +767,8 @@ static int32_t ensure_level_table(cos_index *ix) {
         HIP_TRY(hipDeviceSynchronize());
         free_level_tables(ix);
     }
+    // (from here on every path leaves a definite state for this (graph, key): a table, or "none" — which is also what an operand
+    // that could not be allocated leaves, see below)
     ix->level_table_valid = true;
     ix->table_built_for_key = key;
     clear_current_table(ix);
@@ -807,6 +815,11 @@ static int32_t ensure_level_table(cos_index *ix) {
         if (tcodes) (void)hipFree(tcodes);
         if (tmags) (void)hipFree(tmags);
         if (tcsums) (void)hipFree(tcsums);
+        if (e == hipErrorOutOfMemory) { // the table is an optimisation: short of HBM the walk reads rows (same results)
+            (void)hipGetLastError();
+            return COS_OK;
+        }
+        ix->level_table_valid = false; // anything else is a real failure: reported, and retried by the next search
         HIP_TRY(e);
     }
     ix->d_tcodes = tcodes;
@@ -852,7 +865,7 @@ extern "C" int32_t cos_index_walk_table_info(cos_index *ix, uint32_t *out_level_
 }
 
 // The per-graph tables of big launches (locality order ranks, level-table operand) built when a graph is committed — the end of
-// cos_index_build, the upload of a graph's last level, cos_index_load_reference_dir — instead of inside the first big search, where
+// cos_index_build, the upload of a graph's last level (which is also how cos_index_load_reference_dir commits) — instead of inside the first big search, where
 // the host-side DFS and the device synchronisations ran under ix->mu and held up every concurrent searcher.  The lazy calls in
 // get_workspace stay as a fall-back (knobs changed after the commit).
 int32_t cos_prepare_walk_plans(cos_index *ix) {
@@ -917,18 +930,23 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         const size_t need = (size_t)w->capB * ix->table_stride;
         if (need > w->tab_cap) {
             // every workspace (one per caller stream, up to five per leased host pipe) holds the table of its own launch in flight:
-            // a handle's tables together stay under a budget (COS_WALK_TABLE_MAX_BYTES, default 48 GiB) — a workspace that would
+            // a handle's tables together stay under a budget (tuning knob walk_table_max_bytes, default 48 GiB) — a workspace that would
             // exceed it simply walks without a table (same results)
-            static const size_t budget = [] { const char *e = getenv("COS_WALK_TABLE_MAX_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)48 << 30); }();
+            const size_t budget = (size_t)cosdev::tune_or(cosdev::TUNE_WALK_TABLE_MAX_BYTES, (long long)48 << 30);
             HIP_TRY(hipStreamSynchronize(st));
             if (w->tab) HIP_TRY(hipFree(w->tab));
             ix->table_bytes_total -= w->tab_cap * 4;
             w->tab = nullptr;
             w->tab_cap = 0;
             if (ix->table_bytes_total + need * 4 <= budget) {
-                HIP_TRY(hipMalloc((void **)&w->tab, need * 4));
-                w->tab_cap = need;
-                ix->table_bytes_total += need * 4;
+                if (const hipError_t e = hipMalloc((void **)&w->tab, need * 4); e == hipSuccess) {
+                    w->tab_cap = need;
+                    ix->table_bytes_total += need * 4;
+                } else if (e == hipErrorOutOfMemory) { // HBM is short: this workspace walks without a table (same results)
+                    (void)hipGetLastError();
+                    w->tab = nullptr;
+                } else
+                    HIP_TRY(e);
             }
         }
     }
@@ -1217,29 +1235,11 @@ static int32_t search_host_simple(cos_index *ix, HostPipe *hp, const float *quer
 // next one fills the wave slots the previous one drains; they are not put in the walk chain).  Results are those of one
 // launch: queries are independent.  When other host calls are in flight the same overlap already happens ACROSS calls (their
 // copies hide under this call's chained walk), and whole-batch launches are the better shape — then the simple path is used.
-// COS_HOST_STAGE_THREADS=n (n >= 1; unset or 0 = off, the default until it has been measured): the chunks of a pipelined host call are
-// copied into the pipe's pinned buffer by n helper threads + the caller (host_stage.h) and travel from there, instead of one pageable
-// hipMemcpyAsync per chunk staged by the runtime on the calling thread.  One pool per process, started on first use.
-static cosdev::StagePool *stage_pool() {
-    static cosdev::StagePool *pool = []() -> cosdev::StagePool * {
-        const char *e = getenv("COS_HOST_STAGE_THREADS");
-        const long n = e ? strtol(e, nullptr, 10) : 0;
-        return n >= 1 ? new cosdev::StagePool((unsigned)std::min<long>(n, 32)) : nullptr; // lives as long as the process
-    }();
-    return pool;
-}
-
+// (Round 4 wrote a threaded pinned staging of the chunks, round 5 measured it: one caller 3.26 M QPS with 4 or 8 helper threads against
+// 3.44 M for this plain pageable copy — profiles/r05_candidates_host_stage.txt — and removed it.)
 static int32_t search_host_pipelined(cos_index *ix, HostPipe *hp, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids,
                                      float *out_scores, uint32_t *out_counts, int32_t *out_status) {
     const size_t dim = ix->p.dim;
-    cosdev::StagePool *stage = stage_pool();
-    if (stage && hp->cap_pin < (size_t)B * dim) { // (the pipe is leased: nothing of an earlier call still reads the old buffer)
-        if (hp->pin_q) (void)hipHostFree(hp->pin_q);
-        hp->pin_q = nullptr;
-        hp->cap_pin = 0;
-        if (hipHostMalloc((void **)&hp->pin_q, (size_t)B * dim * 4, hipHostMallocDefault) == hipSuccess) hp->cap_pin = (size_t)B * dim;
-        else { (void)hipGetLastError(); hp->pin_q = nullptr; stage = nullptr; } // no pinned memory to be had: the plain path
-    }
     const u32 chunk = (((B + HostPipe::MAX_CHUNKS - 1) / HostPipe::MAX_CHUNKS) + 255u) & ~255u;
     const u32 nch = (B + chunk - 1) / chunk;
     if (!hp->s[1]) HIP_TRY(hipStreamCreateWithFlags(&hp->s[1], hipStreamNonBlocking));
@@ -1273,10 +1273,6 @@ static int32_t search_host_pipelined(cos_index *ix, HostPipe *hp, const float *q
         if (rc) return rc;
         float *dq = hp->d_q + (size_t)c0 * dim;
         const float *src = queries + (size_t)c0 * dim;
-        if (stage) { // chunk i is staged while chunk i-1 travels and walks
-            stage->copy(hp->pin_q + (size_t)c0 * dim, src, (size_t)cb * dim * 4);
-            src = hp->pin_q + (size_t)c0 * dim;
-        }
         HIP_TRY(hipMemcpyAsync(dq, src, (size_t)cb * dim * 4, hipMemcpyHostToDevice, hp->sc));
         HIP_TRY(hipEventRecord(hp->ev_in[i], hp->sc));
         HIP_TRY(hipStreamWaitEvent(st, hp->ev_in[i], 0));
@@ -1297,9 +1293,8 @@ static int32_t search_host_pipelined(cos_index *ix, HostPipe *hp, const float *q
     return report_status(status.data(), B);
 }
 
-static u32 host_pipeline_min_B() { // COS_HOST_PIPELINE_MIN_B: experiments (0 = never chunk)
-    static const u32 v = [] { const char *e = getenv("COS_HOST_PIPELINE_MIN_B"); return e ? (u32)strtoul(e, nullptr, 10) : 8192u; }();
-    return v;
+static u32 host_pipeline_min_B() { // tuning knob host_pipeline_min_b: experiments (0 = never chunk)
+    return (u32)cosdev::tune_or(cosdev::TUNE_HOST_PIPELINE_MIN_B, 8192);
 }
 
 static int32_t search_host_once(cos_index *ix, const float *queries, uint32_t B, uint32_t top_k, uint32_t *out_ids, float *out_scores,

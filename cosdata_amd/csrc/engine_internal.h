@@ -12,6 +12,7 @@
 
 #include "../../include/cosdata_hip.h"
 #include "engine_types.h"
+#include "tuning.h"
 #include "link_types.h"
 
 namespace cosdev {
@@ -159,8 +160,6 @@ struct HostPipe {
     float *d_scores = nullptr;
     int32_t *d_status = nullptr;
     size_t cap_q = 0, cap_ids = 0, cap_scores = 0, cap_counts = 0, cap_status = 0; // elements, one capacity per buffer
-    float *pin_q = nullptr;     // pinned staging of the call's queries (COS_HOST_STAGE_THREADS: host_stage.h), grown on demand
-    size_t cap_pin = 0;         // elements
 };
 static constexpr u32 COS_MAX_HOST_PIPES = 32; // concurrent host-API calls served at once; further callers wait for a pipe
 

@@ -613,9 +613,9 @@ extern "C" int32_t cos_bruteforce_topk(cos_index *ix, const float *queries, uint
     chunk = std::min(n, std::max<u32>(chunk, BN));
     // Same schedule as cos_flat_search_batch: the first SEED candidates go through the score matrix + segmented selection and
     // seed every query's threshold; later chunks grow 8x and the GEMM epilogue appends only what beats the threshold.  An
-    // append-buffer overflow repeats the call on the unfused path (COS_FLAT_UNFUSED=1 forces it).
+    // append-buffer overflow repeats the call on the unfused path (tuning knob flat_unfused = 1 forces it).
     constexpr u32 SEED = 16384, APP_CAP = 4096;
-    const bool allow_fused = getenv("COS_FLAT_UNFUSED") == nullptr && n > SEED;
+    const bool allow_fused = tune_or(TUNE_FLAT_UNFUSED, 0) == 0 && n > SEED;
     const u64 s_stride = ((u64)chunk + 63) & ~63ull;
     float *d_q = nullptr, *d_qm = nullptr, *d_scores = nullptr, *d_os = nullptr, *d_dummy = nullptr;
     u64 *d_pool = nullptr, *d_part = nullptr, *d_thr = nullptr, *d_app = nullptr;
@@ -751,12 +751,11 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     // and seed every query's threshold; from then on chunks grow 8x (128 K, 1 M, 4 M ...) and the fused GEMM appends only what
     // beats the threshold: a chunk 8x the size of everything seen before lets ~64 * 8 entries per query through, an eighth of
     // the append capacity.  An adversarially ordered corpus can still overflow it; that is detected on the device and the
-    // call is repeated on the unfused path, so the result never depends on the shortcut.  COS_FLAT_UNFUSED=1 forces that path.
-    const bool allow_fused = getenv("COS_FLAT_UNFUSED") == nullptr;
-    const char *pf_env = getenv("COS_FLAT_PF"); // k panels prefetched into registers (1..3); tuning knob, results do not depend on it
-    const int pf = pf_env ? atoi(pf_env) : 1;
-    // fused chunks of quaternary codes run on the query-resident kernel when K has an instantiation (COS_FLAT_TILE_KERNEL=1: never)
-    const bool use_areg = ix->eng == ENG_Q2 && flat_scan_supported(kdims) && getenv("COS_FLAT_TILE_KERNEL") == nullptr;
+    // call is repeated on the unfused path, so the result never depends on the shortcut.  Tuning knob flat_unfused = 1 forces that path.
+    const bool allow_fused = tune_or(TUNE_FLAT_UNFUSED, 0) == 0;
+    const int pf = (int)tune_or(TUNE_FLAT_PF, 1); // k panels prefetched into registers (1..3); results do not depend on it
+    // fused chunks of quaternary codes run on the query-resident kernel when K has an instantiation (tuning knob flat_tile_kernel = 1: never)
+    const bool use_areg = ix->eng == ENG_Q2 && flat_scan_supported(kdims) && tune_or(TUNE_FLAT_TILE_KERNEL, 0) == 0;
     int n_cus = 0;
     if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, ix->p.device) != hipSuccess || n_cus <= 0) n_cus = 256;
     constexpr u32 SEED = 16384, APP_CAP = 4096;
@@ -959,12 +958,10 @@ hipError_t launch_level_table(const uint8_t *qcodes, const float *qmags, u32 *qs
     const u32 kdims = (u32)((row_stride + 63) / 64 * 64);
     dim3 grid((ncols + CN - 1) / CN, (B + CM - 1) / CM);
     FusedOut fo{nullptr, nullptr, nullptr, 0u, nullptr};
-    static const int pf = [] { const char *e = getenv("COS_TABLE_GEMM_PF"); return e ? atoi(e) : 2; }(); // k panels in flight (experiments)
+    // two k panels in flight (one and three were measured slower in round 4)
 #define TAB_GEMM(P) hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, false, P>), grid, dim3(512), 0, st, qcodes, qmags, (const u32 *)qsums, B, tcodes, tmags, \
                                        tcsums, row_stride, 0u, ncols, kdims, metric, tab, tab_stride, fo)
-    if (pf == 3) TAB_GEMM(3);
-    else if (pf == 1) TAB_GEMM(1);
-    else TAB_GEMM(2);
+    TAB_GEMM(2);
 #undef TAB_GEMM
     return hipGetLastError();
 }

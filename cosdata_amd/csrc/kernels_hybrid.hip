@@ -437,7 +437,7 @@ static int32_t bm25_launch(cos_bm25 *b, u32 B, u32 top_k, u32 *d_out_ids, float 
     // launch shape: enough blocks that the heaviest query's share is small against the whole launch, few enough that a block's fixed
     // cost (512 buckets, 8192 accumulators to reset and fold per tile) stays small against its postings.  c5, 256 queries
     // (profiles/r02_c5_bm25_*): 2048 blocks 0.72 ms, 4096 0.67, 8192 0.66, 16384 0.69, 32768 0.89.  COS_BM25_BLOCKS overrides (experiments).
-    static const u32 target_blocks = [] { const char *e = getenv("COS_BM25_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? (u32)v : 8192u; }();
+    const u32 target_blocks = (u32)std::max<long long>(1, tune_or(TUNE_BM25_BLOCKS, 8192));
     const u32 n_tiles = (span + TILE - 1) / TILE;
     const u32 splits = std::max(1u, std::min(n_tiles, std::max(1u, target_blocks / B)));
     hipLaunchKernelGGL(bm25_score_kernel, dim3(B * splits), dim3(256), 0, st, b->d_docs, b->d_tfs, b->d_qt, span, b->d_tile_dir, b->d_buckets,

@@ -777,9 +777,10 @@ extern "C" int32_t cos_sparse_create(int32_t device, uint32_t quantization_bits,
     std::vector<u32> tile_dir;
     s->h_dir.assign(n_dims, SNO_DIR);
     s->h_mult.assign(n_dims, 1u);
-    // COS_SPARSE_PACKED=1: the one-word-per-posting layout and its kernel (sparse_packed_kernel); vector ids must fit 24 bits
-    const char *pk_env = getenv("COS_SPARSE_PACKED");
-    s->packed = pk_env && atoi(pk_env) != 0 && n_vectors <= SPK_MAX_N;
+    // the one-word-per-posting layout and its kernel (sparse_packed_kernel) wherever vector ids fit 24 bits — measured in round 5:
+    // 0.453 ms against 0.540 ms per 256-query batch, 256 / 256 queries identical to the oracle (profiles/r05_candidates_sparse.txt);
+    // tuning knob sparse_layout = 0 keeps the (u32 id, u8 key) layout (the parity tests run both)
+    s->packed = tune_or(TUNE_SPARSE_LAYOUT, 1) != 0 && n_vectors <= SPK_MAX_N;
     std::vector<u64> tmp;
     u32 rows = 0;
     const u32 nt1 = s->n_tiles + 1;
@@ -988,11 +989,8 @@ extern "C" int32_t cos_sparse_search_batch(cos_sparse *s, const uint32_t *q_dims
     HIP_TRY(hipMemcpy(d_order.p, order.data(), (size_t)B * 4, hipMemcpyHostToDevice));
     SparseDev dev{nullptr, nullptr, nullptr, s->d_row_off, s->d_raw_dims, s->d_raw_vals, s->T, Q, s->n, s->bits, s->upper};
     HIP_TRY(hipEventRecord(s->ev0, 0));
-    static const int packed_pu = [] { const char *e = getenv("COS_SPARSE_SPU"); return e && atoi(e) == 16 ? 16 : 8; }(); // postings per lane per step
-    if (s->packed && packed_pu == 16)
-        hipLaunchKernelGGL(sparse_packed_kernel<16>, dim3(B * splits), dim3(256), 0, 0, s->d_pk, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,
-                           d_order.as<u32>(), splits, d_part.as<u64>());
-    else if (s->packed)
+    // eight postings per lane and step; sixteen measured the same (0.447 against 0.453 ms) and was dropped
+    if (s->packed)
         hipLaunchKernelGGL(sparse_packed_kernel<8>, dim3(B * splits), dim3(256), 0, 0, s->d_pk, d_terms.as<STerm>(), d_qt_off.as<u32>(), s->n, s->d_tile_dir,
                            d_order.as<u32>(), splits, d_part.as<u64>());
     else

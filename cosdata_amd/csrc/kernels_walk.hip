@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "engine_types.h"
+#include "tuning.h"
 #include "dot_engines.h"
 
 using namespace cosdev;
@@ -458,23 +459,20 @@ size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     return b + 16;
 }
 
-// rows in flight per wave on the G = 64 u8 path (see PB64 above); COS_WALK_PB=4|8 overrides the default (experiments).
+// rows in flight per wave on the G = 64 u8 path (see PB64 above); tuning knob walk_pb = 4|8 overrides the default (experiments).
 // The widest pool (ef > 256: 16 VGPRs of pool) with eight row buffers needs 110 VGPRs = 4 waves per SIMD; with four it fits 5 waves
 // without spills and measured 3.3 % faster (c2 at ef 512: 50.9 vs 52.6 ms per 32768 queries, profiles/r03_order_probe_c2_ef512_pb4.jsonl).
-// COS_WALK_PB_UPPER=4|8 (experiments, unset = no effect): the variant of the UPPER range of a split walk only.  With the level table
-// that range is almost all table levels — a latency chain that fetches no rows (c2: 91 M table evaluations against 2 M row evaluations) —
-// and the four-buffer variant needs 53 VGPRs at ef <= 64 = 8 waves per SIMD where the eight-buffer one has 69 = 7.
+// The UPPER range of a split walk (tuning knob walk_pb_upper = 4|8 overrides): with the level table that range is almost all table
+// levels, which fetch no rows (c2: 91 M table evaluations against 2 M row evaluations), and the four-buffer variant leaves more waves
+// per SIMD.  Measured in round 5 (profiles/r05_candidates_walk_pb_upper.txt, c2): ef 64 2.798 against 2.799 ms (nothing: 8 stays),
+// ef 256 10.47 against 11.33 ms per 32 768 queries (+4.4 % QPS on the whole step): four buffers above ef 64.
 static int walk_pb_policy(u32 B, u32 ef, bool upper_range_of_a_split_walk) {
-    static const int forced = [] { const char *e = getenv("COS_WALK_PB"); return e ? atoi(e) : 0; }();
-    static const int forced_upper = [] { const char *e = getenv("COS_WALK_PB_UPPER"); return e ? atoi(e) : 0; }();
+    const int forced = (int)tune_or(TUNE_WALK_PB, 0), forced_upper = (int)tune_or(TUNE_WALK_PB_UPPER, 0);
     if (upper_range_of_a_split_walk && (forced_upper == 4 || forced_upper == 8)) return forced_upper;
     if (forced == 4 || forced == 8) return forced;
+    if (upper_range_of_a_split_walk && ef > 64u) return 4;
     return ef > 256u ? 4 : 8;
 }
-
-// kernels_walk_spec.hip: the candidate kernel that gathers table values ahead (COS_WALK_SPEC_TABLE=1; off by default)
-size_t walk_spec_extra_smem();
-hipError_t launch_walk_spec(const IndexDev &ix, const WalkArgs &wa, int row_buffers, size_t smem, hipStream_t st);
 
 template <int ENG, int CH, bool G64>
 static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
@@ -483,10 +481,6 @@ static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStrea
     const bool exact = ix.visited_mode != 0;
     constexpr bool HAS_PB8 = ENG == ENG_U8 && G64 && CH == 1; // the headline path (u8, 513..1024 dims)
     const bool pb8 = HAS_PB8 && walk_pb_policy(wa.B, wa.ef, wa.phase != 0u && wa.level_last >= 1u) == 8;
-    if constexpr (HAS_PB8) {
-        static const bool spec_env = [] { const char *e = getenv("COS_WALK_SPEC_TABLE"); return e && atoi(e) != 0; }();
-        if (spec_env && !exact && wa.tab != nullptr) return launch_walk_spec(ix, wa, pb8 ? 8 : 4, smem + walk_spec_extra_smem(), st);
-    }
 #define WALK(R_)                                                                                                          \
     do {                                                                                                                  \
         if constexpr (HAS_PB8) {                                                                                          \
@@ -517,12 +511,11 @@ hipError_t launch_walk_lat4(int eng, const IndexDev &ix, const WalkArgs &wa, hip
 
 // lat_max_B: launches of at most this many queries take the latency kernel where it applies (cos_index_set_latency_mode; 0 = never);
 // lat4_max_B: the smallest of them give every query four waves (cos_index_set_latency_waves; 0 = never).
-// COS_WALK_LAT=<n> / COS_WALK_LAT4=<n> override the handle's values (experiments: 0 = off, 4294967295 = always)
+// tuning knobs walk_lat / walk_lat4 = <n> override the handle's values (experiments: 0 = off, 4294967295 = always)
 // does the kernel launch_walk would pick for this launch read WalkArgs::tab?  (the throughput kernel and the four-wave latency
 // kernel do; the one-wave latency kernel does not: engine.hip then skips the table GEMM)
 static void walk_env_overrides(u32 &lat_max_B, u32 &lat4_max_B) {
-    static const long long lat_env = [] { const char *e = getenv("COS_WALK_LAT"); return e ? atoll(e) : -1ll; }();
-    static const long long lat4_env = [] { const char *e = getenv("COS_WALK_LAT4"); return e ? atoll(e) : -1ll; }();
+    const long long lat_env = tune_or(TUNE_WALK_LAT, -1), lat4_env = tune_or(TUNE_WALK_LAT4, -1);
     if (lat_env >= 0) lat_max_B = lat_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat_env;
     if (lat4_env >= 0) lat4_max_B = lat4_env > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)lat4_env;
 }
@@ -533,7 +526,7 @@ static void walk_env_overrides(u32 &lat_max_B, u32 &lat4_max_B) {
 // (1.73 against 2.20 at ef 256).  profiles/r04_single_batch_probe.jsonl, r04_mid_size_probe.jsonl.
 int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, bool table_available) { // 0 throughput, 1 one-wave latency, 4 four-wave latency
     walk_env_overrides(lat_max_B, lat4_max_B);
-    static const bool tk_small = [] { const char *e = getenv("COS_WALK_SMALL_TABLE_TK"); return !e || atoi(e) != 0; }();
+    const bool tk_small = tune_or(TUNE_WALK_SMALL_TABLE_TK, 1) != 0;
     if (table_available && tk_small && eng == ENG_U8) {
         if (wa.phase == 0u && wa.ef > 64u && walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return 4;
         return 0;
@@ -582,8 +575,8 @@ hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_strid
     const u32 total = (ix.num_layers + 1) * per_level;
     dim3 grid(B), block(64);
     // the screened kernel first (5k + 1 <= 64 entries per level list), then the general kernel over the list of queries it left;
-    // COS_FINALIZE_FAST=0 keeps the general kernel alone (experiments)
-    static const bool fast_on = [] { const char *e = getenv("COS_FINALIZE_FAST"); return !e || atoi(e) != 0; }();
+    // tuning knob finalize_fast = 0 keeps the general kernel alone (experiments)
+    const bool fast_on = tune_or(TUNE_FINALIZE_FAST, 1) != 0;
     bool listed = false;
     if (fast_on && slow_list && ix.mdim == 0u && 5u * top_k + 1u <= 64u && KEEP_SEARCH >= 5u * top_k + 1u) { // base collections: only the root is ever dropped
         fa.slow_list = slow_list + 1;

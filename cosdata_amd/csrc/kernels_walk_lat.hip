@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "engine_types.h"
+#include "tuning.h"
 #include "dot_engines.h"
 
 using namespace cosdev;
@@ -387,7 +388,7 @@ template <int ENG, int CH>
 hipError_t launch_lat_r(const IndexDev &ix, const WalkArgs &wa, u32 la, hipStream_t st) {
     const size_t smem = walk_lat_smem_bytes(ix, wa.ef);
     dim3 grid(wa.B), block(64);
-    static const bool warm = [] { const char *e = getenv("COS_WALK_LAT_WARM"); return !e || atoi(e) != 0; }(); // experiments: 0 = off
+    const bool warm = tune_or(TUNE_WALK_LAT_WARM, 1) != 0; // experiments: 0 = off
     if (warm) {
         if (wa.ef <= 64) hipLaunchKernelGGL((walk_lat_kernel<ENG, CH, 1, true>), grid, block, smem, st, ix, wa, la);
         else hipLaunchKernelGGL((walk_lat_kernel<ENG, CH, 4, true>), grid, block, smem, st, ix, wa, la);
@@ -426,9 +427,8 @@ bool walk_lat_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 ma
 hipError_t launch_walk_lat(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     // window size: 4 (profiles/r02_latency_walk_sweep_first_version_window4_vs_8.jsonl: an 8-entry window needs 24 % fewer rounds but only 3.9
     // of its 8 entries are consumed before it goes stale, and the wasted evaluations cost more issue time than the rounds save; the
-    // kernel has been unrolled for at most LAL = 4 since); COS_WALK_LAT_LA=1..4 narrows it per launch (experiments)
-    const char *la_s = getenv("COS_WALK_LAT_LA");
-    const u32 la_env = la_s ? (u32)atoi(la_s) : 0u;
+    // kernel has been unrolled for at most LAL = 4 since); tuning knob walk_lat_la = 1..4 narrows it per launch (experiments)
+    const u32 la_env = (u32)std::max<long long>(0, tune_or(TUNE_WALK_LAT_LA, 0));
     u32 la = la_env ? la_env : 4u;
     if (la > (u32)LAL) la = LAL;
     const u32 ch = (ix.nchunks + GL - 1) / GL;

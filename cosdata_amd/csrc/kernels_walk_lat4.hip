@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "engine_types.h"
+#include "tuning.h"
 #include "dot_engines.h"
 
 using namespace cosdev;
@@ -497,7 +498,7 @@ bool walk_lat4_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 m
 hipError_t launch_walk_lat4(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     // window: 4 entries (one per wave).  8 (two per wave, COS_WALK_LAT4_E=2) needs 24 % fewer rounds but measured 2.6x slower per
     // round (profiles/r03_latency_sweep_*): the wasted evaluations and the wider merge cost every wave more than the rounds save
-    static const int e_env = [] { const char *e = getenv("COS_WALK_LAT4_E"); return e ? atoi(e) : 1; }();
+    const int e_env = (int)tune_or(TUNE_WALK_LAT4_E, 1);
     const u32 ch = (ix.nchunks + GL4 - 1) / GL4;
     if (e_env == 1) {
         if (eng == ENG_U8) return launch_lat4_ch<ENG_U8, 1>(ix, wa, ch, st);

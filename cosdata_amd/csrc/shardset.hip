@@ -160,7 +160,7 @@ extern "C" int32_t cos_shardset_create(cos_index *const *shards, uint32_t n_loca
     }
     // RCCL communicators: needed whenever records cross a device boundary
     // (COS_SHARDSET_FORCE_RCCL=1: also for a world of one, so the RCCL call path can be exercised on a single-GPU box)
-    const bool force = getenv("COS_SHARDSET_FORCE_RCCL") && world_size == 1;
+    const bool force = cosdev::tune_or(cosdev::TUNE_SHARDSET_FORCE_RCCL, 0) != 0 && world_size == 1;
     ss->use_rccl = (world_size > 1 && (n_local == 1 || distinct)) || force;
     if (ss->use_rccl) {
         RcclApi *r = rccl();

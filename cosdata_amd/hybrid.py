@@ -155,7 +155,7 @@ InvertedIndex.last_stats = _sparse_last_stats
 
 
 def _sparse_packed(self) -> bool:
-    """True when the handle keeps one packed u32 per posting (cos_sparse_layout; COS_SPARSE_PACKED=1 at creation)"""
+    """True when the handle keeps one packed u32 per posting (cos_sparse_layout): the default since round 5 wherever vector ids fit 24 bits"""
     v = C.c_uint32(0)
     check(_lib.lib().cos_sparse_layout(self._h, C.byref(v)))
     return bool(v.value)

@@ -267,12 +267,12 @@ class HNSWIndex:
 
     WALK_TABLE_DEFAULT_MIN_B = 1         # COS_WALK_TABLE_DEFAULT_MIN_B (include/cosdata_hip.h): every launch
     WALK_TABLE_DEFAULT_MAX_COLS = 8192   # COS_WALK_TABLE_DEFAULT_MAX_COLS
-    WALK_TABLE_AUTO = 0xFFFFFFFF         # COS_WALK_TABLE_AUTO: levels of at most 6 x ef_search x neighbors_count nodes
+    WALK_TABLE_AUTO = 0xFFFFFFFF         # COS_WALK_TABLE_AUTO: levels of at most c x ef_search x neighbors_count nodes (c = 8 up to ef 64, 6 above)
 
     def set_walk_table(self, max_cols: int = WALK_TABLE_AUTO, min_queries: int = WALK_TABLE_DEFAULT_MIN_B):
         """Launches of at least `min_queries` queries over u8 codes precompute similarity(query, node) for every node of the top
         levels (one i8 MFMA GEMM) and walk those levels from the table; same results.  max_cols: WALK_TABLE_AUTO (levels of at most
-        6 x ef_search x neighbors_count nodes each) or a cap on the table levels' nodes together.  0 for either = never."""
+        c x ef_search x neighbors_count nodes each, c = 8 up to ef_search 64 and 6 above: include/cosdata_hip.h) or a cap on the table levels' nodes together.  0 for either = never."""
         check(_lib.lib().cos_index_set_walk_table(self._h, max_cols, min_queries))
 
     def walk_table_info(self):

@@ -225,7 +225,7 @@ int32_t cos_index_walk_order_cuts(cos_index *ix, uint32_t *out_levels, uint32_t 
  * columns, +45 % QPS over a fixed 8 192).  An explicit max_cols caps the columns of all table levels together; 0 = no table.  The
  * operand follows ef_search (cos_index_set_ef_search rebuilds it on the next big launch).
  * A launch holds queries x columns x 4 bytes of table (32 768 x 20 928: 2.7 GB; 32 768 x 65 184: 8.5 GB); a handle's tables together
- * stay under 48 GiB (COS_WALK_TABLE_MAX_BYTES): a launch whose workspace would exceed that walks without a table.
+ * stay under 48 GiB (tuning knob walk_table_max_bytes): a launch whose workspace would exceed that walks without a table.
  * Device memory of the search side in general: every caller stream (cos_search_batch_device) and every host call in flight
  * (cos_search_batch: up to 32 leased pipes, a lone big call uses up to five workspaces) owns a workspace sized for its largest launch
  * — query codes, per-level result lists ((num_layers + 1) x 100 x 8 B per query: 8 KB at ten levels), statistics, the level table —
@@ -437,8 +437,9 @@ typedef struct cos_sparse_stats {
 } cos_sparse_stats;
 int32_t cos_sparse_last_stats(cos_sparse *s, cos_sparse_stats *out);
 /* Device layout of the handle's postings: 0 = a u32 id + a u8 key per posting (5 B), 1 = one packed u32 per posting
- * (key << 24 | id + 1; chosen at cos_sparse_create when COS_SPARSE_PACKED=1 is set in the environment and the collection holds
- * fewer than 2^24 - 16384 vectors).  Same results either way; a tuning choice, not a reference interface. */
+ * (key << 24 | id + 1; what cos_sparse_create builds whenever the collection holds fewer than 2^24 - 16384 vectors: measured in
+ * round 5 at 0.453 ms against 0.540 ms per 256-query batch; tuning knob sparse_layout = 0 keeps the 5-byte layout).  Same results
+ * either way; a tuning choice, not a reference interface. */
 int32_t cos_sparse_layout(cos_sparse *s, uint32_t *packed);
 
 /* ---- multi-GPU helper ----------------------------------------------------------------------- */
@@ -484,6 +485,17 @@ int32_t cos_shardset_search_batch(cos_shardset *ss, const float *queries, uint32
 int32_t cos_shardset_exchange_device(cos_shardset *ss, const uint32_t *d_packed_local, uint32_t B, uint32_t top_k,
                                      uint32_t *d_gathered, uint32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts,
                                      void *stream);
+
+/* ---- tuning knobs (experiments; NOT a reference interface) ------------------------------------------------------------------
+ * Launch-policy knobs of the kernels — which of two implementations of one operator runs, launch sizes at which a policy
+ * switches, prefetch depths.  None changes a result; the parity tests use them to compare implementations, the profiling
+ * scripts to time them.  Names: cosdata_amd/csrc/tuning.h.  The library reads ONE environment variable,
+ * COS_TUNING="name=value,name=value" (parsed once, on first use), so that an unmodified process can be steered under rocprofv3;
+ * nothing else of the process environment influences a kernel.  A knob that is not set leaves the built-in, measured default.
+ * Process-wide, thread-safe (relaxed atomics); knobs read at cos_index_create apply to handles created afterwards. */
+int32_t cos_tuning_set(const char *name, int64_t value);
+int32_t cos_tuning_clear(const char *name /* NULL = every knob */);
+int32_t cos_tuning_get(const char *name, int64_t *out_value, int32_t *out_is_set);
 
 #ifdef __cplusplus
 }

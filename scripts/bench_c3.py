@@ -53,10 +53,10 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
     # full-size parity property: three implementations of the scan (query-resident kernel, 256x128 tile kernel with the fused
     # epilogue, unfused score-matrix path) must return the same ids / score bits / counts
     same = {}
-    for env in ("COS_FLAT_TILE_KERNEL", "COS_FLAT_UNFUSED"):
-        os.environ[env] = "1"
-        i2, s2, c2 = ix.flat_search(Qh, 10)
-        del os.environ[env]
+    from cosdata_amd import _lib
+    for env in ("flat_tile_kernel", "flat_unfused"):
+        with _lib.tuning(**{env: 1}):
+            i2, s2, c2 = ix.flat_search(Qh, 10)
         same[env] = bool(np.array_equal(i2, ids) and np.array_equal(s2.view(np.uint32), sc.view(np.uint32)) and np.array_equal(c2, cnt))
     rec_flat = float(np.mean([len(set(ids[i].tolist()) & set(gt[i].tolist())) / 10 for i in range(B)]))
     tops = st.int8_ops / gemm_ms / 1e9
@@ -74,7 +74,7 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
            "flat": {"gemm_ms": gemm_ms, "gemm_launches": st.gemm_launches, "int8_tops": tops, "int8_peak_tops_dense": I8_PEAK_TOPS,
                     "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall,
                     "timing": f"median of {reps} calls after one untimed call", "qps_end_to_end": B / wall, "upload_quantize_s": t_up,
-                    "same_answer_as_tile_kernel": same["COS_FLAT_TILE_KERNEL"], "same_answer_as_unfused_path": same["COS_FLAT_UNFUSED"]},
+                    "same_answer_as_tile_kernel": same["flat_tile_kernel"], "same_answer_as_unfused_path": same["flat_unfused"]},
            "cpu_baseline": None, "parity_vs_oracle": None}
 
     # ---- CPU baseline + parity at the full corpus size: the oracle quantizes the corpus itself (streamed: no 30 GB host table),

@@ -78,7 +78,7 @@ print(json.dumps({"config": {"workload": f"learned-sparse inverted index (SURVEY
                   "ms_per_batch_host_api": ms, "qps_host_api": B / (ms * 1e-3), "postings_visited_per_batch": visited,
                   "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
                                "kernel": ("sparse_packed_kernel" if ix.packed else "sparse_tile_kernel") + " (+ sparse_finish_kernel)",
-                               "posting_layout": "packed u32 (COS_SPARSE_PACKED=1)" if ix.packed else "u32 id + u8 key",
+                               "posting_layout": "packed u32 (key << 24 | id + 1)" if ix.packed else "u32 id + u8 key",
                                "per_launch": {"algorithmic_bytes": float(st.posting_bytes), "avg_ms": kernel_ms, "blocks": st.blocks},
                                "note": "achieved = 4 B x the postings the reference's traversal visits for the batch / the HIP-event time of the call's kernels "
                                        "(median of the timed calls); the device layout reads " + ("4 B per posting (key << 24 | id + 1)" if ix.packed else "5 B per posting (u32 id + u8 key)")},

@@ -113,9 +113,9 @@ def test_flat_code_scan_fused_overflow_falls_back_exactly(storage, res):
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
 
 
-def test_flat_code_scan_query_resident_kernel_equals_tile_kernel(monkeypatch):
+def test_flat_code_scan_query_resident_kernel_equals_tile_kernel():
     """quaternary fused chunks run on the query-resident kernel (A fragments in registers, candidates streamed through LDS);
-    COS_FLAT_TILE_KERNEL=1 forces the 256 x 128 tile kernel, COS_FLAT_UNFUSED=1 the score-matrix path: three implementations,
+    tuning knob flat_tile_kernel = 1 forces the 256 x 128 tile kernel, flat_unfused = 1 the score-matrix path: three implementations,
     one answer"""
     import cosdata_amd as ca
     n, dim, B, k = 50000, 768, 64, 10
@@ -124,10 +124,10 @@ def test_flat_code_scan_query_resident_kernel_equals_tile_kernel(monkeypatch):
     ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType(ca.StorageKind(O.STORAGE_SUBBYTE), 2))
     ix.upload_vectors(X)
     ref = ix.flat_search(Q, k)
-    for env in ("COS_FLAT_TILE_KERNEL", "COS_FLAT_UNFUSED"):
-        monkeypatch.setenv(env, "1")
-        got = ix.flat_search(Q, k)
-        monkeypatch.delenv(env)
+    from cosdata_amd import _lib
+    for env in ("flat_tile_kernel", "flat_unfused"):
+        with _lib.tuning(**{env: 1}):
+            got = ix.flat_search(Q, k)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), env
 
 

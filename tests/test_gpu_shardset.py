@@ -71,7 +71,7 @@ def test_shardset_error_propagates():
 _RCCL_CHILD = r"""
 import os, sys
 sys.path.insert(0, %(root)r)
-os.environ["COS_SHARDSET_FORCE_RCCL"] = "1"
+os.environ["COS_TUNING"] = "shardset_force_rccl=1"
 import numpy as np, torch
 from oracle import oracle as O
 from tests import helpers as H

@@ -97,14 +97,25 @@ def test_oracle_matches_python_restatement(bits, thr):
         assert [e[1] for e in exp[:5]] == rid.tolist() and np.allclose([e[0] for e in exp[:5]], rsc, rtol=0, atol=0)
 
 
+def _index_with_layout(layout, *args, **kw):
+    """layout 0 = (u32 id, u8 key) per posting, 1 = packed u32 (the default where ids fit 24 bits): tuning knob sparse_layout"""
+    import cosdata_amd as ca
+    from cosdata_amd import _lib
+    with _lib.tuning(sparse_layout=layout):
+        ix = ca.InvertedIndex(*args, **kw)
+    assert ix.packed == bool(layout)
+    return ix
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("bits,thr", [(6, 0.0), (4, 0.5), (8, 0.3)])
-def test_device_matches_oracle(bits, thr):
+def test_device_matches_oracle(bits, thr, layout):
     import cosdata_amd as ca
     upper = 3.0
     n = 20000
     rows, dims, key_off, vec_ids, row_off, raw_dims, raw_vals = _corpus(n=n, vocab=600, bits=bits, upper=upper, seed=10 + bits)
-    ix = ca.InvertedIndex(bits, upper, dims, key_off, vec_ids, n, row_off, raw_dims, raw_vals)
+    ix = _index_with_layout(layout, bits, upper, dims, key_off, vec_ids, n, row_off, raw_dims, raw_vals)
     qs = _queries(70, 600, seed=3)
     qo = np.cumsum([0] + [len(q[0]) for q in qs]).astype(np.uint32)
     qd = np.concatenate([q[0] for q in qs]).astype(np.uint32)
@@ -167,7 +178,8 @@ def test_index_created_from_vectors_answers_like_the_index_created_from_the_csr(
 
 
 @pytest.mark.gpu
-def test_device_edge_cases_single_query_empty_queries_zero_weights_ragged_last_tile():
+@pytest.mark.parametrize("layout", [0, 1])
+def test_device_edge_cases_single_query_empty_queries_zero_weights_ragged_last_tile(layout):
     """one query per launch (a block per tile), a query without terms / with unknown dimensions only (no results), query values
     that quantize to 0 (every visited vector is a result with similarity 0), n not a multiple of the 8192-id tile or of 64,
     a duplicate dimension inside one query (visited twice, like the reference's loop), out-of-order ids inside a key list"""
@@ -178,7 +190,7 @@ def test_device_edge_cases_single_query_empty_queries_zero_weights_ragged_last_t
     ko = np.asarray(key_off).reshape(len(dims), (1 << bits) + 1)
     lo, hi = int(ko[3, 10]), int(ko[3, 11])
     vec_ids[lo:hi] = vec_ids[lo:hi][::-1]                     # the order inside a (dimension, key) list is the caller's: sums commute
-    ix = ca.InvertedIndex(bits, upper, dims, key_off, vec_ids, n)
+    ix = _index_with_layout(layout, bits, upper, dims, key_off, vec_ids, n)
     d0, d1 = int(dims[0]), int(dims[1])
     queries = [(np.array([d0], np.uint32), np.array([0.0], np.float32)),                       # quantizes to 0: all similarities 0
                (np.array([100000, 100001], np.uint32), np.array([1.0, 2.0], np.float32)),      # unknown dimensions only
@@ -201,25 +213,14 @@ def test_device_edge_cases_single_query_empty_queries_zero_weights_ragged_last_t
     assert st.blocks > 0 and st.kernel_ms > 0
 
 
-# ---- packed posting layout (COS_SPARSE_PACKED=1 at creation; kernels_sparse.hip: sparse_packed_kernel) --------------------------
-# Not the default layout yet: written at the end of round 4 without a device at hand, so these run when COS_CANDIDATES=1 names the
-# candidates to check (scripts/round5_candidates.sh), and become ordinary GPU tests once the layout is the default.
-import os
-
-candidates = pytest.mark.skipif(os.environ.get("COS_CANDIDATES", "") != "1", reason="candidate kernels: set COS_CANDIDATES=1")
+# ---- packed posting layout (kernels_sparse.hip: sparse_packed_kernel) -------------------------------------------------------------
+# The default layout since round 5 (measured: profiles/r05_candidates_sparse.txt) wherever vector ids fit 24 bits; the tests above this
+# line run both layouts (`_index_with_layout`: tuning knob sparse_layout).
 
 
 def _packed_index(*args, **kw):
     import cosdata_amd as ca
-    old = os.environ.get("COS_SPARSE_PACKED")
-    os.environ["COS_SPARSE_PACKED"] = "1"
-    try:
-        ix = ca.InvertedIndex(*args, **kw)
-    finally:
-        if old is None:
-            del os.environ["COS_SPARSE_PACKED"]
-        else:
-            os.environ["COS_SPARSE_PACKED"] = old
+    ix = ca.InvertedIndex(*args, **kw)
     assert ix.packed
     return ix
 
@@ -242,7 +243,6 @@ def _assert_like_oracle(ix, dims, key_off, vec_ids, n, bits, upper, thr, qs, k, 
 
 
 @pytest.mark.gpu
-@candidates
 @pytest.mark.parametrize("bits,thr", [(6, 0.0), (4, 0.5), (8, 0.3), (8, 0.0)])
 def test_packed_layout_matches_oracle(bits, thr):
     upper, n = 3.0, 20000
@@ -254,7 +254,6 @@ def test_packed_layout_matches_oracle(bits, thr):
 
 
 @pytest.mark.gpu
-@candidates
 def test_packed_layout_long_queries_and_table_windows():
     """queries of 65..300 terms (term groups of 64; more than 256 terms: one table window per tile and 256 terms), few queries per
     launch (a block owns many tiles: several table windows of tiles), 8-bit keys with large query values (the sum bound of the
@@ -273,7 +272,6 @@ def test_packed_layout_long_queries_and_table_windows():
 
 
 @pytest.mark.gpu
-@candidates
 def test_packed_layout_edge_cases_and_repeated_ids():
     """the edge cases of the unpacked layout's test, plus a CSR that names one vector in two key lists of a dimension (the touch
     count of the packed accumulator then exceeds the term count: the host's bound must account for it)"""
