@@ -742,8 +742,12 @@ class DenseWorkload:
                     best = min(best, secs.value)
                 secs.value = best
                 same = all(np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b_).view(np.uint32)) for a, b_ in zip((i0, s0, c0), direct))
+                cst = ix.coalescing_stats()     # over the three runs: how many launches the callers' requests became, and why they left
                 small.append({"callers": nc, "queries_per_call": Bc, "coalescing_max_queries": maxq, "coalescing_window_us": 300, "calls_per_caller": reps_s, "runs": 3,
-                              "qps": nc * reps_s * Bc / secs.value, "failed_calls": int(nfail), "identical_to_uncoalesced_call": bool(same)})
+                              "qps": nc * reps_s * Bc / secs.value, "failed_calls": int(nfail), "identical_to_uncoalesced_call": bool(same),
+                              "launches": cst["launches"], "queries_per_launch": round(cst["queries"] / max(1, cst["launches"]), 1),
+                              "launches_left_full_quiet_deadline": [cst["closed_full"], cst["closed_quiet"], cst["closed_deadline"]],
+                              "solo_calls": cst["solo_calls"]})
             ix.set_coalescing(0, 0)
             host["concurrent_256_query_callers"] = small
             del qh, qsmall
@@ -796,13 +800,20 @@ class DenseWorkload:
             parts = {}
             if sp["table_level_min"]:
                 tops = sp["table_int8_ops"] / (sp_alone["table_ms"] * 1e-3) / 1e12 if sp_alone["table_ms"] > 0 else 0.0
-                parts["level_table_gemm"] = {"bound": "mfma", "kernel": "flat_codes_gemm_i8<ENG_U8> (+ code sums)", "levels": f">= {sp['table_level_min']}",
-                                             "columns": sp["table_cols"], "int8_ops": sp["table_int8_ops"], "ms": sp_alone["table_ms"],
-                                             "ms_next_to_a_walk": sp["table_ms"], "achieved": tops,
-                                             "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_PEAK_TOPS,
-                                             "traffic": traffic_parts.get("table_gemm"), "table_bytes_written": float(B) * sp["table_cols"] * 4.0,
-                                             "note": "short-K (768) GEMM with an exact-quotient epilogue per output; it runs on the caller's stream under the "
-                                                     "previous step's walk"}
+                tab_bytes = float(B) * sp["table_cols"] * 4.0
+                wr_gbps = tab_bytes / (sp_alone["table_ms"] * 1e-3) / 1e9 if sp_alone["table_ms"] > 0 else 0.0
+                areg = (d % 64 == 0) and (d // 64) in (2, 4, 6, 8, 12, 16)
+                parts["level_table_gemm"] = {"bound": "hbm", "kernel": ("level_table_areg<%d>" % (d // 64) if areg else "flat_codes_gemm_i8<ENG_U8>") + " (+ code sums)",
+                                             "levels": f">= {sp['table_level_min']}", "columns": sp["table_cols"], "ms": sp_alone["table_ms"],
+                                             "ms_next_to_a_walk": sp["table_ms"], "table_bytes_written": tab_bytes,
+                                             "achieved": wr_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": wr_gbps / HBM_PEAK_GBPS,
+                                             "traffic": traffic_parts.get("table_gemm"),
+                                             "mfma": {"int8_ops": sp["table_int8_ops"], "achieved": tops, "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_PEAK_TOPS},
+                                             "note": "short-K GEMM whose output is the table: queries x columns x 4 bytes written once against 2 x K int8 ops "
+                                                     "per output = 13 TB/s of output at the i8 peak (K = 768), so the bound is the HBM WRITE stream, the "
+                                                     "matrix cores idle most of the time by construction; the epilogue is add + convert + store (the walk "
+                                                     "forms the quotient for the entries it reads).  It runs on the caller's stream under the previous "
+                                                     "step's walk"}
             if sp["cut_after_level"]:
                 parts["walk_upper"] = part("hbm", upper_bytes, sp["upper_ms"], traffic_parts.get("upper"), ms_alone=sp_alone["upper_ms"],
                                            levels=f"{9}..{sp['cut_after_level']} in arrival order", evals=sp["upper_evals"], table_evals=sp["table_evals"],

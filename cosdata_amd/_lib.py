@@ -65,6 +65,11 @@ class CosTimingSummary(C.Structure):
                 ("walk_ms_min", C.c_float), ("walk_ms_max", C.c_float)]
 
 
+class CosCoalescingStats(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("queries", C.c_uint64), ("requests", C.c_uint64), ("closed_full", C.c_uint64),
+                ("closed_quiet", C.c_uint64), ("closed_deadline", C.c_uint64), ("solo_calls", C.c_uint64)]
+
+
 class CosSparseStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("blocks", C.c_uint32), ("postings_visited", C.c_uint64), ("posting_bytes", C.c_uint64)]
 
@@ -96,7 +101,7 @@ ABI_SYMBOLS = [
     "cos_index_upload_vectors", "cos_index_set_root", "cos_index_upload_graph_level", "cos_index_level_count",
     "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build", "cos_index_enable_metadata", "cos_index_upload_meta_nodes", "cos_index_upload_meta_graph_level", "cos_index_build_meta", "cos_index_meta_level_count", "cos_index_download_meta_graph_level", "cos_search_filtered_batch",
     "cos_ann_search_filtered_batch", "cos_index_load_reference_dir", "cos_reference_dir_level_counts", "cos_reference_dir_read_level",
-    "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_coalescing", "cos_index_set_ef_search",
+    "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_coalescing", "cos_index_coalescing_stats", "cos_index_set_ef_search",
     "cos_index_set_visited_mode", "cos_index_set_latency_mode", "cos_index_set_latency_waves", "cos_index_set_walk_order", "cos_index_walk_order_cuts", "cos_index_set_walk_table", "cos_index_walk_table_info", "cos_index_last_walk_split", "cos_index_enable_timing", "cos_index_last_stats", "cos_index_timing_summary", "cos_quantize_batch",
     "cos_code_bytes", "cos_sample_values_range", "cos_distance_batch", "cos_bruteforce_topk", "cos_flat_search_batch", "cos_bm25_create", "cos_bm25_destroy",
     "cos_bm25_search_batch", "cos_bm25_search_batch_device", "cos_rrf_fuse_batch", "cos_hybrid_search_batch", "cos_text_process", "cos_text_count_tokens", "cos_bm25_term_frequency", "cos_xxhash32", "cos_stem_english", "cos_sparse_create", "cos_sparse_build_csr", "cos_sparse_create_from_vectors", "cos_sparse_destroy", "cos_sparse_search_batch", "cos_sparse_last_stats", "cos_sparse_layout", "cos_merge_topk_device", "cos_merge_topk_packed_device", "cos_hbm_probe",
@@ -146,6 +151,7 @@ def lib():
         "cos_ann_search_batch": [vp, vp, u32, vp, vp, vp, vp],
         "cos_index_set_ef_search": [vp, u32],
         "cos_index_set_coalescing": [vp, u32, u32],
+        "cos_index_coalescing_stats": [vp, C.POINTER(CosCoalescingStats)],
         "cos_index_set_visited_mode": [vp, u32],
         "cos_index_build_meta": [vp, u32, vp, vp, vp, u32],
         "cos_index_meta_level_count": [vp, u32, C.POINTER(u32)],

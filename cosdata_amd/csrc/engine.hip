@@ -161,6 +161,9 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
     int nx = 0;
     if (hipDeviceGetAttribute(&nx, hipDeviceAttributeNumberOfXccs, p->device) == hipSuccess && nx >= 1 && nx <= 64) ix->num_xcd = (u32)nx;
     else { (void)hipGetLastError(); ix->num_xcd = 1; }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && ncu >= 1) ix->n_cus = (u32)ncu;
+    else (void)hipGetLastError();
     *out = ix;
     return COS_OK;
 }
@@ -1029,8 +1032,8 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     // on the matrix cores next to the previous launch's walk, which leaves them idle.
     if (tab_level_min) {
         if (timed) HIP_TRY(hipEventRecord(ev[4], st));
-        HIP_TRY(cosdev::launch_level_table(w->q_codes, w->q_mags, w->qsums, B, tcodes, tmags, tcsums, ix->row_stride, tab_cols, ix->p.metric, w->tab,
-                                           tab_stride, st));
+        HIP_TRY(cosdev::launch_level_table(w->q_codes, w->q_mags, w->qsums, B, tcodes, tmags, tcsums, ix->row_stride, tab_cols, w->tab,
+                                           tab_stride, ix->n_cus, st));
         if (timed) HIP_TRY(hipEventRecord(ev[5], st));
     }
     if (timed) HIP_TRY(hipEventRecord(ev[1], st));
@@ -1048,6 +1051,7 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     HIP_TRY(hipMemsetAsync(w->stats2, 0, (size_t)B * 32, st)); // the latency kernels do not write it
     if (tab_level_min) {
         wa.tab = w->tab;
+        wa.tab_mags = tmags;
         wa.tab_stride = tab_stride;
         wa.tab_level_min = tab_level_min;
         memcpy(wa.tab_col0, tab_col0, sizeof(tab_col0));
@@ -1320,19 +1324,33 @@ static int32_t search_host_once(cos_index *ix, const float *queries, uint32_t B,
 // A slot = one launch being assembled: pinned staging for up to `cap` queries and their results.  Callers reserve a range under
 // co_mu, copy their own queries into the slot's pinned buffer IN PARALLEL (128 callers x 786 KB: the copies of a group used to be
 // issued one after the other by the leader, each a pageable H2D of its own with its pinning overhead), and copy their own results out
-// the same way; the leader — the request that opened the slot — only waits for the window, issues ONE H2D / launch / D2H and wakes the
-// others.  Slots are pooled per handle; a slot is recycled when its last request has copied its results out.
+// the same way; the leader — the request that opened the slot — only waits for the slot to close, issues ONE H2D / launch / D2H and
+// wakes the others.  Slots are pooled per handle; a slot is recycled when its last request has copied its results out.
+// Round 5 (64 callers ran at 3.2 M QPS, 128 at 0.75-0.87 M):
+//   * the leader and the followers of a slot slept on ONE condition variable under the handle-wide co_mu, and every arrival
+//     notified all of them: 64 arrivals x 63 sleeping followers, each wake-up a round trip through co_mu, in front of the very
+//     arrivals the leader was waiting for — which then came in a trickle, and the quiet window closed the slot with a fraction of
+//     them.  Now the leader alone is notified by an arrival (`cv_leader`, with co_mu), the followers sleep on the slot's own
+//     mutex / `cv_done`, and a request leaves the slot through an atomic counter;
+//   * WHEN a slot launches follows the device, not only the clock: while two launches of the handle are in flight a third would
+//     only queue behind them, so the open slot keeps gathering requests (up to max_queries) and the completion of a launch wakes
+//     its leader; with fewer than two in flight it launches when it is full or `window_us` after its last arrival (at most 8
+//     windows after its first).  Under load batches grow to what the callers offer; an idle device answers after one window.
 struct CoSlot {
     float *pin_q = nullptr;     // [cap][dim]
     unsigned char *pin_out = nullptr; // ids [cap][k] | scores [cap][k] | counts [cap] | status [cap]
     u32 cap = 0, cap_k = 0;
     u32 top_k = 0;
-    u32 reserved = 0, n_req = 0, left = 0; // queries reserved, requests in the slot, requests that have not left yet
+    u32 reserved = 0, n_req = 0;           // queries reserved, requests in the slot (co_mu)
+    std::atomic<u32> left{0};              // requests that have not left yet
     std::atomic<u32> copied{0};            // requests whose queries are in pin_q
-    bool closed = false, done = false;
+    bool closed = false;                   // (co_mu)
+    bool done = false;                     // (mu)
     int32_t rc = COS_OK;
     std::string err;
-    std::condition_variable cv;            // with co_mu: `reserved` grew (leader) / `done` (followers)
+    std::condition_variable cv_leader;     // with co_mu: `reserved` grew / the slot closed / a launch of the handle completed
+    std::mutex mu;                         // the followers' own lock: nobody but the slot's requests ever takes it
+    std::condition_variable cv_done;       // with mu: `done`
 };
 
 static void co_slot_free(CoSlot *sl) {
@@ -1350,7 +1368,7 @@ void cos_coalesce_release(cos_index *ix) { // cos_index_destroy
 static CoSlot *co_slot_get(cos_index *ix, u32 max_q, u32 top_k) {
     CoSlot *sl = nullptr;
     for (CoSlot *c : ix->co_slots)
-        if (c->left == 0 && !c->closed && c->n_req == 0) { sl = c; break; }
+        if (c->left.load(std::memory_order_acquire) == 0 && !c->closed && c->n_req == 0) { sl = c; break; }
     if (!sl) {
         if (ix->co_slots.size() >= 8) return nullptr; // every slot is in flight: the caller launches on its own
         sl = new CoSlot();
@@ -1372,7 +1390,8 @@ static CoSlot *co_slot_get(cos_index *ix, u32 max_q, u32 top_k) {
         sl->cap_k = top_k;
     }
     sl->top_k = top_k;
-    sl->reserved = sl->n_req = sl->left = 0;
+    sl->reserved = sl->n_req = 0;
+    sl->left.store(0);
     sl->copied.store(0);
     sl->closed = sl->done = false;
     sl->rc = COS_OK;
@@ -1412,6 +1431,14 @@ extern "C" int32_t cos_index_set_coalescing(cos_index *ix, uint32_t max_queries,
     std::lock_guard<std::mutex> g(ix->co_mu);
     ix->co_max_queries = max_queries;
     ix->co_window_us = window_us;
+    ix->co_stats = cos_coalescing_stats{};
+    return COS_OK;
+}
+
+extern "C" int32_t cos_index_coalescing_stats(cos_index *ix, cos_coalescing_stats *out) {
+    if (!ix || !out) return cos_fail(COS_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(ix->co_mu);
+    *out = ix->co_stats;
     return COS_OK;
 }
 
@@ -1432,7 +1459,7 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
             sl = ix->co_open;
             if (sl && (sl->closed || sl->top_k != top_k || sl->reserved + B > max_q || sl->reserved + B > sl->cap)) {
                 sl->closed = true; // full (or another top_k): its leader launches it as it is; a new slot opens
-                sl->cv.notify_all();
+                sl->cv_leader.notify_one();
                 sl = nullptr;
             }
             if (!sl) {
@@ -1444,10 +1471,11 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
                 off = sl->reserved;
                 sl->reserved += B;
                 sl->n_req++;
-                sl->left++;
+                sl->left.fetch_add(1, std::memory_order_relaxed);
                 if (sl->reserved >= max_q) { sl->closed = true; ix->co_open = nullptr; }
-                sl->cv.notify_all();
-            }
+                if (!leader) sl->cv_leader.notify_one(); // the leader alone: the followers sleep on the slot's own cv_done
+            } else
+                ix->co_stats.solo_calls++;
         }
     }
     if (!sl) return search_host_once(ix, queries, B, top_k, out_ids, out_scores, out_counts, out_status);
@@ -1458,37 +1486,57 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
         u32 n_req;
         {
             std::unique_lock<std::mutex> lk(ix->co_mu);
-            // the window restarts with every arrival (a quiet period), up to eight windows in all: callers that outnumber the host's
-            // cores arrive in a trickle, and a launch that leaves when the FIRST window ends carries a fraction of them
+            // Closing rule (see the struct): full -> now; fewer than two launches of the handle in flight -> `window` after the last
+            // arrival, at most eight windows after the first; two or more in flight -> keep gathering, re-examined whenever a launch
+            // completes (and every few windows, so that a lost wake-up costs time, not liveness).
             const auto t0 = std::chrono::steady_clock::now();
             const auto hard = t0 + std::chrono::microseconds(8ull * window);
-            auto deadline = t0 + std::chrono::microseconds(window);
+            auto quiet = t0 + std::chrono::microseconds(window);
             u32 seen = sl->reserved;
+            int why = 0; // 0 full, 1 quiet window, 2 eight windows
             while (!sl->closed) {
-                if (sl->cv.wait_until(lk, std::min(deadline, hard)) == std::cv_status::timeout) break;
-                if (sl->reserved != seen) { seen = sl->reserved; deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window); }
+                const auto now = std::chrono::steady_clock::now();
+                if (ix->co_inflight < 2u) {
+                    if (now >= hard) { why = 2; break; }
+                    if (now >= quiet) { why = 1; break; }
+                    sl->cv_leader.wait_until(lk, std::min(quiet, hard));
+                } else
+                    sl->cv_leader.wait_until(lk, now + std::chrono::microseconds(4ull * std::max(window, 50u)));
+                if (sl->reserved != seen) { seen = sl->reserved; quiet = std::chrono::steady_clock::now() + std::chrono::microseconds(window); }
             }
             sl->closed = true;
             if (ix->co_open == sl) ix->co_open = nullptr;
             n_req = sl->n_req;
+            ix->co_inflight++;
+            ix->co_stats.launches++;
+            ix->co_stats.queries += sl->reserved;
+            ix->co_stats.requests += n_req;
+            if (why == 0) ix->co_stats.closed_full++;
+            else if (why == 1) ix->co_stats.closed_quiet++;
+            else ix->co_stats.closed_deadline++;
         }
         while (sl->copied.load(std::memory_order_acquire) < n_req) std::this_thread::yield(); // followers still copying (microseconds)
         const int32_t r = co_slot_run(ix, sl);
         const std::string e = r ? std::string(cos_last_error_string()) : std::string();
         {
             std::lock_guard<std::mutex> lk(ix->co_mu);
+            ix->co_inflight--;
+            if (ix->co_open) ix->co_open->cv_leader.notify_one(); // the slot that was gathering behind two launches may go now
+        }
+        {
+            std::lock_guard<std::mutex> lk(sl->mu);
             sl->rc = r;
             sl->err = e;
             sl->done = true;
         }
-        sl->cv.notify_all();
+        sl->cv_done.notify_all();
     } else {
-        std::unique_lock<std::mutex> lk(ix->co_mu);
-        while (!sl->done) sl->cv.wait(lk);
+        std::unique_lock<std::mutex> lk(sl->mu);
+        while (!sl->done) sl->cv_done.wait(lk);
     }
     // every request takes its own slice out of the pinned result buffer and judges its own queries
     const int32_t slot_rc = sl->rc;
-    std::string slot_err = sl->err;
+    std::string slot_err = slot_rc != COS_OK ? sl->err : std::string();
     int32_t my_rc = COS_OK;
     u32 bad_q = 0;
     if (slot_rc == COS_OK) {
@@ -1503,9 +1551,10 @@ extern "C" int32_t cos_search_batch(cos_index *ix, const float *queries, uint32_
         for (u32 b = 0; b < B; b++)
             if (p_st[off + b] != COS_OK) { my_rc = p_st[off + b]; bad_q = b; break; } // the reference fails the whole request of THIS caller (collect::<Result<_>>)
     }
-    {
+    if (sl->left.fetch_sub(1, std::memory_order_acq_rel) == 1) { // the last request out: back in the pool
         std::lock_guard<std::mutex> lk(ix->co_mu);
-        if (--sl->left == 0) { sl->n_req = 0; sl->closed = false; } // back in the pool
+        sl->n_req = 0;
+        sl->closed = false;
     }
     if (slot_rc != COS_OK) return cos_fail(slot_rc, "%s", slot_err.c_str()); // HIP errors etc. hit every request of the launch
     if (my_rc != COS_OK) return cos_fail(my_rc, "query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", bad_q, my_rc);

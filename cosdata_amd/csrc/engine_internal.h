@@ -47,7 +47,7 @@ hipError_t launch_level_table_gather(const uint8_t *codes, const float *mags, u6
                                      uint8_t *tcodes, float *tmags, hipStream_t st);
 hipError_t launch_code_sums(const uint8_t *codes, u64 row_stride, u32 n, u32 *sums, hipStream_t st);
 hipError_t launch_level_table(const uint8_t *qcodes, const float *qmags, u32 *qsums, u32 B, const uint8_t *tcodes, const float *tmags,
-                              const u32 *tcsums, u64 row_stride, u32 ncols, u32 metric, float *tab, u64 tab_stride, hipStream_t st);
+                              const u32 *tcsums, u64 row_stride, u32 ncols, float *tab, u64 tab_stride, u32 n_cus, hipStream_t st);
 int32_t quantize_ref_layout(uint32_t storage, uint32_t res, uint32_t dim, const float *x, uint32_t n, void *codes, float *mags);
 int32_t distance_ref_layout(uint32_t metric, uint32_t storage, uint32_t res, uint32_t dim, const void *x_codes, const float *x_mags, uint32_t nx,
                             const void *y_codes, const float *y_mags, uint32_t ny, const uint32_t *pair_x, const uint32_t *pair_y, uint32_t n_pairs,
@@ -194,6 +194,8 @@ struct cos_index {
     std::vector<struct CoSlot *> co_slots; // pooled launches-in-assembly (engine.hip, CoSlot)
     struct CoSlot *co_open = nullptr;      // the slot new requests join
     u32 co_max_queries = 0, co_window_us = 0;
+    u32 co_inflight = 0;                  // coalesced launches issued and not yet complete (co_mu)
+    cos_coalescing_stats co_stats{};      // since the last cos_index_set_coalescing (co_mu)
     bool timing = false;
     // Walk chain: a launch big enough to fill the chip several times over (>= chain_min_B queries) gains nothing from sharing
     // it with ANOTHER stream's walk — two co-running walks only stretch each other — but its prologue/epilogue (quantize,
@@ -201,10 +203,15 @@ struct cos_index {
     // the other with an event, while everything else of a launch stays free to overlap.
     std::mutex chain_mu;
     hipEvent_t chain_ev = nullptr; // walk_done of the most recent chained walk
+    // (Round 5 also chained the two level ranges of a split walk separately, so that the upper range of launch i+1 — table levels,
+    // instruction issue — co-ran with the lower range of launch i — HBM.  Measured: 7.08 against 7.12 ms per step at ef 64, 17.34
+    // against 17.27 at ef 256 (profiles/r05_phase_chain_probe.jsonl): both ranges are limited by the queries in flight, and two
+    // co-running ranges share the wave slots.  Removed.)
     u32 chain_min_B = 16384;
     // launches of at least this many queries split their walk in two (upper levels | level 0) and run level 0 in locality order
     // (kernels_order.hip); 0 = never.  Env COS_WALK_ORDER_MIN_B.
     u32 walk_order_min_B = COS_WALK_ORDER_DEFAULT_MIN_B;
+    u32 n_cus = 256; // hipDeviceAttributeMultiprocessorCount of the handle's device (persistent kernels launch one workgroup per CU)
     u32 num_xcd = 8; // hipDeviceAttributeNumberOfXccs of the handle's device (workgroup b of a grid runs on XCD b % num_xcd)
     // the order keys' tables: position of every node of a key level in a depth-first order of that level's graph, and the key
     // levels themselves, descending (ensure_order_rank, engine.hip); rebuilt after the graph changes

@@ -74,11 +74,14 @@ struct WalkArgs {
     u64 *out_stats2;     // optional [B][4] (walk_kernel only): evals, expansions, adj_bytes of the LAST level range of a split walk
                          // (the whole walk when it is not split), evaluations served by the level table
     // Level table (big search launches over u8 codes; kernels_flat.hip launch_level_table, engine.hip ensure_level_table): for the
-    // levels >= tab_level_min — few nodes, walked by every query — the similarity of every (query, node) pair is computed before
-    // the walk as ONE exact-integer i8 MFMA GEMM with the walk's own conversion and division, tab[q][tab_col0[level] + node].
-    // The walk of those levels reads 4 bytes per evaluation instead of gathering and dotting a code row; which nodes it visits, the
-    // lossy filter and every result are what they were (same bits: the integer dot is exact either way).  nullptr = no table.
+    // levels >= tab_level_min — few nodes, walked by every query — the dot product of every (query, node) pair is computed before
+    // the walk as ONE exact-integer i8 MFMA GEMM, tab[q][tab_col0[level] + node] = dot_product_u8 `as f32` (x86_64.rs:22-66).
+    // The walk of those levels reads 4 bytes (+ the node's norm, tab_mags: a few KB that stay in L2) per evaluation instead of
+    // gathering and dotting a code row, and forms the cosine with the same product and quotient as on a row level
+    // (cosine.rs:223-235); which nodes it visits, the lossy filter and every result are what they were (same bits: the integer
+    // dot is exact either way).  nullptr = no table.
     const float *tab;
+    const float *tab_mags; // [columns] |v| of the table nodes (Storage mag), same column index as tab
     u64 tab_stride;       // floats per query row
     u32 tab_level_min;
     u32 tab_col0[MAX_LEVELS];

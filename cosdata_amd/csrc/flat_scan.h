@@ -27,4 +27,9 @@ hipError_t launch_flat_scan_expand_queries(const uint8_t *qcodes, u64 row_stride
 hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes,
                             const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo);
 
+// the walk's level table as a query-resident GEMM over u8 codes (kernels_scan.hip): tab[q][c] = (f32) exact integer dot
+bool level_table_areg_supported(u64 row_stride);
+hipError_t launch_level_table_areg(u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, u32 B, const uint8_t *tcodes, const u32 *tcsums,
+                                   u64 row_stride, u32 ncols, float *tab, u64 tab_stride);
+
 } // namespace cosdev

@@ -948,13 +948,19 @@ hipError_t launch_code_sums(const uint8_t *codes, u64 row_stride, u32 n, u32 *su
     return hipGetLastError();
 }
 
-// tab[q][c] = similarity(query q, table column c) for q < B, c < ncols; u8 codes only (a zero denominator shows as 0/0 = NaN)
+// tab[q][c] = dot_product_u8(query q, table column c) `as f32` for q < B, c < ncols; u8 codes only.  The walk divides by |q| * |v|
+// for the entries it reads (walk_kernel.inc, table levels): the GEMM's epilogue is an add, a convert and a store.  The
+// query-resident kernel (kernels_scan.hip level_table_areg) wherever the code rows are whole 64-byte chunks with an
+// instantiation (768, 1024, ...), the 256 x 128 tile kernel otherwise (and with tuning knob walk_table_gemm = 0); same table.
 hipError_t launch_level_table(const uint8_t *qcodes, const float *qmags, u32 *qsums /*[B] scratch*/, u32 B, const uint8_t *tcodes,
-                              const float *tmags, const u32 *tcsums, u64 row_stride, u32 ncols, u32 metric, float *tab, u64 tab_stride,
-                              hipStream_t st) {
+                              const float *tmags, const u32 *tcsums, u64 row_stride, u32 ncols, float *tab, u64 tab_stride,
+                              u32 n_cus, hipStream_t st) {
     if (B == 0 || ncols == 0) return hipSuccess;
     hipError_t e = launch_code_sums(qcodes, row_stride, B, qsums, st);
     if (e != hipSuccess) return e;
+    if (level_table_areg_supported(row_stride) && tune_or(TUNE_WALK_TABLE_GEMM, 1) != 0)
+        return launch_level_table_areg(n_cus ? n_cus : 256u, st, qcodes, (const u32 *)qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride);
+    const u32 metric = 1u; // the tile kernel's unfused epilogue with the dot-product metric: the converted integer dot, no quotient
     const u32 kdims = (u32)((row_stride + 63) / 64 * 64);
     dim3 grid((ncols + CN - 1) / CN, (B + CM - 1) / CM);
     FusedOut fo{nullptr, nullptr, nullptr, 0u, nullptr};

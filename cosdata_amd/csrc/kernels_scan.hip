@@ -300,6 +300,134 @@ __global__ __launch_bounds__(256) void flat_scan_q2_areg(const uint8_t *__restri
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Level table of the walk (WalkArgs::tab; engine.hip ensure_level_table / run_search) as a query-resident GEMM over u8 codes.
+// Round 4 ran this product on flat_codes_gemm_i8 (the 256 x 128 tile kernel): 0.15-0.18 of the i8 peak, because every tile
+// restages 256 query rows through LDS for 64 k steps' worth of MFMAs, and its epilogue formed the exact quotient dot / (|q| |v|)
+// for each of B x cols outputs (685 M per launch at c2) of which the walk reads 13 %.  Round 5:
+//   * the table holds the exact integer dot converted like the reference's `as f32` (x86_64.rs:22-66: u64 -> f32, RNE); the WALK
+//     divides by |q| * |v| for the entries it reads — one vector quotient per expansion, the same two roundings in the same order
+//     (cosine.rs:223-235), so the bits are what they were.  The epilogue of an output is one add, one convert, one store;
+//   * the query operand never moves (the scan kernel's structure, above): a workgroup is 4 waves, wave w keeps the MFMA A
+//     fragments of 64 query rows for the whole k range in AccVGPRs; column tiles of 64 table nodes x K code bytes stream
+//     through double-buffered LDS (global -> registers while the MFMAs of the current tile run, registers -> LDS after its
+//     epilogue, one barrier per tile); u8 codes are recentred by 128 on the way in (a' = a ^ 0x80 as i8) and the epilogue adds
+//     128 (sum q + sum c) - 16384 K back (kernels_flat.hip: the same correction);
+//   * what bounds it is the table itself: B x cols x 4 bytes written once (2.7 GB per 32 768 queries at c2) against 1.05 TOP —
+//     13 TB/s of output at the i8 peak — so this is an HBM WRITE stream with the MFMA at ~40 % duty, and is reported as such.
+// One workgroup per CU, persistent over its column tiles; the grid is (column groups, query groups of 256).
+// ------------------------------------------------------------------------------------------------
+template <int KC>
+__global__ __launch_bounds__(256) void level_table_areg(const uint8_t *__restrict__ qcodes, const u32 *__restrict__ qsums, u32 B,
+                                                        const uint8_t *__restrict__ tcodes, const u32 *__restrict__ tcsums, u64 row_stride /* == 64 KC */,
+                                                        u32 ncols, float *__restrict__ tab, u64 tab_stride) {
+    constexpr int K = KC * 64, KS = KC * 2, LDB = K + 16, PC = K / 16; // PC = 16-byte pieces per column; a thread stages KC of a tile's 64 PC
+    extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const u32 row0 = blockIdx.y * 256 + w * 64;
+    const u32 n_tiles = (ncols + 63) / 64, G = gridDim.x;
+    u32 t = blockIdx.x;
+    if (t >= n_tiles) return; // uniform
+    // resident query fragments, recentred; rows past B are zero (their outputs are never stored)
+    i32x4 a[2][KS];
+    static_for<0, 2 * KS>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(Ic)::value / KS, s = decltype(Ic)::value % KS;
+        const u32 row = row0 + 32 * i + l31;
+        i32x4 v = *(const i32x4 *)(qcodes + (u64)(row < B ? row : B - 1) * row_stride + 32 * s + 16 * half);
+        v = v ^ (int)0x80808080;
+        a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
+        asm volatile("" : "+a"(a[i][s])); // the value now IS an AccVGPR tuple: its MFMA uses need no copies
+    });
+    // per-row share of the recentring: 128 * sum(q) - 16384 * K, for this lane's 32 accumulator rows
+    int rqs[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+            rqs[i][r] = 128 * (int)qsums[row < B ? row : B - 1] - 16384 * K;
+        }
+    // staging: piece g = p * 256 + tid of the tile's 64 * PC pieces is bytes [16 (g % PC), +16) of column g / PC — consecutive
+    // threads read consecutive 16 B of one code row (coalesced); columns past ncols re-read the last one (never stored)
+    uint4 raw[KC];
+    auto load_tile = [&](u32 tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < KC; p++) {
+            const u32 g = (u32)p * 256u + (u32)tid, c = g / (u32)PC, pc = g % (u32)PC;
+            const u32 col = tile * 64 + c, cc = col < ncols ? col : ncols - 1;
+            raw[p] = *(const uint4 *)(tcodes + (u64)cc * row_stride + (u64)pc * 16);
+        }
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < KC; p++) {
+            const u32 g = (u32)p * 256u + (u32)tid, c = g / (u32)PC, pc = g % (u32)PC;
+            uint4 v = raw[p];
+            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+            *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + (size_t)c * LDB + (size_t)pc * 16) = v;
+        }
+    };
+    load_tile(t);
+    store_tile(0);
+    __syncthreads();
+    int P = 0;
+    while (true) {
+        const bool more = t + G < n_tiles; // uniform
+        if (more) load_tile(t + G);       // in flight while this tile is multiplied
+        const unsigned char *bt = areg_lds + (size_t)P * 64 * LDB + l31 * LDB + 16 * half;
+        i32x16 acc[2][2];
+        i32x4 bf[3][2]; // column fragments, read two k steps ahead of their MFMAs
+#pragma unroll
+        for (int s = 0; s < 2 && s < KS; s++) {
+            bf[s][0] = *(const i32x4 *)(bt + 32 * s);
+            bf[s][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * s);
+        }
+        static_for<0, KS>([&](auto Sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(Sc)::value;
+            if (s + 2 < KS) { // (pinned: left alone the scheduler sinks each read to just before its MFMAs and exposes the LDS latency)
+                bf[(s + 2) % 3][0] = *(const i32x4 *)(bt + 32 * (s + 2));
+                bf[(s + 2) % 3][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * (s + 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const i32x4 b0 = bf[s % 3][0], b1 = bf[s % 3][1];
+            areg_mfma<s == 0>(acc[0][0], a[0][s], b0);
+            areg_mfma<s == 0>(acc[0][1], a[0][s], b1);
+            areg_mfma<s == 0>(acc[1][0], a[1][s], b0);
+            areg_mfma<s == 0>(acc[1][1], a[1][s], b1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // epilogue: exact u32 dot -> f32 (RNE), 2 rows x 32 columns (two full 128-byte lines) per store instruction; a tile inside
+        // the matrix (all but the last row group / column tile) stores without predication
+        auto epilogue = [&](auto fullc) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(fullc)::value;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const u32 col = t * 64 + 32 * j + l31;
+                const bool cv = FULL || col < ncols;
+                const int cs = 128 * (int)tcsums[cv ? col : ncols - 1];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const u32 rbase = row0 + 32 * i + 4 * half;
+                    float *out = tab + (u64)rbase * tab_stride + col;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const u32 dr = (r & 3) + 8 * (r >> 2);
+                        const u32 dot = (u32)(acc[i][j][r] + rqs[i][r] + cs);
+                        if (FULL || (cv && rbase + dr < B)) out[(u64)dr * tab_stride] = (float)dot;
+                    }
+                }
+            }
+        };
+        if (row0 + 64 <= B && t * 64 + 64 <= ncols) epilogue(std::true_type{}); // wave-uniform
+        else epilogue(std::false_type{});
+        if (!more) break;
+        store_tile(P ^ 1); // the other buffer: every wave finished reading it before the last barrier
+        __syncthreads();
+        P ^= 1;
+        t += G;
+    }
+}
+
 } // namespace
 
 namespace cosdev {
@@ -330,6 +458,33 @@ hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t 
 #undef AREG_CASE
 }
 
+
+// level table as a query-resident GEMM: u8 codes whose rows are a whole number of 64-byte chunks with an instantiation
+bool level_table_areg_supported(u64 row_stride) {
+    return row_stride % 64 == 0 && flat_scan_supported((u32)row_stride);
+}
+template <int KC>
+static hipError_t launch_table_kc(dim3 grid, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, u32 B, const uint8_t *tcodes, const u32 *tcsums,
+                                  u64 row_stride, u32 ncols, float *tab, u64 tab_stride) {
+    const size_t lds = (size_t)2 * 64 * (KC * 64 + 16);
+    hipError_t e = hipFuncSetAttribute((const void *)level_table_areg<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((level_table_areg<KC>), grid, dim3(256), lds, st, qcodes, qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride);
+    return hipGetLastError();
+}
+// tab[q][c] = (f32) dot_product_u8(query q, table column c); grid = (column groups, query groups of 256), about one workgroup per CU
+hipError_t launch_level_table_areg(u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, u32 B, const uint8_t *tcodes, const u32 *tcsums,
+                                   u64 row_stride, u32 ncols, float *tab, u64 tab_stride) {
+    const u32 n_tiles = (ncols + 63) / 64, row_groups = (B + 255) / 256;
+    const u32 G = std::max(1u, std::min(n_tiles, n_cus / std::max(1u, std::min(row_groups, n_cus))));
+    dim3 grid(G, row_groups);
+#define TAB_CASE(KC) case KC: return launch_table_kc<KC>(grid, st, qcodes, qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride)
+    switch (row_stride / 64) {
+        TAB_CASE(2); TAB_CASE(4); TAB_CASE(6); TAB_CASE(8); TAB_CASE(12); TAB_CASE(16);
+        default: return hipErrorInvalidValue;
+    }
+#undef TAB_CASE
+}
 
 hipError_t launch_flat_scan_expand_queries(const uint8_t *qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *digits, hipStream_t st) {
     hipLaunchKernelGGL(expand_q2_digits_perm_kernel, dim3((u32)(((u64)B * (kdims / 64) + 255) / 256)), dim3(256), 0, st, qcodes, row_stride, B, kdims, digits);

@@ -124,9 +124,11 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
         const u32 bitmask = 64u * M - 1u;
         const u32 out_slot = L - (u32)level;
         u32 cur = 0; // pool buffer in use
-        // table level (WalkArgs::tab, u8 codes): similarity(query, node) of every node of this level was computed ahead of the walk
+        // table level (WalkArgs::tab, u8 codes): the integer dot (`as f32`) of the query with every node of this level was computed
+        // ahead of the walk; the cosine is formed here with the product and quotient of the row levels (walk_kernel.inc)
         const bool tab_level = ENG == ENG_U8 && wa.tab != nullptr && (u32)level >= wa.tab_level_min;
         const float *tabq = wa.tab + (u64)qi * wa.tab_stride + wa.tab_col0[level];
+        const float *tabm = wa.tab_mags + wa.tab_col0[level];
 
         // fresh visited filter, pre-seeded with the query / new-node id (vector_store.rs:266-271, :807)
         for (u32 w = tid; w < 2 * M; w += 256) s_vis[w] = 0;
@@ -138,7 +140,12 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
             bool ok;
             if (tab_level) {
                 s0 = uniform_f32(tabq[entry]);
-                ok = !(metric == 0u && s0 != s0); // u8 codes: a zero denominator is exactly a 0/0 = NaN in the table
+                ok = true;
+                if (metric == 0u) {
+                    const float den = uniform_f32(__fmul_rn(qmag, tabm[entry]));
+                    ok = den != 0.0f;
+                    s0 = __fdiv_rn(s0, den); // (0 / 0 when !ok: never used)
+                }
             } else
                 ok = single_distance(erow, s0);
             if (lane == 0) {
@@ -201,12 +208,17 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
             }
             __builtin_amdgcn_wave_barrier();
             if (tab_level) {
-                // table level: every candidate's similarity is ONE 4-byte gather by the lane that holds the slot (no code row, no dot)
+                // table level: every candidate's dot and norm are two 4-byte gathers by the lane that holds the slot (no code row, no dot)
 #pragma unroll
                 for (int i = 0; i < E; i++) {
-                    float sim = 0.0f;
-                    if (cnd[i]) sim = tabq[an[i]];
-                    const bool bad = metric == 0u && sim != sim;
+                    float sim = 0.0f, magv = 1.0f;
+                    if (cnd[i]) { sim = tabq[an[i]]; magv = tabm[an[i]]; }
+                    bool bad = false;
+                    if (metric == 0u) {
+                        const float den = __fmul_rn(qmag, magv);
+                        bad = den == 0.0f;
+                        sim = __fdiv_rn(sim, den);
+                    }
                     if (cnd[i]) my_spec[i * 64 + lane] = (u64)metric_key(metric, sim) | (bad ? (1ull << 32) : 0ull);
                 }
                 T = 0; // nothing left for the row loop below

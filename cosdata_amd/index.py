@@ -235,6 +235,12 @@ class HNSWIndex:
         """Fuse concurrent batch_search() calls of different threads into one launch (0 = off)."""
         check(_lib.lib().cos_index_set_coalescing(self._h, max_queries, window_us))
 
+    def coalescing_stats(self) -> dict:
+        """cos_index_coalescing_stats: launches / queries / requests and why the launches left, since the last set_coalescing()."""
+        st = _lib.CosCoalescingStats()
+        check(_lib.lib().cos_index_coalescing_stats(self._h, C.byref(st)))
+        return {f: int(getattr(st, f)) for f, _ in st._fields_}
+
     def set_visited_mode(self, mode: int):
         check(_lib.lib().cos_index_set_visited_mode(self._h, mode))
 

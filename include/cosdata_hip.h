@@ -171,9 +171,23 @@ int32_t cos_search_batch_device(cos_index *ix, const float *d_queries, uint32_t 
 int32_t cos_ann_search_batch(cos_index *ix, const float *queries, uint32_t B, uint32_t *out_ids, float *out_sims,
                              uint32_t *out_counts, int32_t *out_status);
 /* Dynamic batching for the host API: concurrent cos_search_batch calls (rayon workers / request handlers) with
- * the same top_k are fused into one launch of up to max_queries queries; the first caller waits window_us
- * for followers.  max_queries = 0 (default) turns it off.  Results are identical to un-coalesced calls. */
+ * the same top_k are fused into one launch of up to max_queries queries.  The request that opens a launch issues it when it is
+ * full, or — while fewer than two coalesced launches of the handle are in flight — window_us after its last arrival (at most 8
+ * windows after its first); while two are in flight it keeps gathering and goes when one of them completes, so under load the
+ * launches grow to what the callers offer and an idle device answers after one window.  max_queries = 0 (default) turns it
+ * off.  Results are identical to un-coalesced calls.  Not a reference interface. */
 int32_t cos_index_set_coalescing(cos_index *ix, uint32_t max_queries, uint32_t window_us);
+/* What the batching did since the last cos_index_set_coalescing (diagnostic; bench.py reports it next to the callers' rate). */
+typedef struct cos_coalescing_stats {
+    uint64_t launches;         /* coalesced launches issued */
+    uint64_t queries;          /* queries they carried */
+    uint64_t requests;         /* cos_search_batch calls they carried */
+    uint64_t closed_full;      /* launches that left because max_queries was reached */
+    uint64_t closed_quiet;     /* ... because window_us passed without an arrival */
+    uint64_t closed_deadline;  /* ... because 8 windows passed since the first request */
+    uint64_t solo_calls;       /* calls below max_queries that found every slot in flight and launched on their own */
+} cos_coalescing_stats;
+int32_t cos_index_coalescing_stats(cos_index *ix, cos_coalescing_stats *out);
 int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef_search);
 int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode);
 /* Latency mode.  A launch of at most max_queries queries (default COS_LATENCY_MODE_DEFAULT_MAX_B; 0 = never) runs the latency

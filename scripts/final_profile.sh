@@ -27,8 +27,8 @@ import json
 r = json.load(open("gpurun_out/pmc_fetch_bench.json")); p = r["roofline"]["parts"]; print(int(p["walk_upper"]["evals"] + p["walk_lower"]["evals"]))
 PY
 )
-python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "$K64" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef64.json
-python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "$K256" /tmp/p_w/w_results.db ref 20992 > $OUT/pmc_traffic_ef256.json
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 64 "$K64" /tmp/p_w/w_results.db ref 256 > $OUT/pmc_traffic_ef64.json
+python scripts/pmc_traffic.py /tmp/p_f/f_results.db 32768 c2 256 "$K256" /tmp/p_w/w_results.db ref 256 > $OUT/pmc_traffic_ef256.json
 python scripts/pmc_issue.py /tmp/p_s2/s2_results.db 32768 c2 64 "$K64" $EVALS ref > $OUT/pmc_issue_ef64.json
 python scripts/rocprof_summary.py /tmp/p_f/f_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_fetch_size.txt
 python scripts/rocprof_summary.py /tmp/p_w/w_results.db | grep -v "link_kernel\|evict_kernel\|claim_kernel" > $OUT/final_pmc_write_size.txt

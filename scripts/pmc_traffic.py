@@ -60,9 +60,10 @@ for part, (nd, kb) in f.items():
     parts[part] = {"dispatches": nd, "fetch_size_kb_raw": kb, "write_size_kb_raw": wkb, "bytes": kb * 1024.0 * k_fetch + wkb * 1024.0}
 # the level-table GEMM of the same steps (grid = column tiles x row tiles: match by name only)
 cur = sqlite3.connect(db_fetch).cursor()
-GEMM_Q = ("select count(*), avg(value) from counters_collection where kernel_name like '%flat_codes_gemm_i8%' and counter_name = ? and " +
+GEMM_NAME = "(kernel_name like '%level_table_areg%' or kernel_name like '%flat_codes_gemm_i8%')"   # query-resident kernel (round 5) or the tile kernel
+GEMM_Q = (f"select count(*), avg(value) from counters_collection where {GEMM_NAME} and counter_name = ? and " +
           (f"grid_size/workgroup_size = {gemm_grid}" if gemm_grid else
-           "grid_size = (select max(grid_size) from counters_collection where kernel_name like '%flat_codes_gemm_i8%')"))   # this launch shape's GEMM only
+           f"grid_size = (select max(grid_size) from counters_collection where {GEMM_NAME})"))   # this launch shape's GEMM only
 g = cur.execute(GEMM_Q, ("FETCH_SIZE",)).fetchone()
 gw = (0, 0.0)
 if db_write:

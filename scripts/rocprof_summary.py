@@ -6,7 +6,7 @@ import sys
 
 def short(name):
     for key in ("walk_lat4_kernel", "walk_lat_kernel", "walk_meta_kernel", "walk_spec_kernel", "walk_kernel", "finalize_kernel", "quantize_rows_kernel", "scatter_rows_kernel",
-                "merge_topk_kernel", "deal_to_xcds_kernel", "flat_", "bm25_", "rrf_kernel", "sparse_tile_kernel", "sparse_finish_kernel", "link_kernel", "claim_kernel", "evict_kernel"):
+                "merge_topk_kernel", "deal_to_xcds_kernel", "level_table_areg", "flat_", "bm25_", "rrf_kernel", "sparse_tile_kernel", "sparse_finish_kernel", "link_kernel", "claim_kernel", "evict_kernel"):
         if key in name:
             i = name.index(key)
             if key == "walk_spec_kernel" and name[max(0, i - 7):i].startswith("spec") and name[i - 2:i] == "::":

@@ -62,9 +62,19 @@ def run(in_flight, reps=int(os.environ.get("PROBE_REPS", 12))):
 
 print(json.dumps({"n": N, "dim": D, "visited": "exact" if EXACT else "ref", "build_s": round(build_s, 2), "cut_after_levels": ix.walk_order_cuts(),
                   "level_counts": [ix.level_count(l) for l in range(10)]}), flush=True)
-for ef in EFS:
+# PROBE_VARIANTS="base;walk_chain_phases=1;walk_chain_phases=1,walk_pb_upper=4": tuning-knob settings (cosdata_amd/csrc/tuning.h) to time
+# one after the other on the same index; every variant starts from the built-in defaults
+from cosdata_amd import _lib
+VARIANTS = [v for v in os.environ.get("PROBE_VARIANTS", "base").split(";") if v]
+ref = None
+for variant, ef in [(v, e) for e in EFS for v in VARIANTS]:
+    _lib.tuning_clear(None)
+    for kv in ([] if variant == "base" else variant.split(",")):
+        k, v = kv.split("=")
+        _lib.tuning_set(k.strip(), int(v))
     ix.set_ef_search(ef)
-    ref = None
+    if variant == VARIANTS[0]:
+        ref = None
     for cols in COLS:
         ix.set_walk_table(cols, 4096 if cols else 0)
         info = ix.walk_table_info()
@@ -75,7 +85,7 @@ for ef in EFS:
         ids = torch.cat([out[0][0], out[1][0]]).clone()
         same = True if ref is None else bool(torch.equal(ids, ref))
         ref = ids if ref is None else ref
-        print(json.dumps({"ef": ef, "max_cols": cols, "table_level_min": info[0], "table_cols": info[1],
+        print(json.dumps({"variant": variant, "ef": ef, "max_cols": cols, "table_level_min": info[0], "table_cols": info[1],
                           "ms_per_launch_1_in_flight": round(ms1, 4), "ms_per_launch_2_in_flight": round(ms2, 4), "qps_2_in_flight": round(B / ms2 * 1e3), "ms_per_launch_3_in_flight": round(ms3, 4),
                           "alone": {"table_ms": round(sp.table_ms, 4), "upper_ms": round(sp.upper_ms, 4), "sort_ms": round(sp.sort_ms, 4),
                                     "lower_ms": round(sp.lower_ms, 4), "table_evals": sp.table_evals, "upper_evals": sp.upper_evals,

@@ -121,3 +121,49 @@ def test_one_client_batch_reads_the_table_too(dim, metric):
     assert (res_tab[4][5] == 2) == (metric == O.METRIC_COSINE)
     ok = np.array([b for b in range(0, 256, 7) if res_tab[4][b] == 0])
     _check_against_oracle(oix, res_tab[:3], Q, 10, ok)
+
+
+@pytest.mark.parametrize("dim,metric", [(768, O.METRIC_COSINE), (1024, O.METRIC_COSINE), (128, O.METRIC_DOT), (384, O.METRIC_COSINE)])
+def test_query_resident_table_gemm_equals_tile_kernel_and_rows(dim, metric):
+    """round 5: the table is the integer dot `as f32` written by the query-resident GEMM (kernels_scan.hip level_table_areg: code rows of
+    whole 64-byte chunks) or by the tile kernel (tuning knob walk_table_gemm = 0; other row lengths), the walk forms the quotient.
+    Several query groups of 256 with a ragged last one, several column tiles of 64 with a ragged last one, tiles inside the matrix
+    (unpredicated stores) and on its edges: both kernels, the table-less walk and the oracle agree bit for bit."""
+    from cosdata_amd import _lib
+    n = 2600
+    X = H.clustered_corpus(n, dim, n_centers=20, seed=3 + dim)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=40, ef_search=40, metric=metric)
+    dix = H.device_index_from_oracle(oix, X)
+    B = 256 * 2 + 64 + 37
+    Q = H.queries_from(X, B, noise=0.05, seed=11)
+    lmin, cols = dix.walk_table_info()
+    assert lmin == 1 and cols > 128
+    res = {}
+    for gemm in (1, 0):
+        with _lib.tuning(walk_table_gemm=gemm):
+            res[gemm] = (dix.batch_search(Q, 10), dix.ann_search_batch(Q))
+            assert dix.last_walk_split().table_evals > 0
+    dix.set_walk_table(0, 0)
+    plain = (dix.batch_search(Q, 10), dix.ann_search_batch(Q))
+    for gemm in (1, 0):
+        assert _same(res[gemm][0], plain[0]) and _same(res[gemm][1], plain[1]), gemm
+    _check_against_oracle(oix, res[1][0], Q, 10, np.arange(0, B, 23))
+
+
+def test_set_root_on_a_live_graph_regathers_the_table():
+    """cos_index_set_root re-quantizes the root's code row; the level-table operand holds a gathered copy of it (the root is a node of
+    every level), so the table must be invalidated: with and without a table the second root gives the same answers"""
+    X = H.clustered_corpus(3000, 128, n_centers=12, seed=19)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=32, ef_search=32)
+    dix = H.device_index_from_oracle(oix, X)
+    Q = H.queries_from(X, 64, noise=0.05, seed=4)
+    first = dix.batch_search(Q, 5)
+    assert dix.last_walk_split().table_evals > 0
+    rng = np.random.default_rng(5)
+    new_root = rng.uniform(-0.9, 0.9, size=128).astype(np.float32)
+    dix.set_root(new_root)
+    with_tab = dix.ann_search_batch(Q)
+    assert dix.last_walk_split().table_evals > 0
+    dix.set_walk_table(0, 0)
+    plain = dix.ann_search_batch(Q)
+    assert _same(with_tab, plain)
