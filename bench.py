@@ -66,7 +66,7 @@ WORKLOADS = {
 # this shard); c4shard_ref_m0_256_m_64 = the same reference semantics with level_0_neighbors_count 256 and neighbors_count 64 (both
 # user hyper-parameters, indexes/hnsw/types.rs:10-17; the filter is PerformantFixedSet::new(that count), vector_store.rs:266-270):
 # the configuration that meets the recall target on the metric's own shard in the Rust path's own semantics.
-ALL_CONFIGS = ["c2_uniform", "c5", "c3", "c4shard_ref", "c4shard_ref_m0_256_m_64"]
+ALL_CONFIGS = ["c2_uniform", "c5", "c3", "c4shard_ref", "c4shard_ref_m0_256_m_64", "c4_8shards_one_device"]
 C4_TARGET_CONFIG = "c4shard_ref_m0_256_m_64"
 OPTIONAL_CONFIGS = ["c4shard_exact", "c4shard_ref_m0_128", "c4shard_ref_m0_256", "c4shard_ref_m0_256_m_128"]   # --configs only
 
@@ -140,6 +140,11 @@ def resolve_configs(spec, world, workload):
             print(f"bench.py: configs {dropped} are single-GPU configurations, skipped at N = {world}", file=sys.stderr)
         names = [v for v in names if v.startswith("c4shard")]
     return names
+
+
+def ca_mod():
+    import cosdata_amd
+    return cosdata_amd
 
 
 def native_callers_harness():
@@ -857,6 +862,7 @@ class DenseWorkload:
                        "parallelism": f"id-range shards x{world}" + (" + RCCL all-gather top-k merge" if world > 1 else ""),
                        "exchange": exchange_kind, "corpus": self.corpus_desc},
             "roofline": {"bound": "hbm", "achieved": kernel_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": kernel_gbps / HBM_PEAK_GBPS,
+                         "step_frac": avg_bytes / (elapsed / n_launch) / 1e9 / HBM_PEAK_GBPS,   # the same bytes over the whole step (GEMM, sort, rerank and what does not overlap included)
                          "traffic": traffic, "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac_of_peak": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "traffic_fetch_factor_k": traffic_k, "parts": parts, "issue": issue, "reference_algorithmic_bytes": ref_alg_bytes,
@@ -977,7 +983,7 @@ def compact_dense_record(rec, world):
 def _slim_roofline(r):
     if not r:
         return r
-    keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_GBps", "traffic_frac_of_peak", "traffic_fetch_factor_k",
+    keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "step_frac", "traffic", "traffic_GBps", "traffic_frac_of_peak", "traffic_fetch_factor_k",
                                   "kernel", "kernel_launches_per_step", "reference_algorithmic_bytes", "issue") if k in r}
     if r.get("parts"):
         keep["parts"] = {pn: ({k: v for k, v in pv.items() if k not in ("note", "kernel")} if isinstance(pv, dict) else pv) for pn, pv in r["parts"].items()}
@@ -1025,8 +1031,6 @@ def slim_line(out):
             if k in cc:
                 e[k] = cc[k][:40] if isinstance(cc[k], str) else cc[k]
         e["roofline"] = _slim_roofline(c.get("roofline"))
-        if c.get("roofline_dense_half"):
-            e["roofline_dense_half"] = {k: c["roofline_dense_half"][k] for k in ("achieved", "frac", "kernel")}
         e["cpu_baseline"] = _slim_cpu(c.get("cpu_baseline"))
         e["parity_vs_oracle"] = {k: v for k, v in (c.get("parity_vs_oracle") or {}).items() if k not in ("oracle_mode", "checked", "collection")} or None
         if c.get("hnsw_walk_quaternary"):
@@ -1245,6 +1249,19 @@ def main():
                 mm = int(toks[toks.index("m") + 1]) if "m" in toks else 32
                 r4 = c4.run_mode(v, v, cpu_seconds=args.config_cpu_seconds, exchange=args.exchange, m0=m0, m_upper=mm)
                 out["configs"][name] = compact_dense_record(r4, world)
+            elif name == "c4_8shards_one_device":
+                # the same 12.5M x 1024 corpus as eight id-range shards behind cos_shardset_search_batch: merged recall, exchange + merge cost
+                from scripts import bench_c4_8shards
+                if c4 is None:
+                    c4 = DenseWorkload(env, "c4shard", n_override=0 if scale == 1.0 else int(12_500_000 * scale))
+                if c4.gt_rep is None:   # (the c4shard records ran first in the default order: their ground truth is reused)
+                    hp0 = ca_mod().HNSWHyperParams(num_layers=9, ef_construction=c4.ef_construction, ef_search=64)
+                    ix0 = ca_mod().HNSWIndex(c4.d, hp0, ca_mod().DistanceMetric.Cosine, ca_mod().StorageType.UnsignedByte(), c4.values_range,
+                                             device=env.local_rank, seed=42)
+                    ix0.upload_vectors_device(c4.X.data_ptr(), c4.n, keepalive=c4.X)
+                    c4._ground_truth(ix0)
+                    del ix0
+                out["configs"][name] = bench_c4_8shards.run(c4)
             elif name == "c3":
                 from scripts import bench_c3
                 out["configs"][name] = bench_c3.run(n=int(10_000_000 * scale), cpu_seconds=0.0 if args.no_cpu_baseline else args.config_cpu_seconds,

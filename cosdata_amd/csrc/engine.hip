@@ -1336,6 +1336,12 @@ static int32_t search_host_once(cos_index *ix, const float *queries, uint32_t B,
 //     only queue behind them, so the open slot keeps gathering requests (up to max_queries) and the completion of a launch wakes
 //     its leader; with fewer than two in flight it launches when it is full or `window_us` after its last arrival (at most 8
 //     windows after its first).  Under load batches grow to what the callers offer; an idle device answers after one window.
+// 128 callers: 0.87 -> 3.86 M QPS, 256 callers: 1.13 -> 4.14 M (profiles/r05_callers_probe_*.jsonl).  When every caller fits ONE launch
+// (64 callers x 256 with max_queries 16 384: 2.5-2.8 M) the device idles while the next launch is copied in; max_queries = half of
+// what the callers offer keeps two launches alternating (64 callers, max_queries 8 192: 3.2 M).  Tried and not kept: (i) closing a
+// slot as soon as it holds half of the queries of all requests then inside cos_search_batch — the instantaneous count of callers
+// "inside" swings with every return, slots closed early, 128 / 256 callers fell to 3.3 / 3.1 M; (ii) running a launch that has the
+// device to itself as the chunk pipeline of a lone big host call — 64 callers 2.47 M against 2.77 M, 32 callers 2.0 against 2.5 M.
 struct CoSlot {
     float *pin_q = nullptr;     // [cap][dim]
     unsigned char *pin_out = nullptr; // ids [cap][k] | scores [cap][k] | counts [cap] | status [cap]
@@ -1406,16 +1412,16 @@ static int32_t co_slot_run(cos_index *ix, CoSlot *sl) {
     int32_t rc = lease.acquire();
     if (rc) return rc;
     hipStream_t st = lease.hp->s[0];
+    u32 *p_ids = (u32 *)sl->pin_out;
+    float *p_sc = (float *)(p_ids + (size_t)sl->cap * top_k);
+    u32 *p_cnt = (u32 *)(p_sc + (size_t)sl->cap * top_k);
+    int32_t *p_st = (int32_t *)(p_cnt + sl->cap);
     Workspace *w;
     rc = get_workspace(ix, (void *)st, st, total, top_k, true, &w);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(w->d_queries, sl->pin_q, (size_t)total * ix->p.dim * 4, hipMemcpyHostToDevice, st));
     rc = run_search(ix, w, w->d_queries, total, top_k, w->d_out_ids, w->d_out_scores, w->d_out_counts, w->d_out_status, true, st);
     if (rc) { (void)hipDeviceSynchronize(); return rc; } // the walk may be running on the workspace's side stream
-    u32 *p_ids = (u32 *)sl->pin_out;
-    float *p_sc = (float *)(p_ids + (size_t)sl->cap * top_k);
-    u32 *p_cnt = (u32 *)(p_sc + (size_t)sl->cap * top_k);
-    int32_t *p_st = (int32_t *)(p_cnt + sl->cap);
     hipError_t e = hipMemcpyAsync(p_ids, w->d_out_ids, (size_t)total * top_k * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(p_sc, w->d_out_scores, (size_t)total * top_k * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(p_cnt, w->d_out_counts, (size_t)total * 4, hipMemcpyDeviceToHost, st);

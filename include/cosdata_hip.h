@@ -174,8 +174,10 @@ int32_t cos_ann_search_batch(cos_index *ix, const float *queries, uint32_t B, ui
  * the same top_k are fused into one launch of up to max_queries queries.  The request that opens a launch issues it when it is
  * full, or — while fewer than two coalesced launches of the handle are in flight — window_us after its last arrival (at most 8
  * windows after its first); while two are in flight it keeps gathering and goes when one of them completes, so under load the
- * launches grow to what the callers offer and an idle device answers after one window.  max_queries = 0 (default) turns it
- * off.  Results are identical to un-coalesced calls.  Not a reference interface. */
+ * launches grow to what the callers offer and an idle device answers after one window.  Choose max_queries near HALF of what the
+ * callers offer at once (64 callers x 256 queries: 8 192), so that two launches alternate — one on the device while the other is
+ * copied in and out.  max_queries = 0 (default) turns it off.  Results are identical to un-coalesced calls.  Not a reference
+ * interface. */
 int32_t cos_index_set_coalescing(cos_index *ix, uint32_t max_queries, uint32_t window_us);
 /* What the batching did since the last cos_index_set_coalescing (diagnostic; bench.py reports it next to the callers' rate). */
 typedef struct cos_coalescing_stats {

@@ -37,3 +37,17 @@ def test_more_gpus_than_visible_is_refused_loudly():
     # no GPU in the CPU container (or fewer than 64 anywhere): the launcher must refuse instead of running fewer ranks
     r = _run(["--gpus", "64"])
     assert r.returncode != 0 and "refusing to run fewer ranks" in r.stderr
+
+
+def test_gpus_8_launches_eight_gloo_ranks_and_every_shard_reaches_the_merge():
+    """the shape of BASELINE configs[3] — 8 ranks, ONE packed all-gather per step, a merge that draws on all eight shards — through the
+    launcher the driver uses, on CPU (gloo): eight real processes, one JSON line, max-over-ranks timing"""
+    r = _run(["--gpus", "8", "--launcher-selftest", "--steps", "3"], env={"OMP_NUM_THREADS": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["ranks"] == 8 and j["asked_gpus"] == 8
+    assert j["distinct_processes"] == 8
+    assert j["shards_in_merged_answer"] == list(range(8))
+    assert "--nproc-per-node=8" in r.stderr

@@ -53,6 +53,38 @@ def test_shardset_two_shards_one_device_match_oracle(storage, res):
     ss.close()
 
 
+def test_shardset_eight_shards_one_device_match_oracle():
+    """S = 8 id-range shards of one corpus (ragged sizes, sequential ids like collection.rs:451-468) on one device: the merged answer
+    of cos_shardset_search_batch is, bit for bit, the oracle's per-shard searches followed by the merge rule — the shape of
+    BASELINE configs[3] (8 shards, one exchange, one merge) at a size the oracle finishes in seconds"""
+    from cosdata_amd.shardset import ShardSet
+    dim, sizes = 256, [700, 650, 720, 600, 690, 710, 640, 705]
+    X = H.clustered_corpus(sum(sizes), dim, n_centers=20, sigma=0.03, seed=88)
+    hp = dict(num_layers=3, ef_construction=40, ef_search=48)
+    shards, oracles, base = [], [], 0
+    for s, n_s in enumerate(sizes):
+        Xs = np.ascontiguousarray(X[base:base + n_s])
+        oix = H.oracle_index(Xs, O.STORAGE_U8, 0, seed=11 + s, **hp)
+        shards.append(H.device_index_from_oracle(oix, Xs, id_base=base))
+        oracles.append((base, oix))
+        base += n_s
+    ss = ShardSet(shards)
+    for B, k in ((300, 10), (5, 20)):
+        Q = H.queries_from(X, B, noise=0.004, seed=100 + B)
+        ids, sc, cnt = ss.batch_search(Q, k)
+        e_i, e_s, e_c = _oracle_two_shard(oracles, Q, k)
+        assert np.array_equal(cnt, e_c)
+        owners = set()
+        for b in range(B):
+            c = int(cnt[b])
+            assert np.array_equal(ids[b, :c], e_i[b, :c]), (b, ids[b, :c], e_i[b, :c])
+            assert np.array_equal(sc[b, :c].view(np.uint32), e_s[b, :c].view(np.uint32))
+            owners.update(int(np.searchsorted(np.cumsum(sizes), i, side="right")) for i in ids[b, :c])
+        if B >= 100:
+            assert len(owners) == 8          # every shard contributes to somebody's merged list
+    ss.close()
+
+
 def test_shardset_error_propagates():
     import cosdata_amd as ca
     from cosdata_amd.shardset import ShardSet
