@@ -66,9 +66,11 @@ WORKLOADS = {
 # this shard); c4shard_ref_m0_256_m_64 = the same reference semantics with level_0_neighbors_count 256 and neighbors_count 64 (both
 # user hyper-parameters, indexes/hnsw/types.rs:10-17; the filter is PerformantFixedSet::new(that count), vector_store.rs:266-270):
 # the configuration that meets the recall target on the metric's own shard in the Rust path's own semantics.
-ALL_CONFIGS = ["c2_uniform", "c5", "c3", "c4shard_ref", "c4shard_ref_m0_256_m_64", "c4_8shards_one_device"]
+# (c4shard_ref, the default-hyper-parameter record — recall saturating at 0.846, profiles/r04_final_bench_default_full_record.json —, moved to the
+# optional list in round 5: its minute of the default run went to c4_8shards_one_device.)
+ALL_CONFIGS = ["c2_uniform", "c5", "c3", "c4shard_ref_m0_256_m_64", "c4_8shards_one_device"]
 C4_TARGET_CONFIG = "c4shard_ref_m0_256_m_64"
-OPTIONAL_CONFIGS = ["c4shard_exact", "c4shard_ref_m0_128", "c4shard_ref_m0_256", "c4shard_ref_m0_256_m_128"]   # --configs only
+OPTIONAL_CONFIGS = ["c4shard_ref", "c4shard_exact", "c4shard_ref_m0_128", "c4shard_ref_m0_256", "c4shard_ref_m0_256_m_128"]   # --configs only
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1143,6 +1145,9 @@ def main():
                     help="comma list of extra settings timed after the main run on the same graph: '256' = ef_search 256 (config.toml "
                          "default) with the main visited filter; 'exact:32' / 'ref:128' = that ef with the named visited filter")
     ap.add_argument("--build-batch", type=int, default=4096)
+    ap.add_argument("--m0", type=int, default=64, help="level_0_neighbors_count of the MAIN workload's graph (profiling runs of the metric's own "
+                    "config: --workload c4shard --m0 256 --m 64)")
+    ap.add_argument("--m", type=int, default=32, help="neighbors_count of the main workload's graph")
     ap.add_argument("--recall-queries", type=int, default=8192, help="size of EACH of the two disjoint recall query sets (selection / report)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer API legs (cos_search_batch from 1-256 host threads); the profiler "
@@ -1190,7 +1195,8 @@ def main():
     wl = DenseWorkload(env, args.workload, n_override=args.n, ef_construction=args.ef_construction, quantization=args.quantization,
                        build_batch=args.build_batch)
     rec = wl.run_mode(args.build_visited, args.visited, ef_arg=args.ef, ef_sweep=args.ef_sweep, cpu_seconds=args.cpu_seconds,
-                      single_batch=True, host_api=not args.no_host_api, hbm_probe=not args.no_hbm_probe, exchange=args.exchange)
+                      single_batch=True, host_api=not args.no_host_api, hbm_probe=not args.no_hbm_probe, exchange=args.exchange,
+                      m0=args.m0, m_upper=args.m)
     flat = wl.flat
     n = wl.n
     wl.close()

@@ -201,7 +201,7 @@ static void free_level(LevelHost &l) {
     l.host_valid = false;
 }
 static void free_ws(Workspace *w) {
-    void *ptrs[] = {w->fin_flags, w->stats2, w->tab, w->qsums, w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
+    void *ptrs[] = {w->fin_flags, w->stats2, w->tab, w->qsums, w->qdig, w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
                     w->rerank_rows, w->vis.bits, w->vis.log, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     cosdev::walk_order_free(w->order);
@@ -786,7 +786,7 @@ static int32_t ensure_level_table(cos_index *ix) {
             ix->d_tcsums = t.tcsums;
             return COS_OK;
         }
-    if (ix->eng != ENG_U8 || max_cols == 0) return COS_OK; // u8 codes only
+    if (!cosdev::level_table_eng_supported(ix->eng, ix->row_stride) || max_cols == 0) return COS_OK; // u8 codes; quaternary codes of 128 ... 1024 dims
     const u32 Ltop = ix->p.num_layers;
     u32 cols = 0, lmin = 0;
     for (u32 l = Ltop; l >= 1; l--) { // level 0 (every vector) never takes part
@@ -913,6 +913,7 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         HIP_TRY(regrow(w->stats, (size_t)cap * 4));
         HIP_TRY(regrow(w->stats2, (size_t)cap * 4));
         HIP_TRY(regrow(w->qsums, cap));
+        if (ix->eng == ENG_Q2) HIP_TRY(regrow(w->qdig, (size_t)cap * (ix->row_stride / 16) * 64)); // the table GEMM's digit rows of the queries
         HIP_TRY(regrow(w->fin_flags, (size_t)cap + 1));
         HIP_TRY(regrow(w->rerank_rows, cap));
         HIP_TRY(regrow(w->d_queries, (size_t)cap * ix->p.dim));
@@ -1022,7 +1023,8 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
         probe.B = B;
         probe.ef = ef;
         const int kind = ordered ? 0 : cosdev::walk_kernel_kind(ix->eng, dev, probe, lat_max_B, lat4_max_B, true);
-        if (!(kind == 4 || (kind == 0 && (B >= tab_min_B || B <= lat4_max_B)))) tab_level_min = 0;
+        // (the four-wave kernel reads the table of u8 codes only)
+        if (!((kind == 4 && ix->eng == ENG_U8) || (kind == 0 && (B >= tab_min_B || B <= lat4_max_B)))) tab_level_min = 0;
     }
     hipEvent_t *ev = &w->ev[(size_t)(w->ev_count % Workspace::EV_RING) * Workspace::EV_PER];
     if (timed) HIP_TRY(hipEventRecord(ev[0], st));
@@ -1032,7 +1034,7 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     // on the matrix cores next to the previous launch's walk, which leaves them idle.
     if (tab_level_min) {
         if (timed) HIP_TRY(hipEventRecord(ev[4], st));
-        HIP_TRY(cosdev::launch_level_table(w->q_codes, w->q_mags, w->qsums, B, tcodes, tmags, tcsums, ix->row_stride, tab_cols, w->tab,
+        HIP_TRY(cosdev::launch_level_table(ix->eng, w->q_codes, w->q_mags, w->qsums, w->qdig, B, tcodes, tmags, tcsums, ix->row_stride, tab_cols, w->tab,
                                            tab_stride, ix->n_cus, st));
         if (timed) HIP_TRY(hipEventRecord(ev[5], st));
     }

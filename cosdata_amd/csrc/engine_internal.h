@@ -46,8 +46,9 @@ hipError_t launch_walk_order(WalkOrder &o, u32 B, u32 key_max, u32 num_xcd, hipS
 hipError_t launch_level_table_gather(const uint8_t *codes, const float *mags, u64 row_stride, const u32 *node_vec, u32 n, u32 col0,
                                      uint8_t *tcodes, float *tmags, hipStream_t st);
 hipError_t launch_code_sums(const uint8_t *codes, u64 row_stride, u32 n, u32 *sums, hipStream_t st);
-hipError_t launch_level_table(const uint8_t *qcodes, const float *qmags, u32 *qsums, u32 B, const uint8_t *tcodes, const float *tmags,
+hipError_t launch_level_table(int eng, const uint8_t *qcodes, const float *qmags, u32 *qsums, uint8_t *qdig, u32 B, const uint8_t *tcodes, const float *tmags,
                               const u32 *tcsums, u64 row_stride, u32 ncols, float *tab, u64 tab_stride, u32 n_cus, hipStream_t st);
+bool level_table_eng_supported(int eng, u64 row_stride); // storages the level table exists for (kernels_flat.hip)
 int32_t quantize_ref_layout(uint32_t storage, uint32_t res, uint32_t dim, const float *x, uint32_t n, void *codes, float *mags);
 int32_t distance_ref_layout(uint32_t metric, uint32_t storage, uint32_t res, uint32_t dim, const void *x_codes, const float *x_mags, uint32_t nx,
                             const void *y_codes, const float *y_mags, uint32_t ny, const uint32_t *pair_x, const uint32_t *pair_y, uint32_t n_pairs,
@@ -111,6 +112,7 @@ struct Workspace {
     float *tab = nullptr;       // level table of this workspace's big launches [capB][tab_stride] (WalkArgs::tab), grown on demand
     size_t tab_cap = 0;         // floats
     u32 *qsums = nullptr;       // [capB] code sums of the queries (the table GEMM's recentring term)
+    uint8_t *qdig = nullptr;    // [capB][dims] quaternary codes: the queries' i8 digit rows (the table GEMM's resident operand)
     u32 *fin_flags = nullptr;   // [capB + 1] finalize_fast_kernel -> finalize_list_kernel hand-over: count, then the queries (kernels_walk.hip)
     u64 *rerank_rows = nullptr; // [B]
     VisTab vis; // EXACT mode visited filters

@@ -23,13 +23,14 @@ struct FusedOut {
 // query-resident quaternary scan (kernels_scan.hip)
 bool flat_scan_supported(u32 kdims);
 // queries' planes -> permuted digit bytes [B][kdims] (the layout the scan kernel multiplies)
-hipError_t launch_flat_scan_expand_queries(const uint8_t *qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *digits, hipStream_t st);
+// (fp4: the operands as e2m1 nibbles for the scaled MFMA — flat_scan_q2_fp4 — instead of i8 digits; the buffer is half as long)
+hipError_t launch_flat_scan_expand_queries(const uint8_t *qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *digits, hipStream_t st, bool fp4);
 hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes,
-                            const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo);
+                            const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo, bool fp4);
 
-// the walk's level table as a query-resident GEMM over u8 codes (kernels_scan.hip): tab[q][c] = (f32) exact integer dot
-bool level_table_areg_supported(u64 row_stride);
-hipError_t launch_level_table_areg(u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, u32 B, const uint8_t *tcodes, const u32 *tcsums,
-                                   u64 row_stride, u32 ncols, float *tab, u64 tab_stride);
+// the walk's level table as a query-resident GEMM (kernels_scan.hip): tab[q][c] = (f32) exact integer dot; u8 or quaternary codes
+bool level_table_areg_supported(int eng, u64 row_stride);
+hipError_t launch_level_table_areg(int eng, u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, u32 B, const uint8_t *tcodes,
+                                   const u32 *tcsums, u64 row_stride, u32 ncols, float *tab, u64 tab_stride);
 
 } // namespace cosdev

@@ -756,6 +756,7 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     const int pf = (int)tune_or(TUNE_FLAT_PF, 1); // k panels prefetched into registers (1..3); results do not depend on it
     // fused chunks of quaternary codes run on the query-resident kernel when K has an instantiation (tuning knob flat_tile_kernel = 1: never)
     const bool use_areg = ix->eng == ENG_Q2 && flat_scan_supported(kdims) && tune_or(TUNE_FLAT_TILE_KERNEL, 0) == 0;
+    const bool use_fp4 = use_areg && tune_or(TUNE_FLAT_FP4, 1) != 0; // e2m1 digits on the scaled MFMA (kernels_scan.hip flat_scan_q2_fp4); 0 = i8 digits
     int n_cus = 0;
     if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, ix->p.device) != hipSuccess || n_cus <= 0) n_cus = 256;
     constexpr u32 SEED = 16384, APP_CAP = 4096;
@@ -817,7 +818,7 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
                 const u64 pieces = (u64)B * (kdims / 16);
                 hipLaunchKernelGGL(expand_q2_digits_kernel, dim3((u32)((pieces + 255) / 256)), dim3(256), 0, st, d_qc, ix->row_stride, B, kdims, d_qd);
                 e = hipGetLastError();
-                if (e == hipSuccess && use_areg) e = launch_flat_scan_expand_queries(d_qc, ix->row_stride, B, kdims, d_qdp, st);
+                if (e == hipSuccess && use_areg) e = launch_flat_scan_expand_queries(d_qc, ix->row_stride, B, kdims, d_qdp, st, use_fp4);
             }
             // zero-norm screening (cosine): the reference aborts a search on the first zero denominator it meets; an
             // exhaustive scan meets every vector, so any zero |q| or zero |v| is a CalculationError for the call.
@@ -857,7 +858,7 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
 #define FLAT_LAUNCH(E, F, P) hipLaunchKernelGGL((flat_codes_gemm_i8<E, F, P>), grid, dim3(512), 0, st, FLAT_ARGS)
 #define FLAT_LAUNCH_PF(E, F) do { if (pf == 2) FLAT_LAUNCH(E, F, 2); else if (pf == 3) FLAT_LAUNCH(E, F, 3); else FLAT_LAUNCH(E, F, 1); } while (0)
             if (use_fused && use_areg) {
-                e = launch_flat_scan(kdims, (u32)n_cus, st, d_qdp, d_qm, B, ix->d_codes, ix->d_mags, ix->row_stride, n0, nc, ix->p.metric, fo);
+                e = launch_flat_scan(kdims, (u32)n_cus, st, d_qdp, d_qm, B, ix->d_codes, ix->d_mags, ix->row_stride, n0, nc, ix->p.metric, fo, use_fp4);
                 if (e != hipSuccess) break;
             } else if (ix->eng == ENG_U8) {
                 if (use_fused) FLAT_LAUNCH_PF(ENG_U8, true); else FLAT_LAUNCH_PF(ENG_U8, false);
@@ -948,27 +949,43 @@ hipError_t launch_code_sums(const uint8_t *codes, u64 row_stride, u32 n, u32 *su
     return hipGetLastError();
 }
 
-// tab[q][c] = dot_product_u8(query q, table column c) `as f32` for q < B, c < ncols; u8 codes only.  The walk divides by |q| * |v|
+// storages with a level table: u8 codes (any row length: the tile kernel covers what the query-resident one does not) and quaternary
+// codes whose dims the query-resident kernel is instantiated for (the tile kernel's quaternary path assumes whole 64-dim chunks too)
+bool level_table_eng_supported(int eng, u64 row_stride) {
+    return eng == ENG_U8 || (eng == ENG_Q2 && level_table_areg_supported(ENG_Q2, row_stride));
+}
+
+// tab[q][c] = the integer dot of query q with table column c (dot_product_u8 / dot_product_quaternary) `as f32` for q < B, c < ncols;
+// u8 and quaternary codes.  The walk divides by |q| * |v|
 // for the entries it reads (walk_kernel.inc, table levels): the GEMM's epilogue is an add, a convert and a store.  The
 // query-resident kernel (kernels_scan.hip level_table_areg) wherever the code rows are whole 64-byte chunks with an
 // instantiation (768, 1024, ...), the 256 x 128 tile kernel otherwise (and with tuning knob walk_table_gemm = 0); same table.
-hipError_t launch_level_table(const uint8_t *qcodes, const float *qmags, u32 *qsums /*[B] scratch*/, u32 B, const uint8_t *tcodes,
-                              const float *tmags, const u32 *tcsums, u64 row_stride, u32 ncols, float *tab, u64 tab_stride,
+hipError_t launch_level_table(int eng, const uint8_t *qcodes, const float *qmags, u32 *qsums /*[B] scratch (u8)*/, uint8_t *qdig /*[B][dims] scratch (quaternary)*/,
+                              u32 B, const uint8_t *tcodes, const float *tmags, const u32 *tcsums, u64 row_stride, u32 ncols, float *tab, u64 tab_stride,
                               u32 n_cus, hipStream_t st) {
     if (B == 0 || ncols == 0) return hipSuccess;
-    hipError_t e = launch_code_sums(qcodes, row_stride, B, qsums, st);
+    const bool q2 = eng == ENG_Q2;
+    const u32 kdims = q2 ? (u32)(row_stride / 16) * 64 : (u32)((row_stride + 63) / 64 * 64);
+    hipError_t e = hipSuccess;
+    if (!q2) e = launch_code_sums(qcodes, row_stride, B, qsums, st);
     if (e != hipSuccess) return e;
-    if (level_table_areg_supported(row_stride) && tune_or(TUNE_WALK_TABLE_GEMM, 1) != 0)
-        return launch_level_table_areg(n_cus ? n_cus : 256u, st, qcodes, (const u32 *)qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride);
+    if (level_table_areg_supported(eng, row_stride) && tune_or(TUNE_WALK_TABLE_GEMM, 1) != 0) {
+        if (q2) { // the queries' planes -> the permuted i8 digit rows the kernel keeps resident
+            e = launch_flat_scan_expand_queries(qcodes, row_stride, B, kdims, qdig, st, false);
+            if (e != hipSuccess) return e;
+        }
+        return launch_level_table_areg(eng, n_cus ? n_cus : 256u, st, q2 ? qdig : qcodes, (const u32 *)qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride);
+    }
     const u32 metric = 1u; // the tile kernel's unfused epilogue with the dot-product metric: the converted integer dot, no quotient
-    const u32 kdims = (u32)((row_stride + 63) / 64 * 64);
     dim3 grid((ncols + CN - 1) / CN, (B + CM - 1) / CM);
     FusedOut fo{nullptr, nullptr, nullptr, 0u, nullptr};
     // two k panels in flight (one and three were measured slower in round 4)
-#define TAB_GEMM(P) hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, false, P>), grid, dim3(512), 0, st, qcodes, qmags, (const u32 *)qsums, B, tcodes, tmags, \
-                                       tcsums, row_stride, 0u, ncols, kdims, metric, tab, tab_stride, fo)
-    TAB_GEMM(2);
-#undef TAB_GEMM
+    if (q2)
+        hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_Q2, false, 2>), grid, dim3(512), 0, st, qcodes, qmags, (const u32 *)qsums, B, tcodes, tmags, tcsums, row_stride, 0u,
+                           ncols, kdims, metric, tab, tab_stride, fo);
+    else
+        hipLaunchKernelGGL((flat_codes_gemm_i8<ENG_U8, false, 2>), grid, dim3(512), 0, st, qcodes, qmags, (const u32 *)qsums, B, tcodes, tmags, tcsums, row_stride, 0u,
+                           ncols, kdims, metric, tab, tab_stride, fo);
     return hipGetLastError();
 }
 

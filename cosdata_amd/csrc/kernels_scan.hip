@@ -301,6 +301,242 @@ __global__ __launch_bounds__(256) void flat_scan_q2_areg(const uint8_t *__restri
 
 
 // ------------------------------------------------------------------------------------------------
+// The same scan on the FP4 path of the scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, gfx950).  A quaternary digit d in {0,1,2,3}
+// IS the e2m1 code of d / 2 (0000 = 0, 0001 = 0.5, 0010 = 1.0, 0011 = 1.5), so a code row becomes 4-bit operands with ONE and-or
+// per dword (nibble = plane0 bit | plane1 bit << 1), half the LDS and AccVGPR bytes of the i8 digits, and one MFMA covers 64 dims
+// where the i8 form covers 32 at the same issue cost.  Exactness: every product is a multiple of 1/4 below 2.25, a row's sum is
+// below 2.25 x 4096 — all exactly representable in the f32 accumulator whatever the order of the additions — and unit block scales
+// (E8M0 127 = 2^0) leave the values alone; acc x 4 is the integer dot_product_quaternary returns (dot_product.rs:125, x86_64.rs:
+// 103-160), the epilogue folds the 4 into its reciprocal.  Only k ORDER inside a 64-dim chunk differs from the i8 kernel (both
+// operands share it: the sum does not care).  Structure, staging, deferred epilogue, survivors: flat_scan_q2_areg above.
+// ------------------------------------------------------------------------------------------------
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 16 nibble bytes of piece pp (0, 1) of a 64-dim chunk: nibble n of dword jj is dim 32 * pp + jj + 4 * n
+__device__ __forceinline__ u32 q2_nibble_dword(uint4 raw /*[plane0 8 B | plane1 8 B]*/, int pp, int jj) {
+    const u32 w0 = pp == 0 ? raw.x : raw.y, w1 = pp == 0 ? raw.z : raw.w;
+    const u32 x0 = w0 >> jj, x1 = jj ? (w1 >> (jj - 1)) : (w1 << 1);
+    return (x0 & 0x11111111u) | (x1 & 0x22222222u);
+}
+__device__ __forceinline__ uint4 q2_nibble_piece(uint4 raw, int pp) {
+    return make_uint4(q2_nibble_dword(raw, pp, 0), q2_nibble_dword(raw, pp, 1), q2_nibble_dword(raw, pp, 2), q2_nibble_dword(raw, pp, 3));
+}
+
+__global__ void expand_q2_nibbles_kernel(const uint8_t *__restrict__ qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *__restrict__ nib /*[B][kdims / 2]*/) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 chunks = kdims / 64;
+    if (t >= (u64)B * chunks) return;
+    const u32 q = (u32)(t / chunks), j = (u32)(t % chunks);
+    const uint4 raw = (u64)j * 16 < row_stride ? *(const uint4 *)(qcodes + (u64)q * row_stride + (u64)j * 16) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int pp = 0; pp < 2; pp++) *(uint4 *)(nib + (u64)q * (kdims / 2) + (u64)j * 32 + pp * 16) = q2_nibble_piece(raw, pp);
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void fp4_mfma(f32x16 &acc, const i32x4 &afrag, const i32x4 &bfrag) {
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const i32x8 a8 = {afrag[0], afrag[1], afrag[2], afrag[3], 0, 0, 0, 0}, b8 = {bfrag[0], bfrag[1], bfrag[2], bfrag[3], 0, 0, 0, 0};
+    // cbsz = blgp = 4: both operands FP4 (e2m1), 32 values per lane in the low four registers; scales: E8M0 127 in every byte
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, FIRST ? z : acc, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void flat_scan_q2_fp4(const uint8_t *__restrict__ qnib /*[B][32 KC] nibble bytes*/,
+                                                        const float *__restrict__ qmags, u32 B, const uint8_t *__restrict__ codes,
+                                                        const float *__restrict__ mags, u64 row_stride, u32 n0, u32 n_chunk, u32 metric,
+                                                        const FusedOut fo) {
+    constexpr int KB = KC * 32, KS = KC, LDB = KB + 16, ITS = (KC + 3) / 4, PIECES = ITS * 2; // KB = operand bytes per row, one k step per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB] | survivors [AREG_STAGE][3] u32 | count
+    u32 *stage = (u32 *)(areg_lds + (size_t)2 * 64 * LDB), *stage_cnt = stage + 3 * AREG_STAGE;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const u32 row0 = blockIdx.y * 256 + w * 64;
+    const u32 n_tiles = (n_chunk + 63) / 64, G = gridDim.x;
+    u32 t = blockIdx.x;
+    if (t >= n_tiles) return; // uniform
+    if (tid == 0) *stage_cnt = 0; // published by the barrier after the first tile's expansion
+    i32x4 a[2][KS];
+    static_for<0, 2 * KS>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(Ic)::value / KS, s = decltype(Ic)::value % KS;
+        const u32 row = row0 + 32 * i + l31; // rows past B: clamped loads (no branches in the prologue), zeroed
+        const i32x4 v = *(const i32x4 *)(qnib + (u64)(row < B ? row : B - 1) * KB + 32 * s + 16 * half);
+        a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
+        asm volatile("" : "+a"(a[i][s])); // the value now IS an AccVGPR tuple
+    });
+    // thresholds of this lane's 32 accumulator rows, in the units of dot * (1 / |x|): T = thr_lo * |q| (cosine) or thr_lo (dot)
+    float T[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, rc = row < B ? row : B - 1;
+            const u64 k = fo.thr[rc];
+            const float qm = qmags[rc];
+            const float lo = k == 0ull ? -1.0f : simkey_inv((u32)(k >> 32)) * (1.0f - 4e-6f); // scores of quaternary codes are >= 0
+            const float v = metric == 0u ? lo * qm : lo;
+            T[i][r] = row < B ? v : __builtin_inff();
+        }
+    uint4 raw[2][ITS];
+    auto load_raw = [&](u32 tile, uint4 *dst, int it) __attribute__((always_inline)) {
+        const int j = w + 4 * it;
+        const u32 c = tile * 64 + lane, cc = c < n_chunk ? c : n_chunk - 1;
+        dst[it] = *(const uint4 *)(codes + (u64)(n0 + cc) * row_stride + (u64)(KC % 4 == 0 || j < KC ? j : 0) * 16);
+    };
+    auto store_piece = [&](int buf, const uint4 *src, int it, int pp) __attribute__((always_inline)) {
+        const int j = w + 4 * it;
+        if (KC % 4 == 0 || j < KC) *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + lane * LDB + j * 32 + pp * 16) = q2_nibble_piece(src[it], pp);
+    };
+    float xm[2][2]; // candidate norms of the tile in accumulator set 0 / 1 (consumed by the deferred epilogue)
+    auto load_norms = [&](u32 tile, float *dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const u32 col = tile * 64 + 32 * j + l31;
+            dst[j] = mags[n0 + (col < n_chunk ? col : n_chunk - 1)];
+        }
+    };
+#pragma unroll
+    for (int it = 0; it < ITS; it++) load_raw(t, raw[0], it);
+#pragma unroll
+    for (int it = 0; it < ITS; it++)
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) store_piece(0, raw[0], it, pp);
+#pragma unroll
+    for (int it = 0; it < ITS; it++) {
+        load_raw(t + G, raw[1], it);
+        load_raw(t + 2 * G, raw[0], it);
+    }
+    xm[1][0] = xm[1][1] = 1.0f;
+    __syncthreads();
+    f32x16 acc[2][2][2]; // [set][row block][column block]: dot / 4, an exact multiple of 1/4
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[1][i][j][r] = 0.0f;
+
+    float best = 0.0f;
+    auto epi_rows = [&](auto Pc, int e, int r0) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        const int j = e >> 2, i = (e >> 1) & 1, h8 = (e & 1) * 8;
+        const float rx = metric == 0u ? 4.0f * __builtin_amdgcn_rcpf(xm[P][j]) : 4.0f; // the accumulators hold dot / 4
+        if (h8 == 0 && r0 == 0) best = -__builtin_inff();
+#pragma unroll
+        for (int r = r0; r < r0 + 2; r++) best = fmaxf(best, __builtin_fmaf(acc[P][i][j][h8 + r], rx, -T[i][h8 + r]));
+    };
+    auto epi_finish = [&](auto Pc, int e, u32 tp, bool tp_valid) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        const int j = e >> 2, i = (e >> 1) & 1;
+        if ((e & 1) == 0) return;
+        const u32 col = tp * 64 + 32 * j + l31;
+        if (best >= 0.0f && tp_valid && col < n_chunk) {
+            const float rx = metric == 0u ? 4.0f * __builtin_amdgcn_rcpf(xm[P][j]) : 4.0f;
+            u32 rbase = row0 + 32 * i + 4 * half;
+            asm volatile("" : "+v"(rbase)); // opaque: keeps the 32 rows' addresses from being hoisted out of the tile loop
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32 row = rbase + (r & 3) + 8 * (r >> 2);
+                const float q4 = acc[P][i][j][r];
+                if (row < B && __builtin_fmaf(q4, rx, -T[i][r]) >= 0.0f) {
+                    const u32 dot = (u32)(q4 * 4.0f); // exact: q4 is a multiple of 1/4 below 2^22
+                    const u32 sp = atomicAdd(stage_cnt, 1u);
+                    if (sp < AREG_STAGE) {
+                        stage[3 * sp] = col;
+                        stage[3 * sp + 1] = row;
+                        stage[3 * sp + 2] = dot;
+                    } else
+                        areg_append(fo, qmags, mags, metric, n0, col, row, dot); // staging full: append from here
+                }
+            }
+        }
+    };
+    auto epi_slice = [&](auto Pc, int e, u32 tp, bool tp_valid) __attribute__((always_inline)) {
+        epi_rows(Pc, e, 0); epi_rows(Pc, e, 2); epi_rows(Pc, e, 4); epi_rows(Pc, e, 6);
+        epi_finish(Pc, e, tp, tp_valid);
+    };
+    // One tile: MFMAs of tile tt into set P from LDS buffer P; every k step is four (MFMA, VALU) pairs — one dword of the
+    // expansion of tile tt+G during the first PIECES steps, two rows of the epilogue of tile tt-G (set P^1) during the last 8
+    constexpr int EPI0 = KS >= 8 ? KS - 8 : 0; // first step that carries an epilogue slice
+    auto tile_body = [&](auto Pc, u32 tt, bool prev_valid) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        const unsigned char *bt = areg_lds + (size_t)P * 64 * LDB + l31 * LDB + 16 * half;
+        i32x4 bf[3][2]; // candidate fragments, read two k steps ahead of their MFMAs
+#pragma unroll
+        for (int s = 0; s < 2 && s < KS; s++) {
+            bf[s][0] = *(const i32x4 *)(bt + 32 * s);
+            bf[s][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * s);
+        }
+        load_norms(tt, xm[P]);
+        static_for<0, KS>([&](auto Sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(Sc)::value;
+            constexpr bool expand = s < PIECES, epi = s >= EPI0 && s < EPI0 + 8;
+            constexpr int it = (s < PIECES ? s : 0) >> 1, pp = s & 1;
+            if (s + 2 < KS) {
+                bf[(s + 2) % 3][0] = *(const i32x4 *)(bt + 32 * (s + 2));
+                bf[(s + 2) % 3][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * (s + 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const i32x4 b0 = bf[s % 3][0], b1 = bf[s % 3][1];
+            const bool lane_stores = KC % 4 == 0 || w + 4 * it < KC;
+            u32 o[4] = {0, 0, 0, 0};
+            fp4_mfma<s == 0>(acc[P][0][0], a[0][s], b0);
+            if (expand) { o[0] = q2_nibble_dword(raw[P ^ 1][it], pp, 0); asm volatile("" : "+v"(o[0])); } // pinned behind its MFMA
+            if (epi) epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fp4_mfma<s == 0>(acc[P][0][1], a[0][s], b1);
+            if (expand) { o[1] = q2_nibble_dword(raw[P ^ 1][it], pp, 1); asm volatile("" : "+v"(o[1])); }
+            if (epi) epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            fp4_mfma<s == 0>(acc[P][1][0], a[1][s], b0);
+            if (expand) { o[2] = q2_nibble_dword(raw[P ^ 1][it], pp, 2); asm volatile("" : "+v"(o[2])); }
+            if (epi) epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            fp4_mfma<s == 0>(acc[P][1][1], a[1][s], b1);
+            if (expand) {
+                o[3] = q2_nibble_dword(raw[P ^ 1][it], pp, 3);
+                asm volatile("" : "+v"(o[3]));
+                if (lane_stores)
+                    *(uint4 *)(areg_lds + (size_t)(P ^ 1) * 64 * LDB + lane * LDB + (w + 4 * it) * 32 + pp * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+                if (pp == 1) load_raw(tt + 3 * G, raw[P ^ 1], it); // the chunk's registers are free: reload them for tile tt + 3G
+            }
+            if (epi) {
+                epi_rows(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, 6);
+                epi_finish(std::integral_constant<int, (P ^ 1)>{}, s - EPI0, tt - G, prev_valid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (PIECES > KS) { // (never: 2 * ceil(KC / 4) <= KC for every instantiated KC >= 2; kept as a guard)
+            static_assert(PIECES <= KS, "the expansion must fit the k loop");
+        }
+        if constexpr (EPI0 + 8 > KS) { // short K: the slices that did not fit in the k loop
+            static_for<KS - EPI0, 8>([&](auto Ec) __attribute__((always_inline)) { epi_slice(std::integral_constant<int, (P ^ 1)>{}, decltype(Ec)::value, tt - G, prev_valid); });
+        }
+        __syncthreads();
+    };
+    bool prev_valid = false;
+    int last = 1;
+    while (true) {
+        tile_body(std::integral_constant<int, 0>{}, t, prev_valid);
+        prev_valid = true;
+        last = 0;
+        t += G;
+        if (t >= n_tiles) break;
+        tile_body(std::integral_constant<int, 1>{}, t, true);
+        last = 1;
+        t += G;
+        if (t >= n_tiles) break;
+    }
+    if (last == 0) {
+        static_for<0, 8>([&](auto Ec) __attribute__((always_inline)) { epi_slice(std::integral_constant<int, 0>{}, decltype(Ec)::value, t - G, true); });
+    } else {
+        static_for<0, 8>([&](auto Ec) __attribute__((always_inline)) { epi_slice(std::integral_constant<int, 1>{}, decltype(Ec)::value, t - G, true); });
+    }
+    __syncthreads();
+    const u32 staged = min(*stage_cnt, (u32)AREG_STAGE);
+    for (u32 e = tid; e < staged; e += 256) areg_append(fo, qmags, mags, metric, n0, stage[3 * e], stage[3 * e + 1], stage[3 * e + 2]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Level table of the walk (WalkArgs::tab; engine.hip ensure_level_table / run_search) as a query-resident GEMM over u8 codes.
 // Round 4 ran this product on flat_codes_gemm_i8 (the 256 x 128 tile kernel): 0.15-0.18 of the i8 peak, because every tile
 // restages 256 query rows through LDS for 64 k steps' worth of MFMAs, and its epilogue formed the exact quotient dot / (|q| |v|)
@@ -317,54 +553,67 @@ __global__ __launch_bounds__(256) void flat_scan_q2_areg(const uint8_t *__restri
 //     13 TB/s of output at the i8 peak — so this is an HBM WRITE stream with the MFMA at ~40 % duty, and is reported as such.
 // One workgroup per CU, persistent over its column tiles; the grid is (column groups, query groups of 256).
 // ------------------------------------------------------------------------------------------------
-template <int KC>
-__global__ __launch_bounds__(256) void level_table_areg(const uint8_t *__restrict__ qcodes, const u32 *__restrict__ qsums, u32 B,
-                                                        const uint8_t *__restrict__ tcodes, const u32 *__restrict__ tcsums, u64 row_stride /* == 64 KC */,
-                                                        u32 ncols, float *__restrict__ tab, u64 tab_stride) {
-    constexpr int K = KC * 64, KS = KC * 2, LDB = K + 16, PC = K / 16; // PC = 16-byte pieces per column; a thread stages KC of a tile's 64 PC
+// Q2 = quaternary codes (round 5: the c3 walk's table): the operands are the i8 digits of the exhaustive scan above — queries
+// pre-expanded once per launch (expand_q2_digits_perm_kernel), table columns expanded planes -> digits while they are staged —
+// and the dot needs no recentring.
+template <int KC, bool Q2>
+__global__ __launch_bounds__(256) void level_table_areg(const uint8_t *__restrict__ qcodes /* u8: [B][64 KC] codes; Q2: [B][64 KC] permuted digits */,
+                                                        const u32 *__restrict__ qsums, u32 B, const uint8_t *__restrict__ tcodes,
+                                                        const u32 *__restrict__ tcsums, u64 row_stride /* u8: 64 KC; Q2: 16 KC */, u32 ncols,
+                                                        float *__restrict__ tab, u64 tab_stride) {
+    constexpr int K = KC * 64, KS = KC * 2, LDB = K + 16;
+    constexpr int PC = Q2 ? KC : K / 16;           // 16-byte RAW pieces per column (Q2: one per 64 dims, expanded to four in LDS)
+    constexpr int NP = (64 * PC + 255) / 256;      // raw pieces a thread stages per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const u32 row0 = blockIdx.y * 256 + w * 64;
     const u32 n_tiles = (ncols + 63) / 64, G = gridDim.x;
     u32 t = blockIdx.x;
     if (t >= n_tiles) return; // uniform
-    // resident query fragments, recentred; rows past B are zero (their outputs are never stored)
+    // resident query fragments (u8: recentred); rows past B are zero (their outputs are never stored)
     i32x4 a[2][KS];
     static_for<0, 2 * KS>([&](auto Ic) __attribute__((always_inline)) {
         constexpr int i = decltype(Ic)::value / KS, s = decltype(Ic)::value % KS;
         const u32 row = row0 + 32 * i + l31;
-        i32x4 v = *(const i32x4 *)(qcodes + (u64)(row < B ? row : B - 1) * row_stride + 32 * s + 16 * half);
-        v = v ^ (int)0x80808080;
+        i32x4 v = *(const i32x4 *)(qcodes + (u64)(row < B ? row : B - 1) * K + 32 * s + 16 * half);
+        if constexpr (!Q2) v = v ^ (int)0x80808080;
         a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
         asm volatile("" : "+a"(a[i][s])); // the value now IS an AccVGPR tuple: its MFMA uses need no copies
     });
-    // per-row share of the recentring: 128 * sum(q) - 16384 * K, for this lane's 32 accumulator rows
+    // u8: per-row share of the recentring, 128 * sum(q) - 16384 * K, for this lane's 32 accumulator rows
     int rqs[2][16];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const u32 row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-            rqs[i][r] = 128 * (int)qsums[row < B ? row : B - 1] - 16384 * K;
+            rqs[i][r] = Q2 ? 0 : 128 * (int)qsums[row < B ? row : B - 1] - 16384 * K;
         }
-    // staging: piece g = p * 256 + tid of the tile's 64 * PC pieces is bytes [16 (g % PC), +16) of column g / PC — consecutive
+    // staging: raw piece g = p * 256 + tid of the tile's 64 * PC pieces is bytes [16 (g % PC), +16) of column g / PC — consecutive
     // threads read consecutive 16 B of one code row (coalesced); columns past ncols re-read the last one (never stored)
-    uint4 raw[KC];
+    uint4 raw[NP];
     auto load_tile = [&](u32 tile) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < KC; p++) {
-            const u32 g = (u32)p * 256u + (u32)tid, c = g / (u32)PC, pc = g % (u32)PC;
+        for (int p = 0; p < NP; p++) {
+            const u32 g = (u32)p * 256u + (u32)tid, gg = g < 64u * PC ? g : 0u, c = gg / (u32)PC, pc = gg % (u32)PC;
             const u32 col = tile * 64 + c, cc = col < ncols ? col : ncols - 1;
             raw[p] = *(const uint4 *)(tcodes + (u64)cc * row_stride + (u64)pc * 16);
         }
     };
     auto store_tile = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < KC; p++) {
+        for (int p = 0; p < NP; p++) {
             const u32 g = (u32)p * 256u + (u32)tid, c = g / (u32)PC, pc = g % (u32)PC;
-            uint4 v = raw[p];
-            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-            *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + (size_t)c * LDB + (size_t)pc * 16) = v;
+            if (64 * PC % 256 != 0 && g >= 64u * PC) continue;
+            unsigned char *dst = areg_lds + (size_t)buf * 64 * LDB + (size_t)c * LDB;
+            if constexpr (Q2) {
+#pragma unroll
+                for (int pp = 0; pp < 4; pp++) *(uint4 *)(dst + (size_t)pc * 64 + pp * 16) = q2_piece_perm(raw[p], pp);
+            } else {
+                uint4 v = raw[p];
+                v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+                *(uint4 *)(dst + (size_t)pc * 16) = v;
+            }
         }
     };
     load_tile(t);
@@ -404,7 +653,8 @@ __global__ __launch_bounds__(256) void level_table_areg(const uint8_t *__restric
             for (int j = 0; j < 2; j++) {
                 const u32 col = t * 64 + 32 * j + l31;
                 const bool cv = FULL || col < ncols;
-                const int cs = 128 * (int)tcsums[cv ? col : ncols - 1];
+                int cs = 0;
+                if constexpr (!Q2) cs = 128 * (int)tcsums[cv ? col : ncols - 1];
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const u32 rbase = row0 + 32 * i + 4 * half;
@@ -446,10 +696,29 @@ static hipError_t launch_areg_kc(dim3 grid, hipStream_t st, const uint8_t *qdig,
     hipLaunchKernelGGL((flat_scan_q2_areg<KC>), grid, dim3(256), lds, st, qdig, qmags, B, codes, mags, row_stride, n0, nc, metric, fo);
     return hipGetLastError();
 }
+template <int KC>
+static hipError_t launch_fp4_kc(dim3 grid, hipStream_t st, const uint8_t *qnib, const float *qmags, u32 B, const uint8_t *codes, const float *mags,
+                                u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
+    const size_t lds = (size_t)2 * 64 * (KC * 32 + 16) + (size_t)AREG_STAGE * 12 + 16;
+    hipError_t e = hipFuncSetAttribute((const void *)flat_scan_q2_fp4<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((flat_scan_q2_fp4<KC>), grid, dim3(256), lds, st, qnib, qmags, B, codes, mags, row_stride, n0, nc, metric, fo);
+    return hipGetLastError();
+}
+// fp4 = the e2m1 form of the digits on the scaled MFMA (flat_scan_q2_fp4; qdig then holds the nibble rows of
+// launch_flat_scan_expand_queries(..., fp4 = true)), else the i8 digits (flat_scan_q2_areg)
 hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes,
-                              const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
+                              const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo, bool fp4) {
     const u32 n_tiles = (nc + 63) / 64;
     dim3 grid(std::min(n_tiles, n_cus), (B + 255) / 256);
+    if (fp4) {
+#define FP4_CASE(KC) case KC: return launch_fp4_kc<KC>(grid, st, qdig, qmags, B, codes, mags, row_stride, n0, nc, metric, fo)
+        switch (kdims / 64) {
+            FP4_CASE(2); FP4_CASE(4); FP4_CASE(6); FP4_CASE(8); FP4_CASE(12); FP4_CASE(16);
+            default: return hipErrorInvalidValue;
+        }
+#undef FP4_CASE
+    }
 #define AREG_CASE(KC) case KC: return launch_areg_kc<KC>(grid, st, qdig, qmags, B, codes, mags, row_stride, n0, nc, metric, fo)
     switch (kdims / 64) {
         AREG_CASE(2); AREG_CASE(4); AREG_CASE(6); AREG_CASE(8); AREG_CASE(12); AREG_CASE(16);
@@ -459,34 +728,47 @@ hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t 
 }
 
 
-// level table as a query-resident GEMM: u8 codes whose rows are a whole number of 64-byte chunks with an instantiation
-bool level_table_areg_supported(u64 row_stride) {
-    return row_stride % 64 == 0 && flat_scan_supported((u32)row_stride);
+// level table as a query-resident GEMM: u8 codes whose rows are a whole number of 64-byte chunks with an instantiation, quaternary
+// codes whose rows (16 B per 64 dims) have one
+bool level_table_areg_supported(int eng, u64 row_stride) {
+    if (eng == ENG_U8) return row_stride % 64 == 0 && flat_scan_supported((u32)row_stride);
+    if (eng == ENG_Q2) return row_stride % 16 == 0 && flat_scan_supported((u32)(row_stride / 16) * 64);
+    return false;
 }
-template <int KC>
+template <int KC, bool Q2>
 static hipError_t launch_table_kc(dim3 grid, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, u32 B, const uint8_t *tcodes, const u32 *tcsums,
                                   u64 row_stride, u32 ncols, float *tab, u64 tab_stride) {
     const size_t lds = (size_t)2 * 64 * (KC * 64 + 16);
-    hipError_t e = hipFuncSetAttribute((const void *)level_table_areg<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)level_table_areg<KC, Q2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((level_table_areg<KC>), grid, dim3(256), lds, st, qcodes, qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride);
+    hipLaunchKernelGGL((level_table_areg<KC, Q2>), grid, dim3(256), lds, st, qcodes, qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride);
     return hipGetLastError();
 }
-// tab[q][c] = (f32) dot_product_u8(query q, table column c); grid = (column groups, query groups of 256), about one workgroup per CU
-hipError_t launch_level_table_areg(u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, u32 B, const uint8_t *tcodes, const u32 *tcsums,
+// tab[q][c] = (f32) integer dot of query q with table column c; grid = (column groups, query groups of 256), about one workgroup per CU.
+// u8: qcodes = the queries' code rows, qsums / tcsums = code sums.  Q2: qcodes = the queries' permuted digit rows
+// (launch_flat_scan_expand_queries, fp4 = false), qsums / tcsums unused.
+hipError_t launch_level_table_areg(int eng, u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, u32 B, const uint8_t *tcodes, const u32 *tcsums,
                                    u64 row_stride, u32 ncols, float *tab, u64 tab_stride) {
     const u32 n_tiles = (ncols + 63) / 64, row_groups = (B + 255) / 256;
     const u32 G = std::max(1u, std::min(n_tiles, n_cus / std::max(1u, std::min(row_groups, n_cus))));
     dim3 grid(G, row_groups);
-#define TAB_CASE(KC) case KC: return launch_table_kc<KC>(grid, st, qcodes, qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride)
-    switch (row_stride / 64) {
+    const u32 kc = eng == ENG_Q2 ? (u32)(row_stride / 16) : (u32)(row_stride / 64);
+#define TAB_CASE(KC)                                                                                                                          \
+    case KC:                                                                                                                                  \
+        return eng == ENG_Q2 ? launch_table_kc<KC, true>(grid, st, qcodes, qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride)     \
+                             : launch_table_kc<KC, false>(grid, st, qcodes, qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride)
+    switch (kc) {
         TAB_CASE(2); TAB_CASE(4); TAB_CASE(6); TAB_CASE(8); TAB_CASE(12); TAB_CASE(16);
         default: return hipErrorInvalidValue;
     }
 #undef TAB_CASE
 }
 
-hipError_t launch_flat_scan_expand_queries(const uint8_t *qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *digits, hipStream_t st) {
+hipError_t launch_flat_scan_expand_queries(const uint8_t *qcodes, u64 row_stride, u32 B, u32 kdims, uint8_t *digits, hipStream_t st, bool fp4) {
+    if (fp4) {
+        hipLaunchKernelGGL(expand_q2_nibbles_kernel, dim3((u32)(((u64)B * (kdims / 64) + 255) / 256)), dim3(256), 0, st, qcodes, row_stride, B, kdims, digits);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(expand_q2_digits_perm_kernel, dim3((u32)(((u64)B * (kdims / 64) + 255) / 256)), dim3(256), 0, st, qcodes, row_stride, B, kdims, digits);
     return hipGetLastError();
 }

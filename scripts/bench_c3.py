@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 I8_PEAK_TOPS = 5000.0
+FP4_PEAK_TOPS = 10000.0   # dense FP4 (e2m1) MFMA peak, MI355X_MICROARCH.md: ~10 PF dense; measured 9099 TF (32x32x64)
 
 
 def _cores():
@@ -54,27 +55,42 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
     # epilogue, unfused score-matrix path) must return the same ids / score bits / counts
     same = {}
     from cosdata_amd import _lib
-    for env in ("flat_tile_kernel", "flat_unfused"):
-        with _lib.tuning(**{env: 1}):
+    for env, val in (("flat_fp4", 0), ("flat_tile_kernel", 1), ("flat_unfused", 1)):
+        with _lib.tuning(**{env: val}):
             i2, s2, c2 = ix.flat_search(Qh, 10)
         same[env] = bool(np.array_equal(i2, ids) and np.array_equal(s2.view(np.uint32), sc.view(np.uint32)) and np.array_equal(c2, cnt))
     rec_flat = float(np.mean([len(set(ids[i].tolist()) & set(gt[i].tolist())) / 10 for i in range(B)]))
     tops = st.int8_ops / gemm_ms / 1e9
+    # the same scan with the digits as i8 (round 4's kernel, tuning knob flat_fp4 = 0), timed the same way: what the FP4 operands buy
+    fp4_on = _lib.tuning_get("flat_fp4") in (None, 1) and d % 64 == 0 and (d // 64) in (2, 4, 6, 8, 12, 16)
+    with _lib.tuning(flat_fp4=0):
+        ix.flat_search(Qh, 10)
+        i8_runs = []
+        for _ in range(reps):
+            t = time.time()
+            _, _, _, st8 = ix.flat_search(Qh, 10, with_stats=True)
+            i8_runs.append((st8.gemm_ms, time.time() - t))
+    i8_gemm_ms = float(np.median([r[0] for r in i8_runs])); i8_wall = float(np.median([r[1] for r in i8_runs]))
+    PEAK = FP4_PEAK_TOPS if fp4_on else I8_PEAK_TOPS
     out = {"config": {"workload": f"c3: BASELINE configs[2]: {n} x {d} quaternary (SubByte 2, values_range (-1,1)), exhaustive scan of the codes, "
                                   f"query batch {B}", "standard_size": n == 10_000_000 and d == 768 and B == 256, "vectors": n, "dim": d, "query_batch": B,
                       "step": "one cos_flat_search_batch call = i8-MFMA scan of every code row + top-5k selection + exact f32 rerank + top-k"},
-           "qps": B / wall, "unit": "queries/s", "ms_per_step": wall * 1e3, "steps": reps, "warmup": 1, "dtype": "i8 (2-bit digits)",
+           "qps": B / wall, "unit": "queries/s", "ms_per_step": wall * 1e3, "steps": reps, "warmup": 1, "dtype": "fp4 e2m1 (2-bit digits, exact)" if fp4_on else "i8 (2-bit digits)",
            "recall_at_10": rec_flat, "recall_note": "vs exact f32 brute force; the reference's fixed-range 2-bit quantizer with MSB-first planes "
                                                     "multiplied LSB-first bounds it — the GPU reproduces the oracle exactly, the recall is the reference's",
-           "roofline": {"bound": "mfma", "achieved": tops, "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_PEAK_TOPS, "traffic": None,
-                        "kernel": "flat_scan_q2_areg<KC> (query-resident i8 MFMA scan)",
+           "roofline": {"bound": "mfma", "achieved": tops, "peak": PEAK, "unit": "TOP/s", "frac": tops / PEAK, "traffic": None,
+                        "kernel": ("flat_scan_q2_fp4<%d> (query-resident scan, digits as e2m1 on v_mfma_scale_f32_32x32x64_f8f6f4; peak = dense FP4)" % (d // 64)) if fp4_on
+                                  else "flat_scan_q2_areg<KC> (query-resident i8 MFMA scan)",
+                        "same_scan_with_i8_digits": {"kernel": "flat_scan_q2_areg<KC>", "gemm_ms_all_launches": i8_gemm_ms, "ms_per_step": i8_wall * 1e3,
+                                                     "achieved": st.int8_ops / i8_gemm_ms / 1e9, "peak": I8_PEAK_TOPS, "frac": st.int8_ops / i8_gemm_ms / 1e9 / I8_PEAK_TOPS},
                         "per_launch": {"gemm_ms_all_launches": gemm_ms, "gemm_launches": st.gemm_launches, "int8_ops": float(st.int8_ops),
                                        "code_bytes": float(st.code_bytes), "code_GBps": st.code_bytes / gemm_ms / 1e6},
                         "note": "achieved = 2 x B x N x dim integer ops / the scan kernels' HIP-event time inside the call (median of the timed calls)"},
            "flat": {"gemm_ms": gemm_ms, "gemm_launches": st.gemm_launches, "int8_tops": tops, "int8_peak_tops_dense": I8_PEAK_TOPS,
                     "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall,
                     "timing": f"median of {reps} calls after one untimed call", "qps_end_to_end": B / wall, "upload_quantize_s": t_up,
-                    "same_answer_as_tile_kernel": same["flat_tile_kernel"], "same_answer_as_unfused_path": same["flat_unfused"]},
+                    "same_answer_as_i8_digit_kernel": same["flat_fp4"], "same_answer_as_tile_kernel": same["flat_tile_kernel"],
+                    "same_answer_as_unfused_path": same["flat_unfused"]},
            "cpu_baseline": None, "parity_vs_oracle": None}
 
     # ---- CPU baseline + parity at the full corpus size: the oracle quantizes the corpus itself (streamed: no 30 GB host table),
@@ -124,16 +140,27 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
         def launch(i):
             o = outs[i % 2]
             ix2.batch_search_device(Qb.data_ptr(), Bq, 10, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), ss[i % 2].cuda_stream)
-        for i in range(4):
-            launch(i)
-        torch.cuda.synchronize()
-        ix2.enable_timing(True)
-        t = time.time()
         nrep = 12
-        for i in range(nrep):
-            launch(i)
-        torch.cuda.synchronize()
-        el = time.time() - t
+
+        def timed_launches():
+            for i in range(4):
+                launch(i)
+            torch.cuda.synchronize()
+            t = time.time()
+            for i in range(nrep):
+                launch(i)
+            torch.cuda.synchronize()
+            return time.time() - t
+        # round 5: the level table for quaternary codes (the small top levels from one i8 MFMA GEMM over the digits; same walk, same
+        # bits).  Timed without it first (round 4's path), then with the automatic rule, the launches' answers compared.
+        ix2.enable_timing(True)
+        ix2.set_walk_table(0, 0)
+        el_plain = timed_launches()
+        plain_ids = outs[0][0].clone()
+        ix2.set_walk_table()
+        tab_info = ix2.walk_table_info()
+        el = timed_launches()
+        table_same = bool(torch.equal(plain_ids, outs[0][0]))
         stt = ix2.last_stats(ss[0].cuda_stream)
         ids2, sc2, cnt2 = ix2.batch_search(Qh, 10)
         rec_walk = float(np.mean([len(set(ids2[i].tolist()) & set(gt2[i].tolist())) / 10 for i in range(B)]))
@@ -141,6 +168,8 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
         alg = float(stt.evals * row_b + stt.adj_bytes)
         gbps = alg / (stt.walk_ms * 1e-3) / 1e9 if stt.walk_ms > 0 else 0.0
         walk = {"n": m, "build_s": t_build, "queries_per_launch": Bq, "launches_in_flight": 2, "qps": nrep * Bq / el, "ms_per_launch": el / nrep * 1e3,
+                "level_table": {"level_min": tab_info[0], "columns": tab_info[1], "qps_without_table": nrep * Bq / el_plain,
+                                "ms_per_launch_without_table": el_plain / nrep * 1e3, "same_ids_with_and_without": table_same},
                 "evals_per_query": stt.evals / Bq, "recall_at_10_vs_f32_bruteforce": rec_walk,
                 "recall_note": "quaternary planes are stored MSB first and multiplied LSB first (SURVEY App. C #4): the walk ranks by the reference's "
                                "own quaternary dot, low recall is the reference's behaviour, reproduced bit for bit",

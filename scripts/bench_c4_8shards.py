@@ -8,18 +8,20 @@ brute-force top-10 of the whole corpus.  The shards share one device, so the exc
 all-gather over xGMI (2.75 MB per rank and launch: ~20 us of wire time per link at 153 GB/s) and the eight searches run one after the
 other: `ms_per_step` is NOT a scaling number.
 
-Hyper-parameters: the reference's defaults (level_0_neighbors_count 64, neighbors_count 32).  The 12.5M-vector shard of
-configs[3] needs 256 / 64 to meet the recall target in the reference's semantics (bench.py, c4shard_ref_m0_256_m_64); a
-1.56M-vector shard must NOT take them: the device scans the first 64 neighbour slots of a node (shortlist), a node's own insertion
-fills at most 64 slots (the walk keeps 64 results, vector_store.rs:1194), later back-edges fill slots 64.., and only a FULL node
-evicts its worst neighbour — in a small shard nodes never collect 256 edges, so the scanned slots keep their insertion-time
-neighbours for ever: merged recall saturated at 0.942 for every ef (profiles/r05_c4_8shards_m0_256_m_64_first_run.json)."""
+Hyper-parameters: level_0_neighbors_count 128, neighbors_count 64.  The 12.5M-vector shard of configs[3] needs 256 / 64 to meet the
+recall target in the reference's semantics (bench.py, c4shard_ref_m0_256_m_64); a 1.56M-vector shard must NOT take them.  Measured
+(profiles/r05_c4_8shards_hyperparameter_sweep.jsonl, merged recall@10 of the eight shards): 64 / 32 -> 0.912 at ef 256 (the 4096-bit
+visited filter, 64 x M0 bits, saturates); 256 / 64 and 256 / 128 -> 0.942-0.943 for every ef; **128 / 64 -> 0.991 at ef 96**; 128 / 32
+-> 0.954.  Why 256 loses on a small shard: the device scans the first 64 neighbour slots of a node (shortlist), a node's own insertion
+fills at most 64 slots (the walk keeps 64 results, vector_store.rs:1194), later back-edges fill slots 64.., and only a FULL node evicts
+its worst neighbour — with 256 slots nodes of a small shard never fill, so the scanned slots keep their insertion-time neighbours for
+ever; with 128 they fill and the evictions keep the scanned slots fresh."""
 import time
 
 import numpy as np
 
 
-def run(c4, ef=64, m0=64, m=32, S=8, steps=4, ef_construction=128):
+def run(c4, ef=48, m0=128, m=64, S=8, steps=4, ef_construction=128, recall_only=False):
     """c4: bench.DenseWorkload("c4shard") after a run_mode() (corpus, hold-out queries and their global ground truth in HBM)"""
     import cosdata_amd as ca
     from cosdata_amd.shardset import ShardSet
@@ -53,7 +55,7 @@ def run(c4, ef=64, m0=64, m=32, S=8, steps=4, ef_construction=128):
     gt = c4.gt_rep[:nrq].cpu().numpy()
     ef_used, recall, table = ef, 0.0, []
     best = None
-    for e in [ef] + [x for x in (96, 128, 192, 256) if x > ef]:
+    for e in [ef] + [x for x in (64, 96, 128, 192, 256) if x > ef]:
         for ix in shards:
             ix.set_ef_search(e)
         ids_e = ss.batch_search(Qr, k)
@@ -77,6 +79,10 @@ def run(c4, ef=64, m0=64, m=32, S=8, steps=4, ef_construction=128):
     order = np.argsort(-key, axis=1, kind="stable")[:, :k]
     exp_i = np.take_along_axis(cat_i, order, axis=1)
     merge_ok = bool(all(np.array_equal(ids[b, :cnt[b]], exp_i[b, :cnt[b]]) for b in range(nchk)))
+    if recall_only:     # hyper-parameter sweeps (scripts/sweep_8shards.py)
+        ss.close()
+        return {"M0": m0, "M": m, "ef_construction": ef_construction, "ef_table": table, "merged_recall_at_10": recall, "ef_search": ef_used,
+                "merged_equals_merge_of_shard_answers": merge_ok, "build_seconds": build_s}
     # timing: the host-API call (PCIe-inclusive: queries up once per shard, merged lists down), then its pieces on resident buffers
     B = c4.B
     Qh = c4.Q[:2 * B].cpu().numpy()

@@ -114,9 +114,10 @@ def test_flat_code_scan_fused_overflow_falls_back_exactly(storage, res):
 
 
 def test_flat_code_scan_query_resident_kernel_equals_tile_kernel():
-    """quaternary fused chunks run on the query-resident kernel (A fragments in registers, candidates streamed through LDS);
-    tuning knob flat_tile_kernel = 1 forces the 256 x 128 tile kernel, flat_unfused = 1 the score-matrix path: three implementations,
-    one answer"""
+    """quaternary fused chunks run on the query-resident kernel (A fragments in registers, candidates streamed through LDS) — since
+    round 5 with the digits as e2m1 nibbles on the scaled FP4 MFMA (flat_scan_q2_fp4); tuning knob flat_fp4 = 0 keeps the i8 digits
+    (flat_scan_q2_areg), flat_tile_kernel = 1 forces the 256 x 128 tile kernel, flat_unfused = 1 the score-matrix path: four
+    implementations, one answer"""
     import cosdata_amd as ca
     n, dim, B, k = 50000, 768, 64, 10
     X = H.clustered_corpus(n, dim, n_centers=30, sigma=0.25, seed=31)
@@ -125,8 +126,8 @@ def test_flat_code_scan_query_resident_kernel_equals_tile_kernel():
     ix.upload_vectors(X)
     ref = ix.flat_search(Q, k)
     from cosdata_amd import _lib
-    for env in ("flat_tile_kernel", "flat_unfused"):
-        with _lib.tuning(**{env: 1}):
+    for env, val in (("flat_fp4", 0), ("flat_tile_kernel", 1), ("flat_unfused", 1)):
+        with _lib.tuning(**{env: val}):
             got = ix.flat_search(Q, k)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), env
 

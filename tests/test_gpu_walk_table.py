@@ -167,3 +167,33 @@ def test_set_root_on_a_live_graph_regathers_the_table():
     dix.set_walk_table(0, 0)
     plain = dix.ann_search_batch(Q)
     assert _same(with_tab, plain)
+
+
+@pytest.mark.parametrize("dim,metric", [(768, O.METRIC_COSINE), (128, O.METRIC_COSINE), (384, O.METRIC_DOT)])
+def test_quaternary_codes_walk_the_table_too(dim, metric):
+    """round 5: the level table for SubByte(2) codes — the integer dot_product_quaternary of every (query, table node) pair from one
+    i8 MFMA GEMM over the expanded digits (query-resident kernel; tuning knob walk_table_gemm = 0: the tile kernel), the walk forms
+    the quotient with the nodes' raw-vector norms (scalar.rs:31-32).  Per-level lists and results keep every bit: both GEMM kernels,
+    the table-less walk and the oracle agree."""
+    from cosdata_amd import _lib
+    n = 2600
+    X = H.clustered_corpus(n, dim, n_centers=20, seed=5 + dim) * 0.9
+    oix = H.oracle_index(X, O.STORAGE_SUBBYTE, 2, num_layers=4, ef_construction=40, ef_search=40, metric=metric)
+    dix = H.device_index_from_oracle(oix, X)
+    B = 256 + 64 + 21
+    Q = H.queries_from(X, B, noise=0.05, seed=13) * 0.9
+    dix.set_latency_mode(0)                 # small launches of quaternary codes would take the one-wave latency kernel, which reads no table
+    dix.set_latency_waves(0)
+    lmin, cols = dix.walk_table_info()
+    assert lmin == 1 and cols > 128
+    res = {}
+    for gemm in (1, 0):
+        with _lib.tuning(walk_table_gemm=gemm):
+            res[gemm] = (dix.batch_search(Q, 10), dix.ann_search_batch(Q))
+            assert dix.last_walk_split().table_evals > 0
+    dix.set_walk_table(0, 0)
+    plain = (dix.batch_search(Q, 10), dix.ann_search_batch(Q))
+    assert dix.last_walk_split().table_evals == 0
+    for gemm in (1, 0):
+        assert _same(res[gemm][0], plain[0]) and _same(res[gemm][1], plain[1]), gemm
+    _check_against_oracle(oix, res[1][0], Q, 10, np.arange(0, B, 23))
