@@ -46,7 +46,9 @@ def test_resolve_configs_auto_all_none_and_world_rules():
     assert bench.resolve_configs("auto", 8, "c2") == ["c4shard_ref_m0_256_m_64"]        # N > 1: configs[3] itself, in the Rust path's semantics
     assert bench.resolve_configs("auto", 1, "smoke") == [] and bench.resolve_configs("none", 1, "c2") == []
     assert bench.resolve_configs("c3,c5", 1, "c2") == ["c3", "c5"]
-    assert bench.resolve_configs("all", 2, "c2") == ["c4shard_ref", "c4shard_ref_m0_256_m_64"]    # single-GPU configs are dropped at N > 1
+    assert bench.resolve_configs("all", 2, "c2") == ["c4shard_ref_m0_256_m_64"]    # single-GPU configs (the one-device 8-shard proxy too) are dropped at N > 1
+    assert bench.resolve_configs("c4shard_ref,c4shard_ref_m0_256_m_64", 2, "c2") == ["c4shard_ref", "c4shard_ref_m0_256_m_64"]
+    assert "c4_8shards_one_device" in bench.ALL_CONFIGS and "c4shard_ref" in bench.OPTIONAL_CONFIGS
     assert bench.resolve_configs("c4shard_exact,c4shard_ref_m0_128", 1, "c2") == ["c4shard_exact", "c4shard_ref_m0_128"]   # optional records
     import pytest
     with pytest.raises(SystemExit):
