@@ -1030,8 +1030,9 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     if (timed) HIP_TRY(hipEventRecord(ev[0], st));
     HIP_TRY(launch_quantize_rows(ix->eng, d_queries, ix->p.dim, B, ix->p.dim, ix->p.range_lo, ix->p.range_hi, w->q_codes, ix->row_stride,
                                  w->q_mags, w->q_raw_mags, st));
-    // Level table: on the caller's stream, i.e. BEFORE the walk takes its place in the walk chain — the GEMM of this launch runs
-    // on the matrix cores next to the previous launch's walk, which leaves them idle.
+    // Level table: on the caller's stream, i.e. BEFORE the walk takes its place in the walk chain — the GEMM of this launch runs next
+    // to the previous launch's walk.  (Round 5 also issued it inside the chain, right in front of its own walk, where it shares the
+    // chip with nobody: 7.07-7.12 against 6.69 ms per step — the overlap hides 0.4 ms.  profiles/r05_table_gemm_in_chain_probe_not_kept.jsonl)
     if (tab_level_min) {
         if (timed) HIP_TRY(hipEventRecord(ev[4], st));
         HIP_TRY(cosdev::launch_level_table(ix->eng, w->q_codes, w->q_mags, w->qsums, w->qdig, B, tcodes, tmags, tcsums, ix->row_stride, tab_cols, w->tab,

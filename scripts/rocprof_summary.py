@@ -16,6 +16,24 @@ def short(name):
     return name[:60]
 
 
+def compact_rows(rows, max_grids=12):
+    """a kernel launched with more than `max_grids` different grids (the builder's claim / link / evict kernels: one grid per insertion
+    round, thousands of them) becomes ONE row with grid '*' — calls and total summed, avg = total / calls, min / max over all"""
+    by_name = {}
+    for r in rows:
+        by_name.setdefault(r[0], []).append(r)
+    out = []
+    for name, rs in by_name.items():
+        if len(rs) <= max_grids:
+            out.extend(rs)
+            continue
+        calls = sum(r[2] for r in rs)
+        tot = sum(r[6] for r in rs)
+        out.append((name, "*", calls, tot / max(1, calls), min(r[4] for r in rs), max(r[5] for r in rs), tot))
+    out.sort(key=lambda r: -r[6])
+    return out
+
+
 def main(path):
     con = sqlite3.connect(path)
     cur = con.cursor()
@@ -25,13 +43,15 @@ def main(path):
                        "from kernels group by name, grid_x/workgroup_x order by sum(duration) desc").fetchall()
     # every kernel of this library is printed (a roofline block of bench.py must be recomputable from the file whatever the kernel's
     # share of the trace: round 4's `limit 14` dropped flat_scan_q2_areg and bm25_topk_kernel); foreign kernels (torch): the top 8
+    rows = compact_rows(rows)
     foreign = 0
     for name, grid, calls, avg, mn, mx, tot in rows:
         if "cosdev" not in name and "anonymous namespace" not in name:
             foreign += 1
             if foreign > 8:
                 continue
-        print(f"{short(name):45s} | {grid:8d} | {calls:6d} | {avg/1e3:10.1f} | {mn/1e3:10.1f} | {mx/1e3:10.1f} | {tot/1e6:10.2f}")
+        g = f"{grid:8d}" if isinstance(grid, int) else f"{grid:>8s}"
+        print(f"{short(name):45s} | {g} | {calls:6d} | {avg/1e3:10.1f} | {mn/1e3:10.1f} | {mx/1e3:10.1f} | {tot/1e6:10.2f}")
     # A locality-ordered walk is several dispatches of one kernel per step (WalkArgs::phase): split them by what preceded them ON THE
     # SAME STREAM / QUEUE (the sort's deal_to_xcds_kernel precedes every level range but the first); with several steps in flight the
     # global start order interleaves streams, so the trace's stream or queue column is used when it has one.
