@@ -88,7 +88,7 @@ __device__ __forceinline__ void bm25_apply_chunk(float *acc, u32 d0, float idf, 
 // of the tile) — and always has the NEXT chunk's postings in flight (registers) while it applies the current one to the LDS
 // accumulators, across term barriers and tile flushes alike.  Before, a thread's 4 loads were issued, waited for and applied, so
 // a CU had ~16 KB in flight half of the time: 2.5 TB/s is what Little's law gives for that at ~1.5 us of loaded HBM latency
-// (profiles/r02_c5_hybrid_1M_tile_directory.json).  Now 2 x 16 KB per block, 4 blocks per CU.
+// (profiles/archive/r02_c5_hybrid_1M_tile_directory.json).  Now 2 x 16 KB per block, 4 blocks per CU.
 
 struct Bm25Cursor { // block-uniform
     u32 tile, t;
@@ -436,7 +436,7 @@ static int32_t bm25_launch(cos_bm25 *b, u32 B, u32 top_k, u32 *d_out_ids, float 
     const u32 span = b->max_doc + 1; // doc ids are internal ids; the largest one bounds the tile count
     // launch shape: enough blocks that the heaviest query's share is small against the whole launch, few enough that a block's fixed
     // cost (512 buckets, 8192 accumulators to reset and fold per tile) stays small against its postings.  c5, 256 queries
-    // (profiles/r02_c5_bm25_*): 2048 blocks 0.72 ms, 4096 0.67, 8192 0.66, 16384 0.69, 32768 0.89.  COS_BM25_BLOCKS overrides (experiments).
+    // (profiles/archive/r02_c5_bm25_*): 2048 blocks 0.72 ms, 4096 0.67, 8192 0.66, 16384 0.69, 32768 0.89.  COS_BM25_BLOCKS overrides (experiments).
     const u32 target_blocks = (u32)std::max<long long>(1, tune_or(TUNE_BM25_BLOCKS, 8192));
     const u32 n_tiles = (span + TILE - 1) / TILE;
     const u32 splits = std::max(1u, std::min(n_tiles, std::max(1u, target_blocks / B)));

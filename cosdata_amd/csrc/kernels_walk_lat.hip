@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
             // No lane is ever masked off: a lane group without a candidate re-reads the block's first row and a lane past the
             // row's last chunk re-reads that chunk against a zero query chunk (both dropped / worth 0) — every predicated load
             // was three scalar instructions of exec bookkeeping, 40 % of this kernel's instructions were scalar
-            // (profiles/r02_single_batch_latency_walk_sq_counters.txt).
+            // (profiles/archive/r02_single_batch_latency_walk_sq_counters.txt).
             for (u32 b0 = 0; b0 < T; b0 += RPL * PBL) {
                 uint4 buf[PBL][CH];
                 float pmag[PBL];
@@ -425,7 +425,7 @@ bool walk_lat_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 ma
 }
 
 hipError_t launch_walk_lat(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
-    // window size: 4 (profiles/r02_latency_walk_sweep_first_version_window4_vs_8.jsonl: an 8-entry window needs 24 % fewer rounds but only 3.9
+    // window size: 4 (profiles/archive/r02_latency_walk_sweep_first_version_window4_vs_8.jsonl: an 8-entry window needs 24 % fewer rounds but only 3.9
     // of its 8 entries are consumed before it goes stale, and the wasted evaluations cost more issue time than the rounds save; the
     // kernel has been unrolled for at most LAL = 4 since); tuning knob walk_lat_la = 1..4 narrows it per launch (experiments)
     const u32 la_env = (u32)std::max<long long>(0, tune_or(TUNE_WALK_LAT_LA, 0));
