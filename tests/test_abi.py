@@ -90,3 +90,43 @@ def test_python_mirror_of_header_constants():
     assert m and int(m.group(1)) == ca.HNSWIndex.LATENCY_WAVES_DEFAULT_MAX_B
     m = re.search(r"#define\s+COS_WALK_ORDER_DEFAULT_MIN_B\s+(\d+)u", hdr)
     assert m and int(m.group(1)) == ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B
+
+
+def test_tuning_registry_set_get_clear_and_the_one_environment_variable():
+    """cos_tuning_* (cosdata_amd/csrc/tuning.h): the library's experiment knobs live in ONE registry; the only environment variable it
+    reads is COS_TUNING="name=value,...", parsed once (unknown names and malformed items are skipped).  No device needed."""
+    import subprocess
+    import sys
+    from cosdata_amd import _lib
+    _lib.tuning_clear(None)
+    assert _lib.tuning_get("walk_pb") is None
+    _lib.tuning_set("walk_pb", 4)
+    assert _lib.tuning_get("walk_pb") == 4
+    with _lib.tuning(flat_tile_kernel=1, walk_pb=8):
+        assert _lib.tuning_get("flat_tile_kernel") == 1 and _lib.tuning_get("walk_pb") == 8
+    assert _lib.tuning_get("flat_tile_kernel") is None and _lib.tuning_get("walk_pb") == 4
+    _lib.tuning_clear("walk_pb")
+    assert _lib.tuning_get("walk_pb") is None
+    with pytest.raises(_lib.CosdataError):
+        _lib.tuning_set("no_such_knob", 1)
+    with pytest.raises(_lib.CosdataError):
+        _lib.tuning_set("walk_pb", -(2 ** 63))               # INT64_MIN is the "unset" marker
+    code = ("from cosdata_amd import _lib; print(_lib.tuning_get('walk_pb_upper'), _lib.tuning_get('flat_pf'), _lib.tuning_get('walk_pb'), "
+            "_lib.tuning_get('sparse_layout'))")
+    env = dict(os.environ, COS_TUNING="walk_pb_upper=4,bogus=1,flat_pf=3,sparse_layout=,=5")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.split() == ["4", "3", "None", "None"]
+
+
+def test_the_library_reads_one_environment_variable():
+    """`getenv` appears once in the library's sources (tuning.hip: COS_TUNING) — the launch policies of a library the Rust host links
+    must not depend on whatever else is in the process environment"""
+    import glob
+    hits = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "cosdata_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".inc")):
+            for i, line in enumerate(open(f, errors="replace"), 1):
+                if "getenv(" in line:
+                    hits.append((os.path.basename(f), i))
+    assert [h[0] for h in hits] == ["tuning.hip"], hits
