@@ -36,6 +36,24 @@ __device__ __forceinline__ float metric_key_inv(u32 metric, u32 k) {
 }
 __device__ __forceinline__ u64 pack_key(u32 hi, u32 lo) { return ((u64)hi << 32) | (u64)lo; }
 
+// The IEEE round-to-nearest quotient num / den for the walk's cosine (cosine.rs:223-235: integer dot `as f32` over |q| * |v|): the
+// algorithm of the compiler's own f32 division (v_rcp, one Newton step, two residual corrections through FMAs) WITHOUT v_div_scale /
+// v_div_fmas / v_div_fixup.  Those three only act when an operand is denormal, the denominator's exponent is near the top of the
+// range or the two exponents differ by ~96 or more; for u8 codes 0 <= num < 2^27 and 1 <= den < 2^28 (norms of code rows: roots of
+// integer sums; the SubByte / float storages, whose norms come from the raw vectors, keep the full division), so the scale
+// factors are 1, div_fmas is a plain FMA and the fix-up is the identity: same bits, four instructions less per quotient.
+// (den == 0 never reaches it: the callers test for CalculationError first.)
+__device__ __forceinline__ float div_rn_unscaled(float num, float den) {
+    float r = __builtin_amdgcn_rcpf(den);
+    const float e = __builtin_fmaf(-den, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = num * r;
+    float t = __builtin_fmaf(-den, q, num);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(-den, q, num);
+    return __builtin_fmaf(t, r, q);
+}
+
 __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
     u32 lo = (u32)v, hi = (u32)(v >> 32);
     lo = (u32)__shfl_xor((int)lo, m, WAVE);

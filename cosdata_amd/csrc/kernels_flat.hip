@@ -974,6 +974,8 @@ hipError_t launch_level_table(int eng, const uint8_t *qcodes, const float *qmags
             e = launch_flat_scan_expand_queries(qcodes, row_stride, B, kdims, qdig, st, false);
             if (e != hipSuccess) return e;
         }
+        // (one workgroup per CU; on half the CUs — so that the previous launch's walk keeps the other half — the GEMM takes 1.31 instead
+        // of 0.85 ms and the step 6.57 instead of 6.49: profiles/r05_table_gemm_half_the_cus_probe_not_kept.jsonl)
         return launch_level_table_areg(eng, n_cus ? n_cus : 256u, st, q2 ? qdig : qcodes, (const u32 *)qsums, B, tcodes, tcsums, row_stride, ncols, tab, tab_stride);
     }
     const u32 metric = 1u; // the tile kernel's unfused epilogue with the dot-product metric: the converted integer dot, no quotient
