@@ -84,3 +84,18 @@ def test_stdout_line_keeps_every_result_and_drops_the_prose():
         p = c["parity_vs_oracle"]
         assert p["queries"] >= 256 and sum(v for k, v in p.items() if k != "queries") == 0
     assert bench.rounded(1.23456789012345) == 1.23456789 and bench.rounded({"a": [float("inf"), 2]}) == {"a": [float("inf"), 2]}
+
+
+def test_value_at_query_batch_256_takes_the_best_setting_per_caller_count_and_skips_bad_runs():
+    import bench
+    host = {"concurrent_256_query_callers": [
+        {"callers": 64, "coalescing_max_queries": 8192, "qps": 3.2e6, "failed_calls": 0, "identical_to_uncoalesced_call": True},
+        {"callers": 64, "coalescing_max_queries": 16384, "qps": 2.7e6, "failed_calls": 0, "identical_to_uncoalesced_call": True},
+        {"callers": 128, "coalescing_max_queries": 16384, "qps": 3.9e6, "failed_calls": 0, "identical_to_uncoalesced_call": True},
+        {"callers": 128, "coalescing_max_queries": 32768, "qps": 9.9e6, "failed_calls": 3, "identical_to_uncoalesced_call": True},     # failed calls: ignored
+        {"callers": 256, "coalescing_max_queries": 32768, "qps": 8.8e6, "failed_calls": 0, "identical_to_uncoalesced_call": False}]}   # wrong answers: ignored
+    v = bench.value_at_batch_256(host)
+    assert v["pcie_inclusive"] and set(v["by_callers"]) == {"64", "128"}
+    assert v["by_callers"]["64"] == {"qps": 3.2e6, "coalescing_max_queries": 8192} and v["by_callers"]["128"]["qps"] == 3.9e6
+    assert v["min_over_caller_counts"] == 3.2e6
+    assert bench.value_at_batch_256(None) is None and bench.value_at_batch_256({"concurrent_256_query_callers": []}) is None

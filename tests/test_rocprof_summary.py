@@ -50,3 +50,28 @@ def test_without_a_stream_column_says_approximate(tmp_path):
     _db(p, with_stream=False)
     out = _run(p)
     assert "approximate when steps overlap" in out
+
+
+def test_every_library_kernel_is_printed_and_per_round_builder_kernels_are_one_row(tmp_path):
+    """round 5: no `limit 14` (a roofline block must be recomputable from the file whatever the kernel's share of the trace); a
+    kernel launched with thousands of different grids (the builder's link kernel: one grid per insertion round) is ONE row"""
+    p = tmp_path / "many.db"
+    con = sqlite3.connect(p)
+    con.execute("create table kernels (name text, grid_x int, workgroup_x int, start int, end int, duration int, stream_id int)")
+    link = "cosdev::(anonymous namespace)::link_kernel<1>(cosdev::LinkArgs)"
+    rows, t = [], 0
+    for g in range(1, 41):                      # 40 different grids of one kernel
+        rows.append((link, g * 64, 64, t, t + 50_000, 50_000, 0)); t += 10
+    for i in range(30):                         # 30 different small kernels of the library: all must appear
+        rows.append((f"cosdev::(anonymous namespace)::tiny_kernel_{i}(int)", 64, 64, t, t + 1000, 1000, 0)); t += 10
+    for i in range(20):                         # 20 foreign kernels: only the top 8 are kept
+        rows.append((f"void at::native::foreign_{i}(float*)", 64, 64, t, t + 2000 + i, 2000 + i, 0)); t += 10
+    con.executemany("insert into kernels values (?,?,?,?,?,?,?)", rows)
+    con.commit()
+    con.close()
+    out = _run(p)
+    table = out.split("## kernel trace")[1]
+    link_rows = [l for l in table.splitlines() if l.startswith("link_kernel<1>")]
+    assert len(link_rows) == 1 and "|        * |     40 |" in link_rows[0]            # one row, grid '*', 40 calls
+    assert sum(1 for i in range(30) if f"tiny_kernel_{i}(" in table) == 30
+    assert sum(1 for i in range(20) if f"foreign_{i}(" in table) == 8
