@@ -75,10 +75,16 @@ def test_stdout_line_keeps_every_result_and_drops_the_prose():
               "roofline", "cpu_baseline", "parity_vs_oracle", "recall_at_10", "single_batch_qps", "host_api_pcie_inclusive", "configs"):
         assert k in line, k
     assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"]
-    assert set(line["configs"]) == set(full["configs"]) == {"c2_uniform", "c5", "c3", "c4shard_ref", "c4shard_ref_m0_256_m_64"}
+    assert set(line["configs"]) == set(full["configs"]) == {"c2_uniform", "c5", "c3", "c4shard_ref_m0_256_m_64", "c4_8shards_one_device"}
     assert line["configs"]["c3"]["hnsw_walk_quaternary"]["parity_vs_oracle"]["id_mismatch_queries"] == 0        # c3 (ii): the quaternary walk survives the slimming
+    assert line["value_at_query_batch_256"]["min_over_caller_counts"] >= 3.0e6                                  # the reference's calling pattern, top level
+    assert line["roofline"]["step_frac"] == full["roofline"]["step_frac"] and line["configs"]["c5"]["roofline"]["parts"]["bm25_score"]["frac"] > 0.5
     for name, c in line["configs"].items():
         f = full["configs"][name]
+        if name == "c4_8shards_one_device":       # the 8-shard proxy: merged recall, exchange + merge cost, the merge property — no kernel of its own
+            assert c["merged_recall_at_10"] == f["merged_recall_at_10"] >= 0.95 and c["merged_equals_merge_of_shard_answers"] is True
+            assert c["shards_in_merged_answers"] == list(range(8)) and c["ms_exchange_plus_merge"] < 1.0 and c["shards"] == 8
+            continue
         assert c["qps"] == f["qps"] and c["roofline"]["frac"] == f["roofline"]["frac"] and c["roofline"]["bound"] in ("hbm", "mfma")
         assert c["cpu_baseline"]["value"] == f["cpu_baseline"]["value"] and c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] >= 1
         p = c["parity_vs_oracle"]
