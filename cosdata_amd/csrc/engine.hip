@@ -108,7 +108,7 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
         return cos_fail(COS_ERR_UNIMPLEMENTED, "num_layers > 15 not supported on the device");
     if (std::min(p->neighbors_count, p->shortlist_size) > 64 || std::min(p->level0_neighbors_count, p->shortlist_size) > 64)
         return cos_fail(COS_ERR_UNIMPLEMENTED, "more than 64 scanned neighbour slots per node not supported on the device");
-    if (p->ef_search > 512 || p->ef_construction > 512) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
+    if (p->ef_search > 1024 || p->ef_construction > 1024) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 1024 not supported on the device");
     if (p->metric != COS_METRIC_COSINE && p->metric != COS_METRIC_DOT)
         return cos_fail(COS_ERR_UNIMPLEMENTED, "device walk implements cosine and dot-product metrics");
     int eng;
@@ -557,7 +557,7 @@ static int32_t ensure_level_table(cos_index *ix);
 static u32 walk_table_min_B(const cos_index *ix);
 extern "C" int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
-    if (ef > 512) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 512 not supported on the device");
+    if (ef > 1024) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 1024 not supported on the device");
     const bool live = graph_ready(ix);
     if (live)
         if (int32_t rc = cos_set_device(ix)) return rc;

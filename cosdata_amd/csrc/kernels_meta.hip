@@ -451,6 +451,7 @@ static hipError_t launch_meta_r(const IndexDev &ix, const WalkArgs &wa, hipStrea
     if (wa.ef <= 64) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 1, INDEXING>), grid, block, smem, st, ix, wa);
     else if (wa.ef <= 256) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 4, INDEXING>), grid, block, smem, st, ix, wa);
     else if (wa.ef <= 512) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 8, INDEXING>), grid, block, smem, st, ix, wa);
+    else if (wa.ef <= 1024) hipLaunchKernelGGL((walk_meta_kernel<ENG, CH, 16, INDEXING>), grid, block, smem, st, ix, wa);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

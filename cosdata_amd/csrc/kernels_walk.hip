@@ -496,6 +496,7 @@ static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStrea
     if (wa.ef <= 64) WALK(1);
     else if (wa.ef <= 256) WALK(4);
     else if (wa.ef <= 512) WALK(8);
+    else if (wa.ef <= 1024) WALK(16); // round 5: a pool of 64 x 16 keys per wave (103 VGPRs, no scratch: 4 waves per SIMD)
     else return hipErrorInvalidValue;
 #undef WALK
     return hipGetLastError();

@@ -64,7 +64,7 @@ def test_top_k_range(top_k):
     _assert_same_search(oix, dix, Q, top_k)
 
 
-@pytest.mark.parametrize("ef", [1, 2, 17, 65, 100, 257, 400, 512])
+@pytest.mark.parametrize("ef", [1, 2, 17, 65, 100, 257, 400, 512, 513, 700, 1024])
 def test_ef_range(ef):
     X = H.clustered_corpus(5000, 80, n_centers=10, seed=13)
     oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=48, ef_search=ef)
@@ -72,6 +72,29 @@ def test_ef_range(ef):
     Q = H.queries_from(X, 10, seed=ef)
     _assert_same_walk(oix, dix, Q)
     _assert_same_search(oix, dix, Q, 10)
+
+
+@pytest.mark.parametrize("storage,res,dim", [(O.STORAGE_SUBBYTE, 2, 256), (O.STORAGE_F32, 0, 48), (O.STORAGE_U8, 0, 1024)])
+def test_ef_above_512_other_storages_and_wide_rows(storage, res, dim):
+    """round 5: ef_search up to 1024 (a pool of 64 x 16 keys per wave): quaternary and f32 storages, 1024-byte u8 rows; more pops
+    than the level has nodes on the upper levels (the walk ends when the pool runs dry)"""
+    X = H.clustered_corpus(3000, dim, n_centers=10, seed=21 + dim) * (0.9 if storage == O.STORAGE_SUBBYTE else 1.0)
+    oix = H.oracle_index(X, storage, res, num_layers=4, ef_construction=40, ef_search=1000)
+    dix = H.device_index_from_oracle(oix, X)
+    Q = H.queries_from(X, 6, seed=2) * (0.9 if storage == O.STORAGE_SUBBYTE else 1.0)
+    _assert_same_walk(oix, dix, Q)
+    _assert_same_search(oix, dix, Q, 10)
+
+
+def test_ef_above_1024_is_refused_loudly():
+    import cosdata_amd as ca
+    X = H.clustered_corpus(500, 32, n_centers=4, seed=1)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=2, ef_construction=16, ef_search=16)
+    dix = H.device_index_from_oracle(oix, X)
+    with pytest.raises(ca.CosdataError) as ei:
+        dix.set_ef_search(1025)
+    assert ei.value.status == 4          # Unimplemented: never a silent difference
+    dix.set_ef_search(1024)
 
 
 def test_single_layer_and_deep_hierarchy():

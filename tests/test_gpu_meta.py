@@ -41,7 +41,7 @@ def test_filtered_search_matches_oracle(storage, res, dim):
     Q, off, rows, desc = sc.queries(nq=36, seed=7)
     gi, gc = _assert_same_filtered(sc, oix, dix, Q, off, rows, 10)
     assert (gc > 0).sum() >= 18                                   # is / and / or filters do find their replicas
-    for ef in (16, 200, 400):
+    for ef in (16, 200, 400, 900):                                # (900: the 64 x 16-key pool of round 5)
         oix.set_ef_search(ef)
         dix.set_ef_search(ef)
         _assert_same_filtered(sc, oix, dix, Q[:12], off[:13], rows[:off[12]], 5)
