@@ -48,6 +48,10 @@ def test_walk_and_finalize_kernels_keep_their_occupancy(tmp_path):
     assert ef256["vgpr_count"] <= 96                                                 # 5 waves per SIMD
     ef512 = _find(ks, "walk_kernel<0, 1, 8, true, false, 4>")          # ef > 256 takes four row buffers (walk_pb_policy)
     assert ef512["vgpr_count"] <= 96 and ef512["private_segment_fixed_size"] == 0    # 5 waves per SIMD (eight buffers: 104 VGPRs = 4 waves)
+    ef1024 = _find(ks, "walk_kernel<0, 1, 16, true, false, 4>")        # round 5: ef up to 1024, a pool of 64 x 16 keys per wave
+    assert ef1024["vgpr_count"] <= 128 and ef1024["private_segment_fixed_size"] == 0  # 4 waves per SIMD, nothing in scratch
+    upper256 = _find(ks, "walk_kernel<0, 1, 4, true, false, 4>")       # the upper range of a split walk above ef 64 (four row buffers)
+    assert upper256["vgpr_count"] <= 96 and upper256["private_segment_fixed_size"] == 0
     exact = _find(ks, "walk_kernel<0, 1, 1, true, true, 8>")
     assert exact["vgpr_count"] <= 80
     fin = _find(ks, "finalize_fast_kernel")
