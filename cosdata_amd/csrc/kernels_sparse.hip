@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
     }
 }
 
-// ---- packed layout (cos_sparse::packed; COS_SPARSE_PACKED=1 at cos_sparse_create) -------------------------------------------
+// ---- packed layout (cos_sparse::packed: the default wherever vector ids fit 24 bits; tuning knob sparse_layout = 0 keeps the other) ----
 // One u32 per posting, key << 24 | (vector id + 1), instead of a u32 id + a u8 key: 4 B instead of 5 B of HBM traffic per posting,
 // one load instead of two, and the apply step of a posting shrinks from ~19 to ~9 instructions:
 //   * a step's postings are fetched through a buffer descriptor whose num_records is the step's own length — a lane past the step's

@@ -1,8 +1,8 @@
-"""The packed posting layout of the learned-sparse index (kernels_sparse.hip: cos_sparse_create with COS_SPARSE_PACKED=1 +
-sparse_packed_kernel) restated in numpy with the kernel's own 32-bit arithmetic — the packed word, the wrap of postings that belong
+"""The packed posting layout of the learned-sparse index (kernels_sparse.hip: sparse_packed_kernel, the default layout
+since round 5) restated in numpy with the kernel's own 32-bit arithmetic — the packed word, the wrap of postings that belong
 to other tiles and of the zeros a step's buffer descriptor returns past its end, the dummy slots, the touch count next to the sum,
-the host's overflow bound, table windows / term groups / 512-posting steps — and checked against the oracle.  The kernel itself was
-written without a device at hand; this pins its ALGORITHM on the CPU, the GPU tests behind COS_CANDIDATES=1 pin the code."""
+the host's overflow bound, table windows / term groups / 512-posting steps — and checked against the oracle.  This pins the ALGORITHM on the CPU (it was
+written in round 4 without a device at hand); tests/test_sparse.py pins the code on the GPU, both layouts."""
 import numpy as np
 import pytest
 
