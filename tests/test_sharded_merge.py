@@ -78,14 +78,19 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_two_shard_allgather_merge_gloo(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_allgather_merge_gloo(tmp_path, world):
+    """world 2, and world 8 = the shape of BASELINE configs[3]: eight ranks, each an id-range shard, ONE packed all-gather, the
+    merge rule on every rank — against the single-process restatement of the same scheme"""
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     a, b = np.load(tmp_path / "merged_0.npz"), np.load(tmp_path / "merged_1.npz")
     assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["sc"], b["sc"])   # every rank ends with the same answer
     assert np.array_equal(np.load(tmp_path / "gathered_0.npy"), np.load(tmp_path / "gathered_1.npy"))
-    # single-process restatement of the same 2-shard scheme
+    for r in range(2, world):
+        c = np.load(tmp_path / f"merged_{r}.npz")
+        assert np.array_equal(a["ids"], c["ids"]) and np.array_equal(a["sc"], c["sc"])
+    # single-process restatement of the same scheme
     sys.path.insert(0, ROOT)
     from cosdata_amd.sharding import shard_range
     rng = np.random.default_rng(123)
@@ -99,6 +104,8 @@ def test_two_shard_allgather_merge_gloo(tmp_path):
     # ids are global and each comes from the shard that owns it
     lo1, _ = shard_range(1200, world, 1)
     assert ((a["ids"] < 1200) | (a["ids"] == 0xFFFFFFFF)).all() and (a["ids"] >= lo1).any() and (a["ids"] < lo1).any()
+    owners = {int(np.searchsorted([shard_range(1200, world, r)[1] for r in range(world)], i, side="right")) for i in a["ids"].ravel() if i != 0xFFFFFFFF}
+    assert owners == set(range(world))                   # every shard contributes to somebody's merged list
     # quality: merged result vs exact brute force over the whole corpus
     from oracle import oracle as O
     gt, _ = O.bruteforce_topk(X, Q, k)
