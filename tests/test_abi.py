@@ -130,3 +130,19 @@ def test_the_library_reads_one_environment_variable():
                 if "getenv(" in line:
                     hits.append((os.path.basename(f), i))
     assert [h[0] for h in hits] == ["tuning.hip"], hits
+
+
+def test_tuning_names_follow_the_enum_and_are_documented():
+    """tuning.hip's NAMES[] is indexed by tuning.h's TuneKey: a name out of order would make cos_tuning_set steer a different policy
+    than the one it names.  Every knob is listed in INTEGRATION.md §16."""
+    csrc = os.path.join(ROOT, "cosdata_amd", "csrc")
+    enum = re.findall(r"^\s+TUNE_([A-Z0-9_]+),", open(os.path.join(csrc, "tuning.h")).read(), re.M)
+    body = re.search(r"NAMES\[TUNE_COUNT\] = \{(.*?)\};", open(os.path.join(csrc, "tuning.hip")).read(), re.S).group(1)
+    names = re.findall(r'"([a-z0-9_]+)"', body)
+    assert names == [e.lower() for e in enum] and len(names) == len(set(names)) >= 20
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 16."):]
+    assert re.findall(r"^\| `([a-z0-9_]+)` \|", sec, re.M) == names
+    from cosdata_amd import _lib
+    for n in names:                                   # every documented name is accepted by the library
+        _lib.tuning_get(n)
