@@ -100,6 +100,20 @@ def test_reader_survives_crafted_cbor_lengths_and_nesting(tmp_path):
         assert L.cos_reference_dir_level_counts(d.encode(), 3, 8, 16, counts.ctypes.data_as(C.c_void_p)) == _lib.ERR_INVALID
 
 
+def test_reader_survives_random_damage(tmp_path):
+    """200 seeded mutations (bytes replaced, truncation, runs of 0x00 / 0xFF, garbage appended) of one of the directory's files: the
+    host-only reader answers COS_OK with a well-formed level list or COS_ERR_INVALID — never a crash (child process: a dead reader
+    fails the test instead of pytest)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "tests.fuzz_ref_index_reader", str(tmp_path), "200", "7"], capture_output=True, text=True,
+                         cwd=root, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stderr[-1500:])
+    words = out.stdout.split()
+    assert words[0] == "accepted" and int(words[1]) + int(words[3]) == 200 and int(words[1]) >= 20 and int(words[3]) >= 20      # both outcomes occur
+
+
 def test_cbor_float_encoding_follows_serde_cbor():
     assert cbor_f32(1.0) == b"\xf9\x3c\x00"                 # lossless as half
     assert cbor_f32(0.1)[0] == 0xFA and len(cbor_f32(0.1)) == 5
