@@ -87,3 +87,45 @@ def test_stored_tf_equals_the_oracle_formula():
     L = _lib.lib()
     for c, dl, avg, k1, b in ((1, 10, 12.5, 1.5, 0.75), (7, 300, 120.0, 1.2, 0.6), (3, 1, 1.0, 2.0, 1.0)):
         assert np.float32(L.cos_bm25_term_frequency(c, dl, avg, k1, b)).tobytes() == np.float32(O.bm25_tf(c, dl, avg, k1, b)).tobytes()
+
+
+def test_text_side_survives_arbitrary_bytes_and_tiny_buffers():
+    """cos_text_process / cos_text_count_tokens / cos_stem_english on 4000 seeded inputs the Rust host's `&str` could never hold
+    (invalid UTF-8, truncated sequences) and the ones it can (multi-byte case mappings, apostrophes, tokens of hundreds of bytes),
+    with output capacities of 0..1024 terms and stem buffers of 0..64 bytes: COS_OK with ascending hashes within the capacity,
+    or COS_ERR_INVALID — no overrun of the stem buffer (guard bytes), no crash"""
+    import ctypes as C
+    from cosdata_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    stem = C.cast(L.cos_stem_english, C.c_void_p)
+    letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ'  .,-yYsSeEdDgGiInN", np.uint8)
+    points = [0x41, 0x61, 0x20, 0xE9, 0x130, 0x1E9E, 0x10400, 0x3A3, 0xDF, 0x27]
+    n_ok = n_invalid = 0
+    for _ in range(4000):
+        kind, n = int(rng.integers(4)), int(rng.integers(0, 400))
+        if kind == 0:
+            raw = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        elif kind == 1:
+            raw = bytes(rng.choice(letters, n))
+        elif kind == 2:
+            raw = "".join(chr(int(c)) for c in rng.choice(points, n)).encode()
+        else:
+            raw = bytes(rng.choice(letters, n)) * int(rng.integers(1, 4)) + bytes(rng.integers(128, 256, int(rng.integers(0, 5)), dtype=np.uint8))
+        cap, max_len = int(rng.choice([0, 1, 2, 8, 1024])), int(rng.choice([0, 1, 5, 40, 4000]))
+        h, t, out = np.zeros(max(cap, 1), np.uint32), np.zeros(max(cap, 1), np.float32), C.c_uint32()
+        rc = L.cos_text_process(raw, len(raw), max_len, 1.0, 1.5, 0.75, stem if rng.integers(2) else None, None,
+                                h.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), cap, C.byref(out))
+        if rc == 0:
+            n_ok += 1
+            assert out.value <= cap and np.all(np.diff(h[:out.value].astype(np.int64)) > 0)
+        else:
+            n_invalid += 1
+            assert rc == _lib.ERR_INVALID
+        L.cos_text_count_tokens(raw, len(raw), max_len)
+        tok, oc = raw[:int(rng.integers(0, 60))], int(rng.choice([0, 1, 3, 64]))
+        buf = C.create_string_buffer(oc + 8)
+        buf.raw = b"\xAA" * (oc + 8)
+        L.cos_stem_english(None, tok, len(tok), buf, oc)
+        assert buf.raw[oc:] == b"\xAA" * 8, (tok, oc)
+    assert n_ok > 500 and n_invalid > 500
