@@ -9,14 +9,17 @@ wavefront, so a 256-CU chip needs thousands of queries per launch), index and qu
 --warmup W` time exactly K launches after W untimed ones; `--inflight` launches overlap on separate HIP streams.  The
 rate of one un-coalesced 256-query batch at a time is reported alongside (`single_batch_qps`).
 
-`value` = BASELINE.json configs[1] (c2): 1M x 768 dense cosine HNSW, query batch 256, one GPU.  The SAME JSON line then
-carries one record per remaining BASELINE config under `configs` (each with its own roofline / cpu_baseline /
-parity_vs_oracle block): `c2_uniform` (the uniform(-1,1) corpus of tests/test.py:88), `c3` (10M x 768 quaternary codes,
-exhaustive scan + HNSW walk with the quaternary distance), `c4shard_ref` / `c4shard_ref_m0_256_m_64` (one 12.5M x 1024 shard of
-configs[3] with the reference's visited filter: its default hyper-parameters, and level_0_neighbors_count 256 / neighbors_count 64 —
-the setting that meets the recall target in the Rust path's own semantics), `c5` (hybrid dense + BM25 + RRF over 1M documents).
-`--configs` selects them (default: all at N = 1; the second c4shard record only at N > 1, where it IS configs[3]: N shards of
-12.5M x 1024); `c4shard_exact` (exact visited set, an extension the Rust path does not have) and other M0 / M variants on request.
+`value` = BASELINE.json configs[3], the configuration the metric is quoted on ("1024-dim dense cosine, 1/2/4/8 MI355X"): at `--gpus N`
+the corpus is N id-range shards of 12.5M x 1024 (one per GPU; N = 8 is the 100M x 1024 of configs[3], N = 1 is its per-GPU slice and
+the point SCALE's curve starts from), walked with the reference's own visited filter and the hyper-parameters that meet the recall
+target in the Rust path's semantics (level_0_neighbors_count 256, neighbors_count 64: `c4shard` below).  Round 6 moved `value` here
+from c2 (configs[1], 768-dim), which now rides along under `configs` with every block it had.  The SAME JSON line carries one
+record per remaining BASELINE config under `configs` (each with its own roofline / cpu_baseline / parity_vs_oracle block):
+`c4_8shards_one_device` (the same corpus as eight id-range shards behind cos_shardset_search_batch on one device), `c2` (1M x 768,
+query batch 256: single-batch rate, host API and concurrent 256-query callers included), `c2_uniform` (the uniform(-1,1) corpus of
+tests/test.py:88), `c5` (hybrid dense + BM25 + RRF over 1M documents), `c3` (10M x 768 quaternary codes, exhaustive scan + HNSW
+walk with the quaternary distance).  `--configs` selects them (default: all at N = 1, none at N > 1); other c4shard variants
+(`c4shard_ref` = default hyper-parameters, `c4shard_exact`, other M0 / M) on request.
 
 N > 1: one process per GPU.  `--gpus N` without WORLD_SIZE in the environment starts the N ranks itself
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); under an external
@@ -68,9 +71,19 @@ WORKLOADS = {
 # the configuration that meets the recall target on the metric's own shard in the Rust path's own semantics.
 # (c4shard_ref, the default-hyper-parameter record — recall saturating at 0.846, profiles/r04_final_bench_default_full_record.json —, moved to the
 # optional list in round 5: its minute of the default run went to c4_8shards_one_device.)
-ALL_CONFIGS = ["c2_uniform", "c5", "c3", "c4shard_ref_m0_256_m_64", "c4_8shards_one_device"]
-C4_TARGET_CONFIG = "c4shard_ref_m0_256_m_64"
-OPTIONAL_CONFIGS = ["c4shard_ref", "c4shard_exact", "c4shard_ref_m0_128", "c4shard_ref_m0_256", "c4shard_ref_m0_256_m_128"]   # --configs only
+# Round 6: `value` IS the target-meeting shard (main workload c4shard, M0 256 / M 64); c2 is a record under `configs`.
+ALL_CONFIGS = ["c4_8shards_one_device", "c2", "c2_uniform", "c5", "c3"]
+MAIN_WORKLOAD = "c4shard"
+MAIN_M0, MAIN_M = 256, 64
+OPTIONAL_CONFIGS = ["c4shard_ref", "c4shard_exact", "c4shard_ref_m0_128", "c4shard_ref_m0_256", "c4shard_ref_m0_256_m_64", "c4shard_ref_m0_256_m_128"]   # --configs only
+
+
+def value_workload(world):
+    """what `value` is measured on at `--gpus world` (the same string in the real line's config.workload and in the launcher self-test)"""
+    n, d = WORKLOADS[MAIN_WORKLOAD][0], WORKLOADS[MAIN_WORKLOAD][1]
+    return (f"BASELINE configs[3]: {world} id-range shard(s) of {n} x {d} dense cosine (100M x {d} over 8 GPUs; one shard per GPU), "
+            f"level_0_neighbors_count {MAIN_M0}, neighbors_count {MAIN_M}, reference visited filter"
+            + (", RCCL all-gather of the per-shard top-k + merge inside the timed step" if world > 1 else ""))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -124,14 +137,14 @@ def effective_cores():
 
 
 def resolve_configs(spec, world, workload):
-    """`--configs` -> ordered list of extra config records to run.  auto: every BASELINE config at N = 1 (when the main
-    workload is the standard c2), the target-meeting c4shard record (= configs[3] itself) at N > 1; none for non-standard main workloads."""
+    """`--configs` -> ordered list of extra config records to run.  auto: every other BASELINE config at N = 1 (when the main
+    workload is the standard one), none at N > 1 (the main workload IS configs[3] there) or for non-standard main workloads."""
     if spec in ("none", ""):
         return []
     if spec == "auto":
-        if workload != "c2":
+        if workload != MAIN_WORKLOAD:
             return []
-        return list(ALL_CONFIGS) if world == 1 else [C4_TARGET_CONFIG]
+        return list(ALL_CONFIGS) if world == 1 else []
     names = list(ALL_CONFIGS) if spec == "all" else [v for v in spec.split(",") if v]
     bad = [v for v in names if v not in ALL_CONFIGS + OPTIONAL_CONFIGS]
     if bad:
@@ -251,7 +264,9 @@ def launcher_selftest(args):
         print(json.dumps({"metric": "launcher self-test (gloo, CPU): rank plumbing + packed all-gather; NOT a benchmark", "value": 0.0,
                           "unit": "queries/s", "n_gpus": world, "steps": max(1, args.steps), "warmup": 0,
                           "ms_per_step": float(el.item()) / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "u8", "data": "synthetic (no search)", "config": {"workload": "launcher-selftest"},
+                          "vs_baseline": None, "dtype": "u8", "data": "synthetic (no search)",
+                          "config": {"workload": "launcher-selftest", "value_workload_at_this_n": value_workload(world), "n_gpus": world,
+                                     "dim": WORKLOADS[MAIN_WORKLOAD][1]},
                           "ranks": world, "rank_pids": pids, "distinct_processes": len(set(pids)), "shards_in_merged_answer": owners,
                           "asked_gpus": args.gpus}), flush=True)
     dist.barrier()
@@ -869,7 +884,9 @@ class DenseWorkload:
             "value": merged_qps, "elapsed": elapsed, "steps": n_launch, "warmup": n_warm, "ef": ef, "ef_table": ef_table,
             "recall": (recall, recall_se, recall_lo), "status_bad": status_bad, "props": props, "sweep": sweep, "size_sweep": size_sweep, "serial": serial,
             "host_api": host, "cpu": cpu, "parity": parity, "build_s": build_s, "seconds": time.time() - t_setup, "exchange_kind": exchange_kind,
-            "config": {"workload": self.name + ": " + self.desc, "standard_size": self.standard_size, "vectors_per_gpu": n, "dim": d,
+            "config": {"workload": (value_workload(world) if (self.name, m0, m_upper, visited) == (MAIN_WORKLOAD, MAIN_M0, MAIN_M, "ref")
+                                    else self.name + ": " + self.desc),
+                       "n_gpus": world, "standard_size": self.standard_size, "vectors_per_gpu": n, "dim": d,
                        "step": f"one coalesced launch = {self.C} client batches x {Bc} queries = {B} queries through quantize -> walk -> rerank -> top-k",
                        "query_batch": Bc, "batches_per_launch": self.C, "queries_per_step": B, "launches_in_flight": S, "top_k": k, "ef_search": ef,
                        "ef_policy": ("smallest ef whose recall@10 on the selection query set is >= %.2f with 95%% confidence; recall_at_10 is "
@@ -885,7 +902,7 @@ class DenseWorkload:
                          "traffic_frac_of_peak": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "traffic_fetch_factor_k": traffic_k, "parts": parts, "issue": issue, "reference_algorithmic_bytes": ref_alg_bytes,
                          "empirical": empirical,
-                         "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64, %s>" % (1 if ef <= 64 else (4 if ef <= 256 else 8), visited),
+                         "kernel": "walk_kernel<ENG_U8, CH=1, R=%d, G64, %s>" % (1 if ef <= 64 else (2 if ef <= 128 else (4 if ef <= 256 else 8)), visited),
                          "kernel_launches_per_step": 1 + len(cuts),
                          "walk_order": ({"cut_after_levels": cuts,
                                          "meaning": "one walk = %d launches of the kernel over consecutive level ranges; after each cut level the %d queries "
@@ -987,7 +1004,7 @@ def compact_dense_record(rec, world):
     r, se, lo = rec["recall"]
     c = rec["config"]
     roof = {k: v for k, v in rec["roofline"].items() if k not in ("note", "aggregate", "empirical")}
-    return {"config": {k: c[k] for k in ("workload", "standard_size", "vectors_per_gpu", "dim", "queries_per_step", "launches_in_flight", "top_k", "ef_search",
+    return {"config": {k: c[k] for k in ("workload", "n_gpus", "standard_size", "vectors_per_gpu", "dim", "queries_per_step", "launches_in_flight", "top_k", "ef_search",
                                           "ef_construction", "build_visited", "visited", "storage", "corpus", "parallelism")},
             "qps": rec["value"], "unit": "queries/s", "ms_per_step": rec["elapsed"] / rec["steps"] * 1e3,
             "steps": rec["steps"], "warmup": rec["warmup"], "dtype": "u8",
@@ -1021,7 +1038,7 @@ def _slim_cpu(c):
 def slim_line(out):
     """the stdout line: every result of the full record, none of its prose"""
     o = dict(out)
-    o["config"] = {k: v for k, v in out["config"].items() if k not in ("step", "ef_policy", "exchange", "corpus", "storage", "parallelism")}
+    o["config"] = {k: (v[:200] if k == "workload" else v) for k, v in out["config"].items() if k not in ("step", "ef_policy", "exchange", "corpus", "storage", "parallelism")}
     o["config"]["storage"] = out["config"]["storage"][:48]
     o["config"]["parallelism"] = out["config"]["parallelism"]
     for k in ("value_note", "recall_sets"):
@@ -1060,6 +1077,14 @@ def slim_line(out):
             e["hnsw_walk_quaternary"] = {k: w[k] for k in ("n", "build_s", "qps", "ms_per_launch", "recall_at_10_vs_f32_bruteforce", "parity_vs_oracle") if k in w}
             e["hnsw_walk_quaternary"]["roofline"] = _slim_roofline(w.get("roofline"))
             e["hnsw_walk_quaternary"]["cpu_baseline"] = _slim_cpu(w.get("cpu_baseline"))
+        for k in ("single_batch_qps", "single_batch_qps_one_wave_latency_kernel", "single_batch_qps_throughput_kernel",
+                  "single_batch_latency_walk_identical_to_throughput_walk", "value_at_query_batch_256", "launch_size_sweep", "recall_lower95"):
+            if c.get(k) is not None:
+                e[k] = c[k]
+        if c.get("ef_sweep"):
+            e["ef_sweep"] = [{k: x[k] for k in ("ef_search", "visited", "qps", "recall_at_10", "walk_ms")} for x in c["ef_sweep"]]
+        if c.get("host_api_pcie_inclusive"):
+            e["host_api_pcie_inclusive"] = {k: v for k, v in c["host_api_pcie_inclusive"].items() if k not in ("note", "concurrent_256_query_callers")}
         if c.get("same_graph_exact_visited_set"):
             e["same_graph_exact_visited_set"] = [{k: x[k] for k in ("ef_search", "qps", "recall_at_10")} for x in c["same_graph_exact_visited_set"]]
         cfgs[name] = e
@@ -1138,7 +1163,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; > 1 without WORLD_SIZE in the environment starts them (torchrun)")
     ap.add_argument("--steps", type=int, default=24, help="timed steps; one step = one coalesced launch of --coalesce x --batch queries")
     ap.add_argument("--warmup", type=int, default=4, help="untimed warm-up steps (launches)")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=MAIN_WORKLOAD, choices=sorted(WORKLOADS),
+                    help="the workload `value` is measured on; default = one 12.5M x 1024 shard of BASELINE configs[3] per GPU (the metric's own configuration)")
     ap.add_argument("--configs", default="auto", help="extra BASELINE configs measured after the main workload and appended to the same JSON "
                     "line: auto | all | none | comma list of " + ",".join(ALL_CONFIGS))
     ap.add_argument("--n", type=int, default=0, help="override vectors per GPU of the main workload (marks the run as non-standard)")
@@ -1161,13 +1187,14 @@ def main():
     ap.add_argument("--ef-construction", type=int, default=0, help="0 = the workload's default (config.toml 128; c4shard 256)")
     ap.add_argument("--build-visited", default="ref", choices=["ref", "exact"], help="visited filter used by the builder's walks")
     ap.add_argument("--quantization", default="auto", choices=["auto", "range11"], help="auto = sampled values_range; range11 = (-1,1)")
-    ap.add_argument("--ef-sweep", default="256,exact:32,exact:64",
+    ap.add_argument("--ef-sweep", default="auto",
                     help="comma list of extra settings timed after the main run on the same graph: '256' = ef_search 256 (config.toml "
-                         "default) with the main visited filter; 'exact:32' / 'ref:128' = that ef with the named visited filter")
+                         "default) with the main visited filter; 'exact:32' / 'ref:128' = that ef with the named visited filter; auto = none for "
+                         "the 51 GB shard, '256,exact:32,exact:64' for c2 (as a main workload and as the record under `configs`)")
     ap.add_argument("--build-batch", type=int, default=4096)
-    ap.add_argument("--m0", type=int, default=64, help="level_0_neighbors_count of the MAIN workload's graph (profiling runs of the metric's own "
-                    "config: --workload c4shard --m0 256 --m 64)")
-    ap.add_argument("--m", type=int, default=32, help="neighbors_count of the main workload's graph")
+    ap.add_argument("--m0", type=int, default=0, help="level_0_neighbors_count of the MAIN workload's graph; 0 = the workload's own: 256 for the "
+                    "12.5M x 1024 shard (the setting that meets the recall target with the reference's visited filter), 64 = config.toml otherwise")
+    ap.add_argument("--m", type=int, default=0, help="neighbors_count of the main workload's graph; 0 = the workload's own (64 for the shard, 32 otherwise)")
     ap.add_argument("--recall-queries", type=int, default=8192, help="size of EACH of the two disjoint recall query sets (selection / report)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer API legs (cos_search_batch from 1-256 host threads); the profiler "
@@ -1212,32 +1239,46 @@ def main():
     t_setup = time.time()
 
     # ---- the main workload: `value` -------------------------------------------------------------------------------
+    C2_SWEEP = "256,exact:32,exact:64"
+    is_shard = args.workload == "c4shard"
+    m0 = args.m0 or (MAIN_M0 if is_shard else 64)
+    mm = args.m or (MAIN_M if is_shard else 32)
+    main_sweep = ("" if is_shard else C2_SWEEP) if args.ef_sweep == "auto" else args.ef_sweep
     wl = DenseWorkload(env, args.workload, n_override=args.n, ef_construction=args.ef_construction, quantization=args.quantization,
                        build_batch=args.build_batch)
-    rec = wl.run_mode(args.build_visited, args.visited, ef_arg=args.ef, ef_sweep=args.ef_sweep, cpu_seconds=args.cpu_seconds,
-                      single_batch=True, host_api=not args.no_host_api, hbm_probe=not args.no_hbm_probe, exchange=args.exchange,
-                      m0=args.m0, m_upper=args.m)
+    # the host-buffer legs (cos_search_batch from 1-256 host threads: BASELINE configs[1]'s "query-batch=256") belong to c2, as a main
+    # workload or as the record under `configs`
+    rec = wl.run_mode(args.build_visited, args.visited, ef_arg=args.ef, ef_sweep=main_sweep, cpu_seconds=args.cpu_seconds,
+                      single_batch=True, host_api=(not args.no_host_api) and not is_shard, hbm_probe=not args.no_hbm_probe, exchange=args.exchange,
+                      m0=m0, m_upper=mm)
     flat = wl.flat
     n = wl.n
-    wl.close()
+    c4 = wl if is_shard else None      # the 51 GB shard, its ground truth and the oracle's quantized copy serve the 8-shard record too
+    if c4 is None:
+        wl.close()
     del wl
     recall, recall_se, recall_lo = rec["recall"]
     merged_qps = rec["value"]
+
+    def serial_block(r):
+        return {"single_batch_qps": r["serial"]["qps"], "single_batch_qps_one_wave_latency_kernel": r["serial"]["qps_one_wave_latency_kernel"],
+                "single_batch_qps_throughput_kernel": r["serial"]["qps_throughput_kernel"],
+                "single_batch_latency_walk_identical_to_throughput_walk": r["serial"]["identical"]}
     out = {
         "metric": METRIC, "value": merged_qps, "unit": "queries/s", "n_gpus": world, "steps": rec["steps"], "warmup": rec["warmup"],
         "ms_per_step": rec["elapsed"] / rec["steps"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": rec["config"],
         "recall_at_10": recall, "recall_stderr": recall_se, "recall_lower95": recall_lo, "recall_queries": args.recall_queries,
-        "recall_sets": "ef selected on query seed 44, recall reported on query seed 45 (disjoint draws of the same corpus distribution)",
+        "meets_recall_target": bool(recall_lo >= args.recall_target),
+        "recall_sets": "ef selected on query seed 44, recall reported on query seed 45 (disjoint draws of the same corpus distribution); "
+                       "ground truth = exact brute-force cosine top-10 over the GLOBAL corpus (every shard's scan, merged)",
         "failed_queries": rec["status_bad"],
         "merged_qps": merged_qps, "shard_searches_per_s": merged_qps * world, "global_corpus_vectors": n * world,
         "value_note": ("n_gpus == 1: value = queries/s over the whole corpus" if world == 1 else
                        "value = merged answers/s over the GLOBAL corpus (n_gpus x vectors_per_gpu; every query is searched on every "
                        "shard, then all-gathered and merged); shard_searches_per_s = value x n_gpus is the shard-level work"),
-        "single_batch_qps": rec["serial"]["qps"], "single_batch_qps_one_wave_latency_kernel": rec["serial"]["qps_one_wave_latency_kernel"],
-        "single_batch_qps_throughput_kernel": rec["serial"]["qps_throughput_kernel"],
-        "single_batch_latency_walk_identical_to_throughput_walk": rec["serial"]["identical"],
+        **serial_block(rec),
         "ef_selection": rec["ef_table"], "ef_sweep": rec["sweep"], "launch_size_sweep": rec["size_sweep"], "build_seconds": rec["build_s"],
         "setup_seconds": time.time() - t_setup,
         "roofline": rec["roofline"],
@@ -1245,7 +1286,7 @@ def main():
         "host_api_pcie_inclusive": rec["host_api"],
         # BASELINE configs[1] says "query-batch=256": the rate with the reference's own calling pattern — concurrent synchronous callers of
         # ONE 256-query batch each through cos_search_batch on host buffers (PCIe-inclusive), fused by the library's dynamic batching;
-        # `value` itself is measured on device-resident 32 768-query launches
+        # measured on c2 (here when c2 is the main workload, else inside configs.c2)
         "value_at_query_batch_256": value_at_batch_256(rec["host_api"]),
         # every COS_* variable of the process: the library's experiment switches must be visible in the record they shaped
         "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("COS_") and k != "COS_BENCH_FULL_RECORD"},
@@ -1256,11 +1297,29 @@ def main():
     # ---- the remaining BASELINE configs, each to the same parity + roofline + cpu_baseline bar ------------------------
     todo = resolve_configs(args.configs, world, args.workload)
     scale = args.config_scale
-    c4 = None
     for name in todo:
         t_c = time.time()
         try:
-            if name == "c2_uniform":
+            if not (name.startswith("c4shard_") or name == "c4_8shards_one_device") and c4 is not None:
+                c4.close()       # the single-GPU configs below do not share the shard: its 51 GB go back first
+                c4 = None
+                env.torch.cuda.empty_cache()
+            if name == "c2":
+                w2 = DenseWorkload(env, "c2", n_override=0 if scale == 1.0 else int(1_000_000 * scale), quantization="auto")
+                r2 = w2.run_mode("ref", "ref", ef_sweep=C2_SWEEP, cpu_seconds=args.config_cpu_seconds, single_batch=True,
+                                 host_api=not args.no_host_api, exchange=args.exchange)
+                c2r = compact_dense_record(r2, world)
+                c2r.update(serial_block(r2))
+                c2r["ef_sweep"] = r2["sweep"]
+                c2r["launch_size_sweep"] = r2["size_sweep"]
+                c2r["host_api_pcie_inclusive"] = r2["host_api"]
+                c2r["value_at_query_batch_256"] = value_at_batch_256(r2["host_api"])
+                out["configs"][name] = c2r
+                if out["value_at_query_batch_256"] is None:
+                    out["value_at_query_batch_256"] = dict(c2r["value_at_query_batch_256"] or {}, measured_on="configs.c2 (BASELINE configs[1]: 1M x 768, query-batch 256)") or None
+                w2.close()
+                del w2
+            elif name == "c2_uniform":
                 w2 = DenseWorkload(env, "c2_uniform", n_override=0 if scale == 1.0 else int(1_000_000 * scale), quantization="auto")
                 r2 = w2.run_mode("ref", "ref", ef_sweep="exact:512", cpu_seconds=args.config_cpu_seconds, exchange=args.exchange)
                 out["configs"][name] = compact_dense_record(r2, world)
@@ -1275,16 +1334,16 @@ def main():
                     c4 = DenseWorkload(env, "c4shard", n_override=0 if scale == 1.0 else int(12_500_000 * scale))
                 v = "exact" if name == "c4shard_exact" else "ref"
                 toks = name.split("_")
-                m0 = int(toks[toks.index("m0") + 1]) if "m0" in toks else 64
-                mm = int(toks[toks.index("m") + 1]) if "m" in toks else 32
-                r4 = c4.run_mode(v, v, cpu_seconds=args.config_cpu_seconds, exchange=args.exchange, m0=m0, m_upper=mm)
+                cm0 = int(toks[toks.index("m0") + 1]) if "m0" in toks else 64
+                cmm = int(toks[toks.index("m") + 1]) if "m" in toks else 32
+                r4 = c4.run_mode(v, v, cpu_seconds=args.config_cpu_seconds, exchange=args.exchange, m0=cm0, m_upper=cmm)
                 out["configs"][name] = compact_dense_record(r4, world)
             elif name == "c4_8shards_one_device":
                 # the same 12.5M x 1024 corpus as eight id-range shards behind cos_shardset_search_batch: merged recall, exchange + merge cost
                 from scripts import bench_c4_8shards
                 if c4 is None:
                     c4 = DenseWorkload(env, "c4shard", n_override=0 if scale == 1.0 else int(12_500_000 * scale))
-                if c4.gt_rep is None:   # (the c4shard records ran first in the default order: their ground truth is reused)
+                if c4.gt_rep is None:   # (the main workload ran first in the default order: its ground truth is reused)
                     hp0 = ca_mod().HNSWHyperParams(num_layers=9, ef_construction=c4.ef_construction, ef_search=64)
                     ix0 = ca_mod().HNSWIndex(c4.d, hp0, ca_mod().DistanceMetric.Cosine, ca_mod().StorageType.UnsignedByte(), c4.values_range,
                                              device=env.local_rank, seed=42)

@@ -248,9 +248,14 @@ class tuning:
         self.old = {}
 
     def __enter__(self):
-        for k, v in self.knobs.items():
-            self.old[k] = tuning_get(k)
-            tuning_set(k, v)
+        try:
+            for k, v in self.knobs.items():
+                old = tuning_get(k)          # (an unknown name raises here, before anything of it is recorded)
+                tuning_set(k, v)
+                self.old[k] = old
+        except Exception:
+            self.__exit__()                  # a rejected name must not leave the earlier knobs of the block set
+            raise
         return self
 
     def __exit__(self, *exc):

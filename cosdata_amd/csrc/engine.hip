@@ -521,6 +521,18 @@ int32_t cos_set_root_code(cos_index *ix, const uint8_t *ref_code, float mag) {
     if (rc) return rc;
     std::vector<uint8_t> dev(ix->row_stride, 0);
     row_to_device_layout(ix->eng, ix->p.dim, ref_code, dev.data());
+    if (ix->eng == ENG_U8) {
+        // u8 storage: Storage::UnsignedByte::mag IS sqrt(sum of squares of the bytes as f32) (scalar.rs:25-26).  The walk's unscaled
+        // quotient (device_common.h div_rn_unscaled) relies on norms of that form (0, or 1 <= mag < 2^28): a stored value that is not
+        // finite or outside [1, 255 sqrt(dim)] — a damaged file — is replaced by the norm recomputed from the code row, so that
+        // every kernel (throughput, latency, single-distance) divides by the same, valid number.
+        const float hi = 255.0f * sqrtf((float)ix->p.dim) * 1.0001f;
+        if (!(mag == 0.0f || (mag >= 1.0f && mag <= hi))) { // (NaN fails every comparison)
+            uint32_t ss = 0;
+            for (u32 i = 0; i < ix->p.dim; i++) ss += (uint32_t)ref_code[i] * (uint32_t)ref_code[i];
+            mag = sqrtf((float)ss);
+        }
+    }
     HIP_TRY(hipMemcpy(ix->d_codes + (size_t)ix->n * ix->row_stride, dev.data(), dev.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ix->d_mags + ix->n, &mag, 4, hipMemcpyHostToDevice));
     ix->root_raw.assign(ix->p.dim, 0.0f);
@@ -558,15 +570,18 @@ static u32 walk_table_min_B(const cos_index *ix);
 extern "C" int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
     if (ef > 1024) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 1024 not supported on the device");
+    std::lock_guard<std::mutex> g(ix->mu); // searches snapshot ef / visited mode under the same lock (run_search); the graph state is read under it too
     const bool live = graph_ready(ix);
     if (live)
-        if (int32_t rc = cos_set_device(ix)) return rc;
-    std::lock_guard<std::mutex> g(ix->mu); // searches snapshot ef / visited mode under the same lock (run_search)
+        if (int32_t rc = cos_set_device(ix)) return rc; // (nothing changed yet)
     ix->p.ef_search = ef;
     // the automatic level-table rule depends on ef: the operand of the new rule is gathered HERE, by the caller that changes the
     // knob, not inside the next search (where the gather and its device synchronisation ran under ix->mu in front of every
-    // concurrent searcher); operands are cached per (graph, rule), so going back and forth costs nothing the second time
-    if (live && walk_table_min_B(ix)) return ensure_level_table(ix);
+    // concurrent searcher); operands are cached per (graph, rule), so going back and forth costs nothing the second time.
+    // Best effort: the table is an accelerator, not a result — a gather that fails (out of memory is already absorbed inside
+    // ensure_level_table) leaves the new ef in force, the next search walks without a table or retries the gather, and the
+    // setter reports success: an error here would say "ef unchanged" while it has changed.
+    if (live && walk_table_min_B(ix)) (void)ensure_level_table(ix);
     return COS_OK;
 }
 extern "C" int32_t cos_index_set_visited_mode(cos_index *ix, uint32_t mode) {

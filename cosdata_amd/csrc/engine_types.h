@@ -85,6 +85,8 @@ struct WalkArgs {
     u64 tab_stride;       // floats per query row
     u32 tab_level_min;
     u32 tab_col0[MAX_LEVELS];
+    u32 merge_min;        // table levels: an expansion with at least this many winners past the screen inserts them by ONE ranked merge
+                          // (walk_kernel.inc commit_merge) instead of one pool shift each; 0 = always the serial insert.  Set by launch_walk.
     // Locality-ordered walk (big search launches; kernels_order.hip, engine.hip run_search).  The walk of a launch is split
     // into launches of the same kernel over consecutive level ranges [level_first .. level_last]; between two of them the
     // launch's queries are sorted by an ORDER KEY and dealt to the XCDs in contiguous runs (workgroup b runs on XCD b % 8, each

@@ -474,8 +474,20 @@ static int walk_pb_policy(u32 B, u32 ef, bool upper_range_of_a_split_walk) {
     return ef > 256u ? 4 : 8;
 }
 
+// Table levels (walk_kernel.inc, commit_merge): winners past the screen from which an expansion takes the ranked merge instead of
+// the serial insert.  Tuning knob walk_merge_min overrides (0 = never merge).  Defaults measured in round 6
+// (profiles/r06_merge_probe_*.jsonl): one key per lane (ef <= 64) the serial insert is a dozen instructions and only a big batch
+// of winners pays for the permutation; from two keys per lane on the merge wins from three winners.
+static u32 walk_merge_min_policy(u32 ef) {
+    const long long forced = tune_or(TUNE_WALK_MERGE_MIN, -1);
+    if (forced >= 0) return (u32)std::min<long long>(forced, 65);
+    return ef <= 64u ? 4u : 3u;
+}
+
 template <int ENG, int CH, bool G64>
-static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
+static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa_in, hipStream_t st) {
+    WalkArgs wa = wa_in;
+    wa.merge_min = wa.tab != nullptr ? walk_merge_min_policy(wa.ef) : 0u;
     const size_t smem = walk_smem_bytes(ix, wa.ef, ENG);
     dim3 grid(wa.B), block(64);
     const bool exact = ix.visited_mode != 0;
@@ -494,6 +506,7 @@ static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa, hipStrea
         else hipLaunchKernelGGL((walk_kernel<ENG, CH, R_, G64, false>), grid, block, smem, st, ix, wa);                   \
     } while (0)
     if (wa.ef <= 64) WALK(1);
+    else if (wa.ef <= 128 && tune_or(TUNE_WALK_R2, 1) != 0) WALK(2); // round 6: the metric's shard runs at ef 128 — half the pool registers, half the insert
     else if (wa.ef <= 256) WALK(4);
     else if (wa.ef <= 512) WALK(8);
     else if (wa.ef <= 1024) WALK(16); // round 5: a pool of 64 x 16 keys per wave (103 VGPRs, no scratch: 4 waves per SIMD)

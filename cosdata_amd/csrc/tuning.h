@@ -24,8 +24,8 @@ enum TuneKey : int {
     TUNE_HOST_PIPELINE_MIN_B, // host calls of at least this many queries run as a chunk pipeline (default 8192; 0 = never)
     TUNE_FLAT_UNFUSED,        // 1 = exhaustive scans take the score-matrix path
     TUNE_FLAT_TILE_KERNEL,    // 1 = quaternary scans take the 256 x 128 tile kernel instead of the query-resident one
-    TUNE_FLAT_PF,             // k panels prefetched by the tile kernel (1..3; default 2)
-    TUNE_FLAT_FP4,            // 0 = quaternary scans multiply i8 digits, 1 = e2m1 digits on the f8f6f4 MFMA (default 1 where it exists)
+    TUNE_FLAT_PF,             // k panels prefetched by the tile kernel of cos_flat_search_batch (1..3; default 1 — the level table's tile GEMM is fixed at 2)
+    TUNE_FLAT_FP4,            // 0 = quaternary scans multiply i8 digits, 1 = e2m1 digits on the f8f6f4 MFMA (default 1: the library is built for gfx950 only)
     TUNE_BM25_BLOCKS,         // workgroups of bm25_score_kernel (default 8192)
     TUNE_SPARSE_LAYOUT,       // cos_sparse_create: 0 = u32 id + u8 key per posting, 1 = packed u32 (default: packed when ids fit 24 bits)
     TUNE_WALK_PB,             // 4 | 8 code rows in flight per wave (u8, 513..1024 dims), every launch
@@ -39,6 +39,8 @@ enum TuneKey : int {
     TUNE_FINALIZE_FAST,       // 0 = the general finalize kernel alone
     TUNE_SHARDSET_FORCE_RCCL, // 1 = a world of one still goes through the RCCL exchange (tests)
     TUNE_BUILD_PROFILE,       // 1 = cos_index_build prints its phase times to stderr
+    TUNE_WALK_MERGE_MIN,      // table levels: winners from which an expansion takes the ranked merge (0 = never; default 4 up to ef 64, 3 above)
+    TUNE_WALK_R2,             // 0 = ef 65..128 walks with the 256-key pool of ef 129..256 (default 1: a 128-key pool)
     TUNE_COUNT
 };
 

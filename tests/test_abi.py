@@ -98,6 +98,20 @@ def test_tuning_registry_set_get_clear_and_the_one_environment_variable():
     import subprocess
     import sys
     from cosdata_amd import _lib
+    names = re.findall(r'"([a-z0-9_]+)"', re.search(r"NAMES\[TUNE_COUNT\] = \{(.*?)\};", open(os.path.join(ROOT, "cosdata_amd", "csrc", "tuning.hip")).read(), re.S).group(1))
+    saved = {n: _lib.tuning_get(n) for n in names}         # a run steered through COS_TUNING keeps its knobs for the tests after this one
+    try:
+        _tuning_registry_checks(_lib)
+    finally:
+        _lib.tuning_clear(None)
+        for n, v in saved.items():
+            if v is not None:
+                _lib.tuning_set(n, v)
+
+
+def _tuning_registry_checks(_lib):
+    import subprocess
+    import sys
     _lib.tuning_clear(None)
     assert _lib.tuning_get("walk_pb") is None
     _lib.tuning_set("walk_pb", 4)
@@ -109,6 +123,10 @@ def test_tuning_registry_set_get_clear_and_the_one_environment_variable():
     assert _lib.tuning_get("walk_pb") is None
     with pytest.raises(_lib.CosdataError):
         _lib.tuning_set("no_such_knob", 1)
+    with pytest.raises(_lib.CosdataError):                  # a block with a rejected name leaves nothing of itself behind
+        with _lib.tuning(walk_pb=8, no_such_knob=1):
+            pass
+    assert _lib.tuning_get("walk_pb") is None
     with pytest.raises(_lib.CosdataError):
         _lib.tuning_set("walk_pb", -(2 ** 63))               # INT64_MIN is the "unset" marker
     code = ("from cosdata_amd import _lib; print(_lib.tuning_get('walk_pb_upper'), _lib.tuning_get('flat_pf'), _lib.tuning_get('walk_pb'), "

@@ -42,17 +42,31 @@ def test_effective_cores_is_bounded_by_affinity():
 
 def test_resolve_configs_auto_all_none_and_world_rules():
     import bench
-    assert bench.resolve_configs("auto", 1, "c2") == bench.ALL_CONFIGS                  # every BASELINE config at N = 1
-    assert bench.resolve_configs("auto", 8, "c2") == ["c4shard_ref_m0_256_m_64"]        # N > 1: configs[3] itself, in the Rust path's semantics
-    assert bench.resolve_configs("auto", 1, "smoke") == [] and bench.resolve_configs("none", 1, "c2") == []
-    assert bench.resolve_configs("c3,c5", 1, "c2") == ["c3", "c5"]
-    assert bench.resolve_configs("all", 2, "c2") == ["c4shard_ref_m0_256_m_64"]    # single-GPU configs (the one-device 8-shard proxy too) are dropped at N > 1
-    assert bench.resolve_configs("c4shard_ref,c4shard_ref_m0_256_m_64", 2, "c2") == ["c4shard_ref", "c4shard_ref_m0_256_m_64"]
-    assert "c4_8shards_one_device" in bench.ALL_CONFIGS and "c4shard_ref" in bench.OPTIONAL_CONFIGS
-    assert bench.resolve_configs("c4shard_exact,c4shard_ref_m0_128", 1, "c2") == ["c4shard_exact", "c4shard_ref_m0_128"]   # optional records
+    main = bench.MAIN_WORKLOAD
+    assert main == "c4shard" and (bench.MAIN_M0, bench.MAIN_M) == (256, 64)             # `value` = the metric's own configuration
+    assert bench.resolve_configs("auto", 1, main) == bench.ALL_CONFIGS                  # every other BASELINE config at N = 1
+    assert bench.resolve_configs("auto", 8, main) == []                                 # N > 1: the main workload IS configs[3]
+    assert bench.resolve_configs("auto", 1, "smoke") == [] and bench.resolve_configs("none", 1, main) == []
+    assert bench.resolve_configs("auto", 1, "c2") == []                                 # a non-standard main workload runs alone
+    assert bench.resolve_configs("c3,c5", 1, main) == ["c3", "c5"]
+    assert bench.resolve_configs("all", 2, main) == []                  # single-GPU configs (the one-device 8-shard proxy too) are dropped at N > 1
+    assert bench.resolve_configs("c4shard_ref,c4shard_ref_m0_256_m_64", 2, main) == ["c4shard_ref", "c4shard_ref_m0_256_m_64"]
+    assert {"c4_8shards_one_device", "c2", "c2_uniform", "c3", "c5"} == set(bench.ALL_CONFIGS) and "c4shard_ref" in bench.OPTIONAL_CONFIGS
+    assert bench.resolve_configs("c4shard_exact,c4shard_ref_m0_128", 1, main) == ["c4shard_exact", "c4shard_ref_m0_128"]   # optional records
     import pytest
     with pytest.raises(SystemExit):
-        bench.resolve_configs("c9", 1, "c2")
+        bench.resolve_configs("c9", 1, main)
+
+
+def test_value_is_quoted_on_the_metrics_configuration_at_every_n():
+    """`value` at --gpus N = N id-range shards of 12.5M x 1024 (BASELINE configs[3]; the metric says 1024-dim, 1/2/4/8 GPUs): the name the
+    real line carries in config.workload, for N = 1 (BENCH) and N = 8 (SCALE) alike"""
+    import bench
+    for n in (1, 2, 4, 8):
+        w = bench.value_workload(n)
+        assert "configs[3]" in w and "12500000 x 1024" in w and f"{n} id-range shard" in w
+        assert ("all-gather" in w) == (n > 1)
+    assert "1024-dim" in bench.METRIC and bench.WORKLOADS[bench.MAIN_WORKLOAD][:2] == (12_500_000, 1024)
 
 
 def test_launcher_command_is_the_drivers_own():

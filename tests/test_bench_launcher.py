@@ -48,6 +48,10 @@ def test_gpus_8_launches_eight_gloo_ranks_and_every_shard_reaches_the_merge():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 8 and j["ranks"] == 8 and j["asked_gpus"] == 8
+    # the workload `value` is quoted on at this N: eight 12.5M x 1024 shards = BASELINE configs[3] itself, exchange inside the step
+    w = j["config"]["value_workload_at_this_n"]
+    assert "configs[3]" in w and "8 id-range shard" in w and "12500000 x 1024" in w and "all-gather" in w
+    assert j["config"]["n_gpus"] == 8 and j["config"]["dim"] == 1024
     assert j["distinct_processes"] == 8
     assert j["shards_in_merged_answer"] == list(range(8))
     assert "--nproc-per-node=8" in r.stderr

@@ -48,11 +48,12 @@ def reference_pops(adj, keys, entry, ef, M):
 class Walk:
     """the kernels' state: sorted bounded pool + window rounds"""
 
-    def __init__(self, adj, keys, entry, ef, M, cap, la, prescreen):
+    def __init__(self, adj, keys, entry, ef, M, cap, la, prescreen, merge_min=0):
         self.adj, self.keys, self.ef, self.mask, self.cap, self.la, self.prescreen = adj, keys, ef, 64 * M - 1, cap, la, prescreen
         self.vis = {entry & self.mask}
         self.pool = [(keys[entry], entry)]  # descending by key
         self.pops = []
+        self.merge_min = merge_min
 
     def _insert(self, item, limit):
         pos = sum(1 for e in self.pool if e[0] > item[0])
@@ -96,12 +97,45 @@ class Walk:
                     assert sum(1 for e in self.pool if e[0] > w[0]) >= limit
             elif self.prescreen:
                 win = []
-            for w in win:
-                pos = self._insert(w, limit)
-                if pos is not None and pos < ahead:
-                    stale = True
+            if self.merge_min and len(win) >= self.merge_min:
+                stale = self._merge(win, ahead)
+            else:
+                for w in win:
+                    pos = self._insert(w, limit)
+                    if pos is not None and pos < ahead:
+                        stale = True
             if stale:
                 break
+
+    def _merge(self, win, ahead):
+        """walk_kernel.inc commit_merge (round 6): every screened winner is ranked against the pool and against the other winners, each
+        pool entry counts the winners below it, then ONE permutation: pool entry j -> j + (winners above it), winner -> (pool entries
+        above it) + (winners above it); places past the pool's end are dropped.  Stale window = some winner has fewer than `ahead`
+        POOL entries above it.  Empty pool slots are key 0 (below every winner)."""
+        W = len(win)
+        pool = self.pool + [(0, None)] * (self.cap - len(self.pool))
+        below = [0] * self.cap
+        rank, above = [], []
+        for k, _ in win:
+            rank.append(sum(1 for e in pool if e[0] > k))
+            above.append(sum(1 for k2, _ in win if k2 > k))
+            for j, e in enumerate(pool):
+                below[j] += 1 if e[0] > k else 0
+        out = [None] * self.cap
+        for j, e in enumerate(pool):
+            np_ = j + (W - below[j])
+            if np_ < self.cap:
+                assert out[np_] is None
+                out[np_] = e
+        for i, w in enumerate(win):
+            np_ = rank[i] + above[i]
+            if np_ < self.cap:
+                assert out[np_] is None
+                out[np_] = w
+        assert all(o is not None for o in out)                       # every place below the pool's end is written exactly once
+        self.pool = [e for e in out if e[1] is not None]
+        assert all(o[1] is None for o in out[len(self.pool):])       # empties stay at the end
+        return min(rank) < ahead
 
     def round_parallel(self):
         kwin = min(len(self.pool), self.la, self.ef - len(self.pops))
@@ -174,3 +208,29 @@ def test_data_parallel_window_commit_is_indistinguishable_from_the_sequential_on
             assert a.pool[:limit] == b.pool[:limit], seed                          # everything that can still be popped
             assert min(len(a.pool), la, limit) == min(len(b.pool), la, limit), seed  # next round's window size
         assert not (b.pool and len(b.pops) < ef)
+
+
+@pytest.mark.parametrize("n,M,ef,cap,la", CASES + [(600, 64, 128, 128, 4), (900, 64, 100, 128, 4), (500, 32, 200, 256, 4)])
+def test_ranked_merge_commit_is_indistinguishable_from_the_serial_insert(n, M, ef, cap, la):
+    """round 6: the table levels insert an expansion's screened winners by ONE ranked merge (walk_kernel.inc commit_merge) from
+    `merge_min` winners on; the serial loop stays below that.  Same pops, same filter, same pool wherever it can still be popped,
+    same stale-window decisions (= the same rounds), same window size next round — and the reference heap's pops at the end."""
+    for seed in range(10):
+        rng = random.Random(9100 * n + seed)
+        adj, keys = _level(rng, n, M, p_empty=0.05)
+        entry = rng.randrange(n)
+        want, want_vis = reference_pops(adj, keys, entry, ef, M)
+        for merge_min in (1, 3):
+            a = Walk(adj, keys, entry, ef, M, cap, la, prescreen=True)
+            b = Walk(adj, keys, entry, ef, M, cap, la, prescreen=True, merge_min=merge_min)
+            rounds = 0
+            while a.pool and len(a.pops) < ef:
+                a.round_sequential()
+                b.round_sequential()
+                rounds += 1
+                assert a.pops == b.pops and a.vis == b.vis, (seed, merge_min, rounds)   # equal pops after every round = equal stale decisions
+                limit = ef - len(a.pops)
+                assert a.pool[:limit] == b.pool[:limit], (seed, merge_min)
+                assert min(len(a.pool), la, limit) == min(len(b.pool), la, limit), (seed, merge_min)
+            assert not (b.pool and len(b.pops) < ef)
+            assert b.pops == want and b.vis == want_vis

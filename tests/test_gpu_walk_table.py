@@ -197,3 +197,31 @@ def test_quaternary_codes_walk_the_table_too(dim, metric):
     for gemm in (1, 0):
         assert _same(res[gemm][0], plain[0]) and _same(res[gemm][1], plain[1]), gemm
     _check_against_oracle(oix, res[1][0], Q, 10, np.arange(0, B, 23))
+
+
+@pytest.mark.parametrize("ef,m0,m", [(64, 64, 32), (128, 64, 64), (100, 128, 64), (256, 64, 32)])
+def test_ranked_merge_of_the_table_levels_keeps_every_bit(ef, m0, m):
+    """round 6 (walk_kernel.inc commit_merge): on table levels an expansion's screened winners go into the pool by ONE ranked merge
+    from `walk_merge_min` winners on.  Pools of one / two / four keys per lane (ef 64 / 65..128 / 129..256; `walk_r2` = 0 puts ef
+    65..128 back on the four-key pool), merge thresholds 1 (always) / default / 0 (never): per-level lists and results identical to
+    each other, to the walk without a table, and to the oracle."""
+    import cosdata_amd as ca
+    from cosdata_amd import _lib
+    X = H.clustered_corpus(6000, 96, n_centers=24, seed=300 + ef)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=64, ef_search=ef, level0_neighbors_count=m0, neighbors_count=m)
+    dix = H.device_index_from_oracle(oix, X)
+    B = ca.HNSWIndex.WALK_TABLE_DEFAULT_MIN_B + 19
+    Q = H.queries_from(X, B, noise=0.05, seed=12)
+    assert dix.walk_table_info()[0] == 1
+    ref_res = ref_walk = None
+    for knobs in ({"walk_merge_min": 0}, {"walk_merge_min": 1}, {}, {"walk_merge_min": 2, "walk_r2": 0}, {"walk_merge_min": 64}):
+        with _lib.tuning(**knobs):
+            res = dix.batch_search(Q, 10)
+            assert dix.last_walk_split().table_evals > 0
+            walk = dix.ann_search_batch(Q)
+        if ref_res is None:
+            ref_res, ref_walk = res, walk
+        assert _same(res, ref_res) and _same(walk, ref_walk), knobs
+    dix.set_walk_table(0, 0)
+    assert _same(dix.ann_search_batch(Q), ref_walk)
+    _check_against_oracle(oix, ref_res, Q, 10, np.arange(0, B, 37))
