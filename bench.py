@@ -74,6 +74,7 @@ WORKLOADS = {
 # Round 6: `value` IS the target-meeting shard (main workload c4shard, M0 256 / M 64); c2 is a record under `configs`.
 ALL_CONFIGS = ["c4_8shards_one_device", "c2", "c2_uniform", "c5", "c3"]
 MAIN_WORKLOAD = "c4shard"
+EF_CANDIDATES = [32, 48, 64, 80, 96, 112, 128, 160, 192, 256, 384, 512]   # ef_search is a user parameter (indexes/hnsw/types.rs:14): the grid it is selected from
 MAIN_M0, MAIN_M = 256, 64
 OPTIONAL_CONFIGS = ["c4shard_ref", "c4shard_exact", "c4shard_ref_m0_128", "c4shard_ref_m0_256", "c4shard_ref_m0_256_m_64", "c4shard_ref_m0_256_m_128"]   # --configs only
 
@@ -544,7 +545,7 @@ class DenseWorkload:
 
         ef_table = []
         if ef_arg == "auto":
-            ef, ef_table = select_ef([32, 48, 64, 96, 128, 192, 256, 384, 512], lambda e: measure_recall(e, self.Q_sel, gt_sel), args.recall_target)
+            ef, ef_table = select_ef(EF_CANDIDATES, lambda e: measure_recall(e, self.Q_sel, gt_sel), args.recall_target)
         recall, recall_se, recall_lo = measure_recall(ef, self.Q_rep, gt_rep)     # the reported figure: hold-out set
         status_bad = int((o_st != 0).sum().item())
 
@@ -1176,7 +1177,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=0, help="launches kept in flight (HIP streams); 0 = auto: 2, or 3 when every launch is followed by "
                     "the exchange step (N > 1): the all-gather waits for a finalize that shares the HBM with the next walk, a third launch keeps "
                     "the walk chain fed meanwhile (forced-dist run: 0.96 of the non-dist rate against 0.91 with two)")
-    ap.add_argument("--ef", default="auto", help="ef_search: an integer, or 'auto' = smallest of 32,48,64,96,128,192,256,384,512 whose recall@10 "
+    ap.add_argument("--ef", default="auto", help="ef_search: an integer, or 'auto' = smallest of 32,48,64,80,96,112,128,160,192,256,384,512 whose recall@10 "
                     "on the SELECTION query set clears --recall-target with 95 %% confidence (the metric is QPS AT recall@10 >= 0.95); "
                     "config.toml default is 256")
     ap.add_argument("--recall-target", type=float, default=0.95)

@@ -85,6 +85,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
 
     ix->order_rank_valid = false; // the order key's table follows the graph (engine.hip, ensure_order_rank)
     ix->level_table_valid = false; // and so does the level table's operand (ensure_level_table)
+    ix->adj_mag_valid = false;     // the builder's walks gather mags[]; the adjacency-side norms are written when the graph is committed
     // ---- root + level draws (same RNG stream as the oracle builders) ----------------------------
     uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
     std::vector<float> root(ix->p.dim);

@@ -90,6 +90,8 @@ IndexDev cos_make_index_dev(const cos_index *ix) {
         d.lv[l].n = h.n;
         d.lv[l].M = h.M;
         d.lv[l].root_idx = h.n ? h.n - 1 : 0;
+        d.lv[l].adj_mag = (ix->adj_mag_valid && cosdev::tune_or(cosdev::TUNE_WALK_ADJ_MAG, 1) != 0) ? h.d_adj_mag : nullptr;
+        d.lv[l].mag_stride = std::min(h.M, ix->p.shortlist_size);
     }
     return d;
 }
@@ -193,6 +195,8 @@ static void free_level(LevelHost &l) {
     if (l.d_child) (void)hipFree(l.d_child);
     if (l.d_node_id) (void)hipFree(l.d_node_id);
     if (l.d_node_meta) (void)hipFree(l.d_node_meta);
+    if (l.d_adj_mag) (void)hipFree(l.d_adj_mag);
+    l.d_adj_mag = nullptr;
     l.d_node_id = l.d_node_meta = nullptr;
     l.d_adj_vec = l.d_adj_node = l.d_node_vec = l.d_child = nullptr;
     l.n = 0;
@@ -286,6 +290,7 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     for (auto &l : ix->lv) free_level(l); // a graph refers to vector rows: new vectors invalidate it
     ix->order_rank_valid = false;
     ix->level_table_valid = false;
+    ix->adj_mag_valid = false;
     reset_meta(ix);                       // ... and so do the pseudo-root component, its node table and the id stride
     const u64 dim = ix->p.dim;
     struct Rollback { // a failed upload leaves the handle empty instead of half-populated
@@ -345,6 +350,7 @@ extern "C" int32_t cos_index_set_root(cos_index *ix, const float *root_raw) {
     // the root is a node of every level: the level-table operand holds a gathered COPY of its code row, norm and code sum, which a
     // second set_root on a live graph would leave stale (the row levels would use the new row) — the next search regathers
     ix->level_table_valid = false;
+    ix->adj_mag_valid = false; // ... and the adjacency-side norms hold the old root's |v| wherever the root is a neighbour
     return COS_OK;
 }
 
@@ -387,6 +393,7 @@ static int32_t push_level_to_device(cos_index *ix, u32 level) {
     L.host_valid = true;
     ix->order_rank_valid = false; // the order key's table follows the graph (ensure_order_rank)
     ix->level_table_valid = false;
+    ix->adj_mag_valid = false;
     return COS_OK;
 }
 
@@ -537,6 +544,8 @@ int32_t cos_set_root_code(cos_index *ix, const uint8_t *ref_code, float mag) {
     HIP_TRY(hipMemcpy(ix->d_mags + ix->n, &mag, 4, hipMemcpyHostToDevice));
     ix->root_raw.assign(ix->p.dim, 0.0f);
     ix->have_root = true;
+    ix->level_table_valid = false;
+    ix->adj_mag_valid = false;
     return COS_OK;
 }
 
@@ -886,8 +895,37 @@ extern "C" int32_t cos_index_walk_table_info(cos_index *ix, uint32_t *out_level_
 // cos_index_build, the upload of a graph's last level (which is also how cos_index_load_reference_dir commits) — instead of inside the first big search, where
 // the host-side DFS and the device synchronisations ran under ix->mu and held up every concurrent searcher.  The lazy calls in
 // get_workspace stay as a fall-back (knobs changed after the commit).
+// LevelDev::adj_mag of every level: the norm of each scanned neighbour slot next to the adjacency.  Caller holds ix->mu; graph
+// changes are exclusive (no search in flight).  Out of memory leaves the walk on its mags[] gathers (same results).
+static int32_t ensure_adj_mags(cos_index *ix) {
+    if (ix->adj_mag_valid) return COS_OK;
+    if (!graph_ready(ix) || ix->meta.mdim != 0u) return COS_OK; // (collections with a metadata schema keep the gathers: their walks are walk_meta_kernel's)
+    HIP_TRY(hipDeviceSynchronize()); // a build or an upload on another stream may still be writing the adjacency
+    for (u32 l = 0; l <= ix->p.num_layers; l++) {
+        LevelHost &H = ix->lv[l];
+        if (H.d_adj_mag) (void)hipFree(H.d_adj_mag);
+        H.d_adj_mag = nullptr;
+    }
+    for (u32 l = 0; l <= ix->p.num_layers; l++) {
+        LevelHost &H = ix->lv[l];
+        const u32 slots = std::min(H.M, ix->p.shortlist_size);
+        const hipError_t e = hipMalloc((void **)&H.d_adj_mag, (size_t)H.n * slots * 4);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            for (u32 k = 0; k <= l; k++) { if (ix->lv[k].d_adj_mag) (void)hipFree(ix->lv[k].d_adj_mag); ix->lv[k].d_adj_mag = nullptr; }
+            return COS_OK; // adj_mag_valid stays false: the next graph change tries again
+        }
+        HIP_TRY(e);
+        HIP_TRY(cosdev::launch_fill_adj_mag(H.d_adj_vec, ix->d_mags, H.d_adj_mag, H.n, H.M, slots, ix->own_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ix->own_stream));
+    ix->adj_mag_valid = true;
+    return COS_OK;
+}
+
 int32_t cos_prepare_walk_plans(cos_index *ix) {
     std::lock_guard<std::mutex> g(ix->mu);
+    if (int32_t rc = ensure_adj_mags(ix)) return rc;
     if (ix->walk_order_min_B)
         if (int32_t rc = ensure_order_rank(ix)) return rc;
     if (walk_table_min_B(ix))
@@ -937,6 +975,8 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
         w->capB = cap;
         w->cap_topk = 0;
     }
+    if (!ix->adj_mag_valid && B >= 1024u) // (a root replaced on a live graph; small launches keep their gathers until a big one pays for the refill)
+        if (int32_t rc = ensure_adj_mags(ix)) return rc;
     if (ix->walk_order_min_B && B >= ix->walk_order_min_B && ix->p.ef_search <= 256u) { // wider beams keep the single launch (run_search)
         if (w->order.cap < w->capB) {
             HIP_TRY(hipStreamSynchronize(st));

@@ -17,6 +17,7 @@
 
 namespace cosdev {
 hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st);
+hipError_t launch_fill_adj_mag(const u32 *adj_vec, const float *mags, float *adj_mag, u32 n, u32 M, u32 slots, hipStream_t st);
 hipError_t launch_link_round(const LinkArgs &a, u32 maxM, const u32 *pend, const u32 *pcount, u32 *next, u32 *next_count, u32 *evq, u32 *evq_count,
                              u32 count_ub, u32 round, hipStream_t st);
 hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
@@ -84,6 +85,7 @@ struct LevelHost {
     std::vector<u32> nbr_ids;  // [n][M] internal ids / COS_SLOT_EMPTY
     u32 *d_adj_vec = nullptr, *d_adj_node = nullptr, *d_node_vec = nullptr, *d_child = nullptr;
     u32 *d_node_id = nullptr, *d_node_meta = nullptr; // pseudo-root component only (metadata-filtered search)
+    float *d_adj_mag = nullptr; // [n][min(M, shortlist)] norms of the scanned neighbour slots (LevelDev::adj_mag), valid while cos_index::adj_mag_valid
     u32 n = 0, M = 0;
     u32 root_idx = 0;        // pseudo-root component: node index of the pseudo root (base graph: the root is the last node)
     bool host_valid = false; // node_ids/nbr_ids mirror the device arrays
@@ -226,6 +228,7 @@ struct cos_index {
     // to the top hold at most walk_table_max_cols nodes together (0 = no table).  Env COS_WALK_TABLE_COLS / COS_WALK_TABLE_MIN_B.
     u32 walk_table_max_cols = COS_WALK_TABLE_AUTO, walk_table_min_B = COS_WALK_TABLE_DEFAULT_MIN_B;
     size_t table_bytes_total = 0;    // tables held by this handle's workspaces (budget: get_workspace)
+    bool adj_mag_valid = false;      // LevelHost::d_adj_mag follows the graph, the norms and the root (ensure_adj_mags)
     bool level_table_valid = false;  // the arrays below follow the graph and walk_table_max_cols
     u32 table_level_min = 0, table_cols = 0;
     u64 table_built_for_key = 0;    // max_cols, or the automatic rule's per-level bound: a change rebuilds the operand

@@ -14,6 +14,14 @@ struct LevelDev {
     u32 n;
     u32 M;
     u32 root_idx;
+    // |v| of every SCANNED neighbour slot, beside the adjacency: adj_mag[node * mag_stride + slot] = mags[adj_vec[node * M + slot]]
+    // (mag_stride = min(M, shortlist_size); empty slots hold 1).  An expansion on a row level then gets its winners' norms with the
+    // adjacency row it fetches anyway (coalesced, one more line or two per expansion) instead of one 4-byte gather per winner, each
+    // of which pulled a whole line from a 50 MB array (12 % of the lower range's HBM traffic at 12.5M x 1024).  Written when a
+    // graph is committed (engine.hip ensure_adj_mags); nullptr while a graph is being built or after the root changed: the walk then
+    // gathers mags[] as before.  Same values, same bits.
+    const float *adj_mag;
+    u32 mag_stride;
     // pseudo-root component (metadata-filtered search): nodes are replicas, not vectors
     const u32 *node_id;   // [n] internal (replica) id of a node; nullptr on the base graph (id = vector row * id_stride)
     const u32 *node_meta; // [n] row of the node's metadata dimensions in IndexDev::mbits

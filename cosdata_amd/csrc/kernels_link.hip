@@ -355,6 +355,17 @@ __global__ void fill_i32_kernel(int32_t *p, u64 n, int32_t v) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// LevelDev::adj_mag (engine_types.h): the norm of every scanned neighbour slot, next to the adjacency.  slots is a power of two
+// (min of two powers of two) or the shortlist size: plain division.
+__global__ void fill_adj_mag_kernel(const u32 *__restrict__ adj_vec, const float *__restrict__ mags, float *__restrict__ adj_mag, u64 total, u32 M, u32 slots) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 node = i / slots;
+        const u32 slot = (u32)(i - node * slots);
+        const u32 v = adj_vec[node * M + slot];
+        adj_mag[i] = v == NONE ? 1.0f : mags[v];
+    }
+}
+
 } // namespace
 
 namespace cosdev {
@@ -363,6 +374,14 @@ hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st) {
     if (n == 0) return hipSuccess;
     const u32 blocks = (u32)std::min<u64>((n + 255) / 256, 65535);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, st, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_adj_mag(const u32 *adj_vec, const float *mags, float *adj_mag, u32 n, u32 M, u32 slots, hipStream_t st) {
+    const u64 total = (u64)n * slots;
+    if (total == 0) return hipSuccess;
+    const u32 blocks = (u32)std::min<u64>((total + 255) / 256, 1u << 20);
+    hipLaunchKernelGGL(fill_adj_mag_kernel, dim3(blocks), dim3(256), 0, st, adj_vec, mags, adj_mag, total, M, slots);
     return hipGetLastError();
 }
 

@@ -452,7 +452,7 @@ hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u3
 
 size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
-    size_t b = (size_t)Mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2 + (size_t)LA * 64 * 4 * 2;
+    size_t b = (size_t)Mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2 + (size_t)LA * 64 * 4 * 3; // (window: vector rows, node indices, norms)
     b = (b + 15) & ~(size_t)15;
     if (eng == ENG_F32) b += (size_t)ix.row_stride;
     if (eng == ENG_F16) b += ((size_t)ix.dim * 4 + 15) & ~(size_t)15;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64) void walk_lat_kernel(const IndexDev ix, const W
                     if (lane == 0) s_res[npop] = wkey[wi];
                     npop++;
                     n_exp++;
-                    adj_bytes += (u64)M * 4;
+                    adj_bytes += (u64)slots * 4;
                     const int limit = (int)wa.ef - (int)npop;     // future pops still allowed
                     const int ahead = (int)kwin - 1 - wi;         // window entries still waiting at pool positions 0..ahead-1
 

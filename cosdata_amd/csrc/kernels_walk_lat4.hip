@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void walk_lat4_kernel(const IndexDev ix, const
             }
             n_evals += n_valid;
             n_exp += j + 1u;
-            adj_bytes += (u64)(j + 1u) * M * 4;
+            adj_bytes += (u64)(j + 1u) * slots * 4;
             npop += j + 1u;
             npool = npool - (j + 1u) + n_valid;
             if (npool > CAP) npool = CAP;

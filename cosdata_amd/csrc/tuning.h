@@ -40,6 +40,7 @@ enum TuneKey : int {
     TUNE_SHARDSET_FORCE_RCCL, // 1 = a world of one still goes through the RCCL exchange (tests)
     TUNE_BUILD_PROFILE,       // 1 = cos_index_build prints its phase times to stderr
     TUNE_WALK_MERGE_MIN,      // table levels: winners from which an expansion takes the ranked merge (0 = never; default 4 up to ef 64, 3 above)
+    TUNE_WALK_ADJ_MAG,        // 0 = row levels gather the winners' norms from mags[] instead of reading them beside the adjacency (LevelDev::adj_mag)
     TUNE_WALK_R2,             // 0 = ef 65..128 walks with the 256-key pool of ef 129..256 (default 1: a 128-key pool)
     TUNE_COUNT
 };

@@ -87,7 +87,7 @@ typedef struct cos_index cos_index; /* opaque: one immutable device-resident ind
 typedef struct {
     uint64_t evals;        /* distance evaluations (walk) */
     uint64_t expansions;   /* popped + expanded nodes */
-    uint64_t adj_bytes;    /* sum over expansions of M_level * 4 */
+    uint64_t adj_bytes;    /* sum over expansions of min(M_level, shortlist_size) * 4: the scanned slots of the row */
     uint64_t rerank_rows;  /* raw f32 rows gathered by the exact rerank */
     float walk_ms;         /* HIP-event time of the walk kernel of the last call on this stream (0 if timing off) */
     float finalize_ms;

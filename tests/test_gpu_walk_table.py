@@ -213,6 +213,8 @@ def test_ranked_merge_of_the_table_levels_keeps_every_bit(ef, m0, m):
     B = ca.HNSWIndex.WALK_TABLE_DEFAULT_MIN_B + 19
     Q = H.queries_from(X, B, noise=0.05, seed=12)
     assert dix.walk_table_info()[0] == 1
+    dix.set_latency_waves(0)      # above ef 64 one small launch would take the four-wave latency kernel: this test is about walk_kernel
+    dix.enable_timing(True)
     ref_res = ref_walk = None
     for knobs in ({"walk_merge_min": 0}, {"walk_merge_min": 1}, {}, {"walk_merge_min": 2, "walk_r2": 0}, {"walk_merge_min": 64}):
         with _lib.tuning(**knobs):
@@ -225,3 +227,32 @@ def test_ranked_merge_of_the_table_levels_keeps_every_bit(ef, m0, m):
     dix.set_walk_table(0, 0)
     assert _same(dix.ann_search_batch(Q), ref_walk)
     _check_against_oracle(oix, ref_res, Q, 10, np.arange(0, B, 37))
+
+
+@pytest.mark.parametrize("dim,visited,m0,m", [(768, 0, 64, 32), (1024, 0, 128, 64), (640, 1, 64, 32)])
+def test_norms_beside_the_adjacency_keep_every_bit(dim, visited, m0, m):
+    """round 6 (LevelDev::adj_mag): on row levels the winners' norms come with the adjacency row instead of one gather each; the same
+    per-level lists and results with the knob off, after a root replaced on a live graph (the arrays are refilled), and as the oracle"""
+    from cosdata_amd import _lib
+    X = H.clustered_corpus(3000, dim, n_centers=16, seed=dim + 5)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=4, ef_construction=48, ef_search=40, level0_neighbors_count=m0, neighbors_count=m)
+    dix = H.device_index_from_oracle(oix, X, visited_mode=visited)
+    if visited:
+        oix.set_visited_mode(O.VISITED_EXACT)
+    dix.set_latency_mode(0)
+    dix.set_latency_waves(0)      # the throughput kernel at every launch size
+    Q = H.queries_from(X, 1500, noise=0.05, seed=3)
+    on = dix.batch_search(Q, 10)
+    walk_on = dix.ann_search_batch(Q)
+    with _lib.tuning(walk_adj_mag=0):
+        off = dix.batch_search(Q, 10)
+        walk_off = dix.ann_search_batch(Q)
+    assert _same(on, off) and _same(walk_on, walk_off)
+    _check_against_oracle(oix, on, Q, 10, np.arange(0, 1500, 23))
+    root2 = np.ascontiguousarray(X[7] * 0.5 + X[11] * 0.5)
+    dix.set_root(root2)
+    oix.set_root_raw(root2)
+    again = dix.batch_search(Q, 10)
+    with _lib.tuning(walk_adj_mag=0):
+        assert _same(again, dix.batch_search(Q, 10))
+    _check_against_oracle(oix, again, Q, 10, np.arange(0, 1500, 23))
