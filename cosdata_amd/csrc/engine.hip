@@ -785,7 +785,7 @@ static int32_t ensure_level_table(cos_index *ix) {
     // (1M x 768, M 32: at ef 64 level 3 = 7.6 x ef x M pays, 7.53 -> 7.13 ms per 32 768 queries; at ef 256 level 2 = 7.7 x ef x M
     // costs 5.4 ms of GEMM and saves nothing, level 3 = 1.9 x pays; profiles/r04_table_level_rule_probe.jsonl).
     const bool automatic = max_cols == COS_WALK_TABLE_AUTO;
-    const u64 c_rule = ix->p.ef_search <= 64u ? 8u : 6u;
+    const u64 c_rule = (u64)cosdev::tune_or(cosdev::TUNE_WALK_TABLE_RULE_C, ix->p.ef_search <= 64u ? 8 : 6);
     const u64 per_level = automatic ? std::min<u64>(c_rule * ix->p.ef_search * ix->p.neighbors_count, 1u << 20) : (u64)(1u << 20);
     const u64 total_cap = automatic ? (u64)(1u << 20) : (u64)max_cols;
     const u64 key = automatic ? (0x8000000000000000ull | per_level) : (u64)max_cols;
@@ -1063,6 +1063,13 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
         lat4_max_B = ix->lat4_max_B;
         dev.visited_mode = ix->p.visited_mode;
     }
+    // Norms beside the adjacency (LevelDev::adj_mag) cost two more lines per window entry and save one line per winner: they pay while an
+    // expansion still finds several winners, i.e. while the level's filter (64 x M bits) is not saturated by the ef pops of the level.
+    // Measured (profiles/r06_adjmag_probe_*.jsonl): 1M x 768, M0 64 — ef 64: 7.8 evaluations per expansion, lower range 2.64 -> 2.42 ms;
+    // ef 256: 2.35 per expansion, 5.10 -> 5.31 ms; 12.5M x 1024, M0 256 / M 64, ef 128: 9.8 per expansion, 26.5 -> 24.3 ms.
+    if (cosdev::tune_or(cosdev::TUNE_WALK_ADJ_MAG, 1) != 2) // (2 = at every ef: experiments)
+        for (u32 l = 0; l <= dev.num_layers; l++)
+            if (ef > 2u * dev.lv[l].M) dev.lv[l].adj_mag = nullptr;
     WalkArgs wa;
     memset(&wa, 0, sizeof(wa));
     if (dev.visited_mode == COS_VISITED_EXACT) {

@@ -131,6 +131,12 @@ int coso_index_build(coso_index *ix);
 int coso_index_build_batched(coso_index *ix, uint32_t batch_size);
 /* prototype of the round-synchronous link schedule; stats[4] = rounds, (batch,level) pairs, nodes, first-round nodes */
 int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uint64_t *stats);
+/* index_embeddings on a LIVE index (vector_store.rs:714-780 called again; index_embedding :782-975 per vector): m more vectors take
+ * the ids [n, n + m); raw_all = the caller's whole [n + m][dim] table (borrowed).  Then coso_index_build_rounds_continue inserts them
+ * with the schedule of coso_index_build_rounds continued (same RNG stream, same batch rule); needs a graph built by
+ * coso_index_build_rounds on this handle.  CPU statement of cos_index_append (include/cosdata_hip.h). */
+int coso_index_append_vectors(coso_index *ix, const float *raw_all, uint32_t m);
+int coso_index_build_rounds_continue(coso_index *ix, uint32_t batch_size, uint64_t *stats);
 /* Flat export/import (the same arrays include/cosdata_hip.h uploads). */
 uint32_t coso_index_level_count(const coso_index *ix, uint32_t level);
 int coso_index_export_level(const coso_index *ix, uint32_t level, uint32_t *node_ids /*[n_l]*/,

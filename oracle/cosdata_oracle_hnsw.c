@@ -38,6 +38,11 @@ struct coso_index {
     float *root_raw;
     level_t *lv; /* [num_layers+1] */
     int has_root;
+    /* coso_index_build_rounds leaves what a later coso_index_build_rounds_continue needs: the RNG stream after the last level draw
+     * and how many vectors the graph holds (index_embeddings called again on a live index, vector_store.rs:714-780) */
+    uint64_t rng_state;
+    uint32_t n_built;
+    int rounds_state_valid, rounds_greedy;
     /* corpora too large for a host copy of the raw f32 table (bench.py --workload c4shard): the rerank reads the raw rows of
      * the few candidates it needs from a caller-provided subset (ids ascending) instead of ix->raw */
     const uint32_t *sub_ids;
@@ -131,6 +136,7 @@ void coso_index_destroy(coso_index *ix) {
 
 int coso_index_set_vectors(coso_index *ix, const float *raw, uint32_t n) {
     if (!ix || (!raw && n)) return COSO_ERR_INVALID;
+    ix->rounds_state_valid = 0;
     free(ix->codes); free(ix->mags);
     ix->n = n;
     ix->raw = raw;
@@ -206,6 +212,7 @@ void coso_index_set_visited_mode(coso_index *ix, uint32_t mode) { ix->p.visited_
 /* drop every level (the vectors stay): lets one quantized corpus take several imported graphs in turn */
 void coso_index_clear_graph(coso_index *ix) {
     if (!ix) return;
+    ix->rounds_state_valid = 0;
     for (uint32_t l = 0; l <= ix->p.num_layers; l++) level_free(&ix->lv[l]);
 }
 /* level_0_neighbors_count of the NEXT graph (indexes/hnsw/types.rs:10-17): also the size of the visited filter,
@@ -776,27 +783,12 @@ static int add_neighbor_deferred(level_t *L, int metric, uint32_t self, uint32_t
     return (int)lowest_idx;
 }
 
-int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uint64_t *stats) {
-    if (!ix || !ix->codes) return COSO_ERR_INVALID;
+/* the batch loop of coso_index_build_rounds for the vectors [first_row, ix->n): max_level_of[i] is the level of vector first_row + i */
+static int build_rounds_range(coso_index *ix, uint32_t first_row, uint32_t Bmax, int greedy, const uint8_t *max_level_of, uint64_t *st) {
     const uint32_t Ltop = ix->p.num_layers, L1 = Ltop + 1;
-    const uint32_t Bmax = batch_size ? batch_size : 4096u;
     const int metric = (int)ix->p.metric;
-    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
-    uint64_t st[4] = {0, 0, 0, 0};
-    for (uint32_t l = 0; l <= Ltop; l++) level_free(&ix->lv[l]);
-    for (uint32_t i = 0; i < ix->p.dim; i++) ix->root_raw[i] = ix->p.range_lo + rand_f32(&rng) * (ix->p.range_hi - ix->p.range_lo);
-    int rc = coso_index_set_root_raw(ix, ix->root_raw);
-    if (rc != COSO_OK) return rc;
-    for (uint32_t l = 0; l <= Ltop; l++) {
-        uint32_t r = level_append(&ix->lv[l], COSO_ROOT_ID, metric);
-        ix->lv[l].root_idx = r;
-        if (l > 0) ix->lv[l].child[r] = ix->lv[l - 1].root_idx;
-    }
-    double *pv = (double *)malloc(L1 * sizeof(double));
-    uint8_t *pl = (uint8_t *)malloc(L1);
-    coso_level_probs(4.0, (int)Ltop, pv, pl);
-    uint8_t *max_level = (uint8_t *)malloc(ix->n ? ix->n : 1);
-    for (uint32_t id = 0; id < ix->n; id++) max_level[id] = (uint8_t)coso_max_insert_level((double)rand_f32(&rng), pv, pl, (int)L1);
+    const uint8_t *max_level = max_level_of - first_row; /* indexed by vector row below */
+    int rc = COSO_OK;
     scratch_t *s = scratch_new(ix);
     zent *z = (zent *)malloc((size_t)Bmax * L1 * KEEP_INDEX * sizeof(zent));
     uint32_t *zn = (uint32_t *)malloc((size_t)Bmax * L1 * 4);
@@ -806,7 +798,7 @@ int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uin
     uint32_t round_id = 0;
     uint32_t *pending = (uint32_t *)malloc((size_t)Bmax * 4), *next = (uint32_t *)malloc((size_t)Bmax * 4);
     evict_t *q = (evict_t *)malloc((size_t)Bmax * 2 * KEEP_INDEX * sizeof(evict_t));
-    uint32_t inserted = 0;
+    uint32_t inserted = first_row;
     while (inserted < ix->n && rc == COSO_OK) {
         uint32_t bs = inserted / 4u;
         if (bs < 1) bs = 1;
@@ -911,9 +903,78 @@ int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uin
         }
         inserted += bs;
     }
-    if (stats) memcpy(stats, st, sizeof(st));
-    free(z); free(zn); free(me); free(max_level); free(pv); free(pl); free(claim_round); free(claim_owner); free(pending); free(next); free(q);
+    free(z); free(zn); free(me); free(claim_round); free(claim_owner); free(pending); free(next); free(q);
     scratch_free(s);
+    return rc;
+}
+
+int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uint64_t *stats) {
+    if (!ix || !ix->codes) return COSO_ERR_INVALID;
+    const uint32_t Ltop = ix->p.num_layers, L1 = Ltop + 1;
+    const uint32_t Bmax = batch_size ? batch_size : 4096u;
+    const int metric = (int)ix->p.metric;
+    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
+    uint64_t st[4] = {0, 0, 0, 0};
+    ix->rounds_state_valid = 0;
+    for (uint32_t l = 0; l <= Ltop; l++) level_free(&ix->lv[l]);
+    for (uint32_t i = 0; i < ix->p.dim; i++) ix->root_raw[i] = ix->p.range_lo + rand_f32(&rng) * (ix->p.range_hi - ix->p.range_lo);
+    int rc = coso_index_set_root_raw(ix, ix->root_raw);
+    if (rc != COSO_OK) return rc;
+    for (uint32_t l = 0; l <= Ltop; l++) {
+        uint32_t r = level_append(&ix->lv[l], COSO_ROOT_ID, metric);
+        ix->lv[l].root_idx = r;
+        if (l > 0) ix->lv[l].child[r] = ix->lv[l - 1].root_idx;
+    }
+    double *pv = (double *)malloc(L1 * sizeof(double));
+    uint8_t *pl = (uint8_t *)malloc(L1);
+    coso_level_probs(4.0, (int)Ltop, pv, pl);
+    uint8_t *max_level = (uint8_t *)malloc(ix->n ? ix->n : 1);
+    for (uint32_t id = 0; id < ix->n; id++) max_level[id] = (uint8_t)coso_max_insert_level((double)rand_f32(&rng), pv, pl, (int)L1);
+    rc = build_rounds_range(ix, 0, Bmax, greedy, max_level, st);
+    if (rc == COSO_OK) { ix->rng_state = rng; ix->n_built = ix->n; ix->rounds_state_valid = 1; ix->rounds_greedy = greedy; }
+    if (stats) memcpy(stats, st, sizeof(st));
+    free(max_level); free(pv); free(pl);
+    return rc;
+}
+
+/* index_embeddings on a LIVE index (vector_store.rs:714-780 called with a later batch of a transaction): m more vectors take the
+ * internal ids [n, n + m) (collection.rs:451-468: sequential).  raw_all is the caller's WHOLE table [n + m][dim] (rows [0, n)
+ * unchanged; borrowed like coso_index_set_vectors').  The root's code row moves behind the new rows (row_of(root) = n). */
+int coso_index_append_vectors(coso_index *ix, const float *raw_all, uint32_t m) {
+    if (!ix || !ix->codes || !raw_all || m == 0 || (uint64_t)ix->n + m >= 0xFFFFFFF0ull) return COSO_ERR_INVALID;
+    const uint32_t n0 = ix->n, n1 = n0 + m;
+    uint8_t *codes = (uint8_t *)calloc((size_t)n1 + 2, ix->cb);
+    float *mags = (float *)calloc((size_t)n1 + 2, sizeof(float));
+    if (!codes || !mags) { free(codes); free(mags); return COSO_ERR_INVALID; }
+    memcpy(codes, ix->codes, (size_t)n0 * ix->cb);
+    memcpy(mags, ix->mags, (size_t)n0 * 4);
+    memcpy(codes + (size_t)n1 * ix->cb, ix->codes + (size_t)n0 * ix->cb, 2 * ix->cb); /* root + the pseudo nodes' vector */
+    memcpy(mags + n1, ix->mags + n0, 8);
+    free(ix->codes); free(ix->mags);
+    ix->codes = codes; ix->mags = mags; ix->raw = raw_all; ix->n = n1;
+    return coso_index_quantize_rows(ix, n0, raw_all + (size_t)n0 * ix->p.dim, m);
+}
+
+/* ... and their insertion: the schedule of coso_index_build_rounds CONTINUED at inserted = the vectors already in the graph — level
+ * draws from the same RNG stream (the draws a full build would have given these ids), batches of min(batch_size, max(1,
+ * inserted / 4)) walking the snapshot that precedes them, ordered claims.  The graph equals a full build's only if the earlier
+ * build ended on one of its batch boundaries; it always equals the device's cos_index_append (builder.hip), which runs this. */
+int coso_index_build_rounds_continue(coso_index *ix, uint32_t batch_size, uint64_t *stats) {
+    if (!ix || !ix->codes || !ix->rounds_state_valid || ix->n_built > ix->n) return COSO_ERR_INVALID;
+    const uint32_t Ltop = ix->p.num_layers, L1 = Ltop + 1, first = ix->n_built, m = ix->n - first;
+    uint64_t st[4] = {0, 0, 0, 0};
+    if (m == 0) { if (stats) memcpy(stats, st, sizeof(st)); return COSO_OK; }
+    double *pv = (double *)malloc(L1 * sizeof(double));
+    uint8_t *pl = (uint8_t *)malloc(L1);
+    coso_level_probs(4.0, (int)Ltop, pv, pl);
+    uint8_t *max_level = (uint8_t *)malloc(m);
+    uint64_t rng = ix->rng_state;
+    for (uint32_t i = 0; i < m; i++) max_level[i] = (uint8_t)coso_max_insert_level((double)rand_f32(&rng), pv, pl, (int)L1);
+    ix->rounds_state_valid = 0;
+    int rc = build_rounds_range(ix, first, batch_size ? batch_size : 4096u, ix->rounds_greedy, max_level, st);
+    if (rc == COSO_OK) { ix->rng_state = rng; ix->n_built = ix->n; ix->rounds_state_valid = 1; }
+    if (stats) memcpy(stats, st, sizeof(st));
+    free(max_level); free(pv); free(pl);
     return rc;
 }
 
@@ -965,6 +1026,7 @@ static int resolve_children(coso_index *ix, uint32_t level) {
     return COSO_OK;
 }
 int coso_index_import_level(coso_index *ix, uint32_t level, uint32_t n_nodes, const uint32_t *node_ids, const uint32_t *nbr_ids) {
+    if (ix) ix->rounds_state_valid = 0; /* an imported graph has no similarities / lowest caches to continue from */
     if (level > ix->p.num_layers || n_nodes == 0) return COSO_ERR_INVALID;
     level_t *L = &ix->lv[level];
     level_free(L);

@@ -83,6 +83,8 @@ def lib():
         "coso_index_build": (C.c_int, [vp]),
         "coso_index_build_batched": (C.c_int, [vp, C.c_uint32]),
         "coso_index_build_rounds": (C.c_int, [vp, C.c_uint32, C.c_int, vp]),
+        "coso_index_append_vectors": (C.c_int, [vp, vp, C.c_uint32]),
+        "coso_index_build_rounds_continue": (C.c_int, [vp, C.c_uint32, vp]),
         "coso_index_level_count": (C.c_uint32, [vp, C.c_uint32]),
         "coso_index_export_level": (C.c_int, [vp, C.c_uint32, vp, vp, vp]),
         "coso_index_import_level": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
@@ -334,6 +336,22 @@ class OracleIndex:
         rc = lib().coso_index_build_rounds(self._h, batch_size, 1 if greedy else 0, st.ctypes.data_as(C.c_void_p))
         if rc != OK:
             raise ValueError(f"build_rounds status {rc}")
+        return self, {"rounds": int(st[0]), "batch_levels": int(st[1]), "nodes": int(st[2]), "first_round_nodes": int(st[3])}
+
+    def append(self, raw_new, batch_size=0):
+        """index_embeddings on a live index: `raw_new` [m][dim] take the ids [n, n + m) and are inserted by the rounds schedule continued
+        (needs a graph built by build_rounds on this handle); returns (self, stats dict)"""
+        x = _c(raw_new, np.float32)
+        if self._raw is None:
+            raise ValueError("append needs the raw table (set_vectors)")
+        self._raw = np.ascontiguousarray(np.concatenate([self._raw, x.reshape(-1, self._raw.shape[1])]))   # the oracle borrows the WHOLE table
+        rc = lib().coso_index_append_vectors(self._h, _p(self._raw), x.shape[0])
+        if rc != OK:
+            raise ValueError(f"append_vectors status {rc}")
+        st = np.zeros(4, np.uint64)
+        rc = lib().coso_index_build_rounds_continue(self._h, batch_size, st.ctypes.data_as(C.c_void_p))
+        if rc != OK:
+            raise ValueError(f"build_rounds_continue status {rc}")
         return self, {"rounds": int(st[0]), "batch_levels": int(st[1]), "nodes": int(st[2]), "first_round_nodes": int(st[3])}
 
     @property
