@@ -54,115 +54,78 @@ struct HostBuf {
 
 } // namespace
 
-extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
-    if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
-    if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before building");
-    int32_t rc = cos_set_device(ix);
-    if (rc) return rc;
-    const u32 n = ix->n, Ltop = ix->p.num_layers, L1 = Ltop + 1, metric = ix->p.metric;
-    const u32 Bmax = std::min<u32>(batch_size ? batch_size : 4096u, LINK_MAX_BATCH);
-    hipStream_t st = ix->own_stream;
+namespace {
 
-    // a failed build leaves the handle WITHOUT a graph (search returns NotReady) instead of a half-linked one
-    struct Guard {
-        cos_index *ix;
-        bool armed = true;
-        ~Guard() {
-            if (!armed) return;
-            (void)hipStreamSynchronize(ix->own_stream);
-            for (auto &l : ix->lv) {
-                void *ptrs[] = {l.d_adj_vec, l.d_adj_node, l.d_node_vec, l.d_child};
-                for (void *p : ptrs) if (p) (void)hipFree(p);
-                l.d_adj_vec = l.d_adj_node = l.d_node_vec = l.d_child = nullptr;
-                l.n = 0;
-                l.node_ids.clear();
-                l.nbr_ids.clear();
-                l.host_valid = false;
-            }
-            ix->have_root = false;
-        }
-    } guard{ix};
-
-    ix->order_rank_valid = false; // the order key's table follows the graph (engine.hip, ensure_order_rank)
-    ix->level_table_valid = false; // and so does the level table's operand (ensure_level_table)
-    ix->adj_mag_valid = false;     // the builder's walks gather mags[]; the adjacency-side norms are written when the graph is committed
-    // ---- root + level draws (same RNG stream as the oracle builders) ----------------------------
-    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
-    std::vector<float> root(ix->p.dim);
-    for (u32 i = 0; i < ix->p.dim; i++) root[i] = ix->p.range_lo + rand_f32(rng) * (ix->p.range_hi - ix->p.range_lo); // vector_store.rs:30-36
-    rc = cos_index_set_root(ix, root.data());
-    if (rc) return rc;
-    std::vector<double> pv(L1);
-    for (u32 k = 0; k <= Ltop; k++) { // generate_level_probs(4.0, L): 1 - 4^-n, n = L..0 (common.rs:421-429)
+// generate_level_probs(4.0, L): 1 - 4^-n, n = L..0 (common.rs:421-429), and get_max_insert_level (common.rs:373-379) for one draw
+std::vector<double> level_probs(u32 Ltop) {
+    std::vector<double> pv(Ltop + 1);
+    for (u32 k = 0; k <= Ltop; k++) {
         const int nn = (int)(Ltop - k);
         double r = 1.0, a = 4.0;
         for (int b = nn;;) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; }
         pv[k] = 1.0 - 1.0 / r;
     }
-    std::vector<uint8_t> max_level(n);
-    for (u32 id = 0; id < n; id++) {
-        const double x = (double)rand_f32(rng);
-        u32 k = 0;
-        while (k < Ltop && !(x >= pv[k])) k++; // get_max_insert_level (common.rs:373-379)
-        max_level[id] = (uint8_t)(Ltop - k);
-    }
+    return pv;
+}
+inline uint8_t draw_level(uint64_t &rng, const std::vector<double> &pv, u32 Ltop) {
+    const double x = (double)rand_f32(rng);
+    u32 k = 0;
+    while (k < Ltop && !(x >= pv[k])) k++;
+    return (uint8_t)(Ltop - k);
+}
 
-    // ---- level skeletons: nodes of a level in ascending id, root last; every slot empty ------------------------
-    u32 maxM = 0;
-    std::vector<DevBuf> key(L1), low_idx(L1), low_key(L1), owner(L1); // link state, released when the build ends
-    LinkArgs la;
-    memset(&la, 0, sizeof(la));
-    for (u32 l = 0; l <= Ltop; l++) {
-        LevelHost &H = ix->lv[l];
-        void *old[] = {H.d_adj_vec, H.d_adj_node, H.d_node_vec, H.d_child};
-        for (void *p : old) if (p) (void)hipFree(p);
-        H.d_adj_vec = H.d_adj_node = H.d_node_vec = H.d_child = nullptr;
-        H.host_valid = false;
-        H.nbr_ids.clear();
-        H.node_ids.clear();
-        for (u32 id = 0; id < n; id++)
-            if (max_level[id] >= l) H.node_ids.push_back(id * ix->id_stride); // internal id of vector row `id`
-        H.node_ids.push_back(COS_ROOT_ID);
-        const u32 nl = (u32)H.node_ids.size(), M = H.M;
-        maxM = std::max(maxM, M);
-        HIP_TRY(hipMalloc((void **)&H.d_adj_vec, (size_t)nl * M * 4));
-        HIP_TRY(hipMemsetAsync(H.d_adj_vec, 0xFF, (size_t)nl * M * 4, st));
-        if (l > 0) {
-            std::vector<u32> node_vec(nl), child(nl);
-            const std::vector<u32> &D = ix->lv[l - 1].node_ids;
-            for (u32 i = 0; i < nl; i++) {
-                node_vec[i] = H.node_ids[i] == COS_ROOT_ID ? n : H.node_ids[i] / ix->id_stride;
-                child[i] = (u32)(std::lower_bound(D.begin(), D.end(), H.node_ids[i]) - D.begin()); // same id one level down (vector_store.rs:897-903)
-            }
-            HIP_TRY(hipMalloc((void **)&H.d_adj_node, (size_t)nl * M * 4));
-            HIP_TRY(hipMemsetAsync(H.d_adj_node, 0xFF, (size_t)nl * M * 4, st));
-            HIP_TRY(hipMalloc((void **)&H.d_node_vec, (size_t)nl * 4));
-            HIP_TRY(hipMemcpy(H.d_node_vec, node_vec.data(), (size_t)nl * 4, hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc((void **)&H.d_child, (size_t)nl * 4));
-            HIP_TRY(hipMemcpy(H.d_child, child.data(), (size_t)nl * 4, hipMemcpyHostToDevice));
+// a failed build / append leaves the handle WITHOUT a graph (search returns NotReady) instead of a half-linked one
+struct GraphGuard {
+    cos_index *ix;
+    bool armed = true;
+    ~GraphGuard() {
+        if (!armed) return;
+        (void)hipStreamSynchronize(ix->own_stream);
+        for (auto &l : ix->lv) {
+            void *ptrs[] = {l.d_adj_vec, l.d_adj_node, l.d_node_vec, l.d_child, l.d_adj_mag};
+            for (void *p : ptrs) if (p) (void)hipFree(p);
+            l.d_adj_vec = l.d_adj_node = l.d_node_vec = l.d_child = nullptr;
+            l.d_adj_mag = nullptr;
+            l.n = 0;
+            l.node_ids.clear();
+            l.nbr_ids.clear();
+            l.host_valid = false;
         }
-        H.n = nl;
-        // link state: slot keys (all empty), cached lowest = (0, MetricResult::min) (prob_node.rs:140), claim tags
-        HIP_TRY(key[l].alloc((size_t)nl * M * 4));
-        HIP_TRY(low_idx[l].alloc(nl));
-        HIP_TRY(low_key[l].alloc((size_t)nl * 4));
-        HIP_TRY(owner[l].alloc((size_t)nl * 4));
-        HIP_TRY(launch_fill_i32(key[l].as<int32_t>(), (u64)nl * M, INT32_MIN, st));
-        HIP_TRY(hipMemsetAsync(low_idx[l].p, 0, nl, st));
-        HIP_TRY(launch_fill_i32(low_key[l].as<int32_t>(), nl, order_key(metric, metric_min(metric)), st));
-        HIP_TRY(hipMemsetAsync(owner[l].p, 0, (size_t)nl * 4, st));
+        ix->link.release();
+        ix->adj_mag_valid = false;
+        ix->have_root = false;
+    }
+};
+
+// LinkArgs over the handle's level arrays and link state
+void fill_link_levels(cos_index *ix, LinkArgs &la, u32 &maxM) {
+    maxM = 0;
+    for (u32 l = 0; l <= ix->p.num_layers; l++) {
+        LevelHost &H = ix->lv[l];
         LinkLevelDev &D = la.lv[l];
         D.adj_vec = H.d_adj_vec;
         D.adj_node = l == 0 ? H.d_adj_vec : H.d_adj_node;
         D.node_vec = l == 0 ? nullptr : H.d_node_vec;
-        D.key = key[l].as<int32_t>();
-        D.low_idx = low_idx[l].as<uint8_t>();
-        D.low_key = low_key[l].as<int32_t>();
-        D.owner = owner[l].as<u32>();
-        D.M = M;
+        D.key = ix->link.key[l].as<int32_t>();
+        D.low_idx = ix->link.low_idx[l].as<uint8_t>();
+        D.low_key = ix->link.low_key[l].as<int32_t>();
+        D.owner = ix->link.owner[l].as<u32>();
+        D.M = H.M;
+        maxM = std::max(maxM, H.M);
     }
+}
+
+// The batch loop of index_embeddings for the vectors [first, ix->n): batches of min(Bmax, max(1, inserted / 4)) ids run the reference
+// walk against the snapshot that precedes the batch, then the round-synchronous link kernels connect them.  max_level is indexed by
+// vector row - first; cursor[l] = the node index the next inserted vector takes on level l (nodes are in id order, the root last).
+int32_t run_batches(cos_index *ix, u32 first, const uint8_t *max_level, std::vector<u32> &cursor, u32 Bmax) {
+    const u32 n = ix->n, Ltop = ix->p.num_layers, L1 = Ltop + 1, metric = ix->p.metric;
+    hipStream_t st = ix->own_stream;
+    LinkArgs la;
+    memset(&la, 0, sizeof(la));
+    u32 maxM = 0;
+    fill_link_levels(ix, la, maxM);
     if (maxM > 256) return cos_fail(COS_ERR_UNIMPLEMENTED, "more than 256 neighbour slots per node");
-    HIP_TRY(hipStreamSynchronize(st));
 
     // ---- batch workspace (device) + pinned staging -----------------------------------------------------------
     const u32 KEEP = (u32)KEEP_INDEX;
@@ -199,8 +162,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     la.kmax = order_key(metric, metric_max(metric));
 
     IndexDev dev = cos_make_index_dev(ix);
-    std::vector<u32> cursor(L1, 0); // first node of each level not yet inserted (nodes are in id order)
-    u32 inserted = 0, round = 0;
+    u32 inserted = first, round = 0;
     u64 n_rounds = 0, n_batches = 0;
     const bool prof = cosdev::tune_or(cosdev::TUNE_BUILD_PROFILE, 0) != 0;
     double t_walk = 0, t_link = 0;
@@ -217,7 +179,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
             h_rows.as<u32>()[b] = id;
             for (u32 l = 0; l <= Ltop; l++) {
                 u32 m = NONE;
-                if (max_level[id] >= l) { m = cursor[l]++; h_pend.as<u32>()[np++] = (l << 16) | b; }
+                if (max_level[id - first] >= l) { m = cursor[l]++; h_pend.as<u32>()[np++] = (l << 16) | b; }
                 h_me.as<u32>()[(size_t)b * L1 + l] = m;
             }
         }
@@ -260,7 +222,7 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
             const u32 chunk = pending_ub > 64 ? 2 : 4;
             for (u32 r = 0; r < chunk; r++) {
                 if (++round > LINK_MAX_ROUND) { // claim tags would wrap: start a new tag epoch
-                    for (u32 l = 0; l <= Ltop; l++) HIP_TRY(hipMemsetAsync(owner[l].p, 0, (size_t)ix->lv[l].n * 4, st));
+                    for (u32 l = 0; l <= Ltop; l++) HIP_TRY(hipMemsetAsync(ix->link.owner[l].p, 0, (size_t)ix->lv[l].n * 4, st));
                     round = 1;
                 }
                 HIP_TRY(launch_link_round(la, maxM, d_pend[cur].as<u32>(), cnt + cur, d_pend[cur ^ 1].as<u32>(), cnt + (cur ^ 1), d_evq.as<u32>(), cnt + 2,
@@ -277,11 +239,243 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     }
     HIP_TRY(hipStreamSynchronize(st));
     if (prof)
-        fprintf(stderr, "[cos_index_build] n=%u batches=%llu link rounds=%llu walk %.2fs link %.2fs\n", n, (unsigned long long)n_batches,
+        fprintf(stderr, "[cos_index_build] vectors [%u, %u) batches=%llu link rounds=%llu walk %.2fs link %.2fs\n", first, n, (unsigned long long)n_batches,
                 (unsigned long long)n_rounds, t_walk, t_link);
+    return COS_OK;
+}
+
+} // namespace
+
+extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
+    if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before building");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    const u32 n = ix->n, Ltop = ix->p.num_layers, metric = ix->p.metric;
+    const u32 Bmax = std::min<u32>(batch_size ? batch_size : 4096u, LINK_MAX_BATCH);
+    hipStream_t st = ix->own_stream;
+    GraphGuard guard{ix};
+
+    ix->order_rank_valid = false; // the order key's table follows the graph (engine.hip, ensure_order_rank)
+    ix->level_table_valid = false; // and so does the level table's operand (ensure_level_table)
+    ix->adj_mag_valid = false;     // the builder's walks gather mags[]; the adjacency-side norms are written when the graph is committed
+    ix->link.release();
+    // ---- root + level draws (same RNG stream as the oracle builders) ----------------------------
+    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
+    std::vector<float> root(ix->p.dim);
+    for (u32 i = 0; i < ix->p.dim; i++) root[i] = ix->p.range_lo + rand_f32(rng) * (ix->p.range_hi - ix->p.range_lo); // vector_store.rs:30-36
+    rc = cos_index_set_root(ix, root.data());
+    if (rc) return rc;
+    const std::vector<double> pv = level_probs(Ltop);
+    std::vector<uint8_t> max_level(n);
+    for (u32 id = 0; id < n; id++) max_level[id] = draw_level(rng, pv, Ltop);
+
+    // ---- level skeletons: nodes of a level in ascending id, root last; every slot empty ------------------------
+    for (u32 l = 0; l <= Ltop; l++) {
+        LevelHost &H = ix->lv[l];
+        void *old[] = {H.d_adj_vec, H.d_adj_node, H.d_node_vec, H.d_child, H.d_adj_mag};
+        for (void *p : old) if (p) (void)hipFree(p);
+        H.d_adj_vec = H.d_adj_node = H.d_node_vec = H.d_child = nullptr;
+        H.d_adj_mag = nullptr;
+        H.host_valid = false;
+        H.nbr_ids.clear();
+        H.node_ids.clear();
+        for (u32 id = 0; id < n; id++)
+            if (max_level[id] >= l) H.node_ids.push_back(id * ix->id_stride); // internal id of vector row `id`
+        H.node_ids.push_back(COS_ROOT_ID);
+        const u32 nl = (u32)H.node_ids.size(), M = H.M;
+        if (M > 256) return cos_fail(COS_ERR_UNIMPLEMENTED, "more than 256 neighbour slots per node");
+        HIP_TRY(hipMalloc((void **)&H.d_adj_vec, (size_t)nl * M * 4));
+        HIP_TRY(hipMemsetAsync(H.d_adj_vec, 0xFF, (size_t)nl * M * 4, st));
+        if (l > 0) {
+            std::vector<u32> node_vec(nl), child(nl);
+            const std::vector<u32> &D = ix->lv[l - 1].node_ids;
+            for (u32 i = 0; i < nl; i++) {
+                node_vec[i] = H.node_ids[i] == COS_ROOT_ID ? n : H.node_ids[i] / ix->id_stride;
+                child[i] = (u32)(std::lower_bound(D.begin(), D.end(), H.node_ids[i]) - D.begin()); // same id one level down (vector_store.rs:897-903)
+            }
+            HIP_TRY(hipMalloc((void **)&H.d_adj_node, (size_t)nl * M * 4));
+            HIP_TRY(hipMemsetAsync(H.d_adj_node, 0xFF, (size_t)nl * M * 4, st));
+            HIP_TRY(hipMalloc((void **)&H.d_node_vec, (size_t)nl * 4));
+            HIP_TRY(hipMemcpy(H.d_node_vec, node_vec.data(), (size_t)nl * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void **)&H.d_child, (size_t)nl * 4));
+            HIP_TRY(hipMemcpy(H.d_child, child.data(), (size_t)nl * 4, hipMemcpyHostToDevice));
+        }
+        H.n = nl;
+        // link state: slot keys (all empty), cached lowest = (0, MetricResult::min) (prob_node.rs:140), claim tags
+        HIP_TRY(ix->link.key[l].alloc((size_t)nl * M * 4));
+        HIP_TRY(ix->link.low_idx[l].alloc(nl));
+        HIP_TRY(ix->link.low_key[l].alloc((size_t)nl * 4));
+        HIP_TRY(ix->link.owner[l].alloc((size_t)nl * 4));
+        HIP_TRY(launch_fill_i32(ix->link.key[l].as<int32_t>(), (u64)nl * M, INT32_MIN, st));
+        HIP_TRY(hipMemsetAsync(ix->link.low_idx[l].p, 0, nl, st));
+        HIP_TRY(launch_fill_i32(ix->link.low_key[l].as<int32_t>(), nl, order_key(metric, metric_min(metric)), st));
+        HIP_TRY(hipMemsetAsync(ix->link.owner[l].p, 0, (size_t)nl * 4, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+
+    std::vector<u32> cursor(Ltop + 1, 0); // first node of each level not yet inserted (nodes are in id order)
+    rc = run_batches(ix, 0, max_level.data(), cursor, Bmax);
+    if (rc) return rc;
     guard.armed = false;
+    ix->link.rng = rng;
+    ix->link.n_built = n;
+    ix->link.valid = ix->id_stride == 1u; // (collections with a metadata schema reserve ids per embedding: not appendable here)
     if (int32_t rc2 = cos_prepare_walk_plans(ix)) return rc2; // order ranks + level-table operand of the new graph, outside any search
     return COS_OK; // the id-format host copy is made on demand (cos_index_download_graph_level)
+}
+
+extern "C" int32_t cos_index_release_link_state(cos_index *ix) {
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ix->own_stream));
+    ix->link.release();
+    return COS_OK;
+}
+
+// vector_store::index_embeddings called AGAIN on a live index (vector_store.rs:714-780; index_embedding :782-975 per vector): m more
+// vectors take the internal ids [n, n + m) (sequential: collection.rs:451-468) and are inserted into the resident graph by the
+// schedule of cos_index_build CONTINUED at inserted = n — level draws from the same RNG stream, batches of min(batch, max(1,
+// inserted / 4)) walking the snapshot that precedes them, the round-synchronous link kernels on the link state cos_index_build left
+// (slot similarities and lowest caches of EVERY node: a new vector's back edges evict from old nodes' rows).  oracle/
+// cosdata_oracle_hnsw.c: coso_index_append_vectors + coso_index_build_rounds_continue is the CPU statement; tests/test_gpu_append.py
+// asserts identical graphs.  Exclusive like every graph change: no search in flight.
+extern "C" int32_t cos_index_append(cos_index *ix, const float *raw, uint32_t m, uint32_t flags, uint32_t batch_size) {
+    if (!ix || !raw || m == 0) return cos_fail(COS_ERR_INVALID, "null/empty vectors");
+    if (!ix->have_vectors || !ix->have_root) return cos_fail(COS_ERR_NOT_READY, "append needs a built index");
+    for (auto &l : ix->lv) if (l.n == 0) return cos_fail(COS_ERR_NOT_READY, "append needs a built index");
+    if (!ix->link.valid || ix->link.n_built != ix->n)
+        return cos_fail(COS_ERR_NOT_READY, "no link state to continue from: the graph was uploaded (not built by cos_index_build on this handle), its root "
+                                           "was replaced, or cos_index_release_link_state freed it");
+    if (ix->id_stride != 1u || ix->meta.mdim != 0u) return cos_fail(COS_ERR_UNIMPLEMENTED, "append on a collection with a metadata schema");
+    if ((u64)ix->n + m >= 0xFFFFFFF0ull) return cos_fail(COS_ERR_INVALID, "too many vectors");
+    const bool borrow = (flags & COS_UPLOAD_BORROW_DEVICE) != 0;
+    if (borrow != ix->raw_borrowed)
+        return cos_fail(COS_ERR_INVALID, borrow ? "the index owns its raw rows: append host rows" : "the index borrows its raw rows: append with COS_UPLOAD_BORROW_DEVICE and the whole grown table");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    const u32 n0 = ix->n, n1 = n0 + m, Ltop = ix->p.num_layers, metric = ix->p.metric;
+    const u32 Bmax = std::min<u32>(batch_size ? batch_size : 4096u, LINK_MAX_BATCH);
+    const u64 dim = ix->p.dim, rs = ix->row_stride;
+    hipStream_t st = ix->own_stream;
+    HIP_TRY(hipDeviceSynchronize()); // exclusive: whatever read the old arrays is done
+    GraphGuard guard{ix};
+    ix->order_rank_valid = false;
+    ix->level_table_valid = false;
+    ix->adj_mag_valid = false;
+    ix->link.valid = false; // until the append is complete
+    cos_flat_ws_release(ix); // cached sums of the stored codes, scan buffers sized for the old corpus
+
+    // ---- 1. the vector tables grow: rows [0, n0) stay, rows [n0, n1) are the new vectors, the root and the pseudo nodes' vector move behind them
+    {
+        uint8_t *codes = nullptr;
+        float *mags = nullptr, *raw_mags = nullptr, *new_raw = nullptr;
+        struct Tmp { void **p[4]; ~Tmp() { for (auto q : p) if (q && *q) (void)hipFree(*q); } } tmp{{(void **)&codes, (void **)&mags, (void **)&raw_mags, (void **)&new_raw}};
+        HIP_TRY(hipMalloc((void **)&codes, ((size_t)n1 + 2) * rs));
+        HIP_TRY(hipMalloc((void **)&mags, ((size_t)n1 + 2) * 4));
+        HIP_TRY(hipMalloc((void **)&raw_mags, ((size_t)n1 + 2) * 4));
+        HIP_TRY(hipMemcpyAsync(codes, ix->d_codes, (size_t)n0 * rs, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(codes + (size_t)n1 * rs, ix->d_codes + (size_t)n0 * rs, 2 * rs, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(mags, ix->d_mags, (size_t)n0 * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(mags + n1, ix->d_mags + n0, 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(raw_mags, ix->d_raw_mags, (size_t)n0 * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemsetAsync(raw_mags + n1, 0, 8, st));
+        const float *new_rows;
+        if (borrow) {
+            new_rows = raw + (size_t)n0 * dim; // raw = the caller's whole grown table (device)
+        } else {
+            HIP_TRY(hipMalloc((void **)&new_raw, (size_t)n1 * dim * 4));
+            HIP_TRY(hipMemcpyAsync(new_raw, ix->d_raw, (size_t)n0 * dim * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(new_raw + (size_t)n0 * dim, raw, (size_t)m * dim * 4, hipMemcpyHostToDevice, st));
+            new_rows = new_raw + (size_t)n0 * dim;
+        }
+        HIP_TRY(launch_quantize_rows(ix->eng, new_rows, dim, m, ix->p.dim, ix->p.range_lo, ix->p.range_hi, codes + (size_t)n0 * rs, rs, mags + n0, raw_mags + n0, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::swap(codes, ix->d_codes);
+        std::swap(mags, ix->d_mags);
+        std::swap(raw_mags, ix->d_raw_mags);
+        if (borrow) ix->d_raw = const_cast<float *>(raw);
+        else std::swap(new_raw, ix->d_raw);
+        ix->n = n1; // (tmp frees the old arrays)
+    }
+
+    // ---- 2. level draws of the new ids: the draws a full build would have given them
+    uint64_t rng = ix->link.rng;
+    const std::vector<double> pv = level_probs(Ltop);
+    std::vector<uint8_t> max_level(m);
+    for (u32 i = 0; i < m; i++) max_level[i] = draw_level(rng, pv, Ltop);
+
+    // ---- 3. every level grows: the new nodes (ascending id) go between the old nodes and the root, every slot empty; references to
+    //         the root (vector row n0 -> n1, node index nl - 1 -> nl' - 1) are rewritten
+    std::vector<u32> cursor(Ltop + 1, 0);
+    std::vector<u32> add(Ltop + 1, 0);
+    for (u32 l = 0; l <= Ltop; l++)
+        for (u32 i = 0; i < m; i++) add[l] += max_level[i] >= l ? 1u : 0u;
+    for (u32 l = 0; l <= Ltop; l++) {
+        LevelHost &H = ix->lv[l];
+        const u32 nl0 = H.n, nl1 = nl0 + add[l], M = H.M;
+        cursor[l] = nl0 - 1; // the first new node takes the root's old index
+        H.node_ids.pop_back();
+        for (u32 i = 0; i < m; i++) if (max_level[i] >= l) H.node_ids.push_back(n0 + i);
+        H.node_ids.push_back(COS_ROOT_ID);
+        H.host_valid = false;
+        H.nbr_ids.clear();
+        if (H.d_adj_mag) { (void)hipFree(H.d_adj_mag); H.d_adj_mag = nullptr; }
+        u32 *adj_vec = nullptr, *adj_node = nullptr, *node_vec = nullptr, *child = nullptr;
+        DevBuf key, low_idx, low_key;
+        struct Tmp { void **p[4]; ~Tmp() { for (auto q : p) if (q && *q) (void)hipFree(*q); } } tmp{{(void **)&adj_vec, (void **)&adj_node, (void **)&node_vec, (void **)&child}};
+        HIP_TRY(hipMalloc((void **)&adj_vec, (size_t)nl1 * M * 4));
+        HIP_TRY(launch_grow_rows(H.d_adj_vec, adj_vec, nl0, nl1, M, n0, n1, ROW_EMPTY, st)); // vector rows: the root is row n
+        if (l > 0) {
+            HIP_TRY(hipMalloc((void **)&adj_node, (size_t)nl1 * M * 4));
+            HIP_TRY(launch_grow_rows(H.d_adj_node, adj_node, nl0, nl1, M, nl0 - 1, nl1 - 1, ROW_EMPTY, st)); // node indices: the root is the last node
+            // node -> vector row and node -> node one level down: old nodes keep theirs, the root's follow it, the new nodes' are known
+            std::vector<u32> nv(add[l] + 1), ch(add[l] + 1);
+            const u32 below0 = ix->lv[l - 1].n - add[l - 1] - 1; // first new node index one level down (level l - 1 has grown already)
+            u32 k = 0, kb = 0;
+            for (u32 i = 0; i < m; i++) {
+                if (max_level[i] >= l) { nv[k] = n0 + i; ch[k] = below0 + kb; k++; }
+                if (max_level[i] >= l - 1) kb++;
+            }
+            nv[k] = n1;                       // the root's vector row
+            ch[k] = ix->lv[l - 1].n - 1;      // ... and its node one level down
+            HIP_TRY(hipMalloc((void **)&node_vec, (size_t)nl1 * 4));
+            HIP_TRY(hipMalloc((void **)&child, (size_t)nl1 * 4));
+            HIP_TRY(hipMemcpyAsync(node_vec, H.d_node_vec, (size_t)(nl0 - 1) * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(child, H.d_child, (size_t)(nl0 - 1) * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpy(node_vec + (nl0 - 1), nv.data(), nv.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(child + (nl0 - 1), ch.data(), ch.size() * 4, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(key.alloc((size_t)nl1 * M * 4));
+        HIP_TRY(low_idx.alloc(nl1));
+        HIP_TRY(low_key.alloc((size_t)nl1 * 4));
+        HIP_TRY(launch_grow_rows(ix->link.key[l].as<u32>(), key.as<u32>(), nl0, nl1, M, 0xFFFFFFFFu, 0xFFFFFFFFu, (u32)INT32_MIN, st));
+        HIP_TRY(launch_grow_rows(ix->link.low_key[l].as<u32>(), low_key.as<u32>(), nl0, nl1, 1, 0xFFFFFFFFu, 0xFFFFFFFFu, (u32)order_key(metric, metric_min(metric)), st));
+        HIP_TRY(launch_grow_bytes(ix->link.low_idx[l].as<uint8_t>(), low_idx.as<uint8_t>(), nl0, nl1, st));
+        HIP_TRY(ix->link.owner[l].alloc((size_t)nl1 * 4));
+        HIP_TRY(hipMemsetAsync(ix->link.owner[l].p, 0, (size_t)nl1 * 4, st)); // a new tag epoch (run_batches starts at round 1)
+        HIP_TRY(hipStreamSynchronize(st));
+        std::swap(adj_vec, H.d_adj_vec);
+        std::swap(adj_node, H.d_adj_node);
+        std::swap(node_vec, H.d_node_vec);
+        std::swap(child, H.d_child);
+        std::swap(key.p, ix->link.key[l].p);
+        std::swap(low_idx.p, ix->link.low_idx[l].p);
+        std::swap(low_key.p, ix->link.low_key[l].p);
+        H.n = nl1; // (tmp / the DevBufs free the old arrays)
+    }
+    // child links INTO a level that grew: level l's root entry was written above; the old nodes' children are old nodes (unchanged)
+
+    // ---- 4. the new vectors, batch by batch
+    rc = run_batches(ix, n0, max_level.data(), cursor, Bmax);
+    if (rc) return rc;
+    guard.armed = false;
+    ix->link.rng = rng;
+    ix->link.n_built = n1;
+    ix->link.valid = true;
+    if (int32_t rc2 = cos_prepare_walk_plans(ix)) return rc2;
+    return COS_OK;
 }
 
 // ================================================================================================================================

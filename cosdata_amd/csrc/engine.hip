@@ -291,6 +291,7 @@ extern "C" int32_t cos_index_upload_vectors(cos_index *ix, const float *raw, uin
     ix->order_rank_valid = false;
     ix->level_table_valid = false;
     ix->adj_mag_valid = false;
+    ix->link.release();
     reset_meta(ix);                       // ... and so do the pseudo-root component, its node table and the id stride
     const u64 dim = ix->p.dim;
     struct Rollback { // a failed upload leaves the handle empty instead of half-populated
@@ -351,6 +352,7 @@ extern "C" int32_t cos_index_set_root(cos_index *ix, const float *root_raw) {
     // second set_root on a live graph would leave stale (the row levels would use the new row) — the next search regathers
     ix->level_table_valid = false;
     ix->adj_mag_valid = false; // ... and the adjacency-side norms hold the old root's |v| wherever the root is a neighbour
+    if (ix->link.valid && graph_ready(ix)) ix->link.release(); // the slot similarities of edges to the root were computed with the old root
     return COS_OK;
 }
 
@@ -394,6 +396,7 @@ static int32_t push_level_to_device(cos_index *ix, u32 level) {
     ix->order_rank_valid = false; // the order key's table follows the graph (ensure_order_rank)
     ix->level_table_valid = false;
     ix->adj_mag_valid = false;
+    ix->link.release();           // an uploaded level carries no slot similarities / lowest caches to continue from
     return COS_OK;
 }
 
@@ -780,12 +783,18 @@ static int32_t ensure_level_table(cos_index *ix) {
     // while n < ~40 x that.  Measured on both ends — 1M x 768 at ef 64, M 32: level 4 (3 917 nodes) pays, level 3 (15 570) does not;
     // one 12.5M x 1024 shard at ef 128, M 64: level 5 (12 225) +24 % QPS, level 4 (48 870) another +17 %, both far above a fixed
     // 8 192 columns (profiles/r04_c4_table_cols_probe.jsonl) — the automatic rule is n_level <= c x ef_search x neighbors_count, level
-    // by level from the top; an explicit max_cols caps the columns of all table levels together instead.  c = 8 up to ef 64 and 6
-    // above: the wider pools of ef > 64 make a walk spend its time ranking and inserting, so a row it does not fetch saves less
+    // by level from the top; an explicit max_cols caps the columns of all table levels together instead.  Round 4-5: c = 8 up to ef 64
+    // and 6 above: the wider pools of ef > 64 make a walk spend its time ranking and inserting, so a row it does not fetch saves less
     // (1M x 768, M 32: at ef 64 level 3 = 7.6 x ef x M pays, 7.53 -> 7.13 ms per 32 768 queries; at ef 256 level 2 = 7.7 x ef x M
     // costs 5.4 ms of GEMM and saves nothing, level 3 = 1.9 x pays; profiles/r04_table_level_rule_probe.jsonl).
     const bool automatic = max_cols == COS_WALK_TABLE_AUTO;
-    const u64 c_rule = (u64)cosdev::tune_or(cosdev::TUNE_WALK_TABLE_RULE_C, ix->p.ef_search <= 64u ? 8 : 6);
+    // Round 6 (profiles/r06_rule_probe_*.jsonl): what decides is how many rows an expansion still evaluates, i.e. how far the level's
+    // filter (64 x M bits) is from saturation after ef pops — ef relative to M, not ef alone.  12.5M x 1024 with M 64: level 4 (48 870
+    // nodes) at ef 80 / 96 / 112 (9.5 / 8.0 / 6.8 x ef x M) +25 % / +25 % / +25 % QPS, 14 evaluations per expansion; 1M x 768 with M 32:
+    // level 2 (62 869 nodes) at ef 128 / 256 (15.3 / 7.7 x) -20 % / -15 %, 3-5 evaluations per expansion.  c = 10 up to ef = 1.5 M, 8 up
+    // to 2 M, 6 above (M 32: the old rule — 8 up to ef 64, 6 above — except c = 10 up to ef 48).
+    const u32 efs = ix->p.ef_search, Mup = ix->p.neighbors_count;
+    const u64 c_rule = (u64)cosdev::tune_or(cosdev::TUNE_WALK_TABLE_RULE_C, 2u * efs <= 3u * Mup ? 10 : (efs <= 2u * Mup ? 8 : 6));
     const u64 per_level = automatic ? std::min<u64>(c_rule * ix->p.ef_search * ix->p.neighbors_count, 1u << 20) : (u64)(1u << 20);
     const u64 total_cap = automatic ? (u64)(1u << 20) : (u64)max_cols;
     const u64 key = automatic ? (0x8000000000000000ull | per_level) : (u64)max_cols;

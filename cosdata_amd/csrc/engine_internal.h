@@ -17,6 +17,8 @@
 
 namespace cosdev {
 hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st);
+hipError_t launch_grow_rows(const u32 *src, u32 *dst, u32 old_n, u32 new_n, u32 M, u32 remap_from, u32 remap_to, u32 fill, hipStream_t st);
+hipError_t launch_grow_bytes(const uint8_t *src, uint8_t *dst, u32 old_n, u32 new_n, hipStream_t st);
 hipError_t launch_fill_adj_mag(const u32 *adj_vec, const float *mags, float *adj_mag, u32 n, u32 M, u32 slots, hipStream_t st);
 hipError_t launch_link_round(const LinkArgs &a, u32 maxM, const u32 *pend, const u32 *pcount, u32 *next, u32 *next_count, u32 *evq, u32 *evq_count,
                              u32 count_ub, u32 round, hipStream_t st);
@@ -73,7 +75,8 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    hipError_t alloc(size_t bytes) { release(); return hipMalloc(&p, bytes ? bytes : 1); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
     template <typename T> T *as() const { return (T *)p; }
 };
 
@@ -89,6 +92,21 @@ struct LevelHost {
     u32 n = 0, M = 0;
     u32 root_idx = 0;        // pseudo-root component: node index of the pseudo root (base graph: the root is the last node)
     bool host_valid = false; // node_ids/nbr_ids mirror the device arrays
+};
+
+// What cos_index_build leaves behind so that cos_index_append can CONTINUE it (builder.hip): the link state of every level — the
+// similarity key of every neighbour slot and every node's cached (lowest index, lowest similarity), prob_node.rs:108, which is
+// history (remove_neighbor_by_id does not refresh it) and cannot be recomputed from the graph —, the RNG stream after the last level
+// draw, and how many vectors the graph holds.  As large as the adjacency itself; cos_index_release_link_state frees it.
+struct LinkState {
+    DevBuf key[cosdev::MAX_LEVELS], low_idx[cosdev::MAX_LEVELS], low_key[cosdev::MAX_LEVELS], owner[cosdev::MAX_LEVELS];
+    uint64_t rng = 0;
+    u32 n_built = 0;
+    bool valid = false;
+    void release() {
+        for (int l = 0; l < cosdev::MAX_LEVELS; l++) { key[l].release(); low_idx[l].release(); low_key[l].release(); owner[l].release(); }
+        valid = false;
+    }
 };
 
 // EXACT-mode visited filters of one stream (WalkArgs::vis_bits / vis_log).  The bitset is zeroed once, when it is
@@ -229,6 +247,7 @@ struct cos_index {
     u32 walk_table_max_cols = COS_WALK_TABLE_AUTO, walk_table_min_B = COS_WALK_TABLE_DEFAULT_MIN_B;
     size_t table_bytes_total = 0;    // tables held by this handle's workspaces (budget: get_workspace)
     bool adj_mag_valid = false;      // LevelHost::d_adj_mag follows the graph, the norms and the root (ensure_adj_mags)
+    LinkState link;                  // cos_index_build -> cos_index_append (builder.hip); dropped with the graph
     bool level_table_valid = false;  // the arrays below follow the graph and walk_table_max_cols
     u32 table_level_min = 0, table_cols = 0;
     u64 table_built_for_key = 0;    // max_cols, or the automatic rule's per-level bound: a change rebuilds the operand

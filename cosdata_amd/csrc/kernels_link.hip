@@ -355,6 +355,25 @@ __global__ void fill_i32_kernel(int32_t *p, u64 n, int32_t v) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// cos_index_append (builder.hip): a level's [n][M] array grows.  Rows [0, old_n - 1) keep their place, the LAST old row (the root) becomes
+// the last new row, the rows between (the new nodes) are filled; a value equal to remap_from (a reference to the root) becomes remap_to.
+__global__ void grow_rows_kernel(const u32 *__restrict__ src, u32 *__restrict__ dst, u32 old_n, u32 new_n, u32 M, u32 remap_from, u32 remap_to, u32 fill) {
+    const u64 total = (u64)new_n * M;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 row = i / M;
+        const u32 col = (u32)(i - row * M);
+        u32 v = fill;
+        if (row + 1 < old_n) v = src[row * M + col];
+        else if (row + 1 == new_n) v = src[(u64)(old_n - 1) * M + col];
+        else { dst[i] = fill; continue; }
+        dst[i] = v == remap_from ? remap_to : v;
+    }
+}
+__global__ void grow_bytes_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, u32 old_n, u32 new_n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < new_n; i += (u64)gridDim.x * blockDim.x)
+        dst[i] = i + 1 < old_n ? src[i] : (i + 1 == new_n ? src[old_n - 1] : (uint8_t)0);
+}
+
 // LevelDev::adj_mag (engine_types.h): the norm of every scanned neighbour slot, next to the adjacency.  slots is a power of two
 // (min of two powers of two) or the shortlist size: plain division.
 __global__ void fill_adj_mag_kernel(const u32 *__restrict__ adj_vec, const float *__restrict__ mags, float *__restrict__ adj_mag, u64 total, u32 M, u32 slots) {
@@ -374,6 +393,20 @@ hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st) {
     if (n == 0) return hipSuccess;
     const u32 blocks = (u32)std::min<u64>((n + 255) / 256, 65535);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks), dim3(256), 0, st, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_grow_rows(const u32 *src, u32 *dst, u32 old_n, u32 new_n, u32 M, u32 remap_from, u32 remap_to, u32 fill, hipStream_t st) {
+    const u64 total = (u64)new_n * M;
+    if (total == 0 || old_n == 0) return hipErrorInvalidValue;
+    const u32 blocks = (u32)std::min<u64>((total + 255) / 256, 1u << 20);
+    hipLaunchKernelGGL(grow_rows_kernel, dim3(blocks), dim3(256), 0, st, src, dst, old_n, new_n, M, remap_from, remap_to, fill);
+    return hipGetLastError();
+}
+hipError_t launch_grow_bytes(const uint8_t *src, uint8_t *dst, u32 old_n, u32 new_n, hipStream_t st) {
+    if (new_n == 0 || old_n == 0) return hipErrorInvalidValue;
+    const u32 blocks = (u32)std::min<u64>(((u64)new_n + 255) / 256, 1u << 20);
+    hipLaunchKernelGGL(grow_bytes_kernel, dim3(blocks), dim3(256), 0, st, src, dst, old_n, new_n);
     return hipGetLastError();
 }
 

@@ -226,6 +226,29 @@ class HNSWIndex:
         check(_lib.lib().cos_index_build(self._h, batch_size))
         return self
 
+    def append(self, raw_new, batch_size: int = 0):
+        """vector_store::index_embeddings on a LIVE index (cos_index_append): `raw_new` [m][dim] take the ids [n, n + m) and are inserted
+        into the resident graph — the schedule of build() continued, no rebuild.  For an index that owns its raw rows (upload_vectors)."""
+        x = _c(np.atleast_2d(raw_new), np.float32)
+        if x.ndim != 2 or x.shape[1] != self.dim or x.shape[0] == 0:
+            raise CosdataError(_lib.ERR_INVALID, f"new vectors must be [m][{self.dim}] f32, got shape {tuple(x.shape)}")
+        check(_lib.lib().cos_index_append(self._h, _p(x), x.shape[0], 0, batch_size))
+        self.n += x.shape[0]
+        return self
+
+    def append_device(self, dev_ptr_all: int, m: int, batch_size: int = 0, keepalive=None):
+        """the same for an index that BORROWS its raw rows (upload_vectors_device): `dev_ptr_all` = the caller's whole grown table
+        [n + m][dim] in HBM (rows [0, n) unchanged), borrowed from now on"""
+        check(_lib.lib().cos_index_append(self._h, C.c_void_p(dev_ptr_all), m, 1, batch_size))
+        self.n += m
+        self._keepalive = keepalive
+        return self
+
+    def release_link_state(self):
+        """frees what build() keeps for append() (4 bytes per neighbour slot); append() then fails with NotReady"""
+        check(_lib.lib().cos_index_release_link_state(self._h))
+        return self
+
     # ---- search -----------------------------------------------------------------------------
     def set_ef_search(self, ef: int):
         check(_lib.lib().cos_index_set_ef_search(self._h, ef))

@@ -152,6 +152,21 @@ int32_t cos_reference_dir_read_level(const char *dense_hnsw_dir, uint32_t num_la
 /* vector_store::index_embeddings (vector_store.rs:714) on the device: builds every level for the
  * uploaded vectors with the reference's edge semantics, batch-synchronously. */
 int32_t cos_index_build(cos_index *ix, uint32_t batch_size);
+/* vector_store::index_embeddings called AGAIN on a live index (vector_store.rs:714-780; index_embedding :782-975 per vector): m more
+ * vectors take the internal ids [n, n + m) (sequential: collection.rs:451-468) and are inserted into the RESIDENT graph — no rebuild —
+ * by the schedule of cos_index_build continued at inserted = n: level draws from the same RNG stream (the draws a full build would
+ * have given these ids), batches of min(batch_size, max(1, inserted / 4)) walking the snapshot that precedes them, the link kernels on
+ * the link state cos_index_build left on the handle (similarity of every neighbour slot + every node's cached lowest slot,
+ * prob_node.rs:108).  The graph equals a full build's when the earlier build ended on one of its batch boundaries, and always the
+ * oracle's coso_index_append_vectors + coso_index_build_rounds_continue.
+ *   raw, flags = 0:                        HOST pointer to the m new rows [m][dim]; the index owns its raw rows
+ *   raw, flags = COS_UPLOAD_BORROW_DEVICE: DEVICE pointer to the caller's WHOLE grown table [n + m][dim] (rows [0, n) unchanged), borrowed
+ *                                          from now on — for an index whose rows were uploaded with the same flag
+ * COS_ERR_NOT_READY: no graph, or no link state to continue from (the graph was uploaded, its root replaced, or the state released).
+ * Exclusive like every graph change (no search in flight); a failed append leaves the handle without a graph. */
+int32_t cos_index_append(cos_index *ix, const float *raw, uint32_t m, uint32_t flags, uint32_t batch_size /* 0 = 4096 */);
+/* frees the link state (as large as the adjacency: 4 bytes per neighbour slot); cos_index_append then returns COS_ERR_NOT_READY */
+int32_t cos_index_release_link_state(cos_index *ix);
 
 /* ---- search --------------------------------------------------------------------------------- */
 /* IndexOps::batch_search -> HNSWIndex::search_internal (indexes/mod.rs:260, indexes/hnsw/mod.rs:390):

@@ -1,0 +1,112 @@
+"""GPU: cos_index_append — vector_store::index_embeddings called again on a live index (vector_store.rs:714-780, index_embedding
+:782-975): the new vectors are inserted into the RESIDENT graph by the schedule of cos_index_build continued.  The oracle's
+coso_index_append_vectors + coso_index_build_rounds_continue is the CPU statement: per-level adjacency must be identical, slot for slot."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_graph(a, b):
+    assert len(a) == len(b)
+    for l, ((ia, na), (ib, nb)) in enumerate(zip(a, b)):
+        assert np.array_equal(ia, ib), f"level {l}: node ids differ"
+        assert np.array_equal(na, nb), f"level {l}: {int((na != nb).any(axis=1).sum())} rows differ"
+
+
+def _device(X, p, visited=0, **kw):
+    import cosdata_amd as ca
+    st = ca.StorageType(ca.StorageKind(p.storage), p.resolution)
+    hp = ca.HNSWHyperParams(num_layers=p.num_layers, ef_construction=p.ef_construction, ef_search=p.ef_search,
+                            level_0_neighbors_count=p.level0_neighbors_count, neighbors_count=p.neighbors_count)
+    dix = ca.HNSWIndex(p.dim, hp, ca.DistanceMetric(p.metric), st, (p.range_lo, p.range_hi), p.shortlist_size, seed=p.seed, visited_mode=visited)
+    return dix.upload_vectors(X)
+
+
+@pytest.mark.parametrize("storage,res,dim,n0,adds,batch,m0,m", [
+    (O.STORAGE_U8, 0, 96, 3000, (1, 700, 1300), 256, 64, 32),
+    (O.STORAGE_U8, 0, 768, 1500, (600,), 128, 64, 32),
+    (O.STORAGE_SUBBYTE, 2, 128, 2000, (500, 500), 64, 32, 16),
+    (O.STORAGE_F32, 0, 48, 1200, (400,), 1, 16, 8),          # batches of one = the sequential reference order
+    (O.STORAGE_U8, 0, 64, 2500, (2500,), 512, 128, 64),
+])
+def test_append_equals_the_oracles_continued_build(storage, res, dim, n0, adds, batch, m0, m):
+    total = n0 + sum(adds)
+    X = H.clustered_corpus(total, dim, n_centers=20, seed=dim + n0)
+    p = O.HNSWParams(dim=dim, storage=storage, resolution=res, num_layers=4, ef_construction=48, ef_search=40, seed=11,
+                     level0_neighbors_count=m0, neighbors_count=m)
+    oix = O.OracleIndex(p).set_vectors(X[:n0])
+    oix.build_rounds(batch)
+    dix = _device(X[:n0], p).build(batch)
+    _same_graph(dix.download_graph(), oix.export_graph())
+    at = n0
+    for a in adds:
+        oix.append(X[at:at + a], batch)
+        dix.append(X[at:at + a], batch)
+        at += a
+        assert dix.n == at and dix.level_count(0) == at + 1
+        _same_graph(dix.download_graph(), oix.export_graph())
+    # the appended index searches like the oracle's (ids, score bits), incl. queries near the NEW vectors
+    Q = H.queries_from(X[n0:], 300, noise=0.05, seed=3)
+    ids, sc, cnt = dix.batch_search(Q, 10)
+    oids, osc, ocnt = oix.search_batch(Q, 10, threads=4)[:3]
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    assert (ids >= n0).any()                                    # new vectors are found
+    gt, _ = O.bruteforce_topk(X[:at], Q, 10, threads=4)
+    recall = np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(len(Q))])
+    assert recall > 0.85, recall
+
+
+def test_append_on_a_batch_boundary_equals_the_full_build():
+    """the schedule's batches are min(B, max(1, inserted / 4)): a build that stops on one of those boundaries and is then continued IS
+    the full build (same level draws, same batches, same snapshots)"""
+    dim, B = 64, 200
+    bounds, ins = [], 0
+    while ins < 4000:
+        ins += min(B, max(1, ins // 4))
+        bounds.append(ins)
+    n0 = [b for b in bounds if b >= 1500][0]
+    n1 = [b for b in bounds if b >= 3000][0]
+    X = H.clustered_corpus(n1, dim, n_centers=16, seed=5)
+    p = O.HNSWParams(dim=dim, num_layers=4, ef_construction=40, ef_search=32, seed=3)
+    full = _device(X, p).build(B)
+    part = _device(X[:n0], p).build(B)
+    part.append(X[n0:], B)
+    _same_graph(part.download_graph(), full.download_graph())
+
+
+def test_append_device_rows_and_refusals():
+    import torch
+    import cosdata_amd as ca
+    dim, n0, m = 96, 2000, 800
+    X = H.clustered_corpus(n0 + m, dim, n_centers=16, seed=9)
+    p = O.HNSWParams(dim=dim, num_layers=4, ef_construction=40, ef_search=32, seed=2)
+    oix = O.OracleIndex(p).set_vectors(X[:n0])
+    oix.build_rounds(128)
+    oix.append(X[n0:], 128)
+    Xd = torch.from_numpy(X).cuda()
+    hp = ca.HNSWHyperParams(num_layers=4, ef_construction=40, ef_search=32)
+    dix = ca.HNSWIndex(dim, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), (p.range_lo, p.range_hi), seed=2)
+    dix.upload_vectors_device(Xd.data_ptr(), n0, keepalive=Xd).build(128)
+    with pytest.raises(ca.CosdataError):
+        dix.append(X[n0:], 128)                                  # the index borrows its rows: host rows are refused
+    dix.append_device(Xd.data_ptr(), m, 128, keepalive=Xd)
+    _same_graph(dix.download_graph(), oix.export_graph())
+    Q = H.queries_from(X, 200, noise=0.05, seed=4)
+    ids, sc, cnt = dix.batch_search(Q, 10)
+    oids, osc, _ = oix.search_batch(Q, 10, threads=4)[:3]
+    assert np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    # no link state -> NotReady: an uploaded graph, a released state
+    up = H.device_index_from_oracle(oix, X)
+    with pytest.raises(ca.CosdataError) as e:
+        up.append(X[:10])
+    assert e.value.status == ca._lib.ERR_NOT_READY
+    dix.release_link_state()
+    with pytest.raises(ca.CosdataError) as e:
+        dix.append_device(Xd.data_ptr(), 1)
+    assert e.value.status == ca._lib.ERR_NOT_READY
+    ids2, sc2, _ = dix.batch_search(Q, 10)                       # the graph is untouched by the refusals
+    assert np.array_equal(ids2, ids) and np.array_equal(sc2.view(np.uint32), sc.view(np.uint32))
