@@ -321,8 +321,15 @@ static inline int node_distance(const coso_index *ix, const uint8_t *qcode, floa
 /* traverse_find_nearest (vector_store.rs:1112-1204) on one level.
  * self_id: id pre-inserted in the visited filter (query id :271, or the new node's id :807).
  * Returns number of results in s->res (sorted desc), or a negative status. */
+static int walk_level_ex(const coso_index *ix, uint32_t level, uint32_t entry_idx, const uint8_t *qcode, float qmag,
+                         uint32_t self_id, int seed_self, uint32_t ef, uint32_t keep, scratch_t *s, coso_stats *st);
 static int walk_level(const coso_index *ix, uint32_t level, uint32_t entry_idx, const uint8_t *qcode, float qmag,
                       uint32_t self_id, uint32_t ef, uint32_t keep, scratch_t *s, coso_stats *st) {
+    return walk_level_ex(ix, level, entry_idx, qcode, qmag, self_id, 1, ef, keep, s, st);
+}
+/* seed_self = 0: delete_embedding's walks (vector_store.rs:1232-1248) start from a filter nothing was inserted into */
+static int walk_level_ex(const coso_index *ix, uint32_t level, uint32_t entry_idx, const uint8_t *qcode, float qmag,
+                         uint32_t self_id, int seed_self, uint32_t ef, uint32_t keep, scratch_t *s, coso_stats *st) {
     const level_t *L = &ix->lv[level];
     const uint32_t M = L->M;
     const int metric = (int)ix->p.metric;
@@ -331,7 +338,7 @@ static int walk_level(const coso_index *ix, uint32_t level, uint32_t entry_idx, 
         for (size_t t = 0; t < s->ntouched; t++) s->visited[s->touched[t]] = 0;
         s->ntouched = 0;
     } else memset(s->visited, 0, (size_t)M * 8);
-    visited_set(ix, s, M, self_id);
+    if (seed_self) visited_set(ix, s, M, self_id);
 
     size_t hn = 0, rn = 0;
     float d0;
@@ -975,6 +982,71 @@ int coso_index_build_rounds_continue(coso_index *ix, uint32_t batch_size, uint64
     if (rc == COSO_OK) { ix->rng_state = rng; ix->n_built = ix->n; ix->rounds_state_valid = 1; }
     if (stats) memcpy(stats, st, sizeof(st));
     free(max_level); free(pv); free(pl);
+    return rc;
+}
+
+/* delete_embedding (vector_store.rs:1206-1400) for one internal id.  Per level, top down: a walk for the vector's OWN code from the entry
+ * node with ef = 512, keep 100, on a filter nothing was pre-inserted into (:1232-1248; nodes_visited is a fresh `&mut 0` per level);
+ * descend through the best hit's child (:1250-1259); if the node is among the results (:1261-1275) it is taken out of them
+ * (swap_remove), every neighbour drops its back edge (remove_neighbor_by_id :1303: the first slot holding the id; the neighbour's
+ * lowest cache is NOT refreshed), and a neighbour left with no neighbour at all is linked again (:1305-1357): the remaining results
+ * minus the neighbour itself, re-scored against the neighbour, sorted descending, create_node_edges.  The node itself is dropped
+ * (:1366-1369): here its slots are emptied and it stays in the arrays, unreachable (edges are symmetric by construction).  Ties in
+ * the re-sort: larger id first, like everywhere.  Returns COSO_OK also when the walk did not reach the node on some level. */
+int coso_index_delete(coso_index *ix, uint32_t id) {
+    if (!ix || !ix->codes || id == COSO_ROOT_ID || row_of(ix, id) >= ix->n) return COSO_ERR_INVALID;
+    const uint32_t Ltop = ix->p.num_layers;
+    const int metric = (int)ix->p.metric;
+    if (ix->lv[Ltop].root_idx == IDX_NONE) return COSO_ERR_INVALID;
+    const uint32_t row = row_of(ix, id);
+    const uint8_t *code = ix->codes + (size_t)row * ix->cb;
+    scratch_t *s = scratch_new(ix);
+    zent *res = (zent *)malloc(KEEP_SEARCH * sizeof(zent)), *rel = (zent *)malloc(KEEP_SEARCH * sizeof(zent));
+    hent *srt = (hent *)malloc(KEEP_SEARCH * sizeof(hent));
+    uint32_t entry = ix->lv[Ltop].root_idx;
+    int rc = COSO_OK;
+    for (int level = (int)Ltop; level >= 0 && rc == COSO_OK; level--) {
+        level_t *L = &ix->lv[level];
+        int cnt = walk_level_ex(ix, (uint32_t)level, entry, code, ix->mags[row], id, 0, 512, KEEP_SEARCH, s, NULL);
+        if (cnt < 0) { rc = -cnt; break; }
+        if (cnt == 0) { if (level > 0) entry = L->child[entry]; continue; }
+        for (int i = 0; i < cnt; i++) { res[i].idx = s->res[i].idx; res[i].sim = s->res[i].sim; }
+        if (level > 0) entry = L->child[res[0].idx];
+        int at = -1;
+        for (int i = 0; i < cnt; i++) if (L->node_id[res[i].idx] == id) { at = i; break; }
+        if (at < 0) continue;
+        const uint32_t node = res[at].idx;
+        res[at] = res[cnt - 1]; /* swap_remove */
+        cnt--;
+        uint32_t *nb = L->nbr + (size_t)node * L->M;
+        for (uint32_t j = 0; j < L->M && rc == COSO_OK; j++) {
+            const uint32_t x = nb[j];
+            if (x == IDX_NONE) continue;
+            uint32_t *xb = L->nbr + (size_t)x * L->M;
+            int removed = 0, empty = 1;
+            for (uint32_t k = 0; k < L->M; k++) if (xb[k] == node) { xb[k] = IDX_NONE; removed = 1; break; }
+            for (uint32_t k = 0; k < L->M; k++) if (xb[k] != IDX_NONE) { empty = 0; break; }
+            if (!(removed && empty)) continue;
+            /* the orphan is linked again from the walk's results, re-scored against it */
+            const uint32_t xrow = row_of(ix, L->node_id[x]);
+            int rn = 0;
+            for (int i = 0; i < cnt; i++) {
+                if (res[i].idx == x) continue;
+                float d;
+                rc = node_distance(ix, ix->codes + (size_t)xrow * ix->cb, ix->mags[xrow], row_of(ix, L->node_id[res[i].idx]), &d);
+                if (rc != COSO_OK) break;
+                hent e = {order_key(metric, d), L->node_id[res[i].idx], res[i].idx, d};
+                srt[rn++] = e;
+            }
+            if (rc != COSO_OK) break;
+            qsort(srt, (size_t)rn, sizeof(hent), cmp_hent_desc);
+            for (int i = 0; i < rn; i++) { rel[i].idx = srt[i].idx; rel[i].sim = srt[i].sim; }
+            create_node_edges(ix, (uint32_t)level, x, rel, rn);
+        }
+        for (uint32_t j = 0; j < L->M; j++) nb[j] = IDX_NONE; /* the node is dropped */
+    }
+    free(res); free(rel); free(srt);
+    scratch_free(s);
     return rc;
 }
 

@@ -85,6 +85,7 @@ def lib():
         "coso_index_build_rounds": (C.c_int, [vp, C.c_uint32, C.c_int, vp]),
         "coso_index_append_vectors": (C.c_int, [vp, vp, C.c_uint32]),
         "coso_index_build_rounds_continue": (C.c_int, [vp, C.c_uint32, vp]),
+        "coso_index_delete": (C.c_int, [vp, C.c_uint32]),
         "coso_index_level_count": (C.c_uint32, [vp, C.c_uint32]),
         "coso_index_export_level": (C.c_int, [vp, C.c_uint32, vp, vp, vp]),
         "coso_index_import_level": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
@@ -337,6 +338,14 @@ class OracleIndex:
         if rc != OK:
             raise ValueError(f"build_rounds status {rc}")
         return self, {"rounds": int(st[0]), "batch_levels": int(st[1]), "nodes": int(st[2]), "first_round_nodes": int(st[3])}
+
+    def delete(self, ids):
+        """delete_embedding for every id of `ids`, one after the other in the given order"""
+        for i in np.atleast_1d(np.asarray(ids, np.uint32)):
+            rc = lib().coso_index_delete(self._h, int(i))
+            if rc != OK:
+                raise ValueError(f"delete status {rc} (id {int(i)})")
+        return self
 
     def append(self, raw_new, batch_size=0):
         """index_embeddings on a live index: `raw_new` [m][dim] take the ids [n, n + m) and are inserted by the rounds schedule continued

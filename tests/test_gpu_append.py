@@ -55,9 +55,10 @@ def test_append_equals_the_oracles_continued_build(storage, res, dim, n0, adds, 
     oids, osc, ocnt = oix.search_batch(Q, 10, threads=4)[:3]
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
     assert (ids >= n0).any()                                    # new vectors are found
-    gt, _ = O.bruteforce_topk(X[:at], Q, 10, threads=4)
-    recall = np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(len(Q))])
-    assert recall > 0.85, recall
+    if storage != O.STORAGE_SUBBYTE:   # (the reference's quaternary walk ranks by its plane-order quirk, SURVEY App. C #4: ID parity is the bar there)
+        gt, _ = O.bruteforce_topk(X[:at], Q, 10, threads=4)
+        recall = np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(len(Q))])
+        assert recall > 0.85, recall
 
 
 def test_append_on_a_batch_boundary_equals_the_full_build():
