@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 #include "engine_internal.h"
 
@@ -475,6 +476,238 @@ extern "C" int32_t cos_index_append(cos_index *ix, const float *raw, uint32_t m,
     ix->link.n_built = n1;
     ix->link.valid = true;
     if (int32_t rc2 = cos_prepare_walk_plans(ix)) return rc2;
+    return COS_OK;
+}
+
+// delete_embedding (vector_store.rs:1206-1400) for the internal ids of `ids`, one after the other in the given order (the reference
+// deletes inside a transaction one embedding at a time; a later delete's walk sees the graph the earlier ones left).  Per id: ONE walk
+// launch for the vector's own code — every level, ef = 512, keep 100, nothing pre-inserted in the filters (:1232-1248) — then, per
+// level where the walk's list holds the node, unlink_kernel: every neighbour drops its back edge, the node's slots are emptied.  A level
+// on which a neighbour would be left without any neighbour (the reference links it again between the removals, :1305-1357) is run on
+// the host in the reference's order over a small cache of the rows involved (rare: a node whose ONLY neighbour is the deleted one).
+// The vector's rows stay in the tables; the node is unreachable (edges are symmetric by construction) and its id is never returned by a
+// walk again.  Needs the link state (slot keys / lowest caches are kept consistent: a later append continues from them).
+// oracle/cosdata_oracle_hnsw.c: coso_index_delete is the CPU statement; tests/test_gpu_append.py asserts identical graphs.
+namespace {
+
+struct RowCache { // host copies of the level rows a slow-path delete touches; written back at the end
+    struct Row { std::vector<u32> adj; std::vector<int32_t> key; uint8_t low_idx; int32_t low_key; bool dirty = false; };
+    cos_index *ix; u32 level; u32 M;
+    std::map<u32, Row> rows;
+    hipError_t err = hipSuccess;
+    Row &get(u32 node) {
+        auto it = rows.find(node);
+        if (it != rows.end()) return it->second;
+        Row &r = rows[node];
+        LevelHost &H = ix->lv[level];
+        r.adj.resize(M); r.key.resize(M);
+        auto cp = [&](void *dst, const void *src, size_t n) { if (err == hipSuccess) err = hipMemcpy(dst, src, n, hipMemcpyDeviceToHost); };
+        cp(r.adj.data(), (level == 0 ? H.d_adj_vec : H.d_adj_node) + (size_t)node * M, (size_t)M * 4);
+        cp(r.key.data(), ix->link.key[level].as<int32_t>() + (size_t)node * M, (size_t)M * 4);
+        cp(&r.low_idx, ix->link.low_idx[level].as<uint8_t>() + node, 1);
+        cp(&r.low_key, ix->link.low_key[level].as<int32_t>() + node, 4);
+        return r;
+    }
+    hipError_t flush(const std::vector<u32> &node_vec /* node -> vector row (level 0: identity) */) {
+        LevelHost &H = ix->lv[level];
+        for (auto &kv : rows) {
+            if (!kv.second.dirty || err != hipSuccess) continue;
+            const u32 node = kv.first;
+            Row &r = kv.second;
+            auto cp = [&](void *dst, const void *src, size_t n) { if (err == hipSuccess) err = hipMemcpy(dst, src, n, hipMemcpyHostToDevice); };
+            if (level == 0) cp(H.d_adj_vec + (size_t)node * M, r.adj.data(), (size_t)M * 4);
+            else {
+                std::vector<u32> av(M);
+                for (u32 j = 0; j < M; j++) av[j] = r.adj[j] == NONE ? NONE : node_vec[r.adj[j]];
+                cp(H.d_adj_node + (size_t)node * M, r.adj.data(), (size_t)M * 4);
+                cp(H.d_adj_vec + (size_t)node * M, av.data(), (size_t)M * 4);
+            }
+            cp(ix->link.key[level].as<int32_t>() + (size_t)node * M, r.key.data(), (size_t)M * 4);
+            cp(ix->link.low_idx[level].as<uint8_t>() + node, &r.low_idx, 1);
+            cp(ix->link.low_key[level].as<int32_t>() + node, &r.low_key, 4);
+        }
+        return err;
+    }
+};
+
+// ProbNode::add_neighbor (prob_node.rs:210-283) on cached rows; returns the slot or -1
+int add_neighbor_host(RowCache &rc, u32 self, u32 nbr, int32_t k, int32_t kmin, int32_t kmax) {
+    RowCache::Row &r = rc.get(self);
+    const u32 M = rc.M, li = r.low_idx;
+    if (k <= r.low_key) return -1;
+    const bool ok = r.adj[li] == NONE || k > r.key[li];
+    u32 old = NONE;
+    if (ok) { old = r.adj[li]; r.adj[li] = nbr; r.key[li] = k; }
+    u32 nl = 0;
+    int32_t nk = kmax;
+    for (u32 j = 0; j < M; j++) {
+        if (r.adj[j] == NONE) { nk = kmin; nl = j; break; }
+        if (r.key[j] < nk) { nk = r.key[j]; nl = j; }
+    }
+    r.low_idx = (uint8_t)nl;
+    r.low_key = nk;
+    r.dirty = true;
+    if (!ok) return -1;
+    if (old != NONE) { // the evictee drops its back edge; its cache is NOT refreshed
+        RowCache::Row &o = rc.get(old);
+        for (u32 j = 0; j < M; j++) if (o.adj[j] == self) { o.adj[j] = NONE; o.key[j] = INT32_MIN; o.dirty = true; break; }
+    }
+    return (int)li;
+}
+
+} // namespace
+
+extern "C" int32_t cos_index_delete(cos_index *ix, const uint32_t *ids, uint32_t m) {
+    if (!ix || (!ids && m)) return cos_fail(COS_ERR_INVALID, "null argument");
+    if (!ix->have_vectors || !ix->have_root) return cos_fail(COS_ERR_NOT_READY, "delete needs a built index");
+    for (auto &l : ix->lv) if (l.n == 0) return cos_fail(COS_ERR_NOT_READY, "delete needs a built index");
+    if (!ix->link.valid) return cos_fail(COS_ERR_NOT_READY, "no link state (the graph was uploaded, its root replaced, or cos_index_release_link_state freed it)");
+    if (ix->id_stride != 1u || ix->meta.mdim != 0u) return cos_fail(COS_ERR_UNIMPLEMENTED, "delete on a collection with a metadata schema");
+    for (u32 i = 0; i < m; i++) if (ids[i] >= ix->n) return cos_fail(COS_ERR_INVALID, "id %u is not a resident vector", ids[i]);
+    if (m == 0) return COS_OK;
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize()); // exclusive: no search in flight
+    const u32 Ltop = ix->p.num_layers, L1 = Ltop + 1, metric = ix->p.metric, KEEP = (u32)KEEP_SEARCH, EF = 512;
+    hipStream_t st = ix->own_stream;
+    LinkArgs la;
+    memset(&la, 0, sizeof(la));
+    u32 maxM = 0;
+    fill_link_levels(ix, la, maxM);
+    la.L1 = L1;
+    la.metric = metric;
+    const int32_t kmin = order_key(metric, metric_min(metric)), kmax = order_key(metric, metric_max(metric));
+    DevBuf d_row, d_out_ids, d_out_nodes, d_out_sims, d_out_counts, d_status, d_dn, d_ust, d_px, d_py, d_ds, d_dst;
+    HIP_TRY(d_row.alloc(4));
+    HIP_TRY(d_out_ids.alloc((size_t)L1 * KEEP * 4));
+    HIP_TRY(d_out_nodes.alloc((size_t)L1 * KEEP * 4));
+    HIP_TRY(d_out_sims.alloc((size_t)L1 * KEEP * 4));
+    HIP_TRY(d_out_counts.alloc((size_t)L1 * 4));
+    HIP_TRY(d_status.alloc(4));
+    HIP_TRY(d_dn.alloc((size_t)L1 * 4));
+    HIP_TRY(d_ust.alloc((size_t)L1 * 4));
+    HIP_TRY(d_px.alloc((size_t)KEEP * 4));
+    HIP_TRY(d_py.alloc((size_t)KEEP * 4));
+    HIP_TRY(d_ds.alloc((size_t)KEEP * 4));
+    HIP_TRY(d_dst.alloc((size_t)KEEP * 4));
+    VisTab vtab;
+    struct VisFree { VisTab &v; ~VisFree() { if (v.bits) (void)hipFree(v.bits); if (v.log) (void)hipFree(v.log); } } visfree{vtab};
+    std::vector<u32> h_ids((size_t)L1 * KEEP), h_nodes((size_t)L1 * KEEP), h_counts(L1), h_dn(L1), h_ust(L1);
+    std::vector<std::vector<u32>> node_vec(L1); // slow path only: node -> vector row, fetched once per level
+    // (the locality order stays a permutation of the level's nodes and the level table's operand holds code rows: both still valid)
+    ix->adj_mag_valid = false;
+    for (auto &l : ix->lv) { l.host_valid = false; l.nbr_ids.clear(); }
+
+    for (u32 t = 0; t < m; t++) {
+        const u32 id = ids[t];
+        IndexDev dev = cos_make_index_dev(ix);
+        for (u32 l = 0; l <= Ltop; l++) dev.lv[l].adj_mag = nullptr; // (removed slots would keep a stale norm: harmless, but not worth a refill per id)
+        WalkArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        HIP_TRY(hipMemcpyAsync(d_row.p, &id, 4, hipMemcpyHostToDevice, st));
+        wa.qcodes = ix->d_codes;
+        wa.qmags = ix->d_mags;
+        wa.q_rows = d_row.as<u32>();
+        wa.no_self_seed = 1u;
+        if (dev.visited_mode == COS_VISITED_EXACT) {
+            const int32_t vrc = vis_tab_prepare(vtab, ix, 1, EF, st, wa);
+            if (vrc) return vrc;
+        }
+        wa.B = 1;
+        wa.ef = EF;
+        wa.keep = KEEP;
+        wa.out_ids = d_out_ids.as<u32>();
+        wa.out_sims = d_out_sims.as<float>();
+        wa.out_nodes = d_out_nodes.as<u32>();
+        wa.out_counts = d_out_counts.as<u32>();
+        wa.out_status = d_status.as<int32_t>();
+        HIP_TRY(launch_walk(ix->eng, dev, wa, 0, 0, st)); // (the throughput kernel: the latency kernels have no unseeded filter)
+        int32_t wst = COS_OK;
+        HIP_TRY(hipMemcpyAsync(&wst, d_status.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_ids.data(), d_out_ids.p, h_ids.size() * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_nodes.data(), d_out_nodes.p, h_nodes.size() * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_counts.data(), d_out_counts.p, (size_t)L1 * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (wst != COS_OK) return cos_fail(wst, "vector %u cannot be walked for (zero norm -> DistanceError::CalculationError)", id);
+        bool any = false;
+        for (u32 l = 0; l <= Ltop; l++) { // list slot = num_layers - level
+            const u32 slot = Ltop - l;
+            h_dn[l] = NONE;
+            for (u32 i = 0; i < h_counts[slot]; i++)
+                if (h_ids[(size_t)slot * KEEP + i] == id) { h_dn[l] = h_nodes[(size_t)slot * KEEP + i]; any = true; break; }
+        }
+        if (!any) continue;
+        HIP_TRY(hipMemcpyAsync(d_dn.p, h_dn.data(), (size_t)L1 * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(launch_unlink(la, d_dn.as<u32>(), d_ust.as<u32>(), st));
+        HIP_TRY(hipMemcpyAsync(h_ust.data(), d_ust.p, (size_t)L1 * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (u32 l = 0; l <= Ltop; l++) {
+            if (h_ust[l] != 1u) continue;
+            // ---- the reference's own order for this level (vector_store.rs:1277-1369)
+            if (ix->eng != ENG_U8 && ix->eng != ENG_Q2 && ix->eng != ENG_F32)
+                return cos_fail(COS_ERR_UNIMPLEMENTED, "delete would leave a node without neighbours: re-linking it is implemented for u8 / quaternary / f32 storage");
+            const LevelHost &H = ix->lv[l];
+            const u32 M = H.M, slot = Ltop - l, node = h_dn[l];
+            if (l > 0 && node_vec[l].empty()) {
+                node_vec[l].resize(H.n);
+                HIP_TRY(hipMemcpy(node_vec[l].data(), H.d_node_vec, (size_t)H.n * 4, hipMemcpyDeviceToHost));
+            }
+            auto vec_row = [&](u32 nd) { return l == 0 ? nd : node_vec[l][nd]; };
+            std::vector<u32> res; // the walk's results minus the node (swap_remove :1277; the order is irrelevant: re-sorted below)
+            for (u32 i = 0; i < h_counts[slot]; i++) if (h_nodes[(size_t)slot * KEEP + i] != node) res.push_back(h_nodes[(size_t)slot * KEEP + i]);
+            RowCache cache{ix, l, M};
+            RowCache::Row &dr = cache.get(node);
+            for (u32 j = 0; j < M; j++) {
+                const u32 x = dr.adj[j];
+                if (x == NONE) continue;
+                RowCache::Row &xr = cache.get(x);
+                bool removed = false, empty = true;
+                for (u32 k = 0; k < M; k++) if (xr.adj[k] == node) { xr.adj[k] = NONE; xr.key[k] = INT32_MIN; xr.dirty = true; removed = true; break; }
+                for (u32 k = 0; k < M; k++) if (xr.adj[k] != NONE) { empty = false; break; }
+                if (!(removed && empty)) continue;
+                std::vector<u32> cand, px, py;
+                for (u32 r : res) if (r != x) { cand.push_back(r); px.push_back(vec_row(x)); py.push_back(vec_row(r)); }
+                std::vector<float> sims(cand.size());
+                std::vector<int32_t> dst(cand.size());
+                if (!cand.empty()) {
+                    HIP_TRY(hipMemcpyAsync(d_px.p, px.data(), px.size() * 4, hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(d_py.p, py.data(), py.size() * 4, hipMemcpyHostToDevice, st));
+                    HIP_TRY(cosdev::launch_index_pair_distances(ix->eng, ix->d_codes, ix->d_mags, ix->row_stride, ix->nchunks, ix->p.dim, metric, d_px.as<u32>(), d_py.as<u32>(),
+                                                               (u32)cand.size(), d_ds.as<float>(), d_dst.as<int32_t>(), st));
+                    HIP_TRY(hipMemcpyAsync(sims.data(), d_ds.p, sims.size() * 4, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipMemcpyAsync(dst.data(), d_dst.p, dst.size() * 4, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    for (int32_t e : dst) if (e != COS_OK) return cos_fail(e, "re-linking node %u after the delete of %u failed (DistanceError)", x, id);
+                }
+                std::vector<u32> ord(cand.size());
+                for (u32 i = 0; i < ord.size(); i++) ord[i] = i;
+                std::sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { // descending; larger id (= node index) first on ties
+                    const int32_t ka = order_key(metric, sims[a]), kb = order_key(metric, sims[b]);
+                    return ka != kb ? ka > kb : cand[a] > cand[b];
+                });
+                u32 succ = 0; // create_node_edges (vector_store.rs:976-1074)
+                for (u32 oi : ord) {
+                    if (succ >= M) break;
+                    const int32_t k = order_key(metric, sims[oi]);
+                    const int r1 = add_neighbor_host(cache, x, cand[oi], k, kmin, kmax);
+                    if (r1 < 0) continue;
+                    const int r2 = add_neighbor_host(cache, cand[oi], x, k, kmin, kmax);
+                    if (r2 >= 0) succ++;
+                    else {
+                        RowCache::Row &xr2 = cache.get(x);
+                        if (xr2.adj[(u32)r1] == cand[oi]) { xr2.adj[(u32)r1] = NONE; xr2.key[(u32)r1] = INT32_MIN; xr2.dirty = true; } // remove_neighbor_by_index_and_id (an empty slot's key is EMPTY_KEY, like the link kernel leaves it)
+                    }
+                }
+            }
+            RowCache::Row &dr2 = cache.get(node);
+            for (u32 j = 0; j < M; j++) { dr2.adj[j] = NONE; dr2.key[j] = INT32_MIN; }
+            dr2.dirty = true;
+            if (cache.err != hipSuccess) HIP_TRY(cache.err);
+            HIP_TRY(cache.flush(node_vec[l]));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (int32_t rc2 = cos_prepare_walk_plans(ix)) return rc2; // the adjacency-side norms of the changed rows
     return COS_OK;
 }
 

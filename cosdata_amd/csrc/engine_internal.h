@@ -17,6 +17,9 @@
 
 namespace cosdev {
 hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st);
+hipError_t launch_unlink(const LinkArgs &a, const u32 *dn, u32 *status, hipStream_t st);
+hipError_t launch_index_pair_distances(int eng, const uint8_t *codes, const float *mags, u64 row_stride, u32 nchunks, u32 dim, u32 metric, const u32 *d_pair_x,
+                                       const u32 *d_pair_y, u32 n_pairs, float *d_out, int32_t *d_status, hipStream_t st); // kernels_misc.hip
 hipError_t launch_grow_rows(const u32 *src, u32 *dst, u32 old_n, u32 new_n, u32 M, u32 remap_from, u32 remap_to, u32 fill, hipStream_t st);
 hipError_t launch_grow_bytes(const uint8_t *src, uint8_t *dst, u32 old_n, u32 new_n, hipStream_t st);
 hipError_t launch_fill_adj_mag(const u32 *adj_vec, const float *mags, float *adj_mag, u32 n, u32 M, u32 slots, hipStream_t st);

@@ -93,6 +93,7 @@ struct WalkArgs {
     u64 tab_stride;       // floats per query row
     u32 tab_level_min;
     u32 tab_col0[MAX_LEVELS];
+    u32 no_self_seed;     // 1 = nothing is pre-inserted in a level's filter (delete_embedding's walks, vector_store.rs:1232-1248); walk_kernel only
     u32 merge_min;        // table levels: an expansion with at least this many winners past the screen inserts them by ONE ranked merge
                           // (walk_kernel.inc commit_merge) instead of one pool shift each; 0 = always the serial insert.  Set by launch_walk.
     // Locality-ordered walk (big search launches; kernels_order.hip, engine.hip run_search).  The walk of a launch is split

@@ -355,6 +355,52 @@ __global__ void fill_i32_kernel(int32_t *p, u64 n, int32_t v) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// cos_index_delete (builder.hip; delete_embedding, vector_store.rs:1277-1369): one wave per level; dn[level] = the deleted vector's node on
+// that level (NONE: the walk did not reach it / it has no node there).  Every neighbour of the node drops its back edge
+// (remove_neighbor_by_id, prob_node.rs:285-306: the first slot holding it; the slot's key goes, the neighbour's lowest cache stays) and
+// the node's own slots are emptied.  The removals touch different rows and commute — unless a neighbour would be left with NO
+// neighbour at all: the reference links such a node again, in slot order, between the removals (:1305-1357).  The kernel looks
+// first and, if it finds one, changes nothing and says so (status 1): the host then runs the level in the reference's order.
+__global__ __launch_bounds__(64) void unlink_kernel(const LinkArgs a, const u32 *__restrict__ dn, u32 *__restrict__ status) {
+    const u32 level = blockIdx.x;
+    const int lane = threadIdx.x;
+    const u32 node = dn[level];
+    if (node == NONE) { if (lane == 0) status[level] = 0; return; }
+    const LinkLevelDev &lv = a.lv[level];
+    const u32 M = lv.M;
+    bool orphan = false;
+    for (u32 s = lane; s < M; s += 64) {
+        const u32 x = ld(&lv.adj_node[(u64)node * M + s]);
+        if (x == NONE) continue;
+        bool found = false, other = false;
+        for (u32 j = 0; j < M; j++) {
+            const u32 v = ld(&lv.adj_node[(u64)x * M + j]);
+            if (v == node && !found) found = true;
+            else if (v != NONE) other = true;
+        }
+        orphan = orphan || (found && !other);
+    }
+    if (__builtin_amdgcn_ballot_w64(orphan)) { if (lane == 0) status[level] = 1; return; }
+    for (u32 s = lane; s < M; s += 64) {
+        const u64 o = (u64)node * M + s;
+        const u32 x = ld(&lv.adj_node[o]);
+        if (x == NONE) continue;
+        for (u32 j = 0; j < M; j++) {
+            const u64 ox = (u64)x * M + j;
+            if (ld(&lv.adj_node[ox]) == node) {
+                st(&lv.adj_node[ox], NONE);
+                if (lv.adj_vec != lv.adj_node) st(&lv.adj_vec[ox], NONE);
+                st(&lv.key[ox], EMPTY_KEY);
+                break;
+            }
+        }
+        st(&lv.adj_node[o], NONE);
+        if (lv.adj_vec != lv.adj_node) st(&lv.adj_vec[o], NONE);
+        st(&lv.key[o], EMPTY_KEY);
+    }
+    if (lane == 0) status[level] = 2;
+}
+
 // cos_index_append (builder.hip): a level's [n][M] array grows.  Rows [0, old_n - 1) keep their place, the LAST old row (the root) becomes
 // the last new row, the rows between (the new nodes) are filled; a value equal to remap_from (a reference to the root) becomes remap_to.
 __global__ void grow_rows_kernel(const u32 *__restrict__ src, u32 *__restrict__ dst, u32 old_n, u32 new_n, u32 M, u32 remap_from, u32 remap_to, u32 fill) {
@@ -396,6 +442,10 @@ hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st) {
     return hipGetLastError();
 }
 
+hipError_t launch_unlink(const LinkArgs &a, const u32 *dn, u32 *status, hipStream_t st) {
+    hipLaunchKernelGGL(unlink_kernel, dim3(a.L1), dim3(64), 0, st, a, dn, status);
+    return hipGetLastError();
+}
 hipError_t launch_grow_rows(const u32 *src, u32 *dst, u32 old_n, u32 new_n, u32 M, u32 remap_from, u32 remap_to, u32 fill, hipStream_t st) {
     const u64 total = (u64)new_n * M;
     if (total == 0 || old_n == 0) return hipErrorInvalidValue;

@@ -185,6 +185,22 @@ void rows_to_device_layout(int eng, u32 dim, const uint8_t *ref, size_t cb, u32 
 
 } // namespace
 
+namespace cosdev {
+// DistanceMetric::calculate for explicit (row, row) pairs of ONE resident code table (cos_index_delete's re-scoring of an orphan's
+// candidates, vector_store.rs:1326-1337): the operator's own kernel on device arrays.  Integer and f32 engines.
+hipError_t launch_index_pair_distances(int eng, const uint8_t *codes, const float *mags, u64 row_stride, u32 nchunks, u32 dim, u32 metric, const u32 *d_pair_x,
+                                       const u32 *d_pair_y, u32 n_pairs, float *d_out, int32_t *d_status, hipStream_t st) {
+    if (n_pairs == 0) return hipSuccess;
+    DistArgs a{codes, codes, mags, mags, d_pair_x, d_pair_y, row_stride, n_pairs, dim, metric, nchunks, d_out, d_status};
+    dim3 grid(n_pairs), block(64);
+    if (eng == ENG_U8) hipLaunchKernelGGL(distance_pairs_kernel<ENG_U8>, grid, block, 0, st, a);
+    else if (eng == ENG_Q2) hipLaunchKernelGGL(distance_pairs_kernel<ENG_Q2>, grid, block, 0, st, a);
+    else if (eng == ENG_F32) hipLaunchKernelGGL(distance_pairs_kernel<ENG_F32>, grid, block, (size_t)row_stride, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+} // namespace cosdev
+
 extern "C" int32_t cos_distance_batch(uint32_t metric, uint32_t storage, uint32_t resolution, uint32_t dim, const void *x_codes,
                                       const float *x_mags, uint32_t nx, const void *y_codes, const float *y_mags, uint32_t ny,
                                       const uint32_t *pair_x, const uint32_t *pair_y, uint32_t n_pairs, float *out, int32_t *status) {

@@ -244,6 +244,12 @@ class HNSWIndex:
         self._keepalive = keepalive
         return self
 
+    def delete(self, ids):
+        """vector_store::delete_embedding (cos_index_delete) for the internal ids of `ids`, in the given order"""
+        a = _c(np.atleast_1d(ids), np.uint32)
+        check(_lib.lib().cos_index_delete(self._h, _p(a), a.size))
+        return self
+
     def release_link_state(self):
         """frees what build() keeps for append() (4 bytes per neighbour slot); append() then fails with NotReady"""
         check(_lib.lib().cos_index_release_link_state(self._h))

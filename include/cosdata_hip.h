@@ -165,6 +165,14 @@ int32_t cos_index_build(cos_index *ix, uint32_t batch_size);
  * COS_ERR_NOT_READY: no graph, or no link state to continue from (the graph was uploaded, its root replaced, or the state released).
  * Exclusive like every graph change (no search in flight); a failed append leaves the handle without a graph. */
 int32_t cos_index_append(cos_index *ix, const float *raw, uint32_t m, uint32_t flags, uint32_t batch_size /* 0 = 4096 */);
+/* vector_store::delete_embedding (vector_store.rs:1206-1400) for the internal ids of `ids`, one after the other in the given order: per id
+ * one walk for the vector's own code on every level (ef 512, keep 100, filters not pre-seeded, :1232-1248); on every level whose list
+ * holds the node, its neighbours drop their back edges (remove_neighbor_by_id, prob_node.rs:285-306), a neighbour left without any
+ * neighbour is linked again from the walk's results re-scored against it (:1305-1357), and the node's own slots are emptied.  The
+ * vector's rows stay resident (ids are never reused, collection.rs:451-468); no walk reaches the node again (exhaustive scans —
+ * cos_flat_search_batch, cos_bruteforce_topk — still see the row: the host filters deleted ids there, as it owns the id map).
+ * Needs the link state like cos_index_append; exclusive like every graph change.  oracle: coso_index_delete. */
+int32_t cos_index_delete(cos_index *ix, const uint32_t *ids, uint32_t m);
 /* frees the link state (as large as the adjacency: 4 bytes per neighbour slot); cos_index_append then returns COS_ERR_NOT_READY */
 int32_t cos_index_release_link_state(cos_index *ix);
 

@@ -111,3 +111,59 @@ def test_append_device_rows_and_refusals():
     assert e.value.status == ca._lib.ERR_NOT_READY
     ids2, sc2, _ = dix.batch_search(Q, 10)                       # the graph is untouched by the refusals
     assert np.array_equal(ids2, ids) and np.array_equal(sc2.view(np.uint32), sc.view(np.uint32))
+
+
+@pytest.mark.parametrize("storage,res,dim,n,m0,m,visited", [
+    (O.STORAGE_U8, 0, 96, 3000, 64, 32, 0),
+    (O.STORAGE_U8, 0, 768, 1500, 64, 32, 1),
+    (O.STORAGE_SUBBYTE, 2, 128, 2000, 32, 16, 0),
+    (O.STORAGE_F32, 0, 48, 1200, 16, 8, 0),
+])
+def test_delete_equals_the_oracles_delete_embedding(storage, res, dim, n, m0, m, visited):
+    """cos_index_delete == coso_index_delete (delete_embedding, vector_store.rs:1206-1400), graph for graph after every chunk of ids;
+    a deleted id is never returned again; append after delete continues from the same link state"""
+    X = H.clustered_corpus(n + 300, dim, n_centers=20, seed=dim + n)
+    p = O.HNSWParams(dim=dim, storage=storage, resolution=res, num_layers=4, ef_construction=48, ef_search=40, seed=21,
+                     level0_neighbors_count=m0, neighbors_count=m, visited_mode=visited)
+    oix = O.OracleIndex(p).set_vectors(X[:n])
+    oix.build_rounds(128)
+    dix = _device(X[:n], p, visited=visited).build(128)
+    rng = np.random.default_rng(5)
+    order = rng.permutation(n)[:240].astype(np.uint32)
+    for chunk in (order[:1], order[1:40], order[40:]):
+        oix.delete(chunk)
+        dix.delete(chunk)
+        _same_graph(dix.download_graph(), oix.export_graph())
+    Q = X[order[:100]]                                           # the deleted vectors themselves as queries
+    ids, sc, cnt = dix.batch_search(Q, 10)
+    oids, osc, ocnt = oix.search_batch(Q, 10, threads=4)[:3]
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    assert not np.isin(ids, order).any()
+    oix.append(X[n:], 128)
+    dix.append(X[n:], 128)
+    _same_graph(dix.download_graph(), oix.export_graph())
+
+
+def test_delete_relinks_a_node_left_without_neighbours():
+    """tiny neighbour lists on a tiny corpus: deleting a node's ONLY neighbour makes delete_embedding link the node again from the walk's
+    results (vector_store.rs:1305-1357) — the device runs such a level on the host in the reference's order"""
+    dim, n = 32, 400
+    X = H.clustered_corpus(n, dim, n_centers=40, seed=77)
+    p = O.HNSWParams(dim=dim, num_layers=3, ef_construction=8, ef_search=16, seed=3, level0_neighbors_count=2, neighbors_count=2)
+    oix = O.OracleIndex(p).set_vectors(X)
+    oix.build_rounds(32)
+    dix = _device(X, p).build(32)
+    g = oix.export_graph()
+    ids0, nbr0 = g[0]
+    lonely = [int(nbr0[i][nbr0[i] != O.SLOT_EMPTY][0]) for i in range(n) if (nbr0[i] != O.SLOT_EMPTY).sum() == 1 and nbr0[i][nbr0[i] != O.SLOT_EMPTY][0] < n]
+    assert lonely, "the corpus has no node with a single neighbour: pick other hyper-parameters"
+    victims = np.array(sorted(set(lonely))[:25], np.uint32)
+    before = oix.export_graph()
+    oix.delete(victims)
+    dix.delete(victims)
+    _same_graph(dix.download_graph(), oix.export_graph())
+    after = oix.export_graph()[0][1]
+    E = O.SLOT_EMPTY
+    relinked = [i for i in range(n) if i not in set(victims.tolist()) and (before[0][1][i] != E).sum() == 1
+                and before[0][1][i][before[0][1][i] != E][0] in set(victims.tolist()) and (after[i] != E).any()]
+    assert relinked, "no orphan was linked again: the slow path was not exercised"

@@ -62,3 +62,27 @@ def test_append_needs_a_rounds_built_graph_and_finds_the_new_vectors():
     imp = O.OracleIndex(p).set_vectors(X).import_graph(a.export_graph(), a.root_raw())   # an imported graph cannot be continued either
     with pytest.raises(ValueError):
         imp.append(X[:5], 64)
+
+
+def test_delete_removes_every_edge_to_the_node_and_the_id_from_every_answer():
+    """coso_index_delete (delete_embedding, vector_store.rs:1206-1400): edges are symmetric by construction, so after the node's neighbours
+    dropped their back edges no slot of any level names it; its own slots are empty; searches for the deleted vectors themselves return
+    other ids; untouched queries keep their answers wherever no deleted id was among them"""
+    X = H.clustered_corpus(2500, 64, n_centers=16, seed=8)
+    p = O.HNSWParams(dim=64, num_layers=4, ef_construction=40, ef_search=48, seed=2)
+    a = O.OracleIndex(p).set_vectors(X)
+    a.build_rounds(128)
+    Q = H.queries_from(X, 150, noise=0.05, seed=3)
+    before = a.search_batch(Q, 10, threads=2)[0]
+    dele = np.arange(0, 400, 3, dtype=np.uint32)
+    a.delete(dele)
+    for ids, nbr in a.export_graph():
+        assert not np.isin(nbr, dele).any()
+        assert (nbr[np.isin(ids, dele)] == O.SLOT_EMPTY).all()
+    after = a.search_batch(Q, 10, threads=2)[0]
+    assert not np.isin(after, dele).any()
+    assert not np.isin(a.search_batch(X[dele[:50]], 5, threads=2)[0], dele).any()
+    untouched = ~np.isin(before, dele).any(axis=1)
+    assert untouched.sum() > 20 and np.mean((before[untouched] == after[untouched]).all(axis=1)) > 0.8
+    with pytest.raises(ValueError):
+        a.delete([2500])                                                       # not a resident vector
