@@ -23,7 +23,7 @@ def compact_text(src, dst):
     by = {}
     for l in rows:
         f = [x.strip() for x in l.split("|")]
-        if len(f) != 7:
+        if len(f) not in (7, 8):
             continue
         try:
             by.setdefault(f[0], []).append((f[0], f[1], int(f[2]), float(f[3]), float(f[4]), float(f[5]), float(f[6])))

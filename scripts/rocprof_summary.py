@@ -38,12 +38,18 @@ def main(path):
     con = sqlite3.connect(path)
     cur = con.cursor()
     print(f"# {path}")
-    print("## kernel trace: name | grid (workgroups) | calls | avg_us | min_us | max_us | total_ms")
+    print("## kernel trace: name | grid (workgroups) | calls | avg_us | min_us | max_us | total_ms | calls per step")
     rows = cur.execute("select name, grid_x/workgroup_x, count(*), avg(duration), min(duration), max(duration), sum(duration) "
                        "from kernels group by name, grid_x/workgroup_x order by sum(duration) desc").fetchall()
     # every kernel of this library is printed (a roofline block of bench.py must be recomputable from the file whatever the kernel's
     # share of the trace: round 4's `limit 14` dropped flat_scan_q2_areg and bm25_topk_kernel); foreign kernels (torch): the top 8
     rows = compact_rows(rows)
+    # calls per step: a step of bench.py ends with ONE finalize_fast_kernel dispatch over the step's queries — the (kernel, grid) row of that
+    # kernel with the largest total is the step count every other row of the same launch shape is divided by (recall passes, parity samples
+    # and single-batch legs use other grids and show up as fractions)
+    fin = [r for r in rows if "finalize_fast_kernel" in r[0] and isinstance(r[1], int)]
+    n_steps = max(fin, key=lambda r: r[6])[2] if fin else 0
+    print(f"## steps in this trace (dispatches of finalize_fast_kernel at its dominant grid): {n_steps}")
     foreign = 0
     for name, grid, calls, avg, mn, mx, tot in rows:
         if "cosdev" not in name and "anonymous namespace" not in name:
@@ -51,7 +57,8 @@ def main(path):
             if foreign > 8:
                 continue
         g = f"{grid:8d}" if isinstance(grid, int) else f"{grid:>8s}"
-        print(f"{short(name):45s} | {g} | {calls:6d} | {avg/1e3:10.1f} | {mn/1e3:10.1f} | {mx/1e3:10.1f} | {tot/1e6:10.2f}")
+        per = f"{calls / n_steps:8.2f}" if n_steps else "       -"
+        print(f"{short(name):45s} | {g} | {calls:6d} | {avg/1e3:10.1f} | {mn/1e3:10.1f} | {mx/1e3:10.1f} | {tot/1e6:10.2f} | {per}")
     # A locality-ordered walk is several dispatches of one kernel per step (WalkArgs::phase): split them by what preceded them ON THE
     # SAME STREAM / QUEUE (the sort's deal_to_xcds_kernel precedes every level range but the first); with several steps in flight the
     # global start order interleaves streams, so the trace's stream or queue column is used when it has one.
@@ -99,7 +106,9 @@ def main(path):
                                f"where (kernel_name like '%walk_kernel%' or kernel_name like '%walk_spec_kernel%') and grid_size/workgroup_size >= 4096 order by {ocol}").fetchall()
             seen, acc = {}, {}
             for name, grid, cn, val, oid in rows:
-                key = (short(name), grid, cn)
+                # (above ef 64 the two level ranges are different instantiations — four / eight row buffers —: the alternation is over the
+                # walk kernel's big dispatches whatever their template arguments)
+                key = (short(name).split("<")[0] + "<...> big dispatches", grid, cn)
                 idx = seen.setdefault(key, {})
                 if oid not in idx:
                     idx[oid] = len(idx)

@@ -138,7 +138,10 @@ def test_delete_equals_the_oracles_delete_embedding(storage, res, dim, n, m0, m,
     ids, sc, cnt = dix.batch_search(Q, 10)
     oids, osc, ocnt = oix.search_batch(Q, 10, threads=4)[:3]
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
-    assert not np.isin(ids, order).any()
+    # (a delete whose walk does not reach the node on some level — keep 100 of 512 pops: the quaternary ranking quirk, tiny neighbour lists —
+    # leaves it linked there, in the reference too: vector_store.rs:1271-1275 `continue`; the bar is the oracle's answer, asserted above)
+    if storage == O.STORAGE_U8:
+        assert not np.isin(ids, order).any()
     oix.append(X[n:], 128)
     dix.append(X[n:], 128)
     _same_graph(dix.download_graph(), oix.export_graph())
