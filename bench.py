@@ -62,6 +62,7 @@ WORKLOADS = {
     # name: (n per GPU, dim, corpus, default ef_construction, description)
     "c2": (1_000_000, 768, "mixture", 128, "BASELINE configs[1]: 1M x 768 dense cosine HNSW, query-batch 256, u8 auto-quantized storage"),
     "c2_uniform": (1_000_000, 768, "uniform", 128, "BASELINE configs[1] on the uniform(-1,1) corpus of tests/test.py:88 (adversarial for ANN)"),
+    "c2_sigma01": (1_000_000, 768, "mixture_sigma01", 128, "BASELINE configs[1] on SURVEY 8(d)'s clustered set: 1 000 Gaussian centres, sigma 0.1 per component, L2-normalised"),
     "c4shard": (12_500_000, 1024, "mixture", 256, "one 12.5M x 1024 shard of BASELINE configs[3] (100M x 1024 over 8 GPUs)"),
     "smoke": (50_000, 768, "mixture", 128, "reduced-size plumbing run (NOT a benchmark number)"),
 }
@@ -72,7 +73,7 @@ WORKLOADS = {
 # (c4shard_ref, the default-hyper-parameter record — recall saturating at 0.846, profiles/r04_final_bench_default_full_record.json —, moved to the
 # optional list in round 5: its minute of the default run went to c4_8shards_one_device.)
 # Round 6: `value` IS the target-meeting shard (main workload c4shard, M0 256 / M 64); c2 is a record under `configs`.
-ALL_CONFIGS = ["c4_8shards_one_device", "c2", "c2_uniform", "c5", "c3"]
+ALL_CONFIGS = ["c4_8shards_one_device", "c2", "c2_sigma01", "c2_uniform", "c5", "c3"]
 MAIN_WORKLOAD = "c4shard"
 EF_CANDIDATES = [32, 48, 64, 80, 96, 112, 128, 160, 192, 256, 384, 512]   # ef_search is a user parameter (indexes/hnsw/types.rs:14): the grid it is selected from
 MAIN_M0, MAIN_M = 256, 64
@@ -373,14 +374,19 @@ class DenseWorkload:
         self.nrq = args.recall_queries
         dev, rank, world = env.dev, env.rank, env.world
         n = self.n
-        if corpus == "mixture":
+        if corpus in ("mixture", "mixture_sigma01"):
             gc = torch.Generator(device=dev)
             gc.manual_seed(4242)
-            self.n_centers = max(64, (n * world) // 1000)
+            # mixture_sigma01 = SURVEY 8(d) literally: 1 000 centres, sigma 0.1 PER COMPONENT (noise norm 0.1 sqrt(d) = 2.8 against unit
+            # centres: the cluster structure is a small perturbation of an isotropic Gaussian — much harder than sigma 0.8 / sqrt(d))
+            hard = corpus == "mixture_sigma01"
+            self.n_centers = 1000 if hard else max(64, (n * world) // 1000)
             centers = torch.randn(self.n_centers, d, generator=gc, device=dev)
             centers /= centers.norm(dim=1, keepdim=True)
-            draw = lambda m, seed: mixture(torch, m, d, seed, dev, centers)
-            self.corpus_desc = f"Gaussian mixture, {self.n_centers} centres, sigma 0.8/sqrt(d), L2-normalised, seed 42"
+            sig = 0.1 * d ** 0.5 if hard else 0.8
+            draw = lambda m, seed: mixture(torch, m, d, seed, dev, centers, sigma=sig)
+            self.corpus_desc = (f"Gaussian mixture, {self.n_centers} centres, sigma " + ("0.1 per component (SURVEY 8d)" if hard else "0.8/sqrt(d)")
+                                + ", L2-normalised, seed 42")
         else:
             draw = lambda m, seed: uniform_corpus(torch, m, d, seed, dev)
             self.corpus_desc = ("uniform(-1,1) per component, not normalised (tests/test.py:88), seed 42; queries are stored vectors, like "
@@ -1318,6 +1324,15 @@ def main():
                 out["configs"][name] = c2r
                 if out["value_at_query_batch_256"] is None:
                     out["value_at_query_batch_256"] = dict(c2r["value_at_query_batch_256"] or {}, measured_on="configs.c2 (BASELINE configs[1]: 1M x 768, query-batch 256)") or None
+                w2.close()
+                del w2
+            elif name == "c2_sigma01":
+                w2 = DenseWorkload(env, "c2_sigma01", n_override=0 if scale == 1.0 else int(1_000_000 * scale), quantization="auto")
+                r2 = w2.run_mode("ref", "ref", ef_sweep="exact:256", cpu_seconds=args.config_cpu_seconds, exchange=args.exchange)
+                out["configs"][name] = compact_dense_record(r2, world)
+                out["configs"][name]["same_graph_exact_visited_set"] = r2["sweep"]
+                out["configs"][name]["note"] = ("SURVEY 8(d)'s suggested clustered set (sigma 0.1 per component): beside `value`'s and c2's sigma 0.8/sqrt(d) mixture; "
+                                                "what the reference's algorithm reaches on it with its default hyper-parameters, bit-identical to the oracle")
                 w2.close()
                 del w2
             elif name == "c2_uniform":

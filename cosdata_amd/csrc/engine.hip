@@ -1802,7 +1802,11 @@ extern "C" int32_t cos_index_enable_metadata(cos_index *ix, uint32_t mdim, uint3
     if (!ix || mdim == 0 || mdim > 64 || max_replicas_per_node == 0) return cos_fail(COS_ERR_INVALID, "metadata dimensions must be in [1, 64] and max_replicas_per_node >= 1");
     if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before enabling the metadata component");
     if ((u64)ix->n * max_replicas_per_node >= PSEUDO_LO) return cos_fail(COS_ERR_INVALID, "replica ids would run into the reserved id range");
-    if (ix->p.id_base != 0) return cos_fail(COS_ERR_UNIMPLEMENTED, "metadata collections are not sharded (id_base must be 0)");
+    // a SHARD of a metadata collection (round 6): the shard's embeddings are rows [0, n) here and embeddings [e0, e0 + n) of the
+    // collection, so its replica ids are id_base + row x max_replicas + i with id_base = e0 x max_replicas — a multiple of max_replicas
+    if (ix->p.id_base % max_replicas_per_node != 0)
+        return cos_fail(COS_ERR_INVALID, "id_base %u of a metadata collection's shard must be a multiple of max_replicas_per_node %u (first embedding x replicas)", ix->p.id_base, max_replicas_per_node);
+    if ((u64)ix->p.id_base + (u64)ix->n * max_replicas_per_node >= PSEUDO_LO) return cos_fail(COS_ERR_INVALID, "replica ids would run into the reserved id range");
     for (auto &l : ix->lv)
         if (l.n) return cos_fail(COS_ERR_INVALID, "enable the metadata component before uploading / building the base graph: it changes the id of every vector (row x max_replicas)");
     int32_t rc = cos_set_device(ix);

@@ -69,13 +69,13 @@ class Scenario:
         oix.meta_set_nodes(self.node_ids, self.mbits).meta_build(self.max_levels)
         return oix
 
-    def device(self, oix):
+    def device(self, oix, id_base=0):
         import cosdata_amd as ca
         p = self.params
         hp = ca.HNSWHyperParams(num_layers=p.num_layers, ef_construction=p.ef_construction, ef_search=p.ef_search,
                                 level_0_neighbors_count=p.level0_neighbors_count, neighbors_count=p.neighbors_count)
         dix = ca.HNSWIndex(self.dim, hp, ca.DistanceMetric(p.metric), ca.StorageType(ca.StorageKind(p.storage), p.resolution),
-                           (p.range_lo, p.range_hi), p.shortlist_size)
+                           (p.range_lo, p.range_hi), p.shortlist_size, id_base=id_base)
         dix.upload_vectors(self.X).enable_metadata(MDIM, REPLICAS)
         dix.upload_graph(oix.export_graph(), oix.root_raw())
         dix.upload_meta_graph(self.node_ids, self.mbits, oix.meta_export_graph())

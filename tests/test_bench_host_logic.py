@@ -51,7 +51,7 @@ def test_resolve_configs_auto_all_none_and_world_rules():
     assert bench.resolve_configs("c3,c5", 1, main) == ["c3", "c5"]
     assert bench.resolve_configs("all", 2, main) == []                  # single-GPU configs (the one-device 8-shard proxy too) are dropped at N > 1
     assert bench.resolve_configs("c4shard_ref,c4shard_ref_m0_256_m_64", 2, main) == ["c4shard_ref", "c4shard_ref_m0_256_m_64"]
-    assert {"c4_8shards_one_device", "c2", "c2_uniform", "c3", "c5"} == set(bench.ALL_CONFIGS) and "c4shard_ref" in bench.OPTIONAL_CONFIGS
+    assert {"c4_8shards_one_device", "c2", "c2_sigma01", "c2_uniform", "c3", "c5"} == set(bench.ALL_CONFIGS) and "c4shard_ref" in bench.OPTIONAL_CONFIGS
     assert bench.resolve_configs("c4shard_exact,c4shard_ref_m0_128", 1, main) == ["c4shard_exact", "c4shard_ref_m0_128"]   # optional records
     import pytest
     with pytest.raises(SystemExit):

@@ -150,3 +150,38 @@ def test_component_built_on_the_device_equals_the_oracle_rounds_builder(storage,
         assert np.array_equal(gn, en), f"level {l}: adjacency differs in {np.count_nonzero((gn != en).any(axis=1))} of {len(en)} rows"
     Q, off, rows, desc = sc.queries(nq=24, seed=5)
     _assert_same_filtered(sc, oix, dix, Q, off, rows, 10)
+
+
+def test_filtered_search_on_two_shards_of_a_metadata_collection():
+    """round 6: a metadata collection may be sharded by embedding range — shard s holds embeddings [e0, e0 + n) and returns replica ids
+    id_base + row x max_replicas + i with id_base = e0 x max_replicas.  Two shards, the same filtered queries on both, merged with the
+    shard-exchange merge rule == the oracle's two filtered searches (ids shifted) under the same rule."""
+    import cosdata_amd as ca
+    from tests.test_sharded_merge import _merge_numpy
+    A = MH.Scenario(n=900, dim=64, seed=4)
+    Bs = MH.Scenario(n=700, dim=64, seed=9)
+    oa, ob = A.oracle(), Bs.oracle()
+    base_b = 900 * MH.REPLICAS
+    da, db = A.device(oa), Bs.device(ob, id_base=base_b)
+    Q, off, rows, _ = A.queries(nq=30, seed=5)
+    k = 10
+    parts_d, parts_o = [], []
+    for dix, oix, base in ((da, oa, 0), (db, ob, base_b)):
+        gi, gs, gc = dix.search_filtered(Q, off, rows.astype(np.int8), k)
+        ei, es, ec = oix.search_filtered_batch(Q, off, rows, k, threads=4)
+        assert np.array_equal(gc, ec)
+        for b in range(Q.shape[0]):
+            c = int(gc[b])
+            assert np.array_equal(gi[b, :c], ei[b, :c] + base) and np.array_equal(gs[b, :c].view(np.uint32), es[b, :c].view(np.uint32)), f"shard base {base}, query {b}"
+        parts_d.append((gi, gs, gc))
+        parts_o.append((np.where(np.arange(k)[None, :] < ec[:, None], ei + base, ei).astype(np.uint32), es, ec))
+    md = _merge_numpy(np.stack([p[0] for p in parts_d]), np.stack([p[1] for p in parts_d]), np.stack([p[2] for p in parts_d]), k)
+    mo = _merge_numpy(np.stack([p[0] for p in parts_o]), np.stack([p[1] for p in parts_o]), np.stack([p[2] for p in parts_o]), k)
+    assert np.array_equal(md[2], mo[2])
+    for b in range(Q.shape[0]):
+        c = int(md[2][b])
+        assert np.array_equal(md[0][b, :c], mo[0][b, :c]) and np.array_equal(md[1][b, :c].view(np.uint32), mo[1][b, :c].view(np.uint32))
+    owners = {int(i) >= base_b for b in range(Q.shape[0]) for i in md[0][b, :int(md[2][b])]}
+    assert owners == {False, True}                               # both shards contribute to merged answers
+    with pytest.raises(ca.CosdataError):                         # a base that is not a whole number of embeddings is refused
+        Bs.device(ob, id_base=base_b + 1)
