@@ -212,6 +212,7 @@ static void free_ws(Workspace *w) {
     for (auto &e : w->ev) if (e) (void)hipEventDestroy(e);
     if (w->walk_done) (void)hipEventDestroy(w->walk_done);
     if (w->walk_fin) (void)hipEventDestroy(w->walk_fin);
+    if (w->last_range) (void)hipEventDestroy(w->last_range);
     if (w->prep_done) (void)hipEventDestroy(w->prep_done);
     if (w->walk_stream) (void)hipStreamDestroy(w->walk_stream);
     delete w;
@@ -688,7 +689,7 @@ int32_t vis_tab_prepare(VisTab &vt, const cos_index *ix, u32 B, u32 ef, hipStrea
 // quarter of the 256 MB memory-side cache, so the levels walked in arrival order stay cache-resident whatever the order, and the
 // key is as fine as that allows (c2: level 2, 62 500 nodes x 768 B = 48 MB, levels 1 and 0 walked in order; a 12.5M x 1024
 // shard: level 4, 48 829 nodes).  Every further cut costs the tail of one more launch (~0.3 ms per 32768 queries) and measured
-// slower: profiles/r03_locality_probe_split_levels.jsonl (cuts after 1 | 2 | 3 | 4 | 3,1 | 4,1 | 5,1 | 4,2,1 | 5,3,1).
+// slower: profiles/archive/r03_locality_probe_split_levels.jsonl (cuts after 1 | 2 | 3 | 4 | 3,1 | 4,1 | 5,1 | 4,2,1 | 5,3,1).
 // COS_WALK_SPLIT=a,b,.. overrides (descending levels; "0" = no split).
 // Built on the host from the adjacency, once per graph: milliseconds for levels this small (<= 2^20 nodes).  Caller holds ix->mu.
 static int32_t ensure_order_rank(cos_index *ix) {
@@ -1029,6 +1030,7 @@ static int32_t get_workspace(cos_index *ix, void *key, hipStream_t st, u32 B, u3
     }
     if (!w->walk_done) HIP_TRY(hipEventCreateWithFlags(&w->walk_done, hipEventDisableTiming));
     if (!w->walk_fin) HIP_TRY(hipEventCreateWithFlags(&w->walk_fin, hipEventDisableTiming));
+    if (!w->last_range) HIP_TRY(hipEventCreateWithFlags(&w->last_range, hipEventDisableTiming));
     *out = w;
     return COS_OK;
 }
@@ -1104,7 +1106,12 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     // Level table: on the caller's stream, i.e. BEFORE the walk takes its place in the walk chain — the GEMM of this launch runs next
     // to the previous launch's walk.  (Round 5 also issued it inside the chain, right in front of its own walk, where it shares the
     // chip with nobody: 7.07-7.12 against 6.69 ms per step — the overlap hides 0.4 ms.  profiles/r05_table_gemm_in_chain_probe_not_kept.jsonl)
+    const bool chained = chain && B >= ix->chain_min_B;
     if (tab_level_min) {
+        if (chained && cosdev::tune_or(cosdev::TUNE_WALK_TABLE_AFTER_SORT, 1) != 0) { // (engine_internal.h, chain_last_range_ev)
+            std::lock_guard<std::mutex> g(ix->chain_mu);
+            if (ix->chain_last_range_ev && ix->chain_last_range_ev != w->last_range) HIP_TRY(hipStreamWaitEvent(st, ix->chain_last_range_ev, 0));
+        }
         if (timed) HIP_TRY(hipEventRecord(ev[4], st));
         HIP_TRY(cosdev::launch_level_table(ix->eng, w->q_codes, w->q_mags, w->qsums, w->qdig, B, tcodes, tmags, tcsums, ix->row_stride, tab_cols, w->tab,
                                            tab_stride, ix->n_cus, st));
@@ -1152,9 +1159,13 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     // Beam widths above 256 keep the single launch: the cut costs the tail of one more launch, a fixed ~3 % of the walk whatever
     // the ef, while what the order saves shrinks as the walk turns from memory-bound to bound by its own serial work (c2: +16 % at
     // ef 64, +3.6 % at 128, +2.6 % at 256, +1 % at 512; nothing measurable at ef 512 on the uniform corpus or on a 12.5M shard:
-    // profiles/r03_order_probe_*.jsonl and the two r03_final_bench_default_* lines, taken with and without this rule).
+    // profiles/archive/r03_order_probe_*.jsonl and the two r03_final_bench_default_* lines, taken with and without this rule).
     auto walk = [&](hipStream_t s) -> int32_t {
-        if (!ordered) { HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, lat4_max_B, s)); return COS_OK; }
+        if (!ordered) {
+            if (chained) HIP_TRY(hipEventRecord(w->last_range, s));
+            HIP_TRY(launch_walk(ix->eng, dev, wa, lat_max_B, lat4_max_B, s));
+            return COS_OK;
+        }
         wa.phase = 1;
         wa.entry0 = w->order.entry0;
         wa.order_key = w->order.order_key;
@@ -1166,6 +1177,7 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
             wa.level_last = last ? 0u : key_level[i];
             wa.key_n = last ? 0u : key_n[i];
             wa.order_rank = last ? nullptr : order_rank[i];
+            if (last && chained) HIP_TRY(hipEventRecord(w->last_range, s));
             HIP_TRY(launch_walk(ix->eng, dev, wa, 0, 0, s));
             if (last) break;
             if (timed && i == 0) HIP_TRY(hipEventRecord(ev[6], s));
@@ -1176,13 +1188,14 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
         }
         return COS_OK;
     };
-    if (chain && B >= ix->chain_min_B) { // walk chain (engine_internal.h): wait for the previous big walk, whichever stream it ran on
+    if (chained) { // walk chain (engine_internal.h): wait for the previous big walk, whichever stream it ran on
         std::lock_guard<std::mutex> g(ix->chain_mu);
         if (ix->chain_ev && ix->chain_ev != w->walk_done) HIP_TRY(hipStreamWaitEvent(sw, ix->chain_ev, 0));
         if (timed) HIP_TRY(hipEventRecord(ev[1], sw)); // the kernel's own duration: after the wait
         if (int32_t rc = walk(sw)) return rc;
         HIP_TRY(hipEventRecord(w->walk_done, sw));
         ix->chain_ev = w->walk_done;
+        ix->chain_last_range_ev = w->last_range;
     } else {
         if (timed && sw != st) HIP_TRY(hipEventRecord(ev[1], sw));
         if (int32_t rc = walk(sw)) return rc;

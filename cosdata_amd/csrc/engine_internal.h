@@ -154,6 +154,7 @@ struct Workspace {
     std::vector<hipEvent_t> ev; // [EV_RING][EV_PER]
     u32 ev_count = 0;           // timed launches since timing was switched on (ring position = ev_count % EV_RING)
     hipEvent_t walk_done = nullptr; // recorded after this workspace's walk kernel (walk chain, see cos_index::chain_*)
+    hipEvent_t last_range = nullptr; // recorded when this workspace's walk reaches its LAST level range (after the order sort; an unsplit walk: its start)
     hipStream_t walk_stream = nullptr; // low-priority stream big walks run on (cos_index::walk_side_min_B), created on first use
     hipEvent_t prep_done = nullptr, walk_fin = nullptr; // caller's stream -> walk stream -> finalize stream
     u32 lastB = 0;
@@ -228,6 +229,11 @@ struct cos_index {
     // the other with an event, while everything else of a launch stays free to overlap.
     std::mutex chain_mu;
     hipEvent_t chain_ev = nullptr; // walk_done of the most recent chained walk
+    // ... and its last_range: the next launch's level-table GEMM waits for it.  Issued freely on the caller's stream the GEMM lands
+    // next to the previous walk's UPPER range and order sort — and the sort's first kernel (32 workgroups) cannot be placed while the
+    // GEMM's 450-register waves hold every SIMD: the chip ran the GEMM alone for 3 ms per step and the lower range waited
+    // (profiles/r06_step_timeline_before.txt).  Behind this event the GEMM shares the chip with the HBM-bound lower range instead.
+    hipEvent_t chain_last_range_ev = nullptr;
     // (Round 5 also chained the two level ranges of a split walk separately, so that the upper range of launch i+1 — table levels,
     // instruction issue — co-ran with the lower range of launch i — HBM.  Measured: 7.08 against 7.12 ms per step at ef 64, 17.34
     // against 17.27 at ef 256 (profiles/r05_phase_chain_probe.jsonl): both ranges are limited by the queries in flight, and two

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
     __syncthreads(); // the slice table
     // ---- stepped path (the usual case: the table holds every slice of the block and a query has <= 64 terms) --------------------
     // A tile's slices average ~900 postings, so the block-wide chunks below (2048 posting slots per (tile, term)) ran 43 % full and
-    // the kernel was instruction-bound (135 lane-instructions per posting, profiles/r03_sparse_tile_kernel_sq_counters_*.txt).  Here every WAVE
+    // the kernel was instruction-bound (135 lane-instructions per posting, profiles/archive/r03_sparse_tile_kernel_sq_counters_*.txt).  Here every WAVE
     // pulls STEPS — 512 consecutive postings of one slice — from a per-tile counter in LDS: a slice of L postings is ceil(L / 512)
     // steps, waves never wait for each other inside a tile (LDS atomic adds commute), a long slice spreads over the four waves, and
     // the next step's postings are in flight while the current one is applied.
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void sparse_tile_kernel(const u32 *__restrict_
             // Branch-free: every lane issues its ds_add — a posting that does not count (past the step's end, another tile of a short
             // list, a key below the term's first visited key) adds 0 to the lane's dummy slot behind the tile.  The block-chunk version spent
             // ~70 instructions per posting slot on exec-mask bookkeeping around two predicated atomics (89 lane-instructions per posting,
-            // profiles/r03_sparse_tile_kernel_sq_counters_wave_steps.txt).  Weight-0 postings (key 0, or a query value that
+            // profiles/archive/r03_sparse_tile_kernel_sq_counters_wave_steps.txt).  Weight-0 postings (key 0, or a query value that
             // quantizes to 0) are rare: one wave-level test per step.
             auto apply_s = [&](const Step &sp, const u32 (&iv)[SPU], const u32 (&kv)[SPU]) {
                 const u32 qq = sp.w & 255u, k0 = sp.w >> 8;

@@ -461,7 +461,7 @@ size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
 
 // rows in flight per wave on the G = 64 u8 path (see PB64 above); tuning knob walk_pb = 4|8 overrides the default (experiments).
 // The widest pool (ef > 256: 16 VGPRs of pool) with eight row buffers needs 110 VGPRs = 4 waves per SIMD; with four it fits 5 waves
-// without spills and measured 3.3 % faster (c2 at ef 512: 50.9 vs 52.6 ms per 32768 queries, profiles/r03_order_probe_c2_ef512_pb4.jsonl).
+// without spills and measured 3.3 % faster (c2 at ef 512: 50.9 vs 52.6 ms per 32768 queries, profiles/archive/r03_order_probe_c2_ef512_pb4.jsonl).
 // The UPPER range of a split walk (tuning knob walk_pb_upper = 4|8 overrides): with the level table that range is almost all table
 // levels, which fetch no rows (c2: 91 M table evaluations against 2 M row evaluations), and the four-buffer variant leaves more waves
 // per SIMD.  Measured in round 5 (profiles/r05_candidates_walk_pb_upper.txt, c2): ef 64 2.798 against 2.799 ms (nothing: 8 stays),

@@ -2,7 +2,7 @@
 // 256-CU chip), same ann_search / traverse_find_nearest (vector_store.rs:256-402, 1112-1204), same per-level lists bit for bit.
 //
 // The one-wave latency kernel (kernels_walk_lat.hip) spends half of a lone batch issuing instructions — 229 k per query at ~4.5
-// clocks each (profiles/r03_single_batch_sq_counters_one_wave_latency_walk.txt) — and the other half parked on two dependent HBM
+// clocks each (profiles/archive/r03_single_batch_sq_counters_one_wave_latency_walk.txt) — and the other half parked on two dependent HBM
 // round trips per round.  A workgroup of four waves (one per SIMD of the query's CU) attacks both:
 //   * the window is NW x E entries (E = 1: four, the default; E = 2: eight), wave w owns entries w (, w + 4): its adjacency rows,
 //     its candidates under the filter as it stands at the start of the round, their similarities — the whole speculative half of
@@ -509,7 +509,7 @@ bool walk_lat4_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 m
 
 hipError_t launch_walk_lat4(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st) {
     // window: 4 entries (one per wave).  8 (two per wave, COS_WALK_LAT4_E=2) needs 24 % fewer rounds but measured 2.6x slower per
-    // round (profiles/r03_latency_sweep_*): the wasted evaluations and the wider merge cost every wave more than the rounds save
+    // round (profiles/archive/r03_latency_sweep_*): the wasted evaluations and the wider merge cost every wave more than the rounds save
     const int e_env = (int)tune_or(TUNE_WALK_LAT4_E, 1);
     const u32 ch = (ix.nchunks + GL4 - 1) / GL4;
     if (e_env == 1) {
