@@ -173,6 +173,19 @@ def value_at_batch_256(host):
             "min_over_caller_counts": min(v["qps"] for v in best.values())}
 
 
+def committed_kernel_traffic(key):
+    """fabric-side bytes PER DISPATCH of a config's dominant kernel from the committed PMC pass of the config's own script
+    (scripts/pmc_traffic_kernel.py -> profiles/pmc_traffic.json), or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            for ent in json.load(fh):
+                if ent.get("workload") == key and "bytes_per_dispatch" in ent and ent.get("dispatches", 0) > 0:
+                    return float(ent["bytes_per_dispatch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def ca_mod():
     import cosdata_amd
     return cosdata_amd

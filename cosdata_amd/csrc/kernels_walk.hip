@@ -488,7 +488,10 @@ template <int ENG, int CH, bool G64>
 static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa_in, hipStream_t st) {
     WalkArgs wa = wa_in;
     wa.merge_min = wa.tab != nullptr ? walk_merge_min_policy(wa.ef) : 0u;
-    const size_t smem = walk_smem_bytes(ix, wa.ef, ENG);
+    size_t smem = walk_smem_bytes(ix, wa.ef, ENG);
+    // experiment knob: extra (unused) dynamic LDS per wave on the upper range of a split walk = fewer resident waves per CU, so that the
+    // table slices of the small top levels of the resident queries fit the XCD's L2 (see DESIGN.md 8.1 for what it measured)
+    if (wa.phase != 0u && wa.level_last >= 1u) smem += (size_t)std::min<long long>(tune_or(TUNE_WALK_UPPER_LDS_PAD, 0), 48 << 10);
     dim3 grid(wa.B), block(64);
     const bool exact = ix.visited_mode != 0;
     constexpr bool HAS_PB8 = ENG == ENG_U8 && G64 && CH == 1; // the headline path (u8, 513..1024 dims)

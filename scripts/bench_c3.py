@@ -20,6 +20,7 @@ def _cores():
 
 def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, device=0):
     import torch
+    import bench
     import cosdata_amd as ca
     t_all = time.time()
     dev = torch.device(f"cuda:{device}")
@@ -78,7 +79,9 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
            "qps": B / wall, "unit": "queries/s", "ms_per_step": wall * 1e3, "steps": reps, "warmup": 1, "dtype": "fp4 e2m1 (2-bit digits, exact)" if fp4_on else "i8 (2-bit digits)",
            "recall_at_10": rec_flat, "recall_note": "vs exact f32 brute force; the reference's fixed-range 2-bit quantizer with MSB-first planes "
                                                     "multiplied LSB-first bounds it — the GPU reproduces the oracle exactly, the recall is the reference's",
-           "roofline": {"bound": "mfma", "achieved": tops, "peak": PEAK, "unit": "TOP/s", "frac": tops / PEAK, "traffic": None,
+           "roofline": {"bound": "mfma", "achieved": tops, "peak": PEAK, "unit": "TOP/s", "frac": tops / PEAK,
+                        # fabric-side bytes of one step's scan kernels from the committed FETCH / WRITE pass of this script (scripts/final_profile.sh)
+                        "traffic": (lambda t: t * st.gemm_launches if t else None)(bench.committed_kernel_traffic("c3_scan" if fp4_on else "c3_scan_i8")),
                         "kernel": ("flat_scan_q2_fp4<%d> (query-resident scan, digits as e2m1 on v_mfma_scale_f32_32x32x64_f8f6f4; peak = dense FP4)" % (d // 64)) if fp4_on
                                   else "flat_scan_q2_areg<KC> (query-resident i8 MFMA scan)",
                         "same_scan_with_i8_digits": {"kernel": "flat_scan_q2_areg<KC>", "gemm_ms_all_launches": i8_gemm_ms, "ms_per_step": i8_wall * 1e3,
@@ -164,6 +167,7 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
         stt = ix2.last_stats(ss[0].cuda_stream)
         ids2, sc2, cnt2 = ix2.batch_search(Qh, 10)
         rec_walk = float(np.mean([len(set(ids2[i].tolist()) & set(gt2[i].tolist())) / 10 for i in range(B)]))
+        walk_dispatches = 1 + (len(ix2.walk_order_cuts()) if Bq >= ca.HNSWIndex.WALK_ORDER_DEFAULT_MIN_B else 0)   # level ranges of one launch
         row_b = 2 * ((d + 63) // 64) * 8 + 4
         alg = float(stt.evals * row_b + stt.adj_bytes)
         gbps = alg / (stt.walk_ms * 1e-3) / 1e9 if stt.walk_ms > 0 else 0.0
@@ -174,7 +178,8 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
                 "recall_note": "quaternary planes are stored MSB first and multiplied LSB first (SURVEY App. C #4): the walk ranks by the reference's "
                                "own quaternary dot, low recall is the reference's behaviour, reproduced bit for bit",
                 "roofline": {"bound": "hbm", "kernel": "walk_kernel<ENG_Q2> (196 B per evaluation: latency / issue, not bandwidth, bounds rows this short)",
-                             "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
+                             "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                             "traffic": (lambda t: t * walk_dispatches if t else None)(bench.committed_kernel_traffic("c3_walk")),
                              "per_launch": {"algorithmic_bytes": alg, "avg_ms": stt.walk_ms, "evals": int(stt.evals), "expansions": int(stt.expansions)}}}
         if cpu_seconds > 0:   # the oracle on the same graph: CPU baseline + parity of the 256 answers, bit for bit
             cores = _cores()

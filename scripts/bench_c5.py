@@ -124,7 +124,7 @@ def run(n=1_000_000, dim=768, vocab=200_000, doc_len=120.0, batch=256, top_k=10,
            # the step's DOMINANT kernel is the dense half's walk (one 256-query batch cannot fill the chip): it is the headline block;
            # the BM25 posting scan, which runs next to it on its own stream, is under `parts`
            "roofline": {"bound": "hbm", "achieved": dense_bytes / (stt.walk_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": dense_bytes / (stt.walk_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                        "frac": dense_bytes / (stt.walk_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": bench.committed_kernel_traffic("c5_walk"),
                         "step_frac": (dense_bytes + post_bytes) / el_h1 / 1e9 / HBM_PEAK_GBPS,
                         "kernel": "walk_lat4_kernel (one 256-query batch, ef 256: four waves per query)",
                         "per_launch": {"algorithmic_bytes": float(dense_bytes), "avg_ms": stt.walk_ms, "evals": float(stt.evals),

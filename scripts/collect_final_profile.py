@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """After `gpurun -- bash scripts/final_profile.sh`: copy what the run left under gpurun_out/ into profiles/ under the round's names
-(usage: collect_final_profile.py r05).  Kernel-trace / PMC summaries written by an older scripts/rocprof_summary.py are compacted with
+(usage: collect_final_profile.py r06).  Kernel-trace / PMC summaries written by an older scripts/rocprof_summary.py are compacted with
 the rule the current one applies (a kernel launched with more than 12 different grids becomes one row)."""
 import os
 import re
@@ -42,14 +42,12 @@ def compact_text(src, dst):
     open(dst, "w").write("\n".join(head + body + rest))
 
 
-texts = {"final_kernel_trace_c2.txt": "final_kernel_trace_c2_rocprofv3.txt", "final_kernel_trace_c3.txt": "final_kernel_trace_c3_rocprofv3.txt",
-         "final_kernel_trace_c5.txt": "final_kernel_trace_c5_rocprofv3.txt", "final_kernel_trace_c4shard.txt": "final_kernel_trace_c4shard_rocprofv3.txt",
-         "final_pmc_fetch_size.txt": "final_pmc_fetch_size_rocprofv3.txt", "final_pmc_write_size.txt": "final_pmc_write_size_rocprofv3.txt",
-         "final_pmc_sq_instruction_mix.txt": "final_pmc_sq_instruction_mix_rocprofv3.txt", "final_pmc_fetch_size_c3.txt": "final_pmc_fetch_size_c3_rocprofv3.txt",
-         "final_pmc_fetch_size_c4shard.txt": "final_pmc_fetch_size_c4shard_rocprofv3.txt", "final_pmc_write_size_c4shard.txt": "final_pmc_write_size_c4shard_rocprofv3.txt"}
+texts = {f"final_kernel_trace_{w}.txt": f"final_kernel_trace_{w}_rocprofv3.txt" for w in ("main", "c2", "c3", "c5")}
+texts.update({f"final_pmc_{c}_{w}.txt": f"final_pmc_{c}_{w}_rocprofv3.txt" for c in ("fetch_size", "write_size", "sq_instruction_mix") for w in ("main", "c2", "c3", "c5")})
 copies = {"final_bench_all_configs.json": "final_bench_default_stdout_line.json", "final_bench_all_configs_full_record.json": "final_bench_default_full_record.json",
-          "final_bench_c2_under_rocprofv3.json": "final_bench_c2_under_rocprofv3.json", "final_bench_c4shard_under_rocprofv3.json": "final_bench_c4shard_under_rocprofv3.json",
-          "final_c3.json": "final_c3.json", "final_c5.json": "final_c5.json", "final_pytest.log": "final_pytest.log", "final_profile.log": "final_profile_script.log"}
+          "final_bench_main_under_rocprofv3.json": "final_bench_main_under_rocprofv3.json", "final_bench_c2_under_rocprofv3.json": "final_bench_c2_under_rocprofv3.json",
+          "final_c3.json": "final_c3.json", "final_c5.json": "final_c5.json", "final_pytest.log": "final_pytest.log", "final_profile.log": "final_profile_script.log",
+          "final_step_timeline_main.txt": "final_step_timeline_main.txt"}
 for a, b in texts.items():
     if os.path.exists(os.path.join(G, a)):
         compact_text(os.path.join(G, a), os.path.join(P, f"{tag}_{b}"))

@@ -1,0 +1,15 @@
+#!/bin/bash
+R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT; TAG=${1:-r06_pad}
+V="base;walk_upper_lds_pad=4096;walk_upper_lds_pad=8192;walk_upper_lds_pad=16384;walk_upper_lds_pad=32768"
+PROBE_N=12500000 PROBE_D=1024 PROBE_M0=256 PROBE_M=64 PROBE_EFC=256 PROBE_VARIANTS="$V" PROBE_EFS=112 PROBE_COLS=4294967295 PROBE_REPS=8 timeout 900 python scripts/table_probe.py > $OUT/${TAG}_probe_c4shard.jsonl 2> $OUT/${TAG}_c4.err; echo "probe c4 rc=$?"
+PROBE_VARIANTS="$V" PROBE_EFS=64 PROBE_COLS=4294967295 PROBE_REPS=16 timeout 600 python scripts/table_probe.py > $OUT/${TAG}_probe_c2.jsonl 2> $OUT/${TAG}_c2.err; echo "probe c2 rc=$?"
+TAG=$TAG python - <<'PY'
+import json, os
+tag = os.environ["TAG"]
+for f in (f"gpurun_out/{tag}_probe_c2.jsonl", f"gpurun_out/{tag}_probe_c4shard.jsonl"):
+    for l in open(f):
+        j = json.loads(l)
+        if "variant" in j:
+            a = j["alone"]
+            print(f[-16:-6], j["variant"].ljust(26), j["ef"], "same", j["ids_identical_to_first_config"], "qps", j["qps_2_in_flight"], "up", a["upper_ms"], "lo", a["lower_ms"], "tab", a["table_ms"])
+PY
