@@ -94,6 +94,10 @@ struct WalkArgs {
     u32 tab_level_min;
     u32 tab_col0[MAX_LEVELS];
     u32 no_self_seed;     // 1 = nothing is pre-inserted in a level's filter (delete_embedding's walks, vector_store.rs:1232-1248); walk_kernel only
+    u32 smem_mmax;        // LDS layout of walk_kernel (set by launch_walk): the widest neighbour row among the levels THIS launch walks (its filter: 8 x M bytes) ...
+    u32 smem_win_bytes;   // ... and the bytes of the window region: 3 x LA x 64 x 4 when a row level is walked, just the ranked merge's scratch when every
+                          // level of the launch is a table level (the upper range of a split walk on the metric's shard: 6.6 -> 2.9 KB per wave, LDS no
+                          // longer caps the resident waves)
     u32 merge_min;        // table levels: an expansion with at least this many winners past the screen inserts them by ONE ranked merge
                           // (walk_kernel.inc commit_merge) instead of one pool shift each; 0 = always the serial insert.  Set by launch_walk.
     // Locality-ordered walk (big search launches; kernels_order.hip, engine.hip run_search).  The walk of a launch is split

@@ -450,9 +450,9 @@ hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u3
     return hipGetLastError();
 }
 
-size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
-    u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
-    size_t b = (size_t)Mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2 + (size_t)LA * 64 * 4 * 3; // (window: vector rows, node indices, norms)
+// LDS of one walk_kernel wave (walk_kernel.inc, WalkSmem): filter | popped list | winners | window | f32 / f16 query
+size_t walk_smem_bytes(const IndexDev &ix, u32 ef, int eng, u32 mmax, u32 win_bytes) {
+    size_t b = (size_t)mmax * 8 + (size_t)ef * 8 + 64 * 4 * 2 + (size_t)win_bytes;
     b = (b + 15) & ~(size_t)15;
     if (eng == ENG_F32) b += (size_t)ix.row_stride;
     if (eng == ENG_F16) b += ((size_t)ix.dim * 4 + 15) & ~(size_t)15;
@@ -488,16 +488,29 @@ template <int ENG, int CH, bool G64>
 static hipError_t launch_walk_r(const IndexDev &ix, const WalkArgs &wa_in, hipStream_t st) {
     WalkArgs wa = wa_in;
     wa.merge_min = wa.tab != nullptr ? walk_merge_min_policy(wa.ef) : 0u;
-    size_t smem = walk_smem_bytes(ix, wa.ef, ENG);
-    // experiment knob: extra (unused) dynamic LDS per wave on the upper range of a split walk = fewer resident waves per CU, so that the
-    // table slices of the small top levels of the resident queries fit the XCD's L2 (see DESIGN.md 8.1 for what it measured)
-    if (wa.phase != 0u && wa.level_last >= 1u) smem += (size_t)std::min<long long>(tune_or(TUNE_WALK_UPPER_LDS_PAD, 0), 48 << 10);
+    // the LDS of a wave follows the levels THIS launch walks: the filter is as wide as their widest row, and a launch of table levels only
+    // (the upper range of a split walk whose cut level is in the table) needs no window staging — just the ranked merge's scratch.  On the
+    // metric's shard (M0 256, ef 112) that is 2.9 KB per wave instead of 6.6: the upper range's 60-register waves were capped at 6 per
+    // SIMD by LDS, and that range is bound by the gathers in flight (fewer resident waves = proportionally slower:
+    // profiles/r06_pad_probe_c4shard.jsonl) — now 8.
+    const u32 lf = wa.phase ? wa.level_first : ix.num_layers, ll = wa.phase ? wa.level_last : 0u;
+    u32 mmax = 1;
+    for (u32 l = ll; l <= lf; l++) mmax = std::max(mmax, ix.lv[l].M);
+    constexpr bool TABLE_ENG = ENG == ENG_U8 || ENG == ENG_Q2;
+    const bool all_tab = TABLE_ENG && wa.tab != nullptr && ll >= wa.tab_level_min && tune_or(TUNE_WALK_UPPER_LDS_PAD, 0) >= 0;
+    wa.smem_mmax = mmax;
+    size_t pad = 0;
+    // experiment knob: extra (unused) dynamic LDS per wave on the upper range of a split walk = fewer resident waves per CU (negative: the
+    // full layout even for table-only launches)
+    if (wa.phase != 0u && wa.level_last >= 1u) pad = (size_t)std::max<long long>(0, std::min<long long>(tune_or(TUNE_WALK_UPPER_LDS_PAD, 0), 48 << 10));
     dim3 grid(wa.B), block(64);
     const bool exact = ix.visited_mode != 0;
     constexpr bool HAS_PB8 = ENG == ENG_U8 && G64 && CH == 1; // the headline path (u8, 513..1024 dims)
     const bool pb8 = HAS_PB8 && walk_pb_policy(wa.B, wa.ef, wa.phase != 0u && wa.level_last >= 1u) == 8;
 #define WALK(R_)                                                                                                          \
     do {                                                                                                                  \
+        wa.smem_win_bytes = (all_tab && (R_) <= 4) ? (u32)(((64 * (R_) + 1) * 8 + 15) & ~15) : (u32)(LA * 64 * 4 * 3);         \
+        const size_t smem = walk_smem_bytes(ix, wa.ef, ENG, mmax, wa.smem_win_bytes) + pad;                                \
         if constexpr (HAS_PB8) {                                                                                          \
             if (pb8) {                                                                                                    \
                 if (exact) hipLaunchKernelGGL((walk_kernel<ENG, CH, R_, G64, true, 8>), grid, block, smem, st, ix, wa);   \
