@@ -1108,7 +1108,11 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     // chip with nobody: 7.07-7.12 against 6.69 ms per step — the overlap hides 0.4 ms.  profiles/r05_table_gemm_in_chain_probe_not_kept.jsonl)
     const bool chained = chain && B >= ix->chain_min_B;
     if (tab_level_min) {
-        if (chained && cosdev::tune_or(cosdev::TUNE_WALK_TABLE_AFTER_SORT, 1) != 0) { // (engine_internal.h, chain_last_range_ev)
+        // (engine_internal.h, chain_last_range_ev.)  Only a GEMM long enough to outlast the previous walk's upper range blocks its sort: the
+        // shard's 65 161 columns x 32 768 queries (3.1 ms alone; gate: 33.3 -> 32.6 ms per step) do, c2's 20 903 (0.85 ms; 6.22 -> 6.29) do not
+        // (profiles/r06_inflight_probe.txt); knob: 0 = never, 2 = always
+        const long long gate = cosdev::tune_or(cosdev::TUNE_WALK_TABLE_AFTER_SORT, 1);
+        if (chained && (gate == 2 || (gate == 1 && (u64)tab_cols * B >= (1ull << 30)))) {
             std::lock_guard<std::mutex> g(ix->chain_mu);
             if (ix->chain_last_range_ev && ix->chain_last_range_ev != w->last_range) HIP_TRY(hipStreamWaitEvent(st, ix->chain_last_range_ev, 0));
         }
