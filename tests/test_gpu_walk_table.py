@@ -242,8 +242,9 @@ def test_norms_beside_the_adjacency_keep_every_bit(dim, visited, m0, m):
     dix.set_latency_mode(0)
     dix.set_latency_waves(0)      # the throughput kernel at every launch size
     Q = H.queries_from(X, 1500, noise=0.05, seed=3)
-    on = dix.batch_search(Q, 10)
-    walk_on = dix.ann_search_batch(Q)
+    with _lib.tuning(walk_adj_mag=2):           # (2 = at every ef and launch size: by default a launch this small keeps the gathers)
+        on = dix.batch_search(Q, 10)
+        walk_on = dix.ann_search_batch(Q)
     with _lib.tuning(walk_adj_mag=0):
         off = dix.batch_search(Q, 10)
         walk_off = dix.ann_search_batch(Q)
@@ -252,7 +253,12 @@ def test_norms_beside_the_adjacency_keep_every_bit(dim, visited, m0, m):
     root2 = np.ascontiguousarray(X[7] * 0.5 + X[11] * 0.5)
     dix.set_root(root2)
     oix.set_root_raw(root2)
-    again = dix.batch_search(Q, 10)
+    with _lib.tuning(walk_adj_mag=2):
+        again = dix.batch_search(Q, 10)
     with _lib.tuning(walk_adj_mag=0):
         assert _same(again, dix.batch_search(Q, 10))
+    Qbig = H.queries_from(X, 4200, noise=0.05, seed=13)   # a launch big enough for the default policy to read the norms beside the adjacency
+    big = dix.batch_search(Qbig, 10)
+    with _lib.tuning(walk_adj_mag=0):
+        assert _same(big, dix.batch_search(Qbig, 10))
     _check_against_oracle(oix, again, Q, 10, np.arange(0, 1500, 23))
