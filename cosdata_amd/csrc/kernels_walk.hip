@@ -553,12 +553,13 @@ static void walk_env_overrides(u32 &lat_max_B, u32 &lat4_max_B) {
 // kernel at every launch size (1M x 768, ms per launch at ef 64 / 256: 256 queries 0.77 / 2.20 against 0.99 / 2.37; 1 024 queries
 // 0.84 / 2.33 against 1.13 / 2.57; 2 048 queries 0.95 / 2.58 against 1.50 / 2.91) and the four-wave kernel up to ef 64 (0.77
 // against 0.82 with the table, 0.88 without); above ef 64 the four-wave kernel with the table stays ahead on one client batch
-// (1.73 against 2.20 at ef 256).  profiles/r04_single_batch_probe.jsonl, r04_mid_size_probe.jsonl.
+// (1.73 against 2.20 at ef 256).  profiles/r04_single_batch_probe.jsonl, r04_mid_size_probe.jsonl.  Round 6 (r06_single_batch_probe.jsonl): one
+// client batch with the automatic table — ef 64 0.642 / 0.643 ms (throughput / four waves), ef 128 1.017 / 1.148, ef 256 1.747 / 1.658.
 int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, bool table_available) { // 0 throughput, 1 one-wave latency, 4 four-wave latency
     walk_env_overrides(lat_max_B, lat4_max_B);
     const bool tk_small = tune_or(TUNE_WALK_SMALL_TABLE_TK, 1) != 0;
     if (table_available && tk_small && eng == ENG_U8) {
-        if (wa.phase == 0u && wa.ef > 64u && walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return 4;
+        if (wa.phase == 0u && wa.ef > 128u && walk_lat4_applicable(eng, ix, wa, lat4_max_B)) return 4; // (round 6: the 128-key pool + ranked merge moved the crossover from ef 64 to 128)
         return 0;
     }
     if (wa.phase == 0u) {
