@@ -170,3 +170,35 @@ def test_delete_relinks_a_node_left_without_neighbours():
     relinked = [i for i in range(n) if i not in set(victims.tolist()) and (before[0][1][i] != E).sum() == 1
                 and before[0][1][i][before[0][1][i] != E][0] in set(victims.tolist()) and (after[i] != E).any()]
     assert relinked, "no orphan was linked again: the slow path was not exercised"
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_interleaving_of_appends_and_deletes_follows_the_oracle(seed):
+    """a transaction history: appends of random sizes (1 .. 400) and deletes of random live ids (single ids, small groups, ids appended a step
+    earlier) in random order — after EVERY operation the device's graph is the oracle's, slot for slot, and at the end so are the searches"""
+    rng = np.random.default_rng(1000 + seed)
+    dim, n0, total = 64, 800, 3200
+    X = H.clustered_corpus(total, dim, n_centers=24, seed=40 + seed)
+    p = O.HNSWParams(dim=dim, num_layers=4, ef_construction=40, ef_search=40, seed=seed, level0_neighbors_count=32, neighbors_count=16)
+    oix = O.OracleIndex(p).set_vectors(X[:n0])
+    oix.build_rounds(96)
+    dix = _device(X[:n0], p).build(96)
+    at, dead = n0, set()
+    for step in range(14):
+        if at < total and (rng.random() < 0.6 or at - len(dead) < 50):
+            m = int(min(total - at, rng.choice([1, 7, 60, 400])))
+            oix.append(X[at:at + m], 96)
+            dix.append(X[at:at + m], 96)
+            at += m
+        else:
+            live = np.array(sorted(set(range(at)) - dead), np.uint32)
+            k = int(rng.choice([1, 3, 25]))
+            ids = rng.choice(live, size=min(k, live.size), replace=False).astype(np.uint32)
+            oix.delete(ids)
+            dix.delete(ids)
+            dead |= set(ids.tolist())
+        _same_graph(dix.download_graph(), oix.export_graph())
+    Q = H.queries_from(X[:at], 200, noise=0.05, seed=seed)
+    ids, sc, cnt = dix.batch_search(Q, 10)
+    oids, osc, ocnt = oix.search_batch(Q, 10, threads=4)[:3]
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
