@@ -370,7 +370,7 @@ class DenseWorkload:
     """One dense corpus resident in HBM + its query sets + ground truth; `run_mode()` builds a graph with the given
     visited filters and measures it.  Several modes share the corpus, the ground truth and the oracle's quantized copy."""
 
-    def __init__(self, env, name, n_override=0, ef_construction=0, quantization="auto", build_batch=4096):
+    def __init__(self, env, name, n_override=0, ef_construction=0, quantization="auto", build_batch=4096, append_rows=0):
         import cosdata_amd as ca
         self.ca = ca
         self.env, self.name = env, name
@@ -405,7 +405,11 @@ class DenseWorkload:
             self.corpus_desc = ("uniform(-1,1) per component, not normalised (tests/test.py:88), seed 42; queries are stored vectors, like "
                                 "tests/test.py:120-139 searches the vectors it inserted (independent uniform draws have no neighbours to find "
                                 "in 768 dimensions)")
-        self.X = draw(n, 42 + 1000 * rank)                       # this rank's shard: global ids [rank*n, (rank+1)*n)
+        # append_rows more vectors of the same distribution behind the shard's n rows: what run_mode's append probe inserts into the RESIDENT
+        # graph (cos_index_append with the caller's grown table, borrowed like the first n rows)
+        self.append_rows = int(append_rows)
+        self.X_all = draw(n + self.append_rows, 42 + 1000 * rank)   # this rank's shard: global ids [rank*n, (rank+1)*n)
+        self.X = self.X_all[:n]
         draw_q = draw
         if corpus == "uniform" and world == 1:
             def draw_q(m, seed):
@@ -447,7 +451,7 @@ class DenseWorkload:
 
     def close(self):
         self.oracle = None
-        for a in ("X", "Q", "Q_sel", "Q_rep", "o_pack", "o_st", "g_pack", "m_ids", "m_sc", "m_cnt", "gt_sel", "gt_rep", "o_ids", "o_sc", "o_cnt"):
+        for a in ("X", "X_all", "Q", "Q_sel", "Q_rep", "o_pack", "o_st", "g_pack", "m_ids", "m_sc", "m_cnt", "gt_sel", "gt_rep", "o_ids", "o_sc", "o_cnt"):
             if hasattr(self, a):
                 setattr(self, a, None)
         self.env.torch.cuda.empty_cache()
@@ -486,7 +490,7 @@ class DenseWorkload:
 
     # ---- one (build filter, search filter) mode -------------------------------------------------------------------
     def run_mode(self, build_visited, visited, ef_arg="auto", ef_sweep="", cpu_seconds=12.0, single_batch=False, host_api=False,
-                 hbm_probe=False, exchange="auto", m0=64, m_upper=32):
+                 hbm_probe=False, exchange="auto", m0=64, m_upper=32, append_probe=False):
         env, ca, torch = self.env, self.ca, self.env.torch
         args = env.args
         dev, rank, world, local_rank, dist, dist_on = env.dev, env.rank, env.world, env.local_rank, env.dist, env.dist_on
@@ -898,12 +902,52 @@ class DenseWorkload:
             empirical["kernel_frac_of_row_gather"] = kernel_gbps / empirical["row_gather_GBps"]
             empirical["kernel_frac_of_stream_read"] = kernel_gbps / empirical["stream_read_GBps"]
 
+        # ---- round 6: insert into / delete from the RESIDENT graph (cos_index_append / cos_index_delete; index_embeddings on a live index,
+        # vector_store.rs:714-780, and delete_embedding, :1206-1400) instead of the rebuild every commit used to be.  LAST: the index grows.
+        append = None
+        if append_probe and self.append_rows and rank == 0 and world == 1:
+            m = self.append_rows
+            torch.cuda.synchronize(dev)
+            t_a = time.perf_counter()
+            ix.append_device(self.X_all.data_ptr(), m, self.build_batch, keepalive=self.X_all)
+            torch.cuda.synchronize(dev)
+            append_s = time.perf_counter() - t_a
+            # queries near the NEW vectors: found?  (recall against brute force over the grown corpus, the engine's own exhaustive scan)
+            nq = 1024
+            gq = torch.Generator(device=dev)
+            gq.manual_seed(4711)
+            pick = torch.randint(n, n + m, (nq,), generator=gq, device=dev)
+            Qn = self.X_all[pick] + (0.05 / d ** 0.5) * torch.randn(nq, d, generator=gq, device=dev)
+            Qn = (Qn / Qn.norm(dim=1, keepdim=True)).contiguous()
+            ix.batch_search_device(Qn.data_ptr(), nq, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(), o_st[0].data_ptr(), streams[0].cuda_stream)
+            streams[0].synchronize()
+            got = o_ids[0][:nq].to(torch.int64) & 0xFFFFFFFF
+            gt_n, _ = ix.bruteforce_topk(Qn.cpu().numpy(), k)
+            gt_n = torch.from_numpy(gt_n.astype(np.int64)).to(dev)
+            rec_new = float((got.unsqueeze(2) == gt_n.unsqueeze(1)).any(dim=2).float().mean().item())
+            self_found = float((got == pick[:, None]).any(dim=1).float().mean().item())
+            # delete a handful of the appended ids (a transaction's deletes), then the same queries: none of them comes back
+            dele = pick[:32].unique().cpu().numpy().astype(np.uint32)
+            t_d = time.perf_counter()
+            ix.delete(dele)
+            torch.cuda.synchronize(dev)
+            delete_s = time.perf_counter() - t_d
+            ix.batch_search_device(Qn.data_ptr(), nq, k, o_ids[0].data_ptr(), o_sc[0].data_ptr(), o_cnt[0].data_ptr(), o_st[0].data_ptr(), streams[0].cuda_stream)
+            streams[0].synchronize()
+            got2 = (o_ids[0][:nq].to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+            append = {"appended_vectors": m, "onto_resident_vectors": n, "append_seconds": append_s, "vectors_per_second": m / append_s,
+                      "full_rebuild_seconds_for_comparison": build_s, "level0_nodes_after": ix.level_count(0),
+                      "queries_near_new_vectors": nq, "recall_at_10_vs_bruteforce_over_grown_corpus": rec_new, "query_finds_its_own_new_vector": self_found,
+                      "deleted_ids": int(dele.size), "delete_seconds": delete_s, "ms_per_delete": delete_s / max(1, dele.size) * 1e3,
+                      "deleted_ids_returned_afterwards": int(np.isin(got2, dele).sum()),
+                      "note": "cos_index_append continues the build's schedule on the link state the build left (graph parity with the oracle doing the same: "
+                              "tests/test_gpu_append.py); cos_index_delete = one walk + one unlink kernel per id"}
         if shardset is not None:
             shardset.close()
         rec = {
             "value": merged_qps, "elapsed": elapsed, "steps": n_launch, "warmup": n_warm, "ef": ef, "ef_table": ef_table,
             "recall": (recall, recall_se, recall_lo), "status_bad": status_bad, "props": props, "sweep": sweep, "size_sweep": size_sweep, "serial": serial,
-            "host_api": host, "cpu": cpu, "parity": parity, "build_s": build_s, "seconds": time.time() - t_setup, "exchange_kind": exchange_kind,
+            "host_api": host, "cpu": cpu, "parity": parity, "append": append, "build_s": build_s, "seconds": time.time() - t_setup, "exchange_kind": exchange_kind,
             "config": {"workload": (value_workload(world) if (self.name, m0, m_upper, visited) == (MAIN_WORKLOAD, MAIN_M0, MAIN_M, "ref")
                                     else self.name + ": " + self.desc),
                        "n_gpus": world, "standard_size": self.standard_size, "vectors_per_gpu": n, "dim": d,
@@ -1217,6 +1261,9 @@ def main():
     ap.add_argument("--m", type=int, default=0, help="neighbors_count of the main workload's graph; 0 = the workload's own (64 for the shard, 32 otherwise)")
     ap.add_argument("--recall-queries", type=int, default=8192, help="size of EACH of the two disjoint recall query sets (selection / report)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--append-rows", type=int, default=100_000, help="vectors the append probe inserts into the main workload's resident graph after "
+                    "everything else was measured (cos_index_append; N = 1 only)")
+    ap.add_argument("--no-append-probe", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer API legs (cos_search_batch from 1-256 host threads); the profiler "
                                                                 "passes of scripts/final_profile*.sh use it: rocprofv3 does not survive a few thousand short-lived native threads")
     ap.add_argument("--no-hbm-probe", action="store_true", help="skip the empirical HBM ceiling probes (cos_hbm_probe)")
@@ -1265,12 +1312,12 @@ def main():
     mm = args.m or (MAIN_M if is_shard else 32)
     main_sweep = ("" if is_shard else C2_SWEEP) if args.ef_sweep == "auto" else args.ef_sweep
     wl = DenseWorkload(env, args.workload, n_override=args.n, ef_construction=args.ef_construction, quantization=args.quantization,
-                       build_batch=args.build_batch)
+                       build_batch=args.build_batch, append_rows=0 if (args.no_append_probe or env.world > 1) else args.append_rows)
     # the host-buffer legs (cos_search_batch from 1-256 host threads: BASELINE configs[1]'s "query-batch=256") belong to c2, as a main
     # workload or as the record under `configs`
     rec = wl.run_mode(args.build_visited, args.visited, ef_arg=args.ef, ef_sweep=main_sweep, cpu_seconds=args.cpu_seconds,
                       single_batch=True, host_api=(not args.no_host_api) and not is_shard, hbm_probe=not args.no_hbm_probe, exchange=args.exchange,
-                      m0=m0, m_upper=mm)
+                      m0=m0, m_upper=mm, append_probe=not args.no_append_probe)
     flat = wl.flat
     n = wl.n
     c4 = wl if is_shard else None      # the 51 GB shard, its ground truth and the oracle's quantized copy serve the 8-shard record too
@@ -1304,6 +1351,7 @@ def main():
         "roofline": rec["roofline"],
         "flat_scan_ground_truth": flat, "result_properties": rec["props"], "cpu_baseline": rec["cpu"], "parity_vs_oracle": rec["parity"],
         "host_api_pcie_inclusive": rec["host_api"],
+        "append_and_delete_on_the_resident_graph": rec["append"],
         # BASELINE configs[1] says "query-batch=256": the rate with the reference's own calling pattern — concurrent synchronous callers of
         # ONE 256-query batch each through cos_search_batch on host buffers (PCIe-inclusive), fused by the library's dynamic batching;
         # measured on c2 (here when c2 is the main workload, else inside configs.c2)

@@ -15,7 +15,7 @@ cd /tmp; export TMPDIR=/tmp
 export COS_BENCH_FULL_RECORD=bench_full_record_of_a_profiler_pass.json
 S="python $R/scripts/rocprof_summary.py"; NOB="link_kernel\|evict_kernel\|claim_kernel"
 # ---- 2. the main workload -------------------------------------------------------------------------------------------------------
-MAIN="--steps 16 --warmup 4 --configs none --no-cpu-baseline --no-hbm-probe"
+MAIN="--steps 16 --warmup 4 --configs none --no-cpu-baseline --no-hbm-probe --no-append-probe"
 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python $R/bench.py $MAIN > $OUT/final_bench_main_under_rocprofv3.json 2> $OUT/final_kt.err
 $S /tmp/p_kt/kt_results.db | grep -v "$NOB" > $OUT/final_kernel_trace_main.txt
 ( cd $R/scripts; python trace_timeline.py /tmp/p_kt/kt_results.db 3 > $OUT/final_step_timeline_main.txt 2>&1 )
@@ -23,7 +23,7 @@ EF=$(python -c "import json; print(json.load(open('$OUT/final_bench_main_under_r
 R_=$(python -c "ef=$EF; print(1 if ef<=64 else (2 if ef<=128 else (4 if ef<=256 else 8)))")
 KMAIN="walk_kernel<0, 1, $R_, true, false"     # both level ranges (four / eight row buffers above ef 64)
 echo "main: ef $EF kernel $KMAIN"
-PM="--ef $EF --steps 8 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --recall-queries 2048"
+PM="--ef $EF --steps 8 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --no-append-probe --recall-queries 2048"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- python $R/bench.py $PM > $OUT/pmc_fetch_bench_main.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- python $R/bench.py $PM > $OUT/pmc_write_bench_main.json 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d /tmp/p_s2 -o s2 -- python $R/bench.py $PM > $OUT/pmc_sq2_bench_main.json 2> $OUT/pmc_sq2.err
@@ -36,10 +36,10 @@ $S /tmp/p_w/w_results.db | grep -v "$NOB" > $OUT/final_pmc_write_size_main.txt
 $S /tmp/p_s2/s2_results.db | grep -v "$NOB" > $OUT/final_pmc_sq_instruction_mix_main.txt 2>> $OUT/pmc_sq2.err
 # ---- 3. c2 as a main workload (ef 64 selected + the ef 256 sweep entry), c2_uniform, c2_sigma01 --------------------------------------
 cd /tmp
-C2="--workload c2 --steps 16 --warmup 4 --configs none --no-cpu-baseline --no-hbm-probe --no-host-api --ef-sweep 256"
+C2="--workload c2 --steps 16 --warmup 4 --configs none --no-cpu-baseline --no-hbm-probe --no-append-probe --no-host-api --ef-sweep 256"
 rocprofv3 --kernel-trace --stats -d /tmp/p_c2 -o c2 -- python $R/bench.py $C2 > $OUT/final_bench_c2_under_rocprofv3.json 2> $OUT/final_c2_kt.err
 $S /tmp/p_c2/c2_results.db | grep -v "$NOB" > $OUT/final_kernel_trace_c2.txt
-C2P="--workload c2 --steps 8 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --no-host-api --ef-sweep 256 --recall-queries 2048"
+C2P="--workload c2 --steps 8 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --no-append-probe --no-host-api --ef-sweep 256 --recall-queries 2048"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_c2f -o c2f -- python $R/bench.py $C2P > $OUT/pmc_fetch_bench_c2.json 2> $OUT/pmc_fetch_c2.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_c2w -o c2w -- python $R/bench.py $C2P > $OUT/pmc_write_bench_c2.json 2> $OUT/pmc_write_c2.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d /tmp/p_c2s -o c2s -- python $R/bench.py $C2P > $OUT/pmc_sq2_bench_c2.json 2> $OUT/pmc_sq2_c2.err
@@ -54,7 +54,7 @@ $S /tmp/p_c2w/c2w_results.db | grep -v "$NOB" > $OUT/final_pmc_write_size_c2.txt
 $S /tmp/p_c2s/c2s_results.db | grep -v "$NOB" > $OUT/final_pmc_sq_instruction_mix_c2.txt 2>> $OUT/pmc_sq2_c2.err
 cd /tmp
 for W in c2_uniform c2_sigma01; do
-  WP="--workload $W --steps 6 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --no-host-api --ef-sweep= --recall-queries 2048"
+  WP="--workload $W --steps 6 --warmup 2 --configs none --no-cpu-baseline --no-hbm-probe --no-append-probe --no-host-api --ef-sweep= --recall-queries 2048"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_${W}f -o f -- python $R/bench.py $WP > $OUT/pmc_fetch_bench_$W.json 2> $OUT/pmc_fetch_$W.err
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_${W}w -o w -- python $R/bench.py $WP > $OUT/pmc_write_bench_$W.json 2> $OUT/pmc_write_$W.err
   EFW=$(python -c "import json; print(json.load(open('$OUT/pmc_fetch_bench_$W.json'))['config']['ef_search'])")
