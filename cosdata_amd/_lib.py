@@ -99,7 +99,7 @@ _lib = None
 ABI_SYMBOLS = [
     "cos_index_create", "cos_index_destroy", "cos_last_error_string", "cos_device_count",
     "cos_index_upload_vectors", "cos_index_set_root", "cos_index_upload_graph_level", "cos_index_level_count",
-    "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build", "cos_index_append", "cos_index_delete", "cos_index_release_link_state", "cos_index_enable_metadata", "cos_index_upload_meta_nodes", "cos_index_upload_meta_graph_level", "cos_index_build_meta", "cos_index_meta_level_count", "cos_index_download_meta_graph_level", "cos_search_filtered_batch",
+    "cos_index_download_graph_level", "cos_index_download_codes", "cos_index_download_root", "cos_index_build", "cos_index_append", "cos_index_delete", "cos_index_restore_link_state", "cos_index_release_link_state", "cos_index_enable_metadata", "cos_index_upload_meta_nodes", "cos_index_upload_meta_graph_level", "cos_index_build_meta", "cos_index_meta_level_count", "cos_index_download_meta_graph_level", "cos_search_filtered_batch",
     "cos_ann_search_filtered_batch", "cos_index_load_reference_dir", "cos_reference_dir_level_counts", "cos_reference_dir_read_level",
     "cos_search_batch", "cos_search_batch_device", "cos_ann_search_batch", "cos_index_set_coalescing", "cos_index_coalescing_stats", "cos_index_set_ef_search",
     "cos_index_set_visited_mode", "cos_index_set_latency_mode", "cos_index_set_latency_waves", "cos_index_set_walk_order", "cos_index_walk_order_cuts", "cos_index_set_walk_table", "cos_index_walk_table_info", "cos_index_last_walk_split", "cos_index_enable_timing", "cos_index_last_stats", "cos_index_timing_summary", "cos_quantize_batch",
@@ -140,6 +140,7 @@ def lib():
         "cos_index_build": [vp, u32],
         "cos_index_append": [vp, vp, u32, u32, u32],
         "cos_index_release_link_state": [vp],
+        "cos_index_restore_link_state": [vp],
         "cos_index_delete": [vp, vp, u32],
         "cos_index_load_reference_dir": [vp, C.c_char_p, u32, u32],
         "cos_index_enable_metadata": [vp, u32, u32],

@@ -326,6 +326,65 @@ extern "C" int32_t cos_index_build(cos_index *ix, uint32_t batch_size) {
     return COS_OK; // the id-format host copy is made on demand (cos_index_download_graph_level)
 }
 
+// The link state of an UPLOADED graph (cos_index_upload_graph_level, cos_index_load_reference_dir), as the reference has it after a
+// reload: it persists every slot's similarity (serializer/hnsw/neighbors.rs:22-61) and recomputes a node's cached lowest slot when it
+// deserializes the node (ProbNode::new_with_neighbors_and_versions, prob_node.rs:145-181).  Here the similarities are recomputed with
+// the distance operator's kernel on the resident codes (the distance is symmetric in its bits), the caches follow the reload rule,
+// and later appends draw their levels from the seed's stream advanced past the resident vectors (a graph built by the same-seed
+// builder and uploaded continues with the draws a native build would make).  oracle: coso_index_restore_link_state.
+extern "C" int32_t cos_index_restore_link_state(cos_index *ix) {
+    if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
+    if (!ix->have_vectors || !ix->have_root) return cos_fail(COS_ERR_NOT_READY, "restore needs vectors, root and every graph level");
+    for (auto &l : ix->lv) if (l.n == 0) return cos_fail(COS_ERR_NOT_READY, "restore needs vectors, root and every graph level");
+    if (ix->id_stride != 1u || ix->meta.mdim != 0u) return cos_fail(COS_ERR_UNIMPLEMENTED, "link state of a collection with a metadata schema");
+    if (ix->eng != ENG_U8 && ix->eng != ENG_Q2 && ix->eng != ENG_F32) return cos_fail(COS_ERR_UNIMPLEMENTED, "restoring the link state is implemented for u8 / quaternary / f32 storage");
+    int32_t rc = cos_set_device(ix);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    const u32 Ltop = ix->p.num_layers, metric = ix->p.metric;
+    const int32_t kmin = order_key(metric, metric_min(metric)), kmax = order_key(metric, metric_max(metric));
+    hipStream_t st = ix->own_stream;
+    ix->link.release();
+    struct Fail { cos_index *ix; bool armed = true; ~Fail() { if (armed) ix->link.release(); } } fail_guard{ix};
+    constexpr u64 CHUNK_PAIRS = 1ull << 24; // 64 MB per pair array
+    DevBuf px, py, sims, dst, d_fail;
+    HIP_TRY(px.alloc(CHUNK_PAIRS * 4));
+    HIP_TRY(py.alloc(CHUNK_PAIRS * 4));
+    HIP_TRY(sims.alloc(CHUNK_PAIRS * 4));
+    HIP_TRY(dst.alloc(CHUNK_PAIRS * 4));
+    HIP_TRY(d_fail.alloc(4));
+    HIP_TRY(hipMemsetAsync(d_fail.p, 0, 4, st));
+    for (u32 l = 0; l <= Ltop; l++) {
+        LevelHost &H = ix->lv[l];
+        const u32 nl = H.n, M = H.M;
+        HIP_TRY(ix->link.key[l].alloc((size_t)nl * M * 4));
+        HIP_TRY(ix->link.low_idx[l].alloc(nl));
+        HIP_TRY(ix->link.low_key[l].alloc((size_t)nl * 4));
+        HIP_TRY(ix->link.owner[l].alloc((size_t)nl * 4));
+        HIP_TRY(hipMemsetAsync(ix->link.owner[l].p, 0, (size_t)nl * 4, st));
+        const u32 step = (u32)std::max<u64>(1, CHUNK_PAIRS / M);
+        for (u32 n0 = 0; n0 < nl; n0 += step) {
+            const u32 cn = std::min(step, nl - n0);
+            HIP_TRY(launch_edge_pairs(H.d_adj_vec, l == 0 ? nullptr : H.d_node_vec, n0, cn, M, px.as<u32>(), py.as<u32>(), st));
+            HIP_TRY(cosdev::launch_index_pair_distances(ix->eng, ix->d_codes, ix->d_mags, ix->row_stride, ix->nchunks, ix->p.dim, metric, px.as<u32>(), py.as<u32>(),
+                                                       (u32)((u64)cn * M), sims.as<float>(), dst.as<int32_t>(), st));
+            HIP_TRY(launch_edge_keys(H.d_adj_vec, sims.as<float>(), dst.as<int32_t>(), n0, cn, M, metric, ix->link.key[l].as<int32_t>(), d_fail.as<int32_t>(), st));
+        }
+        HIP_TRY(launch_low_cache(H.d_adj_vec, ix->link.key[l].as<int32_t>(), nl, M, kmin, kmax, ix->link.low_idx[l].as<uint8_t>(), ix->link.low_key[l].as<int32_t>(), st));
+    }
+    int32_t failed = 0;
+    HIP_TRY(hipMemcpyAsync(&failed, d_fail.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (failed) return cos_fail(failed, "an edge of the uploaded graph has no similarity (zero norm -> DistanceError::CalculationError)");
+    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
+    for (u64 i = 0; i < (u64)ix->p.dim + ix->n; i++) (void)rand_f32(rng); // the root's components, then one level draw per resident vector
+    ix->link.rng = rng;
+    ix->link.n_built = ix->n;
+    ix->link.valid = true;
+    fail_guard.armed = false;
+    return COS_OK;
+}
+
 extern "C" int32_t cos_index_release_link_state(cos_index *ix) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
     int32_t rc = cos_set_device(ix);

@@ -17,6 +17,9 @@
 
 namespace cosdev {
 hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st);
+hipError_t launch_edge_pairs(const u32 *adj_vec, const u32 *node_vec, u32 node0, u32 cn, u32 M, u32 *px, u32 *py, hipStream_t st);
+hipError_t launch_edge_keys(const u32 *adj_vec, const float *sims, const int32_t *st_in, u32 node0, u32 cn, u32 M, u32 metric, int32_t *key, int32_t *fail, hipStream_t st);
+hipError_t launch_low_cache(const u32 *adj_vec, const int32_t *key, u32 n, u32 M, int32_t kmin, int32_t kmax, uint8_t *low_idx, int32_t *low_key, hipStream_t st);
 hipError_t launch_unlink(const LinkArgs &a, const u32 *dn, u32 *status, hipStream_t st);
 hipError_t launch_index_pair_distances(int eng, const uint8_t *codes, const float *mags, u64 row_stride, u32 nchunks, u32 dim, u32 metric, const u32 *d_pair_x,
                                        const u32 *d_pair_y, u32 n_pairs, float *d_out, int32_t *d_status, hipStream_t st); // kernels_misc.hip

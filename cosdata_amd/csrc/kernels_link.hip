@@ -401,6 +401,45 @@ __global__ __launch_bounds__(64) void unlink_kernel(const LinkArgs a, const u32 
     if (lane == 0) status[level] = 2;
 }
 
+// cos_index_restore_link_state (builder.hip): the link state of an UPLOADED graph, as the reference has it after a reload.
+//   edge_pairs_kernel: (node's vector row, neighbour's vector row) of every slot of a chunk of nodes — an empty slot pairs the node with
+//                      itself (a row that is hot anyway; its result is never looked at) — for the distance operator's kernel;
+//   edge_keys_kernel:  slot keys from the similarities (empty: EMPTY_KEY); a failed distance of a real slot raises the flag;
+//   low_cache_kernel:  ProbNode::new_with_neighbors_and_versions (prob_node.rs:145-181): the first empty slot with MetricResult::min,
+//                      else the first strictly smallest similarity.
+__global__ void edge_pairs_kernel(const u32 *__restrict__ adj_vec, const u32 *__restrict__ node_vec, u32 node0, u64 total, u32 M, u32 *__restrict__ px, u32 *__restrict__ py) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u32 node = node0 + (u32)(i / M);
+        const u32 self = node_vec ? node_vec[node] : node;
+        const u32 v = adj_vec[(u64)node0 * M + i];
+        px[i] = self;
+        py[i] = v == NONE ? self : v;
+    }
+}
+__global__ void edge_keys_kernel(const u32 *__restrict__ adj_vec, const float *__restrict__ sims, const int32_t *__restrict__ st_in, u32 node0, u64 total, u32 M, u32 metric,
+                                 int32_t *__restrict__ key, int32_t *__restrict__ fail) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 o = (u64)node0 * M + i;
+        const bool empty = adj_vec[o] == NONE;
+        if (!empty && st_in[i] != 0) atomicMax(fail, st_in[i]);
+        key[o] = empty ? EMPTY_KEY : order_key(metric, sims[i]);
+    }
+}
+__global__ void low_cache_kernel(const u32 *__restrict__ adj_vec, const int32_t *__restrict__ key, u32 n, u32 M, int32_t kmin, int32_t kmax, uint8_t *__restrict__ low_idx,
+                                 int32_t *__restrict__ low_key) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u32 nl = 0;
+        int32_t nk = kmax;
+        for (u32 j = 0; j < M; j++) {
+            if (adj_vec[i * M + j] == NONE) { nl = j; nk = kmin; break; }
+            const int32_t k = key[i * M + j];
+            if (k < nk) { nk = k; nl = j; }
+        }
+        low_idx[i] = (uint8_t)nl;
+        low_key[i] = nk;
+    }
+}
+
 // cos_index_append (builder.hip): a level's [n][M] array grows.  Rows [0, old_n - 1) keep their place, the LAST old row (the root) becomes
 // the last new row, the rows between (the new nodes) are filled; a value equal to remap_from (a reference to the root) becomes remap_to.
 __global__ void grow_rows_kernel(const u32 *__restrict__ src, u32 *__restrict__ dst, u32 old_n, u32 new_n, u32 M, u32 remap_from, u32 remap_to, u32 fill) {
@@ -442,6 +481,23 @@ hipError_t launch_fill_i32(int32_t *p, u64 n, int32_t v, hipStream_t st) {
     return hipGetLastError();
 }
 
+hipError_t launch_edge_pairs(const u32 *adj_vec, const u32 *node_vec, u32 node0, u32 cn, u32 M, u32 *px, u32 *py, hipStream_t st) {
+    const u64 total = (u64)cn * M;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(edge_pairs_kernel, dim3((u32)std::min<u64>((total + 255) / 256, 1u << 20)), dim3(256), 0, st, adj_vec, node_vec, node0, total, M, px, py);
+    return hipGetLastError();
+}
+hipError_t launch_edge_keys(const u32 *adj_vec, const float *sims, const int32_t *st_in, u32 node0, u32 cn, u32 M, u32 metric, int32_t *key, int32_t *fail, hipStream_t st) {
+    const u64 total = (u64)cn * M;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(edge_keys_kernel, dim3((u32)std::min<u64>((total + 255) / 256, 1u << 20)), dim3(256), 0, st, adj_vec, sims, st_in, node0, total, M, metric, key, fail);
+    return hipGetLastError();
+}
+hipError_t launch_low_cache(const u32 *adj_vec, const int32_t *key, u32 n, u32 M, int32_t kmin, int32_t kmax, uint8_t *low_idx, int32_t *low_key, hipStream_t st) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(low_cache_kernel, dim3((u32)std::min<u64>(((u64)n + 255) / 256, 1u << 20)), dim3(256), 0, st, adj_vec, key, n, M, kmin, kmax, low_idx, low_key);
+    return hipGetLastError();
+}
 hipError_t launch_unlink(const LinkArgs &a, const u32 *dn, u32 *status, hipStream_t st) {
     hipLaunchKernelGGL(unlink_kernel, dim3(a.L1), dim3(64), 0, st, a, dn, status);
     return hipGetLastError();

@@ -250,6 +250,12 @@ class HNSWIndex:
         check(_lib.lib().cos_index_delete(self._h, _p(a), a.size))
         return self
 
+    def restore_link_state(self):
+        """an UPLOADED graph becomes appendable / deletable (cos_index_restore_link_state): similarities recomputed, lowest caches by the
+        reference's reload rule"""
+        check(_lib.lib().cos_index_restore_link_state(self._h))
+        return self
+
     def release_link_state(self):
         """frees what build() keeps for append() (4 bytes per neighbour slot); append() then fails with NotReady"""
         check(_lib.lib().cos_index_release_link_state(self._h))

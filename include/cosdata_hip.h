@@ -173,6 +173,12 @@ int32_t cos_index_append(cos_index *ix, const float *raw, uint32_t m, uint32_t f
  * cos_flat_search_batch, cos_bruteforce_topk — still see the row: the host filters deleted ids there, as it owns the id map).
  * Needs the link state like cos_index_append; exclusive like every graph change.  oracle: coso_index_delete. */
 int32_t cos_index_delete(cos_index *ix, const uint32_t *ids, uint32_t m);
+/* The link state of an UPLOADED graph (cos_index_upload_graph_level, cos_index_load_reference_dir), as the reference has it after a reload:
+ * slot similarities (persisted by the reference, serializer/hnsw/neighbors.rs:22-61; recomputed here on the resident codes) and every
+ * node's cached lowest slot by the deserializer's rule (ProbNode::new_with_neighbors_and_versions, prob_node.rs:145-181: the first empty
+ * slot, else the first strictly smallest similarity).  Afterwards cos_index_append / cos_index_delete work on the uploaded graph; appends
+ * draw their levels from the seed's stream advanced past the resident vectors.  u8 / quaternary / f32 storage. */
+int32_t cos_index_restore_link_state(cos_index *ix);
 /* frees the link state (as large as the adjacency: 4 bytes per neighbour slot); cos_index_append then returns COS_ERR_NOT_READY */
 int32_t cos_index_release_link_state(cos_index *ix);
 

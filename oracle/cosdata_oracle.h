@@ -137,10 +137,15 @@ int coso_index_build_rounds(coso_index *ix, uint32_t batch_size, int greedy, uin
  * coso_index_build_rounds on this handle.  CPU statement of cos_index_append (include/cosdata_hip.h). */
 int coso_index_append_vectors(coso_index *ix, const float *raw_all, uint32_t m);
 int coso_index_build_rounds_continue(coso_index *ix, uint32_t batch_size, uint64_t *stats);
+int coso_index_can_continue(const coso_index *ix);
 /* delete_embedding (vector_store.rs:1206-1400) for one internal id: per level a walk for the vector's own code (ef 512, keep 100, filter
  * not pre-seeded), the node's neighbours drop their back edges, a neighbour left without any neighbour is linked again from the walk's
  * results; the node's own slots are emptied.  CPU statement of cos_index_delete. */
 int coso_index_delete(coso_index *ix, uint32_t id);
+/* the state a RELOADED (imported) graph continues from: slot similarities recomputed, lowest caches by the deserializer's rule
+ * (prob_node.rs:145-181), the seed's RNG stream advanced past the resident vectors; coso_index_append_vectors / _build_rounds_continue /
+ * coso_index_delete then work on it.  CPU statement of cos_index_restore_link_state. */
+int coso_index_restore_link_state(coso_index *ix);
 /* Flat export/import (the same arrays include/cosdata_hip.h uploads). */
 uint32_t coso_index_level_count(const coso_index *ix, uint32_t level);
 int coso_index_export_level(const coso_index *ix, uint32_t level, uint32_t *node_ids /*[n_l]*/,

@@ -966,6 +966,9 @@ int coso_index_append_vectors(coso_index *ix, const float *raw_all, uint32_t m) 
  * draws from the same RNG stream (the draws a full build would have given these ids), batches of min(batch_size, max(1,
  * inserted / 4)) walking the snapshot that precedes them, ordered claims.  The graph equals a full build's only if the earlier
  * build ended on one of its batch boundaries; it always equals the device's cos_index_append (builder.hip), which runs this. */
+/* 1 if the graph has the state coso_index_build_rounds_continue / an append continue from (built by the rounds builder, or restored) */
+int coso_index_can_continue(const coso_index *ix) { return ix && ix->codes && ix->rounds_state_valid && ix->n_built == ix->n; }
+
 int coso_index_build_rounds_continue(coso_index *ix, uint32_t batch_size, uint64_t *stats) {
     if (!ix || !ix->codes || !ix->rounds_state_valid || ix->n_built > ix->n) return COSO_ERR_INVALID;
     const uint32_t Ltop = ix->p.num_layers, L1 = Ltop + 1, first = ix->n_built, m = ix->n - first;
@@ -983,6 +986,55 @@ int coso_index_build_rounds_continue(coso_index *ix, uint32_t batch_size, uint64
     if (stats) memcpy(stats, st, sizeof(st));
     free(max_level); free(pv); free(pl);
     return rc;
+}
+
+/* What a RELOADED index continues from (an imported graph; the device's cos_index_restore_link_state): the reference persists every
+ * neighbour slot's similarity (serializer/hnsw/neighbors.rs:22-61) and recomputes a node's cached (lowest index, lowest similarity) when
+ * it deserializes it — ProbNode::new_with_neighbors_and_versions (prob_node.rs:145-181): the first empty slot with MetricResult::min,
+ * else the first strictly smallest similarity.  Here the similarities are recomputed (the distance is symmetric in its bits: integer
+ * dots, one commutative product of norms, one quotient), the caches follow that rule, and the level draws of later appends continue the
+ * seed's stream as if the n resident vectors had been drawn from it. */
+int coso_index_restore_link_state(coso_index *ix) {
+    if (!ix || !ix->codes) return COSO_ERR_INVALID;
+    const uint32_t Ltop = ix->p.num_layers;
+    const int metric = (int)ix->p.metric;
+    for (uint32_t l = 0; l <= Ltop; l++) if (ix->lv[l].n == 0 || ix->lv[l].root_idx == IDX_NONE) return COSO_ERR_INVALID;
+    int bad = COSO_OK;
+    for (uint32_t l = 0; l <= Ltop; l++) {
+        level_t *L = &ix->lv[l];
+        const uint32_t M = L->M;
+#pragma omp parallel for schedule(dynamic, 256)
+        for (int64_t i = 0; i < (int64_t)L->n; i++) {
+            const uint32_t row = row_of(ix, L->node_id[i]);
+            uint32_t nl = 0;
+            float nsim = metric_max(metric);
+            int found_empty = 0;
+            for (uint32_t j = 0; j < M; j++) {
+                const uint32_t x = L->nbr[(size_t)i * M + j];
+                if (x == IDX_NONE) { L->nbr_sim[(size_t)i * M + j] = 0.0f; if (!found_empty) { found_empty = 1; nl = j; nsim = metric_min(metric); } continue; }
+                float d;
+                int rc = node_distance(ix, ix->codes + (size_t)row * ix->cb, ix->mags[row], row_of(ix, L->node_id[x]), &d);
+                if (rc != COSO_OK) {
+#pragma omp critical
+                    bad = rc;
+                    d = 0.0f;
+                }
+                L->nbr_sim[(size_t)i * M + j] = d;
+                if (!found_empty && coso_metric_cmp(metric, d, nsim) < 0) { nsim = d; nl = j; }
+            }
+            L->low_idx[i] = (uint8_t)nl;
+            L->low_sim[i] = nsim;
+        }
+        L->sorted = 0;
+    }
+    if (bad != COSO_OK) return bad;
+    uint64_t rng = ix->p.seed ? ix->p.seed : 0x1234567ull;
+    for (uint64_t i = 0; i < (uint64_t)ix->p.dim + ix->n; i++) (void)rand_f32(&rng); /* the root's components, then one level draw per resident vector */
+    ix->rng_state = rng;
+    ix->n_built = ix->n;
+    ix->rounds_state_valid = 1;
+    ix->rounds_greedy = 0;
+    return COSO_OK;
 }
 
 /* delete_embedding (vector_store.rs:1206-1400) for one internal id.  Per level, top down: a walk for the vector's OWN code from the entry

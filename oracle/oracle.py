@@ -86,6 +86,8 @@ def lib():
         "coso_index_append_vectors": (C.c_int, [vp, vp, C.c_uint32]),
         "coso_index_build_rounds_continue": (C.c_int, [vp, C.c_uint32, vp]),
         "coso_index_delete": (C.c_int, [vp, C.c_uint32]),
+        "coso_index_can_continue": (C.c_int, [vp]),
+        "coso_index_restore_link_state": (C.c_int, [vp]),
         "coso_index_level_count": (C.c_uint32, [vp, C.c_uint32]),
         "coso_index_export_level": (C.c_int, [vp, C.c_uint32, vp, vp, vp]),
         "coso_index_import_level": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
@@ -339,6 +341,13 @@ class OracleIndex:
             raise ValueError(f"build_rounds status {rc}")
         return self, {"rounds": int(st[0]), "batch_levels": int(st[1]), "nodes": int(st[2]), "first_round_nodes": int(st[3])}
 
+    def restore_link_state(self):
+        """an imported graph becomes appendable / deletable: similarities recomputed, lowest caches by the reference's reload rule"""
+        rc = lib().coso_index_restore_link_state(self._h)
+        if rc != OK:
+            raise ValueError(f"restore_link_state status {rc}")
+        return self
+
     def delete(self, ids):
         """delete_embedding for every id of `ids`, one after the other in the given order"""
         for i in np.atleast_1d(np.asarray(ids, np.uint32)):
@@ -353,6 +362,8 @@ class OracleIndex:
         x = _c(raw_new, np.float32)
         if self._raw is None:
             raise ValueError("append needs the raw table (set_vectors)")
+        if not lib().coso_index_can_continue(self._h):     # (checked BEFORE the tables grow, like cos_index_append)
+            raise ValueError("append needs a graph built by build_rounds on this handle, or restore_link_state")
         self._raw = np.ascontiguousarray(np.concatenate([self._raw, x.reshape(-1, self._raw.shape[1])]))   # the oracle borrows the WHOLE table
         rc = lib().coso_index_append_vectors(self._h, _p(self._raw), x.shape[0])
         if rc != OK:

@@ -202,3 +202,33 @@ def test_random_interleaving_of_appends_and_deletes_follows_the_oracle(seed):
     ids, sc, cnt = dix.batch_search(Q, 10)
     oids, osc, ocnt = oix.search_batch(Q, 10, threads=4)[:3]
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+
+
+@pytest.mark.parametrize("storage,res,dim", [(O.STORAGE_U8, 0, 96), (O.STORAGE_SUBBYTE, 2, 128), (O.STORAGE_F32, 0, 48)])
+def test_restored_link_state_of_an_uploaded_graph_takes_appends_and_deletes(storage, res, dim):
+    """cos_index_restore_link_state == coso_index_restore_link_state: an UPLOADED graph (the reader path, the snapshot path) gets the link
+    state the reference has after a reload; appends and deletes on it follow the oracle slot for slot"""
+    import cosdata_amd as ca
+    n0, m = 1800, 700
+    X = H.clustered_corpus(n0 + m, dim, n_centers=16, seed=dim)
+    p = O.HNSWParams(dim=dim, storage=storage, resolution=res, num_layers=4, ef_construction=40, ef_search=40, seed=17)
+    src = O.OracleIndex(p).set_vectors(X[:n0])
+    src.build_rounds(128)
+    G, root = src.export_graph(), src.root_raw()
+    oix = O.OracleIndex(p).set_vectors(X[:n0]).import_graph(G, root).restore_link_state()
+    dix = _device(X[:n0], p)
+    dix.upload_graph(G, root)
+    with pytest.raises(ca.CosdataError):
+        dix.append(X[n0:n0 + 5], 128)                           # an uploaded graph has no link state until it is restored
+    dix.restore_link_state()
+    oix.append(X[n0:], 128)
+    dix.append(X[n0:], 128)
+    _same_graph(dix.download_graph(), oix.export_graph())
+    dele = np.arange(7, n0 + m, 53, dtype=np.uint32)
+    oix.delete(dele)
+    dix.delete(dele)
+    _same_graph(dix.download_graph(), oix.export_graph())
+    Q = H.queries_from(X, 200, noise=0.05, seed=5)
+    ids, sc, cnt = dix.batch_search(Q, 10)
+    oids, osc, ocnt = oix.search_batch(Q, 10, threads=4)[:3]
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))

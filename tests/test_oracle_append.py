@@ -86,3 +86,33 @@ def test_delete_removes_every_edge_to_the_node_and_the_id_from_every_answer():
     assert untouched.sum() > 20 and np.mean((before[untouched] == after[untouched]).all(axis=1)) > 0.8
     with pytest.raises(ValueError):
         a.delete([2500])                                                       # not a resident vector
+
+
+def test_restored_link_state_of_an_imported_graph():
+    """coso_index_restore_link_state = what the reference has after a reload: the slot similarities it persisted (recomputed here: they are
+    the ones the builder stored, bit for bit) and the lowest caches by ProbNode::new_with_neighbors_and_versions (prob_node.rs:145-181).  An
+    imported graph then takes appends and deletes; with the same seed the appended ids get the levels a native build draws."""
+    X = H.clustered_corpus(2600, 64, n_centers=14, seed=6)
+    p = dict(dim=64, num_layers=4, ef_construction=40, ef_search=40, seed=13)
+    a = O.OracleIndex(O.HNSWParams(**p)).set_vectors(X[:1800])
+    a.build_rounds(128)
+    b = O.OracleIndex(O.HNSWParams(**p)).set_vectors(X[:1800]).import_graph(a.export_graph(), a.root_raw())
+    with pytest.raises(ValueError):
+        b.append(X[1800:1810], 128)                                          # nothing to continue from yet
+    b.restore_link_state()
+    for l in range(5):                                                        # recomputed similarities == the ones the builder stored
+        ia, na, sa = a.export_level(l, with_sims=True)
+        ib, nb, sb = b.export_level(l, with_sims=True)
+        assert np.array_equal(ia, ib) and np.array_equal(na, nb)
+        live = na != O.SLOT_EMPTY
+        assert np.array_equal(sa[live].view(np.uint32), sb[live].view(np.uint32))
+    a.append(X[1800:], 128)
+    b.append(X[1800:], 128)
+    ga, gb = a.export_graph(), b.export_graph()
+    assert all(np.array_equal(x[0], y[0]) for x, y in zip(ga, gb))           # the same level draws
+    b.delete(np.arange(3, 300, 11, dtype=np.uint32))
+    Q = H.queries_from(X, 120, noise=0.05, seed=8)
+    ids = b.search_batch(Q, 10, threads=2)[0]
+    gt, _ = O.bruteforce_topk(X, Q, 10, threads=2)
+    keep = ~np.isin(gt, np.arange(3, 300, 11)).any(axis=1)
+    assert np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in np.nonzero(keep)[0]]) > 0.9
