@@ -162,3 +162,32 @@ def test_loaded_directory_searches_like_the_oracle(tmp_path, storage, res):
         with pytest.raises(ca.CosdataError) as ei:
             ca.HNSWIndex(96, h, ca.DistanceMetric.Cosine, ca.StorageType(ca.StorageKind(storage), res), (-1.0, 1.0)).upload_vectors(X).load_reference_dir(d3, rp)
         assert ei.value.status == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2), (O.STORAGE_F32, 0)])
+def test_loaded_directory_takes_appends_and_deletes(tmp_path, storage, res):
+    """round 6: a collection served from the Rust server's files keeps taking inserts and deletes — load the directory, restore the link
+    state the reference has after a reload (cos_index_restore_link_state), append and delete: the oracle that imported the same graph and
+    did the same gives the same graph, slot for slot, and the same answers"""
+    import cosdata_amd as ca
+    X, oix, hp = _oracle(storage, res, n=2400, dim=96, num_layers=4, neighbors_count=32, level0_neighbors_count=64, ef_construction=48, ef_search=64)
+    d = str(tmp_path / "dense_hnsw")
+    root_ptr = write_dense_hnsw_dir(d, oix.export_graph(), oix.codes(), oix.mags(), storage, res, 96, index_file_min_size=1 << 20)
+    h = ca.HNSWHyperParams(num_layers=4, ef_construction=48, ef_search=64)
+    dix = ca.HNSWIndex(96, h, ca.DistanceMetric.Cosine, ca.StorageType(ca.StorageKind(storage), res), (-1.0, 1.0), seed=oix.params.seed)
+    dix.upload_vectors(X).load_reference_dir(d, root_ptr, verify_codes=True)
+    dix.restore_link_state()
+    oix.restore_link_state()                                     # (the oracle built it sequentially: it, too, continues from the reload state)
+    Xn = H.uniform_corpus(500, 96, seed=11) * 0.9
+    oix.append(Xn, 64)
+    dix.append(Xn, 64)
+    dele = np.arange(4, 2900, 61, dtype=np.uint32)
+    oix.delete(dele)
+    dix.delete(dele)
+    for (gi, gn), (ei, en) in zip(dix.download_graph(), oix.export_graph()):
+        assert np.array_equal(gi, ei) and np.array_equal(gn, en)
+    Q = H.queries_from(np.concatenate([X, Xn]), 100, seed=6)
+    ids, sc, cnt = dix.batch_search(Q, 10)
+    oids, osc, ocnt = oix.search_batch(Q, 10, threads=4)[:3]
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
