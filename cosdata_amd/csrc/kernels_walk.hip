@@ -571,7 +571,8 @@ int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_ma
 
 hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, hipStream_t st) {
     if (wa.B == 0) return hipSuccess;
-    const int kind = walk_kernel_kind(eng, ix, wa, lat_max_B, lat4_max_B, wa.tab != nullptr); // the split (locality-ordered) walk exists in the throughput kernel only
+    // the split (locality-ordered) walk and the unseeded filter of delete_embedding's walks (WalkArgs::no_self_seed) exist in the throughput kernel only
+    const int kind = wa.no_self_seed ? 0 : walk_kernel_kind(eng, ix, wa, lat_max_B, lat4_max_B, wa.tab != nullptr);
     if (kind == 4) return launch_walk_lat4(eng, ix, wa, st);
     if (kind == 1) return launch_walk_lat(eng, ix, wa, st);
     const u32 ch = (eng == ENG_F32 || eng == ENG_F16) ? 1 : (ix.nchunks + ix.G - 1) / ix.G;
