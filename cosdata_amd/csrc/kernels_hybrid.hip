@@ -557,7 +557,11 @@ extern "C" int32_t cos_hybrid_search_batch(cos_index *ix, cos_bm25 *b, const flo
     std::lock_guard<std::mutex> g(b->mu);
     int32_t rc = bm25_workspace(b, B, k3);
     if (rc) return rc;
-    if (!b->stream_dense) HIP_TRY(hipStreamCreateWithFlags(&b->stream_dense, hipStreamNonBlocking));
+    if (!b->stream_dense) {
+        int prio_low = 0, prio_high = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        HIP_TRY(hipStreamCreateWithPriority(&b->stream_dense, hipStreamNonBlocking, prio_high));
+    }
     if (!b->ev_sparse) HIP_TRY(hipEventCreateWithFlags(&b->ev_sparse, hipEventDisableTiming));
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream_dense));
@@ -570,17 +574,21 @@ extern "C" int32_t cos_hybrid_search_batch(cos_index *ix, cos_bm25 *b, const flo
     HIP_TRY(grow_buf(b->d_fid, b->cap_fid, (size_t)B * top_k));
     HIP_TRY(grow_buf(b->d_fsc, b->cap_fsc, (size_t)B * top_k));
     HIP_TRY(grow_buf(b->d_fcnt, b->cap_fcnt, (size_t)B));
-    rc = bm25_prepare(b, q_terms, q_offsets, B);
-    if (rc) return rc;
-    // sparse half on its stream
-    rc = bm25_launch(b, B, k3, b->d_ids, b->d_sc, b->d_cnt, b->stream);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(b->ev_sparse, b->stream));
-    // dense half on the other
+    // The dense half goes FIRST, on a stream of the highest priority: its walk is a chain of dependent rounds on a quarter of the chip's
+    // wave slots (one workgroup per query), the sparse half is a bandwidth kernel of 8192 workgroups that fills whatever the walk
+    // leaves free.  Until round 6 the sparse half was enqueued first: its workgroups held every CU until they drained and the dense
+    // half's first dispatch (the query copy) waited for them — the two halves ran one after the other (c5: 2.55 ms per batch,
+    // profiles/r06_final_kernel_trace_c5_rocprofv3.txt: a 256-workgroup copy of 0.52 ms beside a 0.57 ms bm25_score_kernel).
     hipStream_t sd = b->stream_dense;
     HIP_TRY(hipMemcpyAsync(b->d_hq, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, sd));
     rc = cos_search_batch_device(ix, b->d_hq, B, k3, b->d_did, b->d_dsc, b->d_dcnt, b->d_dst, sd);
     if (rc) return rc;
+    // sparse half on its stream, beside the walk; its host side (the term table of the batch) is prepared while the device already walks
+    rc = bm25_prepare(b, q_terms, q_offsets, B);
+    if (rc) return rc;
+    rc = bm25_launch(b, B, k3, b->d_ids, b->d_sc, b->d_cnt, b->stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(b->ev_sparse, b->stream));
     // fusion once both lists are there
     HIP_TRY(hipStreamWaitEvent(sd, b->ev_sparse, 0));
     const size_t smem = (size_t)maxn * 4;

@@ -140,21 +140,55 @@ struct FinalizeArgs {
     u32 *slow_count;      // ... and how many (zeroed before the launch)
 };
 
-template <int FR>
+// Small launches (one client batch: 256 workgroups on 256 CUs) rerank with NWV waves per query.  One wave streams its 5k raw rows
+// (3 KB each at 768 dims) with ~8 KB in flight: ~24 dependent trips to memory for 50 rows, 60 for the 150 rows of a hybrid query's
+// top_k x 3 (0.05 / 0.16 ms per batch: profiles/r06_final_kernel_trace_c5_rocprofv3.txt).  With NWV > 1 wave 0 selects the candidates
+// as before, every wave then dots 8 of them per pass with the eight-lane chains of f32_oct_dot (the pair version's bits, dot_engines.h)
+// and wave 0 sorts the keys the waves left in LDS: same lists, same bits.
+template <int NWV>
+__device__ __forceinline__ void finalize_sync() {
+    if constexpr (NWV > 1) __syncthreads();
+    else { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
+}
+// the exact rerank of candidates [0, ncand) by every wave of a wide workgroup (vector_store.rs:404-445): keys[j] = (score, id) of cand[j]
+template <int NWV>
+__device__ __forceinline__ void rerank_wide(const IndexDev &ix, const float *qf, const u32 *cand, u32 ncand, float mag_query, u64 *keys, int lane, int wave) {
+    for (u32 base = (u32)wave * 8u; base < ncand; base += 8u * (u32)NWV) { // (wave-uniform bounds)
+        const u32 my = base + (u32)(lane >> 3);
+        const u32 id = my < ncand ? cand[my] : 0u;
+        const u32 rrow = id / ix.id_stride; // raw embedding of an id = its base id (collection.rs:368-384)
+        const float dp = f32_oct_dot(ix.raw + (u64)rrow * ix.raw_stride, qf, ix.dim, lane & 7);
+        const float cs = x86_div(dp, __fmul_rn(mag_query, ix.raw_mags[rrow])); // 0/0 (zero raw vector or query) -> x86's -NaN
+        if ((lane & 7) == 0 && my < ncand) keys[my] = pack_key(simkey(cs), id); // total_cmp desc; larger id first on ties
+    }
+}
+
+template <int FR, int NWV = 1>
 __device__ __forceinline__ void finalize_one(const IndexDev &ix, const FinalizeArgs &fa, const u32 qi, unsigned char *smem_raw) {
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 L = ix.num_layers;
     const u32 metric = ix.metric;
     float *qf = (float *)smem_raw;                                   // dim floats (padded to 16 B)
     u32 *cand = (u32 *)(smem_raw + (((size_t)ix.dim * 4 + 15) & ~(size_t)15)); // 64*FR candidate ids
+    u64 *wkeys = (u64 *)(cand + 64 * FR);                            // NWV > 1: 64*FR reranked keys, then [0] of the word behind them = ncand
+    u32 *wmisc = (u32 *)(wkeys + 64 * FR);
 
     const int32_t wst = fa.walk_status[qi];
     if (wst != COS_OK) {
-        if (lane == 0) { fa.out_status[qi] = wst; fa.out_counts[qi] = 0; if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = 0; }
+        if (tid == 0) { fa.out_status[qi] = wst; fa.out_counts[qi] = 0; if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = 0; }
         return;
     }
     const float *q = fa.queries + (u64)qi * fa.q_stride;
-    for (u32 i = lane; i < ix.dim; i += 64) qf[i] = q[i];
+    for (u32 i = tid; i < ix.dim; i += 64 * NWV) qf[i] = q[i];
+    const float mag_query = fa.q_raw_mags[qi];
+    if constexpr (NWV > 1) {
+        if (wave != 0) { // the other waves wait for the candidates, rerank their share and are done
+            __syncthreads();
+            rerank_wide<NWV>(ix, qf, cand, wmisc[0], mag_query, wkeys, lane, wave);
+            __syncthreads();
+            return;
+        }
+    }
 
     // gather the concatenated per-level lists (top level first) as (key, id) pairs
     u64 k[FR];
@@ -213,12 +247,38 @@ __device__ __forceinline__ void finalize_one(const IndexDev &ix, const FinalizeA
             pos++;
         }
     }
+    const u32 nout = ncand < fa.top_k ? ncand : fa.top_k;
+    if constexpr (NWV > 1) {
+        if (lane == 0) wmisc[0] = ncand;
+        __syncthreads();
+        rerank_wide<NWV>(ix, qf, cand, ncand, mag_query, wkeys, lane, 0);
+        __syncthreads();
+        u64 rk[FR];
+#pragma unroll
+        for (int r = 0; r < FR; r++) {
+            const u32 e = (u32)lane * FR + r;
+            rk[r] = e < ncand ? wkeys[e] : 0ull;
+        }
+        bitonic_sort_desc<FR>(rk, lane);
+#pragma unroll
+        for (int r = 0; r < FR; r++) {
+            const u32 e = (u32)lane * FR + r;
+            if (e < nout) {
+                fa.out_ids[(u64)qi * fa.top_k + e] = (u32)rk[r] + ix.id_base;
+                fa.out_scores[(u64)qi * fa.top_k + e] = simkey_inv((u32)(rk[r] >> 32));
+            }
+        }
+        if (lane == 0) {
+            fa.out_counts[qi] = nout;
+            fa.out_status[qi] = COS_OK;
+            if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = ncand;
+        }
+        return;
+    }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
     // exact rerank on raw f32 (vector_store.rs:404-445); 32 candidates per pass (one lane pair each)
-    const float mag_query = fa.q_raw_mags[qi];
-    const u32 nout = ncand < fa.top_k ? ncand : fa.top_k;
     const int pair = lane >> 1;
     if (ncand <= 64) {
         // common case (5k <= 64): survivor j ends in lane j and one 64-key sort finishes the job
@@ -285,6 +345,12 @@ __global__ __launch_bounds__(64) void finalize_kernel(const IndexDev ix, const F
     if (blockIdx.x >= fa.B) return;
     finalize_one<FR>(ix, fa, fa.q_order ? fa.q_order[blockIdx.x] : blockIdx.x, smem_raw);
 }
+template <int FR, int NWV>
+__global__ __launch_bounds__(64 * NWV) void finalize_wide_kernel(const IndexDev ix, const FinalizeArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (blockIdx.x >= fa.B) return;
+    finalize_one<FR, NWV>(ix, fa, fa.q_order ? fa.q_order[blockIdx.x] : blockIdx.x, smem_raw);
+}
 // the queries finalize_fast_kernel left over (slow_list / slow_count): a small fixed grid walks the list — nothing to do costs a
 // launch of a few workgroups instead of B that look at a flag and leave (60 us per 32768-query launch)
 template <int FR>
@@ -309,24 +375,35 @@ __global__ __launch_bounds__(64) void finalize_list_kernel(const IndexDev ix, co
 // ef: level 0 has no (5k + 1)-th entry and nothing is screened) leave the query to finalize_list_kernel through slow_list.
 // ------------------------------------------------------------------------------------------------
 constexpr int FAST_CAP = 128;
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void finalize_fast_kernel(const IndexDev ix, const FinalizeArgs fa) {
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV == 1 ? 7 : 2, 8))) void finalize_fast_kernel(const IndexDev ix, const FinalizeArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (blockIdx.x >= fa.B) return;
     const u32 qi = fa.q_order ? fa.q_order[blockIdx.x] : blockIdx.x;
     const u32 L = ix.num_layers;
     const u32 metric = ix.metric;
     float *qf = (float *)smem_raw;                                                       // dim floats (padded to 16 B)
     u64 *surv = (u64 *)(smem_raw + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));           // FAST_CAP survivor keys
-    u32 *cand = (u32 *)(surv + FAST_CAP);                                                // 64 candidate ids
+    u32 *cand = (u32 *)(surv + FAST_CAP);                                                // 64 candidate ids, then one word: ncand (NWV > 1)
 
     const int32_t wst = fa.walk_status[qi];
     if (wst != COS_OK) {
-        if (lane == 0) { fa.out_status[qi] = wst; fa.out_counts[qi] = 0; if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = 0; }
+        if (tid == 0) { fa.out_status[qi] = wst; fa.out_counts[qi] = 0; if (fa.out_rerank_rows) fa.out_rerank_rows[qi] = 0; }
         return;
     }
     const float *q = fa.queries + (u64)qi * fa.q_stride;
-    for (u32 i = lane; i < ix.dim; i += 64) qf[i] = q[i];
+    for (u32 i = tid; i < ix.dim; i += 64 * NWV) qf[i] = q[i];
+    const float mag_query = fa.q_raw_mags[qi];
+    if constexpr (NWV > 1) { // (finalize_one: the other waves wait for the candidates and rerank their share; keys land where the survivors were)
+        if (wave != 0) {
+            __syncthreads();
+            const u32 nc = cand[64];
+            if (nc != 0xFFFFFFFFu) rerank_wide<NWV>(ix, qf, cand, nc, mag_query, surv, lane, wave);
+            __syncthreads();
+            return;
+        }
+    }
 
     const u32 want = 5u * fa.top_k, per = want + 1u; // truncate(5k) (common.rs:409); entries of a level that can matter
     // counts of every level in one load; the threshold from level 0's list (slot L)
@@ -369,6 +446,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     }
     if (overflow) {
         if (lane == 0) fa.slow_list[atomicAdd(fa.slow_count, 1u)] = qi;
+        if constexpr (NWV > 1) {
+            if (lane == 0) cand[64] = 0xFFFFFFFFu;
+            __syncthreads();
+            __syncthreads();
+        }
         return;
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -395,15 +477,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     const u32 ncand = total < want ? total : want;
     if (keep0) { if (pos < ncand) cand[pos] = (u32)k[0]; pos++; }
     if (keep1) { if (pos < ncand) cand[pos] = (u32)k[1]; }
+    const u32 nout = ncand < fa.top_k ? ncand : fa.top_k;
+    u64 res[1] = {0ull};
+    if constexpr (NWV > 1) {
+        if (lane == 0) cand[64] = ncand;
+        __syncthreads(); // (the survivors were read into registers before the sort: their LDS takes the reranked keys)
+        rerank_wide<NWV>(ix, qf, cand, ncand, mag_query, surv, lane, 0);
+        __syncthreads();
+        res[0] = (u32)lane < ncand ? surv[lane] : 0ull;
+    } else {
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
     // exact rerank on raw f32 (vector_store.rs:404-445); 32 candidates per pass (one lane pair each); survivor j ends in lane j and
     // one 64-key sort finishes the job (5k <= 64)
-    const float mag_query = fa.q_raw_mags[qi];
-    const u32 nout = ncand < fa.top_k ? ncand : fa.top_k;
     const int pair = lane >> 1;
-    u64 res[1] = {0ull};
     for (u32 base = 0; base < ncand; base += 32) {
         const u32 my = base + (u32)pair;
         const u32 id = my < ncand ? cand[my] : 0u;
@@ -414,6 +502,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
         const int from = (2 * (lane - (int)base)) & 63;
         const u32 klo = (u32)__shfl((int)(u32)key, from, 64), khi = (u32)__shfl((int)(u32)(key >> 32), from, 64);
         if ((u32)lane >= base && (u32)lane < base + 32) res[0] = ((u64)khi << 32) | klo;
+    }
     }
     bitonic_sort_desc<1>(res, lane);
     if ((u32)lane < nout) {
@@ -606,6 +695,9 @@ hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_strid
     const u32 per_level = std::min<u32>(KEEP_SEARCH, 5u * top_k + 1u);
     const u32 total = (ix.num_layers + 1) * per_level;
     dim3 grid(B), block(64);
+    // small launches: FIN_WAVES waves per query (finalize_one); tuning knob finalize_wide_max_b = the largest such launch (0 = never)
+    constexpr int FIN_WAVES = 8;
+    const bool wide = B <= (u32)std::max<long long>(0, tune_or(TUNE_FINALIZE_WIDE_MAX_B, 1024));
     // the screened kernel first (5k + 1 <= 64 entries per level list), then the general kernel over the list of queries it left;
     // tuning knob finalize_fast = 0 keeps the general kernel alone (experiments)
     const bool fast_on = tune_or(TUNE_FINALIZE_FAST, 1) != 0;
@@ -615,8 +707,9 @@ hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_strid
         fa.slow_count = slow_list;
         hipError_t e = hipMemsetAsync(slow_list, 0, 4, st);
         if (e != hipSuccess) return e;
-        const size_t smem_f = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + (size_t)FAST_CAP * 8 + 64 * 4;
-        hipLaunchKernelGGL(finalize_fast_kernel, grid, block, smem_f, st, ix, fa);
+        const size_t smem_f = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + (size_t)FAST_CAP * 8 + 64 * 4 + 16;
+        if (wide) hipLaunchKernelGGL(finalize_fast_kernel<FIN_WAVES>, grid, dim3(64 * FIN_WAVES), smem_f, st, ix, fa);
+        else hipLaunchKernelGGL(finalize_fast_kernel<1>, grid, block, smem_f, st, ix, fa);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         listed = true;
@@ -626,6 +719,7 @@ hipError_t launch_finalize(const IndexDev &ix, const float *queries, u64 q_strid
     do {                                                                                                           \
         const size_t smem = (((size_t)ix.dim * 4 + 15) & ~(size_t)15) + 64 * (FR_) * 4;                            \
         if (listed) hipLaunchKernelGGL(finalize_list_kernel<FR_>, grid, block, smem, st, ix, fa);                 \
+        else if (wide) hipLaunchKernelGGL((finalize_wide_kernel<FR_, FIN_WAVES>), grid, dim3(64 * FIN_WAVES), smem + 64 * (FR_) * 8 + 16, st, ix, fa); \
         else hipLaunchKernelGGL(finalize_kernel<FR_>, grid, block, smem, st, ix, fa);                             \
     } while (0)
     if (total <= 64 * 4) FIN(4);

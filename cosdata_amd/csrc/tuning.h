@@ -45,6 +45,7 @@ enum TuneKey : int {
     TUNE_WALK_TABLE_AFTER_SORT, // 0 = the level-table GEMM of a big launch never waits for the previous walk's order sort, 2 = always (default 1: tables of 2^30 entries or more)
     TUNE_WALK_UPPER_LDS_PAD,  // bytes of unused dynamic LDS added per wave on the upper range of a split walk (occupancy experiment; default 0; negative = a launch of table levels only keeps the full LDS layout)
     TUNE_WALK_R2,             // 0 = ef 65..128 walks with the 256-key pool of ef 129..256 (default 1: a 128-key pool)
+    TUNE_FINALIZE_WIDE_MAX_B, // launches of at most this many queries finalize with eight waves per query (default 1024; 0 = never)
     TUNE_COUNT
 };
 
