@@ -108,9 +108,9 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
         return cos_fail(COS_ERR_INVALID, "neighbors_count / level_0_neighbors_count must be powers of two <= 256 (PerformantFixedSet, fixedset.rs)");
     if (p->num_layers + 1 > (u32)MAX_LEVELS || (p->num_layers + 1) * KEEP_SEARCH > 2048)
         return cos_fail(COS_ERR_UNIMPLEMENTED, "num_layers > 15 not supported on the device");
-    if (std::min(p->neighbors_count, p->shortlist_size) > 64 || std::min(p->level0_neighbors_count, p->shortlist_size) > 64)
-        return cos_fail(COS_ERR_UNIMPLEMENTED, "more than 64 scanned neighbour slots per node not supported on the device");
-    if (p->ef_search > 1024 || p->ef_construction > 1024) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 1024 not supported on the device");
+    // (more than 64 scanned neighbour slots per node and ef > 1024 walk with walk_general_kernel: kernels_walk_general.hip)
+    if (p->ef_search > cosdev::WALK_GENERAL_MAX_EF || p->ef_construction > cosdev::WALK_GENERAL_MAX_EF)
+        return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > %u not supported on the device (the candidates of a level live in one workgroup's LDS)", cosdev::WALK_GENERAL_MAX_EF);
     if (p->metric != COS_METRIC_COSINE && p->metric != COS_METRIC_DOT)
         return cos_fail(COS_ERR_UNIMPLEMENTED, "device walk implements cosine and dot-product metrics");
     int eng;
@@ -582,7 +582,7 @@ static int32_t ensure_level_table(cos_index *ix);
 static u32 walk_table_min_B(const cos_index *ix);
 extern "C" int32_t cos_index_set_ef_search(cos_index *ix, uint32_t ef) {
     if (!ix) return cos_fail(COS_ERR_INVALID, "null index");
-    if (ef > 1024) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > 1024 not supported on the device");
+    if (ef > cosdev::WALK_GENERAL_MAX_EF) return cos_fail(COS_ERR_UNIMPLEMENTED, "ef > %u not supported on the device", cosdev::WALK_GENERAL_MAX_EF);
     std::lock_guard<std::mutex> g(ix->mu); // searches snapshot ef / visited mode under the same lock (run_search); the graph state is read under it too
     const bool live = graph_ready(ix);
     if (live)
@@ -910,6 +910,8 @@ extern "C" int32_t cos_index_walk_table_info(cos_index *ix, uint32_t *out_level_
 static int32_t ensure_adj_mags(cos_index *ix) {
     if (ix->adj_mag_valid) return COS_OK;
     if (!graph_ready(ix) || ix->meta.mdim != 0u) return COS_OK; // (collections with a metadata schema keep the gathers: their walks are walk_meta_kernel's)
+    if (std::min(ix->p.neighbors_count, ix->p.shortlist_size) > 64u || std::min(ix->p.level0_neighbors_count, ix->p.shortlist_size) > 64u)
+        return COS_OK; // (walk_general_kernel's indexes: it gathers the norms)
     HIP_TRY(hipDeviceSynchronize()); // a build or an upload on another stream may still be writing the adjacency
     for (u32 l = 0; l <= ix->p.num_layers; l++) {
         LevelHost &H = ix->lv[l];
@@ -1091,7 +1093,10 @@ static int32_t run_search(cos_index *ix, Workspace *w, const float *d_queries, u
     }
     // which kernel walks this launch decides whether the level table is worth its GEMM: the throughput kernel (big launches, from
     // walk_table_min_B queries) and the four-wave latency kernel (one client batch) read it, the one-wave latency kernel does not
-    const bool ordered = order_min_B && B >= order_min_B && n_keys > 0 && w->order.cap >= B && ef <= 256u;
+    // (a launch outside the fast kernels' domain — walk_general_kernel — walks every level from rows, in one launch, in arrival order)
+    const bool general = cosdev::walk_general_needed(dev, ef);
+    const bool ordered = !general && order_min_B && B >= order_min_B && n_keys > 0 && w->order.cap >= B && ef <= 256u;
+    if (general) tab_level_min = 0;
     if (tab_level_min) {
         WalkArgs probe;
         memset(&probe, 0, sizeof(probe));
@@ -1820,6 +1825,10 @@ static constexpr u32 PSEUDO_LO = 0xFFFFFEFEu, PSEUDO_HI = 0xFFFFFFFDu; // u32::M
 extern "C" int32_t cos_index_enable_metadata(cos_index *ix, uint32_t mdim, uint32_t max_replicas_per_node) {
     if (!ix || mdim == 0 || mdim > 64 || max_replicas_per_node == 0) return cos_fail(COS_ERR_INVALID, "metadata dimensions must be in [1, 64] and max_replicas_per_node >= 1");
     if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before enabling the metadata component");
+    // (walk_meta_kernel keeps walk_kernel's domain: register pools, one lane per scanned slot)
+    if (ix->p.ef_construction > cosdev::WALK_FAST_MAX_EF || std::min(ix->p.neighbors_count, ix->p.shortlist_size) > 64u ||
+        std::min(ix->p.level0_neighbors_count, ix->p.shortlist_size) > 64u)
+        return cos_fail(COS_ERR_UNIMPLEMENTED, "metadata collections: ef_construction <= %u and at most 64 scanned neighbour slots per node", cosdev::WALK_FAST_MAX_EF);
     if ((u64)ix->n * max_replicas_per_node >= PSEUDO_LO) return cos_fail(COS_ERR_INVALID, "replica ids would run into the reserved id range");
     // a SHARD of a metadata collection (round 6): the shard's embeddings are rows [0, n) here and embeddings [e0, e0 + n) of the
     // collection, so its replica ids are id_base + row x max_replicas + i with id_base = e0 x max_replicas — a multiple of max_replicas
@@ -1952,6 +1961,7 @@ static int32_t search_filtered_host(cos_index *ix, const float *queries, u32 B, 
     u32 ef, vmode;
     { std::lock_guard<std::mutex> g(ix->mu); ef = ix->p.ef_search; vmode = ix->p.visited_mode; }
     if (vmode != COS_VISITED_REF) return cos_fail(COS_ERR_UNIMPLEMENTED, "filtered search implements the reference's PerformantFixedSet filter only");
+    if (ef > cosdev::WALK_FAST_MAX_EF) return cos_fail(COS_ERR_UNIMPLEMENTED, "filtered search: ef_search <= %u", cosdev::WALK_FAST_MAX_EF);
     int32_t rc = cos_set_device(ix);
     if (rc) return rc;
     const u32 md = ix->meta.mdim, nf = f_off[B], L1 = ix->p.num_layers + 1;

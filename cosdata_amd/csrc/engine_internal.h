@@ -31,6 +31,7 @@ hipError_t launch_link_round(const LinkArgs &a, u32 maxM, const u32 *pend, const
 hipError_t launch_quantize_rows(int eng, const float *x, u64 x_stride, u32 n, u32 dim, float lo, float hi, uint8_t *codes,
                                 u64 row_stride, float *mags, float *raw_mags, hipStream_t st);
 hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, hipStream_t st);
+bool walk_general_needed(const IndexDev &ix, u32 ef); // kernels_walk_general.hip: ef > 1024 or more than 64 scanned slots per node
 int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, bool table_available); // 0 throughput | 1 one-wave | 4 four-wave latency kernel
 hipError_t launch_walk_meta(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
 hipError_t launch_walk_meta_index(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);

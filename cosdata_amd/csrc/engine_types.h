@@ -118,4 +118,10 @@ struct WalkArgs {
     u32 *order_iota;       // [B] order_iota[b] = b (the values the sort carries), written with the key
 };
 
+// Parameter domains of the walk kernels.  walk_kernel (register pools of up to 64 x 16 keys, one lane per scanned slot) and the latency
+// kernels hold ef <= WALK_FAST_MAX_EF and <= 64 scanned slots per node; everything else the reference accepts (hnsw/types.rs:10-17,
+// config.toml:32) goes to walk_general_kernel (kernels_walk_general.hip), whose candidates live in ef x 8 bytes of one workgroup's LDS.
+constexpr u32 WALK_FAST_MAX_EF = 1024u;
+constexpr u32 WALK_GENERAL_MAX_EF = 16384u;
+
 } // namespace cosdev

@@ -627,6 +627,9 @@ hipError_t launch_walk_lat(int eng, const IndexDev &ix, const WalkArgs &wa, hipS
 // kernels_walk_lat4.hip
 bool walk_lat4_applicable(int eng, const IndexDev &ix, const WalkArgs &wa, u32 max_B);
 hipError_t launch_walk_lat4(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
+// kernels_walk_general.hip
+bool walk_general_needed(const IndexDev &ix, u32 ef);
+hipError_t launch_walk_general(int eng, const IndexDev &ix, const WalkArgs &wa, hipStream_t st);
 
 // lat_max_B: launches of at most this many queries take the latency kernel where it applies (cos_index_set_latency_mode; 0 = never);
 // lat4_max_B: the smallest of them give every query four waves (cos_index_set_latency_waves; 0 = never).
@@ -660,6 +663,7 @@ int walk_kernel_kind(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_ma
 
 hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_max_B, u32 lat4_max_B, hipStream_t st) {
     if (wa.B == 0) return hipSuccess;
+    if (walk_general_needed(ix, wa.ef)) return launch_walk_general(eng, ix, wa, st); // ef > 1024 or more than 64 scanned slots per node
     // the split (locality-ordered) walk and the unseeded filter of delete_embedding's walks (WalkArgs::no_self_seed) exist in the throughput kernel only
     const int kind = wa.no_self_seed ? 0 : walk_kernel_kind(eng, ix, wa, lat_max_B, lat4_max_B, wa.tab != nullptr);
     if (kind == 4) return launch_walk_lat4(eng, ix, wa, st);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""dev: dispatches of the last hybrid call in a rocprofv3 kernel trace of scripts/bench_c5.py (start / end relative to the call's first dispatch)."""
+"""Dispatches of the last hybrid call in a rocprofv3 kernel trace of scripts/bench_c5.py (start / end relative to the call's first dispatch)."""
 import sqlite3
 import sys
 

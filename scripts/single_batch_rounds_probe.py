@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""dev probe: one 256-query batch on c2's graph — walk kernel time, expansions, rounds per query, per kernel variant."""
+"""One 256-query batch on c2's graph: walk kernel time, expansions and ROUNDS per query (lookahead windows issued), per kernel variant.
+PROBE_N=30000 gives the control whose corpus sits in L2: what a round costs without HBM."""
 import json
 import os
 import sys
@@ -29,9 +30,7 @@ ix.enable_timing(True)
 o = (torch.zeros(B, K, dtype=torch.int32, device=dev), torch.zeros(B, K, dtype=torch.float32, device=dev),
      torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev))
 st = torch.cuda.Stream(device=dev)
-VARIANTS = (("throughput_auto_table", 0, 0, 2, {}), ("lat4_auto_table_ahead0", 2048, 512, 2, {"walk_small_table_tk": 0, "walk_lat4_ahead": 0}),
-            ("lat4_auto_table_ahead1", 2048, 512, 2, {"walk_small_table_tk": 0, "walk_lat4_ahead": 1}),
-            ("lat4_ahead0", 2048, 512, 0, {"walk_lat4_ahead": 0}), ("lat4_ahead1", 2048, 512, 0, {"walk_lat4_ahead": 1}))
+VARIANTS = (("throughput_auto_table", 0, 0, 2, {}), ("four_waves_auto_table", 2048, 512, 2, {"walk_small_table_tk": 0}), ("four_waves", 2048, 512, 0, {}))
 for ef in EFS:
     ix.set_ef_search(ef)
     ref = None

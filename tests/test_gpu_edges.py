@@ -86,14 +86,15 @@ def test_ef_above_512_other_storages_and_wide_rows(storage, res, dim):
     _assert_same_search(oix, dix, Q, 10)
 
 
-def test_ef_above_1024_is_refused_loudly():
+def test_ef_above_the_general_kernels_lds_is_refused_loudly():
     import cosdata_amd as ca
     X = H.clustered_corpus(500, 32, n_centers=4, seed=1)
     oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=2, ef_construction=16, ef_search=16)
     dix = H.device_index_from_oracle(oix, X)
     with pytest.raises(ca.CosdataError) as ei:
-        dix.set_ef_search(1025)
+        dix.set_ef_search(16385)
     assert ei.value.status == 4          # Unimplemented: never a silent difference
+    dix.set_ef_search(16384)
     dix.set_ef_search(1024)
 
 

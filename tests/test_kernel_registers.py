@@ -54,8 +54,10 @@ def test_walk_and_finalize_kernels_keep_their_occupancy(tmp_path):
     assert upper256["vgpr_count"] <= 96 and upper256["private_segment_fixed_size"] == 0
     exact = _find(ks, "walk_kernel<0, 1, 1, true, true, 8>")
     assert exact["vgpr_count"] <= 80
-    fin = _find(ks, "finalize_fast_kernel")
+    fin = _find(ks, "finalize_fast_kernel<1>")                          # big launches: one wave per query
     assert fin["vgpr_count"] <= 72 and fin["private_segment_fixed_size"] == 0        # 7 waves per SIMD (the general kernel: 121 VGPRs = 4)
+    wide = _find(ks, "finalize_fast_kernel<8>")                         # small launches: eight waves per query, one workgroup per CU
+    assert wide["vgpr_count"] <= 128 and wide["private_segment_fixed_size"] == 0
 
 
 def _disassembly(obj, tmp_path, symbol_part):
