@@ -119,7 +119,7 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
     switch (p->storage) {
     case COS_STORAGE_U8:
         eng = ENG_U8; row_stride = ((u64)p->dim + 15) & ~15ull; nchunks = (u32)(row_stride / 16); G = std::min(64u, pow2ceil(nchunks));
-        if ((nchunks + G - 1) / G > 2) return cos_fail(COS_ERR_UNIMPLEMENTED, "u8 dim > 2048 not supported on the device");
+        // (more than 2048 dimensions: walk_general_kernel, any number of chunks per row)
         break;
     case COS_STORAGE_SUBBYTE:
         // one 16 B chunk holds every plane of 128 / 64 / 32 dims for binary / quaternary / octal
@@ -128,7 +128,7 @@ extern "C" int32_t cos_index_create(const cos_params *p, cos_index **out) {
         else if (p->resolution == 3) { eng = ENG_Q3; nchunks = (p->dim + 31) / 32; }
         else return cos_fail(COS_ERR_CALCULATION, "SubByte resolution %u: the reference's distance arms return CalculationError (cosine.rs:147-154)", p->resolution);
         row_stride = (u64)nchunks * 16; G = std::min(64u, pow2ceil(nchunks));
-        if (nchunks > 64) return cos_fail(COS_ERR_UNIMPLEMENTED, "SubByte dim > %u not supported on the device", 64u * (128u >> (p->resolution - 1)));
+        // (more than 64 chunks per row: walk_general_kernel)
         break;
     case COS_STORAGE_F32:
         if (p->metric == COS_METRIC_DOT) return cos_fail(COS_ERR_STORAGE_MISMATCH, "DotProductDistance has no FullPrecisionFP arm (dotproduct.rs:20-64)");
@@ -1827,8 +1827,9 @@ extern "C" int32_t cos_index_enable_metadata(cos_index *ix, uint32_t mdim, uint3
     if (!ix->have_vectors) return cos_fail(COS_ERR_NOT_READY, "upload vectors before enabling the metadata component");
     // (walk_meta_kernel keeps walk_kernel's domain: register pools, one lane per scanned slot)
     if (ix->p.ef_construction > cosdev::WALK_FAST_MAX_EF || std::min(ix->p.neighbors_count, ix->p.shortlist_size) > 64u ||
-        std::min(ix->p.level0_neighbors_count, ix->p.shortlist_size) > 64u)
-        return cos_fail(COS_ERR_UNIMPLEMENTED, "metadata collections: ef_construction <= %u and at most 64 scanned neighbour slots per node", cosdev::WALK_FAST_MAX_EF);
+        std::min(ix->p.level0_neighbors_count, ix->p.shortlist_size) > 64u ||
+        (ix->nchunks != 0u && (ix->nchunks + ix->G - 1u) / ix->G > (ix->eng == ENG_U8 ? 2u : 1u)))
+        return cos_fail(COS_ERR_UNIMPLEMENTED, "metadata collections: ef_construction <= %u, at most 64 scanned neighbour slots per node, u8 rows of at most 2048 / SubByte rows of at most 64 x 16 bytes", cosdev::WALK_FAST_MAX_EF);
     if ((u64)ix->n * max_replicas_per_node >= PSEUDO_LO) return cos_fail(COS_ERR_INVALID, "replica ids would run into the reserved id range");
     // a SHARD of a metadata collection (round 6): the shard's embeddings are rows [0, n) here and embeddings [e0, e0 + n) of the
     // collection, so its replica ids are id_base + row x max_replicas + i with id_base = e0 x max_replicas — a multiple of max_replicas

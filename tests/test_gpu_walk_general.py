@@ -93,3 +93,41 @@ def test_device_builder_in_the_general_domain(efc, M, M0, shortlist):
         og, dg = oix.export_graph(), dix.download_graph()
         for (on, oa), (dn, da) in zip(og, dg):
             assert np.array_equal(on, dn) and np.array_equal(oa, da)
+
+
+@pytest.mark.parametrize("storage,res,dim", [(O.STORAGE_U8, 0, 3072), (O.STORAGE_U8, 0, 2050), (O.STORAGE_SUBBYTE, 2, 4160), (O.STORAGE_SUBBYTE, 1, 8320),
+                                             (O.STORAGE_SUBBYTE, 3, 2080)])
+def test_rows_wider_than_the_fast_kernels_chunk_passes(storage, res, dim):
+    """u8 above 2048 dimensions (text-embedding-3-large is 3072) and SubByte rows of more than 64 x 16 bytes: refused until round 6.
+    Device build (walks with ef_construction + link) and search against the oracle on the same schedule."""
+    import cosdata_amd as ca
+    scale = 0.9 if storage == O.STORAGE_SUBBYTE else 1.0
+    X = H.clustered_corpus(1200, dim, n_centers=8, seed=dim) * scale
+    p = O.HNSWParams(dim=dim, storage=storage, resolution=res, num_layers=3, ef_construction=32, ef_search=48, seed=3)
+    oix = O.OracleIndex(p).set_vectors(X)
+    oix.build_rounds(256, greedy=False)
+    hp = ca.HNSWHyperParams(num_layers=3, ef_construction=32, ef_search=48, level_0_neighbors_count=p.level0_neighbors_count, neighbors_count=p.neighbors_count)
+    dix = ca.HNSWIndex(dim, hp, ca.DistanceMetric.Cosine, ca.StorageType(ca.StorageKind(storage), res), (p.range_lo, p.range_hi), p.shortlist_size, seed=3)
+    dix.upload_vectors(X)
+    dix.build(256)
+    og, dg = oix.export_graph(), dix.download_graph()
+    assert len(og) == len(dg)
+    for (on, oa), (dn, da) in zip(og, dg):
+        assert np.array_equal(on, dn) and np.array_equal(oa, da)
+    Q = H.queries_from(X, 6, seed=2) * scale
+    _assert_same_walk(oix, dix, Q)
+    _assert_same_search(oix, dix, Q, 10)
+
+
+@pytest.mark.parametrize("storage,res,dim", [(O.STORAGE_U8, 0, 3072), (O.STORAGE_SUBBYTE, 2, 4160)])
+def test_exhaustive_scan_over_wide_rows(storage, res, dim):
+    """cos_flat_search_batch on rows the walk's fast kernels do not hold: the tile GEMM loops over any number of k panels"""
+    import cosdata_amd as ca
+    X = H.uniform_corpus(2200, dim, seed=13) * 0.9
+    Q = H.queries_from(X, 9, noise=0.05, seed=8)
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType(ca.StorageKind(storage), res))
+    ix.upload_vectors(X)
+    ids, sc, cnt = ix.flat_search(Q, 10)
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, storage=storage, resolution=res, num_layers=3)).set_vectors(X)
+    oids, osc, ocnt = oix.flat_search_batch(Q, 10, threads=4)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
