@@ -300,6 +300,22 @@ __global__ void any_zero_kernel(const float *__restrict__ v, u32 n, u32 *__restr
     if (__any(z) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// one launch instead of four memsets in front of every scan: the survivor pools, the thresholds, the append counters, the overflow flag
+__global__ void flat_reset_kernel(u64 *__restrict__ pool, u64 n_pool, u64 *__restrict__ thr, u32 *__restrict__ appcnt, u32 B, u32 *__restrict__ overflow) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x, step = (u64)gridDim.x * blockDim.x;
+    for (u64 i = t; i < n_pool; i += step) pool[i] = 0ull;
+    for (u64 i = t; i < B; i += step) { thr[i] = 0ull; appcnt[i] = 0u; }
+    if (t == 0) *overflow = 0u;
+}
+// the call's results and its two flags side by side, for one copy back
+__global__ void flat_pack_out_kernel(const u32 *__restrict__ oi, const float *__restrict__ os, const u32 *__restrict__ oc, const u32 *__restrict__ flags,
+                                     u32 B, u32 k, u32 *__restrict__ out) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x, nk = (u64)B * k;
+    if (t < nk) { out[t] = oi[t]; out[nk + t] = __float_as_uint(os[t]); }
+    if (t < B) out[2 * nk + t] = oc[t];
+    if (t < 2) out[2 * nk + B + t] = flags[t];
+}
+
 // exact re-score of the survivors in the reference order, sort, top-k
 __global__ __launch_bounds__(64) void flat_rescore(const float *__restrict__ Q, u64 q_stride, const float *__restrict__ qmags, u32 B,
                                                    const float *__restrict__ X, u64 x_stride, const float *__restrict__ xmags, u32 dim,
@@ -703,6 +719,19 @@ struct FlatWs {
     Buf q, zero, qm, qrm, qc, qd, qdp, qs, cs, pool, thr, app, appcnt, oi, os, oc, scores, part;
     bool cs_valid = false; // code sums of the stored vectors (u8 engine) computed for the current upload
     u32 cs_n = 0;
+    bool zn_valid = false, zn_zero = false; // "a stored vector has a zero norm" for the current upload (cosine's CalculationError screen)
+    u32 zn_n = 0;
+    Buf out;                  // [ids B x k | scores B x k | counts B | zero-norm flag, overflow flag]: ONE copy back per call
+    void *h_out = nullptr;    // its pinned landing area
+    size_t h_out_cap = 0;
+    hipError_t need_host(size_t bytes) {
+        if (bytes <= h_out_cap && h_out) return hipSuccess;
+        if (h_out) (void)hipHostFree(h_out);
+        h_out = nullptr; h_out_cap = 0;
+        hipError_t e = hipHostMalloc(&h_out, bytes);
+        if (e == hipSuccess) h_out_cap = bytes;
+        return e;
+    }
     std::vector<hipEvent_t> evs;
     hipError_t need(Buf &b, size_t bytes) {
         if (bytes <= b.cap && b.p) return hipSuccess;
@@ -723,8 +752,9 @@ struct FlatWs {
         return hipSuccess;
     }
     ~FlatWs() {
-        for (Buf *b : {&q, &zero, &qm, &qrm, &qc, &qd, &qdp, &qs, &cs, &pool, &thr, &app, &appcnt, &oi, &os, &oc, &scores, &part})
+        for (Buf *b : {&q, &zero, &qm, &qrm, &qc, &qd, &qdp, &qs, &cs, &pool, &thr, &app, &appcnt, &oi, &os, &oc, &scores, &part, &out})
             if (b->p) (void)hipFree(b->p);
+        if (h_out) (void)hipHostFree(h_out);
         for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
     }
 };
@@ -822,24 +852,33 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
             }
             // zero-norm screening (cosine): the reference aborts a search on the first zero denominator it meets; an
             // exhaustive scan meets every vector, so any zero |q| or zero |v| is a CalculationError for the call.
-            u32 hzero = 0;
+            // The stored vectors' answer is computed once per upload (and read back then); the queries' flag stays on the device and comes
+            // back with the results: a call with a zero-norm query runs its scan for nothing and then reports the error — until round 6
+            // every call stopped here for a device round trip (~50 us of a 1.9 ms call) before its first GEMM.
             if (e == hipSuccess && ix->p.metric == COS_METRIC_COSINE) {
-                hipLaunchKernelGGL(any_zero_kernel, dim3(64), dim3(256), 0, st, (const float *)d_qm, B, d_zero);
-                hipLaunchKernelGGL(any_zero_kernel, dim3(1024), dim3(256), 0, st, (const float *)ix->d_mags, n, d_zero);
-                e = hipGetLastError();
+                if (!W->zn_valid || W->zn_n != n) {
+                    u32 hz = 0;
+                    hipLaunchKernelGGL(any_zero_kernel, dim3(1024), dim3(256), 0, st, (const float *)ix->d_mags, n, d_zero);
+                    e = hipGetLastError();
+                    if (e == hipSuccess) e = hipMemcpyAsync(&hz, d_zero, 4, hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);
+                    if (e == hipSuccess) { W->zn_valid = true; W->zn_n = n; W->zn_zero = hz != 0; }
+                    if (e == hipSuccess) e = hipMemsetAsync(d_zero, 0, 4, st);
+                }
+                if (e == hipSuccess && W->zn_zero) { zero = true; break; }
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(any_zero_kernel, dim3(64), dim3(256), 0, st, (const float *)d_qm, B, d_zero);
+                    e = hipGetLastError();
+                }
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(&hzero, d_zero, 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            zero = hzero != 0;
-            if (zero) break;
         }
         WS_NEED(scores, d_scores, (size_t)B * s_stride * 4)
         WS_NEED(part, d_part, (size_t)B * S * SEL * 8)
 #undef WS_NEED
-        if (e == hipSuccess) e = hipMemsetAsync(d_pool, 0, (size_t)B * SEL * 8, st);
-        if (e == hipSuccess) e = hipMemsetAsync(d_thr, 0, (size_t)B * 8, st);
-        if (e == hipSuccess) e = hipMemsetAsync(d_appcnt, 0, (size_t)B * 4, st);
-        if (e == hipSuccess) e = hipMemsetAsync(d_zero + 1, 0, 4, st); // overflow flag of the fused path
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(flat_reset_kernel, dim3(64), dim3(256), 0, st, d_pool, (u64)B * SEL, d_thr, d_appcnt, B, d_zero + 1); // (d_zero + 1: overflow flag of the fused path)
+            e = hipGetLastError();
+        }
         FusedOut fo{d_thr, d_app, d_appcnt, APP_CAP, d_qd};
         u32 n0 = 0, seen = 0;
         while (n0 < n && e == hipSuccess) {
@@ -882,19 +921,30 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
             n0 += nc;
             seen += nc;
         }
-        u32 hover = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&hover, d_zero + 1, 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess || !fused || hover == 0) break; // done; otherwise the append buffer overflowed: repeat unfused
-    }
-    if (e == hipSuccess && !zero) {
+        // rerank, then ONE copy back: results, the zero-norm flag of the queries and the overflow flag of the fused path.  (Until round 6: a
+        // device round trip for the overflow flag, then the rerank, then three pageable copies.)  An overflow repeats the scan unfused.
+        const size_t nk = (size_t)B * top_k, out_words = 2 * nk + B + 2;
+        if (e == hipSuccess) e = W->need(W->out, out_words * 4);
+        if (e == hipSuccess) e = W->need_host(out_words * 4);
+        if (e != hipSuccess) break;
         hipLaunchKernelGGL(flat_rerank_top5k, dim3(B), dim3(64), (((size_t)dim * 4 + 15) & ~(size_t)15), st, d_q, (u64)dim, d_qrm, B, ix->d_raw, (u64)dim,
                            ix->d_raw_mags, dim, d_pool, 5 * top_k, top_k, ix->p.id_base, d_oi, d_os, d_oc);
+        hipLaunchKernelGGL(flat_pack_out_kernel, dim3((u32)((std::max<size_t>(nk, B) + 255) / 256)), dim3(256), 0, st, d_oi, d_os, d_oc, d_zero, B, top_k, (u32 *)W->out.p);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_oi, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_os, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_oc, (size_t)B * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(W->h_out, W->out.p, out_words * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) break;
+        const u32 *ho = (const u32 *)W->h_out;
+        zero = ho[2 * nk + B] != 0;
+        const u32 hover = ho[2 * nk + B + 1];
+        if (zero) break;
+        if (fused && hover != 0) continue; // the append buffer overflowed: repeat unfused
+        memcpy(out_ids, ho, nk * 4);
+        memcpy(out_scores, ho + nk, nk * 4);
+        memcpy(out_counts, ho + 2 * nk, (size_t)B * 4);
+        break;
+    }
+    if (e == hipSuccess && !zero) {
         for (size_t i = 0; i + 1 < n_ev && e == hipSuccess; i += 2) {
             float ms = 0.f;
             e = hipEventElapsedTime(&ms, W->evs[i], W->evs[i + 1]);
