@@ -206,7 +206,7 @@ static void free_level(LevelHost &l) {
 }
 static void free_ws(Workspace *w) {
     void *ptrs[] = {w->fin_flags, w->stats2, w->tab, w->qsums, w->qdig, w->q_codes, w->q_mags, w->q_raw_mags, w->walk_ids, w->walk_counts, w->walk_sims, w->walk_status, w->stats,
-                    w->rerank_rows, w->vis.bits, w->vis.log, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status};
+                    w->rerank_rows, w->vis.bits, w->vis.log, w->d_queries, w->d_out_ids, w->d_out_counts, w->d_out_scores, w->d_out_status, w->f_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     cosdev::walk_order_free(w->order);
     for (auto &e : w->ev) if (e) (void)hipEventDestroy(e);
@@ -1975,7 +1975,6 @@ static int32_t search_filtered_host(cos_index *ix, const float *queries, u32 B, 
         for (u32 j = 0; j < md; j++) { const int32_t v = f_dims[(size_t)f * md + j]; fd[(size_t)f * md + j] = v; const float x = (float)v; acc = acc + x * x; }
         fm[f] = sqrtf(acc);
     }
-    DevBuf d_fd, d_fm, d_fo; // declared before the lease: the stream is drained (below, on every path) before they are freed
     PipeLease lease(ix);
     rc = lease.acquire();
     if (rc) return rc;
@@ -1984,12 +1983,21 @@ static int32_t search_filtered_host(cos_index *ix, const float *queries, u32 B, 
     Workspace *w;
     rc = get_workspace(ix, (void *)st, st, B, top_k ? top_k : 1, true, &w);
     if (rc) return rc;
-    HIP_TRY(d_fd.alloc(fd.size() * 4));
-    HIP_TRY(d_fm.alloc(fm.size() * 4));
-    HIP_TRY(d_fo.alloc(((size_t)B + 1) * 4));
-    HIP_TRY(hipMemcpyAsync(d_fd.p, fd.data(), fd.size() * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_fm.p, fm.data(), fm.size() * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_fo.p, f_off, ((size_t)B + 1) * 4, hipMemcpyHostToDevice, st));
+    // the batch's filters in the workspace's own buffer, ONE copy: [dims nf x md | norms nf | offsets B + 1]
+    const size_t f_words = fd.size() + fm.size() + (size_t)B + 1;
+    if (f_words * 4 > w->f_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (w->f_buf) (void)hipFree(w->f_buf);
+        w->f_buf = nullptr;
+        w->f_cap = 0;
+        HIP_TRY(hipMalloc((void **)&w->f_buf, f_words * 4 * 2));
+        w->f_cap = f_words * 4 * 2;
+    }
+    std::vector<u32> fpack(f_words);
+    memcpy(fpack.data(), fd.data(), fd.size() * 4);
+    memcpy(fpack.data() + fd.size(), fm.data(), fm.size() * 4);
+    memcpy(fpack.data() + fd.size() + fm.size(), f_off, ((size_t)B + 1) * 4);
+    HIP_TRY(hipMemcpyAsync(w->f_buf, fpack.data(), f_words * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(w->d_queries, queries, (size_t)B * ix->p.dim * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(launch_quantize_rows(ix->eng, w->d_queries, ix->p.dim, B, ix->p.dim, ix->p.range_lo, ix->p.range_hi, w->q_codes, ix->row_stride, w->q_mags,
                                  w->q_raw_mags, st));
@@ -2006,9 +2014,9 @@ static int32_t search_filtered_host(cos_index *ix, const float *queries, u32 B, 
     wa.out_sims = w->walk_sims;
     wa.out_counts = w->walk_counts;
     wa.out_status = w->walk_status;
-    wa.f_dims = d_fd.as<int32_t>();
-    wa.f_mags = d_fm.as<float>();
-    wa.f_off = d_fo.as<u32>();
+    wa.f_dims = (const int32_t *)w->f_buf;
+    wa.f_mags = (const float *)(w->f_buf + fd.size() * 4);
+    wa.f_off = (const u32 *)(w->f_buf + (fd.size() + fm.size()) * 4);
     HIP_TRY(launch_walk_meta(ix->eng, dev, wa, st));
     std::vector<int32_t> status(B);
     if (lvl_ids) {

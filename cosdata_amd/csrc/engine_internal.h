@@ -149,6 +149,10 @@ struct Workspace {
     u32 *d_out_ids = nullptr, *d_out_counts = nullptr;
     float *d_out_scores = nullptr;
     int32_t *d_out_status = nullptr;
+    // filtered search (cos_search_filtered_batch): the batch's filters [f_cap words: dims | norms | offsets], grown on demand — until
+    // round 6 three hipMalloc / hipFree pairs per call (a hipFree drains the device)
+    unsigned char *f_buf = nullptr;
+    size_t f_cap = 0;
     // timing: a ring of event quadruples (before prep | after prep | after walk | after finalize), one per launch, so a
     // run of launches can be summarised afterwards without synchronising between them (cos_index_timing_summary)
     // + the inner marks of a big launch's walk: [4] before / [5] after the level-table GEMM (caller's stream), [6] after the upper
