@@ -299,12 +299,14 @@ struct cos_bm25 {
     // cos_hybrid_search_batch: dense half + fusion (second stream, buffers grown on demand)
     hipStream_t stream_dense = nullptr;
     hipEvent_t ev_sparse = nullptr;
-    float *d_hq = nullptr, *d_dsc = nullptr, *d_fsc = nullptr;
-    u32 *d_did = nullptr, *d_dcnt = nullptr, *d_fid = nullptr, *d_fcnt = nullptr;
-    int32_t *d_dst = nullptr;
+    float *d_hq = nullptr, *d_dsc = nullptr;
+    u32 *d_did = nullptr, *d_dcnt = nullptr;
+    // what goes back to the caller, side by side for ONE copy: [fused ids B x k | fused scores B x k | counts B | dense status B]
+    u32 *d_ret = nullptr;
+    void *h_ret = nullptr; // its pinned landing area
     // one capacity per buffer, written back by grow_buf itself: a failed hipMalloc leaves that buffer null WITH capacity 0,
     // so a later, smaller batch grows it again instead of launching on a null pointer
-    size_t cap_hq = 0, cap_did = 0, cap_dsc = 0, cap_dcnt = 0, cap_dst = 0, cap_fid = 0, cap_fsc = 0, cap_fcnt = 0;
+    size_t cap_hq = 0, cap_did = 0, cap_dsc = 0, cap_dcnt = 0, cap_ret = 0, cap_hret = 0;
 };
 
 extern "C" int32_t cos_bm25_create(int32_t device, const uint32_t *term_hashes, const uint64_t *offsets, uint32_t n_terms, const uint32_t *doc_ids,
@@ -365,9 +367,10 @@ extern "C" int32_t cos_bm25_destroy(cos_bm25 *b) {
     if (b->stream_dense) { (void)hipStreamSynchronize(b->stream_dense); (void)hipStreamDestroy(b->stream_dense); }
     if (b->ev_sparse) (void)hipEventDestroy(b->ev_sparse);
     void *ptrs[] = {b->d_docs, b->d_tfs, b->d_qt, b->d_buckets, b->d_ids, b->d_cnt, b->d_sc, b->d_tile_dir,
-                    b->d_hq, b->d_dsc, b->d_fsc, b->d_did, b->d_dcnt, b->d_fid, b->d_fcnt, b->d_dst};
+                    b->d_hq, b->d_dsc, b->d_did, b->d_dcnt, b->d_ret};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (b->h_qt) (void)hipHostFree(b->h_qt);
+    if (b->h_ret) (void)hipHostFree(b->h_ret);
     delete b;
     return COS_OK;
 }
@@ -570,10 +573,18 @@ extern "C" int32_t cos_hybrid_search_batch(cos_index *ix, cos_bm25 *b, const flo
     HIP_TRY(grow_buf(b->d_did, b->cap_did, (size_t)B * k3));
     HIP_TRY(grow_buf(b->d_dsc, b->cap_dsc, (size_t)B * k3));
     HIP_TRY(grow_buf(b->d_dcnt, b->cap_dcnt, (size_t)B));
-    HIP_TRY(grow_buf(b->d_dst, b->cap_dst, (size_t)B));
-    HIP_TRY(grow_buf(b->d_fid, b->cap_fid, (size_t)B * top_k));
-    HIP_TRY(grow_buf(b->d_fsc, b->cap_fsc, (size_t)B * top_k));
-    HIP_TRY(grow_buf(b->d_fcnt, b->cap_fcnt, (size_t)B));
+    const size_t nk = (size_t)B * top_k, ret_words = 2 * nk + 2 * (size_t)B;
+    HIP_TRY(grow_buf(b->d_ret, b->cap_ret, ret_words));
+    if (ret_words * 4 > b->cap_hret) {
+        if (b->h_ret) (void)hipHostFree(b->h_ret);
+        b->h_ret = nullptr;
+        b->cap_hret = 0;
+        HIP_TRY(hipHostMalloc(&b->h_ret, ret_words * 4));
+        b->cap_hret = ret_words * 4;
+    }
+    u32 *d_fid = b->d_ret, *d_fcnt = b->d_ret + 2 * nk;
+    float *d_fsc = (float *)(b->d_ret + nk);
+    int32_t *d_dst = (int32_t *)(b->d_ret + 2 * nk + B);
     // The dense half goes FIRST, on a stream of the highest priority: its walk is a chain of dependent rounds on a quarter of the chip's
     // wave slots (one workgroup per query), the sparse half is a bandwidth kernel of 8192 workgroups that fills whatever the walk
     // leaves free.  Until round 6 the sparse half was enqueued first: its workgroups held every CU until they drained and the dense
@@ -581,7 +592,7 @@ extern "C" int32_t cos_hybrid_search_batch(cos_index *ix, cos_bm25 *b, const flo
     // profiles/r06_final_kernel_trace_c5_rocprofv3.txt: a 256-workgroup copy of 0.52 ms beside a 0.57 ms bm25_score_kernel).
     hipStream_t sd = b->stream_dense;
     HIP_TRY(hipMemcpyAsync(b->d_hq, queries, (size_t)B * dim * 4, hipMemcpyHostToDevice, sd));
-    rc = cos_search_batch_device(ix, b->d_hq, B, k3, b->d_did, b->d_dsc, b->d_dcnt, b->d_dst, sd);
+    rc = cos_search_batch_device(ix, b->d_hq, B, k3, b->d_did, b->d_dsc, b->d_dcnt, d_dst, sd);
     if (rc) return rc;
     // sparse half on its stream, beside the walk; its host side (the term table of the batch) is prepared while the device already walks
     rc = bm25_prepare(b, q_terms, q_offsets, B);
@@ -592,7 +603,7 @@ extern "C" int32_t cos_hybrid_search_batch(cos_index *ix, cos_bm25 *b, const flo
     // fusion once both lists are there
     HIP_TRY(hipStreamWaitEvent(sd, b->ev_sparse, 0));
     const size_t smem = (size_t)maxn * 4;
-#define LAUNCH(R) hipLaunchKernelGGL(rrf_kernel<R>, dim3(B), dim3(64), smem, sd, b->d_did, b->d_dcnt, k3, b->d_ids, b->d_cnt, k3, B, fusion_constant_k, top_k, b->d_fid, b->d_fsc, b->d_fcnt)
+#define LAUNCH(R) hipLaunchKernelGGL(rrf_kernel<R>, dim3(B), dim3(64), smem, sd, b->d_did, b->d_dcnt, k3, b->d_ids, b->d_cnt, k3, B, fusion_constant_k, top_k, d_fid, d_fsc, d_fcnt)
     if (maxn <= 64) LAUNCH(1);
     else if (maxn <= 128) LAUNCH(2);
     else if (maxn <= 256) LAUNCH(4);
@@ -600,12 +611,13 @@ extern "C" int32_t cos_hybrid_search_batch(cos_index *ix, cos_bm25 *b, const flo
     else LAUNCH(16);
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
-    std::vector<int32_t> status(B);
-    HIP_TRY(hipMemcpyAsync(out_ids, b->d_fid, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, sd));
-    HIP_TRY(hipMemcpyAsync(out_scores, b->d_fsc, (size_t)B * top_k * 4, hipMemcpyDeviceToHost, sd));
-    HIP_TRY(hipMemcpyAsync(out_counts, b->d_fcnt, (size_t)B * 4, hipMemcpyDeviceToHost, sd));
-    HIP_TRY(hipMemcpyAsync(status.data(), b->d_dst, (size_t)B * 4, hipMemcpyDeviceToHost, sd));
+    HIP_TRY(hipMemcpyAsync(b->h_ret, b->d_ret, ret_words * 4, hipMemcpyDeviceToHost, sd)); // (until round 6: four pageable copies)
     HIP_TRY(hipStreamSynchronize(sd));
+    const u32 *hr = (const u32 *)b->h_ret;
+    memcpy(out_ids, hr, nk * 4);
+    memcpy(out_scores, hr + nk, nk * 4);
+    memcpy(out_counts, hr + 2 * nk, (size_t)B * 4);
+    const int32_t *status = (const int32_t *)(hr + 2 * nk + B);
     for (u32 q = 0; q < B; q++)
         if (status[q] != COS_OK) return cos_fail(status[q], "dense half: query %u failed with status %d (zero-norm vector -> DistanceError::CalculationError)", q, status[q]);
     return COS_OK;

@@ -71,9 +71,9 @@ typedef struct {
     uint32_t num_layers;             /* levels 0..num_layers */
     uint32_t neighbors_count;        /* M  (power of two, <= 256) */
     uint32_t level0_neighbors_count; /* M0 (power of two, <= 256) */
-    uint32_t ef_construction;
-    uint32_t ef_search;
-    uint32_t shortlist_size;
+    uint32_t ef_construction;        /* <= 16384: up to 1024 the fast walk kernels, above it walk_general_kernel */
+    uint32_t ef_search;              /* the same domain; cos_index_set_ef_search moves it on a live handle */
+    uint32_t shortlist_size;         /* config.toml [search]: any; more than 64 scanned slots per node walk with walk_general_kernel */
     uint32_t visited_mode; /* COS_VISITED_* */
     int32_t device;        /* HIP device ordinal */
     uint32_t id_base;      /* shard support: global id of local vector 0; output ids = id_base + local id */
