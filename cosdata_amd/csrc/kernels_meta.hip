@@ -147,10 +147,10 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
 
     // CosineSimilarity::calculate's dispatch for (stored node, query with the filter in sm.fq / sm.fqi):
     // returns 0 = the similarity is `sim`, 1 = the vector cosine decides, < 0 = -status.  Executed per LANE (its own node).
-    auto meta_decide = [&](u32 node, u32 nid, const LevelDev &lv, float fmag, int xkind, float &sim) -> int {
+    // (k = the node's metadata row, ymag = its norm: loaded by the caller, TOGETHER with the node's id and vector row — until round 6
+    // they were loaded here, one dependent trip to memory after the other: seven per expansion)
+    auto meta_decide = [&](u32 k, float ymag, u32 nid, float fmag, int xkind, float &sim) -> int {
         if (metric != 0u) return 1; // the other metrics never look at node kinds
-        const u32 k = lv.node_meta[node];
-        const float ymag = ix.mmags[k];
         const int ykind = ymag == 0.0f ? KIND_BASE : ((nid >= PSEUDO_LO && nid <= PSEUDO_HI) ? KIND_PSEUDO : KIND_METADATA);
         const int32_t *yb = ix.mbits + (u64)k * md;
         if (ykind == KIND_PSEUDO && xkind == KIND_METADATA) { // a metadata query strongly matches / mismatches a pseudo node
@@ -206,10 +206,11 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
             pool.clear();
             u32 npool = 0, npop = 0;
             { // start node: evaluated and pushed whatever the visited filter says (vector_store.rs:1144-1148)
-                const u32 eid = lv.node_id[entry];
+                const u32 eid = lv.node_id[entry], ek = lv.node_meta[entry];
+                const float eymag = ix.mmags[ek];
                 float s0 = 0.0f;
                 int dec = 0;
-                if (lane == 0) dec = meta_decide(entry, eid, lv, fmag, xkind, s0);
+                if (lane == 0) dec = meta_decide(ek, eymag, eid, fmag, xkind, s0);
                 dec = (int)readlane_u32((u32)dec, 0);
                 s0 = __uint_as_float(readlane_u32(__float_as_uint(s0), 0));
                 if (dec < 0) { status = -dec; break; }
@@ -230,7 +231,12 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                 u32 nb_node = ROW_EMPTY;
                 if ((u32)lane < slots) nb_node = lv.adj_node[(u64)nd * M + lane];
                 const bool valid = nb_node != ROW_EMPTY;
-                const u32 nid = valid ? lv.node_id[nb_node] : 0u;
+                // what an expansion needs of its neighbours, in two trips to memory instead of five: id, metadata row and vector row
+                // together (no lane masked off: an empty slot reads node 0), then the metadata norm
+                const u32 nbs = valid ? nb_node : 0u;
+                const u32 nid_l = lv.node_id[nbs], nk = lv.node_meta[nbs], nvrow = lv.node_vec[nbs];
+                const float nymag = ix.mmags[nk];
+                const u32 nid = valid ? nid_l : 0u;
                 const u32 bit = nid & bitmask, word = bit >> 5, msk = 1u << (bit & 31);
                 const bool pre = valid && (sm.vis[word] & msk);
                 const bool cand = valid && !pre;
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                 // node-kind dispatch per winner
                 float csim = 0.0f;
                 int dec = 0;
-                if (win) dec = meta_decide(nb_node, nid, lv, fmag, xkind, csim);
+                if (win) dec = meta_decide(nk, nymag, nid, fmag, xkind, csim);
                 const u64 errm = __ballot(win && dec < 0);
                 if (errm) { status = -(int)readlane_u32((u32)dec, __ffsll((long long)errm) - 1); failed = true; break; }
                 // winners whose similarity is already known
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                 const int W = __popcll(vmask);
                 if (vwin) {
                     const int rank = __popcll(vmask & ((1ull << lane) - 1ull));
-                    sm.wl_vec[rank] = lv.node_vec[nb_node];
+                    sm.wl_vec[rank] = nvrow;
                     sm.wl_node[rank] = nb_node;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -397,10 +403,11 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                 __builtin_amdgcn_wave_barrier();
                 const float fmag = wa.f_mags[f];
                 const int xkind = fmag == 0.0f ? KIND_BASE : KIND_METADATA; // (vector_store.rs:329-367: the fallback builds the query without an id)
-                const u32 eid = lv.node_id[entry];
+                const u32 eid = lv.node_id[entry], ek = lv.node_meta[entry];
+                const float eymag = ix.mmags[ek];
                 float s0 = 0.0f;
                 int dec = 0;
-                if (lane == 0) dec = meta_decide(entry, eid, lv, fmag, xkind, s0);
+                if (lane == 0) dec = meta_decide(ek, eymag, eid, fmag, xkind, s0);
                 dec = (int)readlane_u32((u32)dec, 0);
                 s0 = __uint_as_float(readlane_u32(__float_as_uint(s0), 0));
                 if (dec < 0) { status = -dec; break; }
