@@ -56,7 +56,9 @@ struct MetaSmem {
     float *fq;    // current filter's dimensions as f32 [mdim]
     int32_t *fqi; //                             as i32 [mdim]
     float *qf;    // float engines: the query vector
+    u32 *win;     // lookahead window: [5][LA_M][64] neighbour node | its id | metadata row | vector row | metadata norm (as bits)
 };
+constexpr int LA_M = 4; // pool entries whose adjacency rows (and what they name) are fetched together
 
 // INDEXING = the walk of index_embedding for a node of the component itself (vector_store.rs:484-640): the "query" is a pseudo node
 // or a Metadata replica — its vector row is wa.q_rows[b], its id wa.self_ids[b] (pre-inserted in the visited filter, :807; the id
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
         sm.wl_node = (u32 *)p;   p += 64 * 4;
         sm.fq = (float *)p;      p += 64 * 4;
         sm.fqi = (int32_t *)p;   p += 64 * 4;
+        sm.win = (u32 *)p;       p += (size_t)5 * LA_M * 64 * 4;
         p = (unsigned char *)(((size_t)p + 15) & ~(size_t)15);
         sm.qf = (float *)p;
     }
@@ -220,22 +223,57 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                 npool = 1;
             }
             bool failed = false;
+            // Lookahead window (round 6, as in walk_kernel.inc): the adjacency rows of the next LA_M pool entries are fetched together,
+            // then — together again — what every neighbour they name needs (id, metadata row, vector row; then the metadata norm): three
+            // trips to memory per WINDOW where an expansion made them one after the other.  Entry i + 1 of the window is consumed only
+            // while it is still provably the next pop, i.e. while no candidate has been inserted ahead of a waiting entry.  A pool
+            // position past the window holds a real node or the empty key (node 0): its row is fetched and never looked at.
             while (npool > 0 && npop < wa.ef && !failed) {
-                const u64 cur = pool.head();
+                u32 kwin = npool < (u32)LA_M ? npool : (u32)LA_M;
+                if (kwin > wa.ef - npop) kwin = wa.ef - npop;
+                {
+                    const u32 slot_l = (u32)lane < slots ? (u32)lane : slots - 1u;
+                    u32 wnb[LA_M], wid[LA_M], wk[LA_M], wvr[LA_M];
+                    float wym[LA_M];
+                    static_for<0, LA_M>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const u32 wnd = pool.template peek_node<i>();
+                        wnb[i] = lv.adj_node[(u64)wnd * M + slot_l];
+                    });
+                    static_for<0, LA_M>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        if ((u32)lane >= slots) wnb[i] = ROW_EMPTY;
+                        const u32 nbs = wnb[i] != ROW_EMPTY ? wnb[i] : 0u; // no lane masked off: an empty slot reads node 0
+                        wid[i] = lv.node_id[nbs];
+                        wk[i] = lv.node_meta[nbs];
+                        wvr[i] = lv.node_vec[nbs];
+                    });
+                    static_for<0, LA_M>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        wym[i] = ix.mmags[wk[i]];
+                    });
+                    static_for<0, LA_M>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        sm.win[(0 * LA_M + i) * 64 + lane] = wnb[i];
+                        sm.win[(1 * LA_M + i) * 64 + lane] = wid[i];
+                        sm.win[(2 * LA_M + i) * 64 + lane] = wk[i];
+                        sm.win[(3 * LA_M + i) * 64 + lane] = wvr[i];
+                        sm.win[(4 * LA_M + i) * 64 + lane] = __float_as_uint(wym[i]);
+                    });
+                }
+                bool window_ok = true;
+                for (u32 wi = 0; wi < kwin && window_ok && !failed; wi++) {
+                const u64 cur = pool.head(); // the window entry being consumed IS the pool's head
                 pool.pop_head(lane);
                 npool--;
                 if (lane == 0) sm.res[npop] = cur;
                 npop++;
                 const int limit = (int)wa.ef - (int)npop;
-                const u32 nd = (u32)cur;
-                u32 nb_node = ROW_EMPTY;
-                if ((u32)lane < slots) nb_node = lv.adj_node[(u64)nd * M + lane];
+                const int ahead = (int)kwin - 1 - (int)wi; // window entries still waiting at pool positions 0 .. ahead - 1
+                const u32 nb_node = sm.win[(0 * LA_M + wi) * 64 + lane];
                 const bool valid = nb_node != ROW_EMPTY;
-                // what an expansion needs of its neighbours, in two trips to memory instead of five: id, metadata row and vector row
-                // together (no lane masked off: an empty slot reads node 0), then the metadata norm
-                const u32 nbs = valid ? nb_node : 0u;
-                const u32 nid_l = lv.node_id[nbs], nk = lv.node_meta[nbs], nvrow = lv.node_vec[nbs];
-                const float nymag = ix.mmags[nk];
+                const u32 nid_l = sm.win[(1 * LA_M + wi) * 64 + lane], nk = sm.win[(2 * LA_M + wi) * 64 + lane], nvrow = sm.win[(3 * LA_M + wi) * 64 + lane];
+                const float nymag = __uint_as_float(sm.win[(4 * LA_M + wi) * 64 + lane]);
                 const u32 nid = valid ? nid_l : 0u;
                 const u32 bit = nid & bitmask, word = bit >> 5, msk = 1u << (bit & 31);
                 const bool pre = valid && (sm.vis[word] & msk);
@@ -261,6 +299,8 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                 const u64 errm = __ballot(win && dec < 0);
                 if (errm) { status = -(int)readlane_u32((u32)dec, __ffsll((long long)errm) - 1); failed = true; break; }
                 // winners whose similarity is already known
+                // (round 6 also tried walk_kernel.inc's ranked merge for them — under a metadata filter most of a row is a strong mismatch or a
+                // Base replica: parity green, 2.17 -> 2.14 ms per 256-query batch and 3.08 -> 3.28 ms per 4 096 (2 KB more LDS per wave): not kept)
                 u64 cm = __ballot(win && dec == 0);
                 const u32 ckey = metric_key(metric, csim);
                 while (cm) {
@@ -268,7 +308,7 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                     cm &= cm - 1;
                     const u64 kk = pack_key(readlane_u32(ckey, l), readlane_u32(nb_node, l));
                     const int pos = pool.rank_of(kk);
-                    if (pos < limit) { pool.insert_at(kk, pos, lane); if (npool < (u32)(64 * R)) npool++; }
+                    if (pos < limit) { pool.insert_at(kk, pos, lane); if (npool < (u32)(64 * R)) npool++; if (pos < ahead) window_ok = false; }
                 }
                 // winners that need the vector cosine: compact (slot order) and evaluate RP rows per pass
                 const bool vwin = win && dec == 1;
@@ -330,10 +370,11 @@ __global__ __launch_bounds__(64) void walk_meta_kernel(const IndexDev ix, const 
                             if (my >= W) break;
                             const u64 kk = pack_key(readlane_u32(key, g * G), sm.wl_node[my]);
                             const int pos = pool.rank_of(kk);
-                            if (pos < limit) { pool.insert_at(kk, pos, lane); if (npool < (u32)(64 * R)) npool++; }
+                            if (pos < limit) { pool.insert_at(kk, pos, lane); if (npool < (u32)(64 * R)) npool++; if (pos < ahead) window_ok = false; }
                         }
                     }
                 }
+                } // window entries
             }
             if (failed || status != COS_OK) break;
             // this walk's result: popped list sorted descending, first 100; entries with cosine exactly -1.0 are dropped;
@@ -444,7 +485,7 @@ namespace cosdev {
 size_t walk_meta_smem_bytes(const IndexDev &ix, u32 ef, int eng) {
     const u32 Mmax = ix.lv[0].M > ix.lv[ix.num_layers].M ? ix.lv[0].M : ix.lv[ix.num_layers].M;
     const u32 res = ef < 128u ? 128u : ef; // the popped list doubles as the 128-entry staging list of the merge
-    size_t b = (size_t)Mmax * 8 + (size_t)res * 8 + 128 * 8 + 64 * 4 * 4;
+    size_t b = (size_t)Mmax * 8 + (size_t)res * 8 + 128 * 8 + 64 * 4 * 4 + (size_t)5 * LA_M * 64 * 4;
     b = (b + 15) & ~(size_t)15;
     if (eng == ENG_F32) b += (size_t)ix.row_stride;
     if (eng == ENG_F16) b += ((size_t)ix.dim * 4 + 15) & ~(size_t)15;
