@@ -673,7 +673,8 @@ hipError_t launch_walk(int eng, const IndexDev &ix, const WalkArgs &wa, u32 lat_
     case ENG_U8:
         if (ch == 1) return ix.G == 64 ? launch_walk_r<ENG_U8, 1, true>(ix, wa, st) : launch_walk_r<ENG_U8, 1, false>(ix, wa, st);
         if (ch == 2) return launch_walk_r<ENG_U8, 2, true>(ix, wa, st);
-        if (ch == 3) return launch_walk_r<ENG_U8, 3, true>(ix, wa, st); // 2049..3072 dimensions (round 6: three chunk passes; wider rows: walk_general_kernel)
+        if (ch == 3) return launch_walk_r<ENG_U8, 3, true>(ix, wa, st); // 2049..3072 dimensions (round 6: three chunk passes)
+        if (ch == 4) return launch_walk_r<ENG_U8, 4, true>(ix, wa, st); // 3073..4096 dimensions (four; wider rows: walk_general_kernel)
         return hipErrorInvalidValue;
     case ENG_Q2:
         if (ch == 1) return ix.G == 64 ? launch_walk_r<ENG_Q2, 1, true>(ix, wa, st) : launch_walk_r<ENG_Q2, 1, false>(ix, wa, st);

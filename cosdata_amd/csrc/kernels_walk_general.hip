@@ -3,7 +3,7 @@
 //   * beams wider than the widest register pool (ef_search / ef_construction > 1024; hnsw/types.rs:10-17 accepts any u32), and
 //   * more than 64 scanned neighbour slots per node (min(neighbors_count, shortlist_size) > 64; config.toml:32 is a free `usize`,
 //     the reference's own gRPC test config sets 100: grpc/vectors/tests.rs:47), and
-//   * code rows wider than walk_kernel's chunk passes (u8 above 3072 dimensions, SubByte above 64 chunks of 16 bytes: binary 8192,
+//   * code rows wider than walk_kernel's chunk passes (u8 above 4096 dimensions, SubByte above 64 chunks of 16 bytes: binary 8192,
 //     quaternary 4096, octal 2048 dimensions).
 // Rounds 1-5 refused all three at cos_index_create (COS_ERR_UNIMPLEMENTED).  This kernel is the plain statement of the loop — one wave per
 // query, nothing speculative:
@@ -328,8 +328,8 @@ namespace cosdev {
 // the launches walk_kernel and the latency kernels cannot hold (engine.hip: cos_index_create's domain checks follow this)
 bool walk_general_needed(const IndexDev &ix, u32 ef) {
     if (ef > WALK_FAST_MAX_EF) return true;
-    // code rows wider than walk_kernel's chunk passes: u8 above 3072 dims (three passes of 64 lanes x 16 B), SubByte above 64 chunks
-    if (ix.nchunks != 0u && ix.G != 0u && (ix.nchunks + ix.G - 1u) / ix.G > (ix.storage == 0u /* COS_STORAGE_U8 */ ? 3u : 1u)) return true;
+    // code rows wider than walk_kernel's chunk passes: u8 above 4096 dims (four passes of 64 lanes x 16 B), SubByte above 64 chunks
+    if (ix.nchunks != 0u && ix.G != 0u && (ix.nchunks + ix.G - 1u) / ix.G > (ix.storage == 0u /* COS_STORAGE_U8 */ ? 4u : 1u)) return true;
     for (u32 l = 0; l <= ix.num_layers; l++)
         if (std::min(ix.lv[l].M, ix.shortlist) > 64u) return true;
     return false;

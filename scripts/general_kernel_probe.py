@@ -12,7 +12,7 @@ import bench  # noqa: E402
 import cosdata_amd as ca  # noqa: E402
 
 dev = torch.device("cuda:0")
-CASES = (("u8_3072_dims_ef64_three_chunk_passes_of_walk_kernel", 200_000, 3072, 64, 64, 32, 64, 8192), ("u8_4096_dims_ef64", 150_000, 4096, 64, 64, 32, 64, 8192), ("u8_768_dims_ef2048", 200_000, 768, 2048, 64, 32, 64, 2048),
+CASES = (("u8_3072_dims_ef64_three_chunk_passes_of_walk_kernel", 200_000, 3072, 64, 64, 32, 64, 8192), ("u8_4096_dims_ef64_four_chunk_passes_of_walk_kernel", 150_000, 4096, 64, 64, 32, 64, 8192), ("u8_4608_dims_ef64", 130_000, 4608, 64, 64, 32, 64, 8192), ("u8_768_dims_ef2048", 200_000, 768, 2048, 64, 32, 64, 2048),
          ("u8_768_dims_shortlist128", 200_000, 768, 64, 128, 64, 128, 8192), ("u8_768_dims_fast_kernels_ef64", 200_000, 768, 64, 64, 32, 64, 8192),
          ("u8_768_dims_fast_kernels_ef1024", 200_000, 768, 1024, 64, 32, 64, 2048))
 for name, N, D, ef, M0, M, shortlist, B in CASES:

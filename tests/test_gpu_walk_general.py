@@ -99,7 +99,7 @@ def test_device_builder_in_the_general_domain(efc, M, M0, shortlist):
                                              (O.STORAGE_SUBBYTE, 2, 4160), (O.STORAGE_SUBBYTE, 1, 8320), (O.STORAGE_SUBBYTE, 3, 2080)])
 def test_rows_wider_than_the_fast_kernels_chunk_passes(storage, res, dim):
     """u8 above 2048 dimensions (text-embedding-3-large is 3072) and SubByte rows of more than 64 x 16 bytes: refused until round 6.
-    u8 rows of 2049..3072 dimensions take walk_kernel with three chunk passes, wider ones (and the SubByte rows) walk_general_kernel.
+    u8 rows of 2049..4096 dimensions take walk_kernel with three / four chunk passes, wider ones (and the SubByte rows) walk_general_kernel.
     Device build (walks with ef_construction + link) and search against the oracle on the same schedule."""
     import cosdata_amd as ca
     scale = 0.9 if storage == O.STORAGE_SUBBYTE else 1.0
@@ -134,10 +134,11 @@ def test_exhaustive_scan_over_wide_rows(storage, res, dim):
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
 
 
-@pytest.mark.parametrize("dim,ef,visited", [(3072, 48, 0), (2560, 100, 0), (3072, 200, 1), (2100, 400, 0), (3000, 1000, 0)])
-def test_three_chunk_passes_of_the_fast_kernel(dim, ef, visited):
-    """2049..3072-dim u8 rows in walk_kernel (every pool width, both filters, the level table and the locality-ordered split through
-    the walk variants of _assert_same_walk)"""
+@pytest.mark.parametrize("dim,ef,visited", [(3072, 48, 0), (2560, 100, 0), (3072, 200, 1), (2100, 400, 0), (3000, 1000, 0),
+                                            (4096, 64, 0), (3500, 128, 1), (4000, 256, 0), (3100, 512, 0), (4096, 1024, 0)])
+def test_three_and_four_chunk_passes_of_the_fast_kernel(dim, ef, visited):
+    """2049..4096-dim u8 rows in walk_kernel (three / four chunk passes; every pool width, both filters, the level table and the
+    locality-ordered split through the walk variants of _assert_same_walk)"""
     X = H.clustered_corpus(2500, dim, n_centers=10, seed=dim + ef)
     oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=3, ef_construction=40, ef_search=ef)
     dix = H.device_index_from_oracle(oix, X, visited_mode=visited)
