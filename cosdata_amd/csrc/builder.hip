@@ -337,7 +337,6 @@ extern "C" int32_t cos_index_restore_link_state(cos_index *ix) {
     if (!ix->have_vectors || !ix->have_root) return cos_fail(COS_ERR_NOT_READY, "restore needs vectors, root and every graph level");
     for (auto &l : ix->lv) if (l.n == 0) return cos_fail(COS_ERR_NOT_READY, "restore needs vectors, root and every graph level");
     if (ix->id_stride != 1u || ix->meta.mdim != 0u) return cos_fail(COS_ERR_UNIMPLEMENTED, "link state of a collection with a metadata schema");
-    if (ix->eng != ENG_U8 && ix->eng != ENG_Q2 && ix->eng != ENG_F32) return cos_fail(COS_ERR_UNIMPLEMENTED, "restoring the link state is implemented for u8 / quaternary / f32 storage");
     int32_t rc = cos_set_device(ix);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -703,8 +702,6 @@ extern "C" int32_t cos_index_delete(cos_index *ix, const uint32_t *ids, uint32_t
         for (u32 l = 0; l <= Ltop; l++) {
             if (h_ust[l] != 1u) continue;
             // ---- the reference's own order for this level (vector_store.rs:1277-1369)
-            if (ix->eng != ENG_U8 && ix->eng != ENG_Q2 && ix->eng != ENG_F32)
-                return cos_fail(COS_ERR_UNIMPLEMENTED, "delete would leave a node without neighbours: re-linking it is implemented for u8 / quaternary / f32 storage");
             const LevelHost &H = ix->lv[l];
             const u32 M = H.M, slot = Ltop - l, node = h_dn[l];
             if (l > 0 && node_vec[l].empty()) {

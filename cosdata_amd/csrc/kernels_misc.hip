@@ -124,6 +124,12 @@ __global__ __launch_bounds__(64) void distance_pairs_kernel(const DistArgs a) {
             for (u32 i = lane; i < (u32)(a.row_stride / 4); i += 64) qf[i] = ((const float *)xr)[i];
             dotf = f32_pair_dot((const float *)yr, qf, a.dim, lane & 1);
             if (a.metric == COS_METRIC_DOT) st = COS_ERR_STORAGE_MISMATCH; // dotproduct.rs: no FullPrecisionFP arm
+        } else if constexpr (ENG == ENG_F16) { // dot_product_f16 (dot_product.rs:13-19): sequential sum of f32(a) * f32(b), one lane's chain
+            float *qf = (float *)smem_raw;
+            for (u32 i = lane; i < a.dim; i += 64) qf[i] = __half2float(((const __half *)xr)[i]);
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            dotf = __uint_as_float(readlane_u32(__float_as_uint(f16_lane_dot(yr, qf, a.dim)), 0));
         } else {
             u32 acc = 0;
             for (u32 c = lane; c < a.nchunks; c += 64) acc = chunk_dot<ENG>(*(const uint4 *)(xr + (u64)c * 16), *(const uint4 *)(yr + (u64)c * 16), acc);
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(64) void distance_pairs_kernel(const DistArgs a) {
         } else
             val = dotf;
     } else if (a.metric == COS_METRIC_HAMMING) { // hamming.rs:60-98 (integer counts < 2^24: exact in f32 in any order)
-        if constexpr (ENG == ENG_F32) st = COS_ERR_STORAGE_MISMATCH;
+        if constexpr (ENG == ENG_F32 || ENG == ENG_F16) st = COS_ERR_STORAGE_MISMATCH;
         else {
             u32 acc = 0;
             for (u32 c = lane; c < a.nchunks; c += 64) {
@@ -187,7 +193,7 @@ void rows_to_device_layout(int eng, u32 dim, const uint8_t *ref, size_t cb, u32 
 
 namespace cosdev {
 // DistanceMetric::calculate for explicit (row, row) pairs of ONE resident code table (cos_index_delete's re-scoring of an orphan's
-// candidates, vector_store.rs:1326-1337): the operator's own kernel on device arrays.  Integer and f32 engines.
+// candidates, vector_store.rs:1326-1337): the operator's own kernel on device arrays.  Every storage an index can have (cosine / dot).
 hipError_t launch_index_pair_distances(int eng, const uint8_t *codes, const float *mags, u64 row_stride, u32 nchunks, u32 dim, u32 metric, const u32 *d_pair_x,
                                        const u32 *d_pair_y, u32 n_pairs, float *d_out, int32_t *d_status, hipStream_t st) {
     if (n_pairs == 0) return hipSuccess;
@@ -196,6 +202,9 @@ hipError_t launch_index_pair_distances(int eng, const uint8_t *codes, const floa
     if (eng == ENG_U8) hipLaunchKernelGGL(distance_pairs_kernel<ENG_U8>, grid, block, 0, st, a);
     else if (eng == ENG_Q2) hipLaunchKernelGGL(distance_pairs_kernel<ENG_Q2>, grid, block, 0, st, a);
     else if (eng == ENG_F32) hipLaunchKernelGGL(distance_pairs_kernel<ENG_F32>, grid, block, (size_t)row_stride, st, a);
+    else if (eng == ENG_Q1) hipLaunchKernelGGL(distance_pairs_kernel<ENG_Q1>, grid, block, 0, st, a);
+    else if (eng == ENG_Q3) hipLaunchKernelGGL(distance_pairs_kernel<ENG_Q3>, grid, block, 0, st, a);
+    else if (eng == ENG_F16) hipLaunchKernelGGL(distance_pairs_kernel<ENG_F16>, grid, block, ((size_t)dim * 4 + 15) & ~(size_t)15, st, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -177,7 +177,7 @@ int32_t cos_index_delete(cos_index *ix, const uint32_t *ids, uint32_t m);
  * slot similarities (persisted by the reference, serializer/hnsw/neighbors.rs:22-61; recomputed here on the resident codes) and every
  * node's cached lowest slot by the deserializer's rule (ProbNode::new_with_neighbors_and_versions, prob_node.rs:145-181: the first empty
  * slot, else the first strictly smallest similarity).  Afterwards cos_index_append / cos_index_delete work on the uploaded graph; appends
- * draw their levels from the seed's stream advanced past the resident vectors.  u8 / quaternary / f32 storage. */
+ * draw their levels from the seed's stream advanced past the resident vectors.  Every storage an index can have. */
 int32_t cos_index_restore_link_state(cos_index *ix);
 /* frees the link state (as large as the adjacency: 4 bytes per neighbour slot); cos_index_append then returns COS_ERR_NOT_READY */
 int32_t cos_index_release_link_state(cos_index *ix);

@@ -147,12 +147,14 @@ def test_delete_equals_the_oracles_delete_embedding(storage, res, dim, n, m0, m,
     _same_graph(dix.download_graph(), oix.export_graph())
 
 
-def test_delete_relinks_a_node_left_without_neighbours():
+@pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_F16, 0), (O.STORAGE_SUBBYTE, 3)])
+def test_delete_relinks_a_node_left_without_neighbours(storage, res):
     """tiny neighbour lists on a tiny corpus: deleting a node's ONLY neighbour makes delete_embedding link the node again from the walk's
-    results (vector_store.rs:1305-1357) — the device runs such a level on the host in the reference's order"""
+    results (vector_store.rs:1305-1357) — the device runs such a level on the host in the reference's order (the pair distances it needs:
+    the operator's device kernel, every storage since round 6)"""
     dim, n = 32, 400
-    X = H.clustered_corpus(n, dim, n_centers=40, seed=77)
-    p = O.HNSWParams(dim=dim, num_layers=3, ef_construction=8, ef_search=16, seed=3, level0_neighbors_count=2, neighbors_count=2)
+    X = H.clustered_corpus(n, dim, n_centers=40, seed=77) * (0.9 if storage == O.STORAGE_SUBBYTE else 1.0)
+    p = O.HNSWParams(dim=dim, storage=storage, resolution=res, num_layers=3, ef_construction=8, ef_search=16, seed=3, level0_neighbors_count=2, neighbors_count=2)
     oix = O.OracleIndex(p).set_vectors(X)
     oix.build_rounds(32)
     dix = _device(X, p).build(32)
@@ -204,7 +206,8 @@ def test_random_interleaving_of_appends_and_deletes_follows_the_oracle(seed):
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
 
 
-@pytest.mark.parametrize("storage,res,dim", [(O.STORAGE_U8, 0, 96), (O.STORAGE_SUBBYTE, 2, 128), (O.STORAGE_F32, 0, 48)])
+@pytest.mark.parametrize("storage,res,dim", [(O.STORAGE_U8, 0, 96), (O.STORAGE_SUBBYTE, 2, 128), (O.STORAGE_F32, 0, 48),
+                                             (O.STORAGE_SUBBYTE, 1, 256), (O.STORAGE_SUBBYTE, 3, 96), (O.STORAGE_F16, 0, 64)])
 def test_restored_link_state_of_an_uploaded_graph_takes_appends_and_deletes(storage, res, dim):
     """cos_index_restore_link_state == coso_index_restore_link_state: an UPLOADED graph (the reader path, the snapshot path) gets the link
     state the reference has after a reload; appends and deletes on it follow the oracle slot for slot"""
