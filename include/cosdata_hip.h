@@ -339,7 +339,7 @@ int32_t cos_index_upload_meta_graph_level(cos_index *ix, uint32_t level, uint32_
  * thread_rng: replicas from generate_level_probs, pseudo nodes from pseudo_level_probs, metadata/mod.rs:182-209); rows whose
  * metadata dimensions are all zero are Base replicas and stay out of the component.  Replaces the node table and every level. */
 int32_t cos_index_build_meta(cos_index *ix, uint32_t n_nodes, const uint32_t *node_ids, const int32_t *mbits, const uint8_t *max_levels,
-                             uint32_t batch_size /* 0 = 4096 */);
+                             uint32_t batch_size /* 0 = 1024 */);
 /* the component back on the host: node count of a level; (node_ids ascending [n_l], nbr_ids [n_l][M_l], COS_SLOT_EMPTY = null slot) */
 int32_t cos_index_meta_level_count(cos_index *ix, uint32_t level, uint32_t *out);
 int32_t cos_index_download_meta_graph_level(cos_index *ix, uint32_t level, uint32_t *node_ids, uint32_t *nbr_ids);

@@ -46,7 +46,7 @@ del dix, oix
 # ---- timing at N ---------------------------------------------------------------------------------------------------------------------
 sc, dix = make(N, DIM, 5, ef_search=64)
 t = time.perf_counter(); dix.build(4096); t_base = time.perf_counter() - t
-t = time.perf_counter(); dix.build_meta(sc.node_ids, sc.mbits, sc.max_levels, 4096); t_meta = time.perf_counter() - t
+t = time.perf_counter(); dix.build_meta(sc.node_ids, sc.mbits, sc.max_levels, int(os.environ.get("META_BATCH", 0))); t_meta = time.perf_counter() - t
 out["build"] = {"base_graph_s": t_base, "pseudo_root_component_s": t_meta, "component_nodes": int(len(sc.node_ids))}
 for nq in (256, 4096):
     Q, off, rows, _ = sc.queries(nq=nq, seed=3)
