@@ -71,6 +71,31 @@ def test_flat_code_scan_zero_norm_is_calculation_error():
     assert ei.value.status == 2
 
 
+def test_flat_code_scan_zero_norm_query_and_the_cached_stored_flag():
+    """round 6: the stored vectors' zero-norm flag is computed once per upload and the queries' flag comes back with the results (no
+    device round trip before the first GEMM): a zero-norm QUERY is still a CalculationError for the call, a clean call on the same
+    handle still answers, and a re-upload that introduces a zero-norm vector is seen"""
+    import cosdata_amd as ca
+    X = H.uniform_corpus(20000, 64, seed=3)
+    ix = ca.HNSWIndex(64, ca.HNSWHyperParams(num_layers=3))
+    ix.upload_vectors(X)
+    Q = H.queries_from(X, 6, seed=1)
+    ok = ix.flat_search(Q, 5)
+    Qz = Q.copy()
+    Qz[3] = -1.0                                               # all-zero u8 code -> |q| = 0
+    with pytest.raises(ca.CosdataError) as ei:
+        ix.flat_search(Qz, 5)
+    assert ei.value.status == 2
+    again = ix.flat_search(Q, 5)                               # the flag does not stick to the handle
+    assert all(np.array_equal(a, b) for a, b in zip(ok, again))
+    X2 = X.copy()
+    X2[1234] = -1.0
+    ix.upload_vectors(X2)                                      # a new upload: the cached stored flag must not survive it
+    with pytest.raises(ca.CosdataError) as ei:
+        ix.flat_search(Q, 5)
+    assert ei.value.status == 2
+
+
 @pytest.mark.parametrize("storage,res", [(O.STORAGE_U8, 0), (O.STORAGE_SUBBYTE, 2)])
 @pytest.mark.parametrize("n,dim,B,k", [(70000, 96, 70, 10), (40000, 768, 260, 12), (30001, 384, 70, 10), (20003, 1024, 40, 10),
                                        (25000, 200, 300, 5), (21000, 960, 9, 10)])
