@@ -92,6 +92,28 @@ def test_hybrid_search_one_call_matches_oracle_composition():
         assert np.array_equal(sc[i, :c].view(np.uint32), fs.view(np.uint32)), i
 
 
+def test_hybrid_search_dense_failure_is_reported_and_the_handles_stay_usable():
+    """a zero-norm query fails the dense half (CalculationError): the one call reports it (round 6: the dense status comes back in the same
+    pinned copy as the fused lists), and the next call on the same handles answers"""
+    import cosdata_amd as ca
+    n, d, B, k = 3000, 64, 12, 5
+    X = H.uniform_corpus(n, d, seed=8)
+    oix = H.oracle_index(X, O.STORAGE_U8, 0, num_layers=3, ef_construction=32, ef_search=48)
+    dix = H.device_index_from_oracle(oix, X)
+    terms, offsets, docs, tfs = _postings(n, 200, 4)
+    bm = ca.BM25Index(terms, offsets, docs, tfs, n)
+    Q = H.queries_from(X, B, seed=2)
+    q_terms, q_off = _queries(terms, B, 4)
+    good = ca.hybrid_search_batch(dix, bm, Q, q_terms, q_off, k, 60.0)
+    Qz = Q.copy()
+    Qz[5] = -1.0   # quantizes to all-zero bytes -> |q| = 0
+    with pytest.raises(ca.CosdataError) as ei:
+        ca.hybrid_search_batch(dix, bm, Qz, q_terms, q_off, k, 60.0)
+    assert ei.value.status == 2
+    again = ca.hybrid_search_batch(dix, bm, Q, q_terms, q_off, k, 60.0)
+    assert all(np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32)) for a, b in zip(good, again))
+
+
 def test_bm25_many_queries_several_tiles_per_block():
     """a launch with more queries than blocks-per-launch / tiles: a block walks several tiles (reset of the accumulators between
     tiles, the chunk pipeline across a tile boundary), heaviest-first launch order with many ties"""
