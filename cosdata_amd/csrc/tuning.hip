@@ -15,7 +15,7 @@ const char *const NAMES[TUNE_COUNT] = {
     "walk_table_max_bytes", "walk_table_gemm", "host_pipeline_min_b", "flat_unfused", "flat_tile_kernel", "flat_pf", "flat_fp4",
     "bm25_blocks", "sparse_layout", "walk_pb", "walk_pb_upper", "walk_lat", "walk_lat4", "walk_small_table_tk", "walk_lat_warm",
     "walk_lat_la", "walk_lat4_e", "finalize_fast", "shardset_force_rccl", "build_profile",
-    "walk_merge_min", "walk_adj_mag", "walk_table_rule_c", "walk_table_after_sort", "walk_upper_lds_pad", "walk_r2", "finalize_wide_max_b",
+    "walk_merge_min", "walk_adj_mag", "walk_table_rule_c", "walk_table_after_sort", "walk_upper_lds_pad", "walk_r2", "finalize_wide_max_b", "flat_fp4_w8",
 };
 std::atomic<long long> g_values[TUNE_COUNT];
 std::once_flag g_once;

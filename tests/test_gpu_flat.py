@@ -138,11 +138,41 @@ def test_flat_code_scan_fused_overflow_falls_back_exactly(storage, res):
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
 
 
+def test_flat_code_scan_fp4_two_waves_per_simd_adversarial_order_and_ragged_batch():
+    """flat_scan_q2_fp4_w8 (tuning knob flat_fp4_w8, 768-dim quaternary codes) where its staging overflows: vectors ordered so that every
+    later one beats the running thresholds, a batch of 261 queries (a second, almost empty row block), n not a multiple of the 64-column
+    tile — the same answer as the oracle and as the one-wave-per-SIMD kernel"""
+    import cosdata_amd as ca
+    from cosdata_amd import _lib
+    n, dim = 40037, 768
+    rng = np.random.default_rng(14)
+    q = rng.standard_normal(dim).astype(np.float32)
+    q /= np.linalg.norm(q)
+    noise = rng.standard_normal((n, dim)).astype(np.float32)
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    w = np.linspace(0.0, 1.0, n, dtype=np.float32)[:, None]
+    X = (w * q[None, :] + (1.0 - w) * noise).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    X *= 0.9 * np.sqrt(dim) / 8.0                                       # components large enough to leave the zero digit
+    X = np.clip(X, -0.999, 0.999).astype(np.float32)
+    Q = np.concatenate([np.stack([q, -q]) * X[-1].max(), X[rng.integers(0, n, 259)]]).astype(np.float32)
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType(ca.StorageKind(O.STORAGE_SUBBYTE), 2))
+    ix.upload_vectors(X)
+    ref = ix.flat_search(Q, 10)
+    for v in (1, 2, 3):
+        with _lib.tuning(flat_fp4_w8=v):
+            got = ix.flat_search(Q, 10)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), v
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, storage=O.STORAGE_SUBBYTE, resolution=2, num_layers=3)).set_vectors(X)
+    oids, osc, ocnt = oix.flat_search_batch(Q, 10, threads=8)
+    assert np.array_equal(got[2], ocnt) and np.array_equal(got[0], oids) and np.array_equal(got[1].view(np.uint32), osc.view(np.uint32))
+
+
 def test_flat_code_scan_query_resident_kernel_equals_tile_kernel():
     """quaternary fused chunks run on the query-resident kernel (A fragments in registers, candidates streamed through LDS) — since
     round 5 with the digits as e2m1 nibbles on the scaled FP4 MFMA (flat_scan_q2_fp4); tuning knob flat_fp4 = 0 keeps the i8 digits
-    (flat_scan_q2_areg), flat_tile_kernel = 1 forces the 256 x 128 tile kernel, flat_unfused = 1 the score-matrix path: four
-    implementations, one answer"""
+    (flat_scan_q2_areg), flat_tile_kernel = 1 forces the 256 x 128 tile kernel, flat_unfused = 1 the score-matrix path, flat_fp4_w8
+    picks between the FP4 kernel's one-wave-per-SIMD and two-waves-per-SIMD forms (round 6): five implementations, one answer"""
     import cosdata_amd as ca
     n, dim, B, k = 50000, 768, 64, 10
     X = H.clustered_corpus(n, dim, n_centers=30, sigma=0.25, seed=31)
@@ -151,7 +181,7 @@ def test_flat_code_scan_query_resident_kernel_equals_tile_kernel():
     ix.upload_vectors(X)
     ref = ix.flat_search(Q, k)
     from cosdata_amd import _lib
-    for env, val in (("flat_fp4", 0), ("flat_tile_kernel", 1), ("flat_unfused", 1)):
+    for env, val in (("flat_fp4", 0), ("flat_tile_kernel", 1), ("flat_unfused", 1), ("flat_fp4_w8", 1), ("flat_fp4_w8", 2), ("flat_fp4_w8", 3), ("flat_fp4_w8", 0)):
         with _lib.tuning(**{env: val}):
             got = ix.flat_search(Q, k)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), env
