@@ -551,21 +551,24 @@ template <int KC, int ORDER>
 __global__ __launch_bounds__(512) void flat_scan_q2_fp4_w8(const uint8_t *__restrict__ qnib /*[B][32 KC] nibble bytes*/, const float *__restrict__ qmags, u32 B,
                                                            const uint8_t *__restrict__ codes, const float *__restrict__ mags, u64 row_stride, u32 n0,
                                                            u32 n_chunk, u32 metric, const FusedOut fo) {
-    // ORDER 1 (KC 12 only): (a) the expansion is dealt evenly — 64 columns x 12 chunks x 2 sixteen-byte pieces = 1536 pieces = THREE per
-    // thread: wave w expands chunk w (both pieces) and piece w & 1 of chunk 8 + (w >> 1), where ORDER 0 gives chunks 8..11 whole to waves
-    // 0..3 (four pieces against two: the waves of column block 1 wait at the tile's barrier); (b) a two-stage screen — a lane first tests
-    // the LARGEST of its 16 accumulators against the SMALLEST of their thresholds (8 max3 + 1 fma per row block, the minimum in one VGPR)
-    // and only a lane that passes runs the per-row test against the 16 thresholds (which the allocator keeps in AccVGPRs: 16 reads + 16
-    // fma + 8 max3 per row block in ORDER 0).  Monotone: a row that passes the per-row test passes the coarse one (rx > 0, fma rounds
-    // monotonically), so the survivors are the same.
+    // ORDER (tuning knob flat_fp4_w8 = ORDER + 1; each step measured on 10M x 768, profiles/r06_fp4_w8_*):
+    //   0  as described above, instruction order left to the compiler;
+    //   1  (KC 12) the expansion dealt evenly: 64 columns x 12 chunks x 2 sixteen-byte pieces = 1536 pieces = THREE per thread — wave w
+    //      expands chunk w (both pieces) and piece w & 1 of chunk 8 + (w >> 1), where ORDER 0 gives chunks 8..11 whole to waves 0..3;
+    //   2  + the two row blocks' MFMAs pinned to ALTERNATE on two accumulators.  Left alone the allocator folds both row blocks onto one
+    //      16-register accumulator: twelve dependent MFMAs with an s_waitcnt between each pair (an issue slot between two MFMAs on the
+    //      same accumulator costs ~43 cycles), the second row block's chain sunk below the first one's epilogue;
+    //   3  + tiles of 128 columns (two sub-tiles per barrier: a wave multiplies column blocks cb and cb + 2): half the barriers, so
+    //      half the tile tails in which a SIMD's first-finished wave is parked and its other wave runs alone.
     static_assert(ORDER == 0 || KC == 12, "the even deal is written for 12 chunks");
     constexpr int KB = KC * 32, KS = KC, LDB = KB + 16, ITS = (KC + 7) / 8, PIECES = ORDER >= 1 ? 3 : ITS * 2;
+    constexpr int SUB = ORDER >= 3 ? 2 : 1, TW = 64 * SUB, NSET = SUB == 2 ? 1 : 2, AHEAD = NSET + 1; // raw register sets; tiles ahead of a reload
     static_assert(PIECES <= KS, "the expansion must fit the k loop");
-    extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB] | survivors [AREG_STAGE][3] u32 | count
-    u32 *stage = (u32 *)(areg_lds + (size_t)2 * 64 * LDB), *stage_cnt = stage + 3 * AREG_STAGE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][TW][LDB] | survivors [AREG_STAGE][3] u32 | count
+    u32 *stage = (u32 *)(areg_lds + (size_t)2 * TW * LDB), *stage_cnt = stage + 3 * AREG_STAGE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rg = w & 3, cb = w >> 2, half = lane >> 5, l31 = lane & 31;
     const u32 row0 = blockIdx.y * 256 + rg * 64;
-    const u32 n_tiles = (n_chunk + 63) / 64, G = gridDim.x;
+    const u32 n_tiles = (n_chunk + TW - 1) / TW, G = gridDim.x;
     u32 t = blockIdx.x;
     if (t >= n_tiles) return; // uniform
     if (tid == 0) *stage_cnt = 0; // published by the barrier after the first tile's expansion
@@ -577,10 +580,9 @@ __global__ __launch_bounds__(512) void flat_scan_q2_fp4_w8(const uint8_t *__rest
         a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
         asm volatile("" : "+a"(a[i][s])); // the value now IS an AccVGPR tuple
     });
-    float T[2][16], Tmin[2]; // thresholds of this lane's 32 accumulator rows (flat_scan_q2_fp4), and the smallest of each row block
+    float T[2][16]; // thresholds of this lane's 32 accumulator rows (flat_scan_q2_fp4)
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        Tmin[i] = __builtin_inff();
+    for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const u32 row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, rc = row < B ? row : B - 1;
@@ -589,16 +591,14 @@ __global__ __launch_bounds__(512) void flat_scan_q2_fp4_w8(const uint8_t *__rest
             const float lo = k == 0ull ? -1.0f : simkey_inv((u32)(k >> 32)) * (1.0f - 4e-6f);
             const float v = metric == 0u ? lo * qm : lo;
             T[i][r] = row < B ? v : __builtin_inff();
-            Tmin[i] = fminf(Tmin[i], T[i][r]);
         }
-    }
-    // staging registers of one tile: slot 0 = chunk w; slot 1 = ORDER 0: chunk w + 8 (waves 0..3 at KC 12), ORDER 1: the two plane words
-    // (.x plane 0, .z plane 1) of piece w & 1 of chunk 8 + (w >> 1)
+    // staging registers of one tile column (lane + 64 u): slot 0 = chunk w; slot 1 = ORDER 0: chunk w + 8 (waves 0..3 at KC 12), ORDER >= 1:
+    // the two plane words (.x plane 0, .z plane 1) of piece w & 1 of chunk 8 + (w >> 1)
     const int xw = __builtin_amdgcn_readfirstlane(w);
     const int xj = 8 + (xw >> 1), xp = xw & 1;
-    uint4 raw[2][ITS];
-    auto load_raw = [&](u32 tile, uint4 *dst, int it) __attribute__((always_inline)) {
-        const u32 c = tile * 64 + lane, cc = c < n_chunk ? c : n_chunk - 1;
+    uint4 raw[NSET][SUB][ITS];
+    auto load_raw = [&](u32 tile, uint4 *dst, int u, int it) __attribute__((always_inline)) {
+        const u32 c = tile * TW + 64 * u + lane, cc = c < n_chunk ? c : n_chunk - 1;
         const uint8_t *rowp = codes + (u64)(n0 + cc) * row_stride;
         if (ORDER >= 1 && it == 1) {
             dst[1].x = *(const u32 *)(rowp + (u64)xj * 16 + 4 * xp);
@@ -608,115 +608,119 @@ __global__ __launch_bounds__(512) void flat_scan_q2_fp4_w8(const uint8_t *__rest
         const int j = w + 8 * it;
         dst[it] = *(const uint4 *)(rowp + (u64)(KC % 8 == 0 || j < KC ? j : 0) * 16);
     };
-    auto store_piece = [&](int buf, const uint4 *src, int it, int pp) __attribute__((always_inline)) {
+    auto store_piece = [&](int buf, const uint4 *src, int u, int it, int pp) __attribute__((always_inline)) {
+        unsigned char *rowl = areg_lds + (size_t)buf * TW * LDB + (size_t)(64 * u + lane) * LDB;
         if (ORDER >= 1 && it == 1) { // the one extra piece (pp ignored: the registers hold piece xp's words as piece 0)
-            *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + lane * LDB + xj * 32 + xp * 16) = q2_nibble_piece(make_uint4(src[1].x, 0u, src[1].z, 0u), 0);
+            *(uint4 *)(rowl + xj * 32 + xp * 16) = q2_nibble_piece(make_uint4(src[1].x, 0u, src[1].z, 0u), 0);
             return;
         }
         const int j = w + 8 * it;
-        if (KC % 8 == 0 || j < KC) *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + lane * LDB + j * 32 + pp * 16) = q2_nibble_piece(src[it], pp);
+        if (KC % 8 == 0 || j < KC) *(uint4 *)(rowl + j * 32 + pp * 16) = q2_nibble_piece(src[it], pp);
     };
 #pragma unroll
-    for (int it = 0; it < ITS; it++) load_raw(t, raw[0], it);
+    for (int u = 0; u < SUB; u++)
 #pragma unroll
-    for (int it = 0; it < ITS; it++)
+        for (int it = 0; it < ITS; it++) load_raw(t, raw[0][u], u, it);
 #pragma unroll
-        for (int pp = 0; pp < (ORDER >= 1 && it == 1 ? 1 : 2); pp++) store_piece(0, raw[0], it, pp);
+    for (int u = 0; u < SUB; u++)
 #pragma unroll
-    for (int it = 0; it < ITS; it++) {
-        load_raw(t + G, raw[1], it);
-        load_raw(t + 2 * G, raw[0], it);
-    }
+        for (int it = 0; it < ITS; it++)
+#pragma unroll
+            for (int pp = 0; pp < (ORDER >= 1 && it == 1 ? 1 : 2); pp++) store_piece(0, raw[0][u], u, it, pp);
+#pragma unroll
+    for (int u = 0; u < SUB; u++)
+#pragma unroll
+        for (int it = 0; it < ITS; it++) {
+            if (NSET == 2) {
+                load_raw(t + G, raw[NSET - 1][u], u, it);
+                load_raw(t + 2 * G, raw[0][u], u, it);
+            } else
+                load_raw(t + G, raw[0][u], u, it);
+        }
     __syncthreads();
 
-    // one tile: this wave's column block of tile tt from LDS buffer P into the ONE accumulator set, the expansion of tile tt + G into buffer
-    // P ^ 1 spread over the first PIECES k steps, then the tile's epilogue in line
+    // one tile: this wave's column block(s) of tile tt from LDS buffer P, the expansion of tile tt + G into buffer P ^ 1 spread over the
+    // first PIECES k steps of each sub-tile, each sub-tile's epilogue in line
     auto tile_body = [&](auto Pc, u32 tt) __attribute__((always_inline)) {
-        constexpr int P = decltype(Pc)::value;
-        const unsigned char *bt = areg_lds + (size_t)P * 64 * LDB + (size_t)(32 * cb + l31) * LDB + 16 * half;
-        i32x4 bf[3]; // candidate fragments, read two k steps ahead of their MFMAs
+        constexpr int P = decltype(Pc)::value, RS = NSET == 2 ? (P ^ 1) : 0; // the register set that holds tile tt + G
+        static_for<0, SUB>([&](auto Uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(Uc)::value;
+            const unsigned char *bt = areg_lds + (size_t)P * TW * LDB + (size_t)(32 * (cb + 2 * u) + l31) * LDB + 16 * half;
+            i32x4 bf[3]; // candidate fragments, read two k steps ahead of their MFMAs
 #pragma unroll
-        for (int s = 0; s < 2 && s < KS; s++) bf[s] = *(const i32x4 *)(bt + 32 * s);
-        const u32 colx = tt * 64 + 32 * cb + l31;
-        const float xm = mags[n0 + (colx < n_chunk ? colx : n_chunk - 1)];
-        f32x16 acc[2];
-        static_for<0, KS>([&](auto Sc) __attribute__((always_inline)) {
-            constexpr int s = decltype(Sc)::value;
-            constexpr bool expand = s < PIECES;
-            constexpr int it = ORDER >= 1 ? (s == 2 ? 1 : 0) : (s < PIECES ? s : 0) >> 1, pp = ORDER >= 1 && s == 2 ? 0 : s & 1;
-            constexpr bool last_of_slot = ORDER >= 1 ? s >= 1 : pp == 1;
-            if (s + 2 < KS) bf[(s + 2) % 3] = *(const i32x4 *)(bt + 32 * (s + 2));
-            const i32x4 b = bf[s % 3];
-            if constexpr (ORDER == 2) {
-                // pinned: the two row blocks' MFMAs ALTERNATE (two accumulators: consecutive MFMAs never share one — left alone the allocator
-                // folds both row blocks onto one 16-register accumulator and emits twelve dependent MFMAs with an s_waitcnt between each
-                // pair, and an issue slot between two MFMAs on the same accumulator costs ~43 cycles), half a piece's expansion behind each
-                const uint4 src = ORDER >= 1 && it == 1 ? make_uint4(raw[P ^ 1][1].x, 0u, raw[P ^ 1][1].z, 0u) : raw[P ^ 1][it];
-                u32 o[4] = {0, 0, 0, 0};
-                __builtin_amdgcn_sched_barrier(0);
-                fp4_mfma<s == 0>(acc[0], a[0][s], b);
-                __builtin_amdgcn_sched_barrier(0);
-                if (expand) {
-                    o[0] = q2_nibble_dword(src, pp, 0);
-                    o[1] = q2_nibble_dword(src, pp, 1);
+            for (int s = 0; s < 2 && s < KS; s++) bf[s] = *(const i32x4 *)(bt + 32 * s);
+            const u32 colx = tt * TW + 32 * (cb + 2 * u) + l31;
+            const float xm = mags[n0 + (colx < n_chunk ? colx : n_chunk - 1)];
+            f32x16 acc[2];
+            static_for<0, KS>([&](auto Sc) __attribute__((always_inline)) {
+                constexpr int s = decltype(Sc)::value;
+                constexpr bool expand = s < PIECES;
+                constexpr int it = ORDER >= 1 ? (s == 2 ? 1 : 0) : (s < PIECES ? s : 0) >> 1, pp = ORDER >= 1 && s == 2 ? 0 : s & 1;
+                constexpr bool last_of_slot = ORDER >= 1 ? s >= 1 : pp == 1;
+                if (s + 2 < KS) bf[(s + 2) % 3] = *(const i32x4 *)(bt + 32 * (s + 2));
+                const i32x4 b = bf[s % 3];
+                if constexpr (ORDER >= 2) { // pinned: MFMA row block 0 | half a piece | MFMA row block 1 | the other half, its store, the reload
+                    const uint4 src = it == 1 ? make_uint4(raw[RS][u][1].x, 0u, raw[RS][u][1].z, 0u) : raw[RS][u][it];
+                    u32 o[4] = {0, 0, 0, 0};
+                    __builtin_amdgcn_sched_barrier(0);
+                    fp4_mfma<s == 0>(acc[0], a[0][s], b);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (expand) {
+                        o[0] = q2_nibble_dword(src, pp, 0);
+                        o[1] = q2_nibble_dword(src, pp, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    fp4_mfma<s == 0>(acc[1], a[1][s], b);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (expand) {
+                        o[2] = q2_nibble_dword(src, pp, 2);
+                        o[3] = q2_nibble_dword(src, pp, 3);
+                        const int j = it == 1 ? xj : w, ppx = it == 1 ? xp : pp;
+                        *(uint4 *)(areg_lds + (size_t)(P ^ 1) * TW * LDB + (size_t)(64 * u + lane) * LDB + j * 32 + ppx * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+                        if (last_of_slot) load_raw(tt + AHEAD * G, raw[RS][u], u, it);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    fp4_mfma<s == 0>(acc[0], a[0][s], b);
+                    fp4_mfma<s == 0>(acc[1], a[1][s], b);
+                    if (expand) {
+                        store_piece(P ^ 1, raw[RS][u], u, it, pp);
+                        if (last_of_slot) load_raw(tt + AHEAD * G, raw[RS][u], u, it); // the slot's registers are free: reload them
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                fp4_mfma<s == 0>(acc[1], a[1][s], b);
-                __builtin_amdgcn_sched_barrier(0);
-                if (expand) {
-                    o[2] = q2_nibble_dword(src, pp, 2);
-                    o[3] = q2_nibble_dword(src, pp, 3);
-                    const int j = it == 1 ? xj : w, ppx = it == 1 ? xp : pp;
-                    *(uint4 *)(areg_lds + (size_t)(P ^ 1) * 64 * LDB + lane * LDB + j * 32 + ppx * 16) = make_uint4(o[0], o[1], o[2], o[3]);
-                    if (last_of_slot) load_raw(tt + 3 * G, raw[P ^ 1], it);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                fp4_mfma<s == 0>(acc[0], a[0][s], b);
-                fp4_mfma<s == 0>(acc[1], a[1][s], b);
-                if (expand) {
-                    store_piece(P ^ 1, raw[P ^ 1], it, pp);
-                    if (last_of_slot) load_raw(tt + 3 * G, raw[P ^ 1], it); // the slot's registers are free: reload them for tile tt + 3G
-                }
-            }
-        });
-        // ORDER 2: both accumulators are complete HERE (without this the second row block's whole MFMA chain is sunk below the first row
-        // block's epilogue, next to its only use, and the pinned order above is undone)
-        if constexpr (ORDER == 2) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
-        // the tile's epilogue, in line (the SIMD's other wave multiplies meanwhile): "does any of my 16 rows pass" per row block, then the
-        // exact staging of the rare survivors
-        const float rx = metric == 0u ? 4.0f * __builtin_amdgcn_rcpf(xm) : 4.0f; // the accumulators hold dot / 4
+            });
+            // ORDER >= 2: both accumulators are complete HERE (without this the second row block's whole MFMA chain is sunk below the first
+            // row block's epilogue, next to its only use, and the pinned order above is undone)
+            if constexpr (ORDER >= 2) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+            // the sub-tile's epilogue, in line (the SIMD's other wave multiplies meanwhile): "does any of my 16 rows pass" per row block,
+            // then the exact staging of the rare survivors
+            const float rx = metric == 0u ? 4.0f * __builtin_amdgcn_rcpf(xm) : 4.0f; // the accumulators hold dot / 4
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            float best = -__builtin_inff();
-            if (ORDER == 3) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) best = fmaxf(best, acc[i][r]);
-                best = __builtin_fmaf(best, rx, -Tmin[i]);
-            } else {
+            for (int i = 0; i < 2; i++) {
+                float best = -__builtin_inff();
 #pragma unroll
                 for (int r = 0; r < 16; r++) best = fmaxf(best, __builtin_fmaf(acc[i][r], rx, -T[i][r]));
-            }
-            if (best >= 0.0f && colx < n_chunk) {
-                u32 rbase = row0 + 32 * i + 4 * half;
-                asm volatile("" : "+v"(rbase));
+                if (best >= 0.0f && colx < n_chunk) {
+                    u32 rbase = row0 + 32 * i + 4 * half;
+                    asm volatile("" : "+v"(rbase));
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const u32 row = rbase + (r & 3) + 8 * (r >> 2);
-                    const float q4 = acc[i][r];
-                    if (row < B && __builtin_fmaf(q4, rx, -T[i][r]) >= 0.0f) {
-                        const u32 dot = (u32)(q4 * 4.0f); // exact: q4 is a multiple of 1/4 below 2^22
-                        const u32 sp = atomicAdd(stage_cnt, 1u);
-                        if (sp < AREG_STAGE) {
-                            stage[3 * sp] = colx;
-                            stage[3 * sp + 1] = row;
-                            stage[3 * sp + 2] = dot;
-                        } else
-                            areg_append(fo, qmags, mags, metric, n0, colx, row, dot); // staging full: append from here
+                    for (int r = 0; r < 16; r++) {
+                        const u32 row = rbase + (r & 3) + 8 * (r >> 2);
+                        const float q4 = acc[i][r];
+                        if (row < B && __builtin_fmaf(q4, rx, -T[i][r]) >= 0.0f) {
+                            const u32 dot = (u32)(q4 * 4.0f); // exact: q4 is a multiple of 1/4 below 2^22
+                            const u32 sp = atomicAdd(stage_cnt, 1u);
+                            if (sp < AREG_STAGE) {
+                                stage[3 * sp] = colx;
+                                stage[3 * sp + 1] = row;
+                                stage[3 * sp + 2] = dot;
+                            } else
+                                areg_append(fo, qmags, mags, metric, n0, colx, row, dot); // staging full: append from here
+                        }
                     }
                 }
             }
-        }
+        });
         __syncthreads();
     };
     while (true) {
@@ -895,26 +899,21 @@ template <int KC>
 static hipError_t launch_fp4_kc(dim3 grid, hipStream_t st, const uint8_t *qnib, const float *qmags, u32 B, const uint8_t *codes, const float *mags,
                                 u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
     const size_t lds = (size_t)2 * 64 * (KC * 32 + 16) + (size_t)AREG_STAGE * 12 + 16;
-    if constexpr (KC == 12) { // the two-waves-per-SIMD variant (768 dims: 96 AccVGPRs of query fragments; at 1024 dims they take all 128 and the rest spills): tuning knob flat_fp4_w8
-        const long long w8 = tune_or(TUNE_FLAT_FP4_W8, 0);
-        if (w8 == 3) {
-            hipError_t e8 = hipFuncSetAttribute((const void *)flat_scan_q2_fp4_w8<KC, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (KC == 12) { // the two-waves-per-SIMD kernel (768 dims: 96 AccVGPRs of query fragments; at 1024 dims they take all 128 and the rest spills): tuning knob flat_fp4_w8 = 0 (off) or the kernel's ORDER + 1
+        const long long w8 = tune_or(TUNE_FLAT_FP4_W8, 4);
+        auto go = [&](auto Oc) -> hipError_t {
+            constexpr int ORDER = decltype(Oc)::value, TW = ORDER >= 3 ? 128 : 64;
+            const size_t lds8 = (size_t)2 * TW * (KC * 32 + 16) + (size_t)AREG_STAGE * 12 + 16;
+            hipError_t e8 = hipFuncSetAttribute((const void *)flat_scan_q2_fp4_w8<KC, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
             if (e8 != hipSuccess) return e8;
-            hipLaunchKernelGGL((flat_scan_q2_fp4_w8<KC, 2>), grid, dim3(512), lds, st, qnib, qmags, B, codes, mags, row_stride, n0, nc, metric, fo);
+            const dim3 g8(std::min(grid.x, (nc + TW - 1) / TW), grid.y);
+            hipLaunchKernelGGL((flat_scan_q2_fp4_w8<KC, ORDER>), g8, dim3(512), lds8, st, qnib, qmags, B, codes, mags, row_stride, n0, nc, metric, fo);
             return hipGetLastError();
-        }
-        if (w8 == 2) {
-            hipError_t e8 = hipFuncSetAttribute((const void *)flat_scan_q2_fp4_w8<KC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e8 != hipSuccess) return e8;
-            hipLaunchKernelGGL((flat_scan_q2_fp4_w8<KC, 1>), grid, dim3(512), lds, st, qnib, qmags, B, codes, mags, row_stride, n0, nc, metric, fo);
-            return hipGetLastError();
-        }
-        if (w8 != 0) {
-            hipError_t e8 = hipFuncSetAttribute((const void *)flat_scan_q2_fp4_w8<KC, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e8 != hipSuccess) return e8;
-            hipLaunchKernelGGL((flat_scan_q2_fp4_w8<KC, 0>), grid, dim3(512), lds, st, qnib, qmags, B, codes, mags, row_stride, n0, nc, metric, fo);
-            return hipGetLastError();
-        }
+        };
+        if (w8 == 1) return go(std::integral_constant<int, 0>{});
+        if (w8 == 2) return go(std::integral_constant<int, 1>{});
+        if (w8 == 3) return go(std::integral_constant<int, 2>{});
+        if (w8 >= 4) return go(std::integral_constant<int, 3>{});
     }
     hipError_t e = hipFuncSetAttribute((const void *)flat_scan_q2_fp4<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -46,7 +46,7 @@ enum TuneKey : int {
     TUNE_WALK_UPPER_LDS_PAD,  // bytes of unused dynamic LDS added per wave on the upper range of a split walk (occupancy experiment; default 0; negative = a launch of table levels only keeps the full LDS layout)
     TUNE_WALK_R2,             // 0 = ef 65..128 walks with the 256-key pool of ef 129..256 (default 1: a 128-key pool)
     TUNE_FINALIZE_WIDE_MAX_B, // launches of at most this many queries finalize with eight waves per query (default 1024; 0 = never)
-    TUNE_FLAT_FP4_W8,         // 1 = the FP4 scan of 768-dim quaternary codes runs eight waves per workgroup (two per SIMD, one accumulator set, epilogue in line)
+    TUNE_FLAT_FP4_W8,         // the FP4 scan of 768-dim quaternary codes: 0 = one wave per SIMD (flat_scan_q2_fp4), 1..4 = two waves per SIMD, flat_scan_q2_fp4_w8<ORDER = value - 1> (default 4: even deal, alternating accumulators, 128-column tiles)
     TUNE_COUNT
 };
 

@@ -56,7 +56,7 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
     # epilogue, unfused score-matrix path) must return the same ids / score bits / counts
     same = {}
     from cosdata_amd import _lib
-    for env, val in (("flat_fp4", 0), ("flat_tile_kernel", 1), ("flat_unfused", 1)):
+    for env, val in (("flat_fp4", 0), ("flat_tile_kernel", 1), ("flat_unfused", 1), ("flat_fp4_w8", 0)):
         with _lib.tuning(**{env: val}):
             i2, s2, c2 = ix.flat_search(Qh, 10)
         same[env] = bool(np.array_equal(i2, ids) and np.array_equal(s2.view(np.uint32), sc.view(np.uint32)) and np.array_equal(c2, cnt))
@@ -82,7 +82,8 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
            "roofline": {"bound": "mfma", "achieved": tops, "peak": PEAK, "unit": "TOP/s", "frac": tops / PEAK,
                         # fabric-side bytes of one step's scan kernels from the committed FETCH / WRITE pass of this script (scripts/final_profile.sh)
                         "traffic": (lambda t: t * st.gemm_launches if t else None)(bench.committed_kernel_traffic("c3_scan" if fp4_on else "c3_scan_i8")),
-                        "kernel": ("flat_scan_q2_fp4<%d> (query-resident scan, digits as e2m1 on v_mfma_scale_f32_32x32x64_f8f6f4; peak = dense FP4)" % (d // 64)) if fp4_on
+                        "kernel": (("flat_scan_q2_fp4_w8<12, 3> (query-resident scan, two waves per SIMD" if d == 768 and _lib.tuning_get("flat_fp4_w8") in (None, 4) else
+                                   "flat_scan_q2_fp4<%d> (query-resident scan" % (d // 64)) + ", digits as e2m1 on v_mfma_scale_f32_32x32x64_f8f6f4; peak = dense FP4)") if fp4_on
                                   else "flat_scan_q2_areg<KC> (query-resident i8 MFMA scan)",
                         "same_scan_with_i8_digits": {"kernel": "flat_scan_q2_areg<KC>", "gemm_ms_all_launches": i8_gemm_ms, "ms_per_step": i8_wall * 1e3,
                                                      "achieved": st.int8_ops / i8_gemm_ms / 1e9, "peak": I8_PEAK_TOPS, "frac": st.int8_ops / i8_gemm_ms / 1e9 / I8_PEAK_TOPS},
@@ -92,7 +93,7 @@ def run(n=10_000_000, dim=768, batch=256, walk_n=0, reps=3, cpu_seconds=5.0, dev
            "flat": {"gemm_ms": gemm_ms, "gemm_launches": st.gemm_launches, "int8_tops": tops, "int8_peak_tops_dense": I8_PEAK_TOPS,
                     "code_GBps": st.code_bytes / gemm_ms / 1e6, "wall_s_incl_select_rerank_copies": wall,
                     "timing": f"median of {reps} calls after one untimed call", "qps_end_to_end": B / wall, "upload_quantize_s": t_up,
-                    "same_answer_as_i8_digit_kernel": same["flat_fp4"], "same_answer_as_tile_kernel": same["flat_tile_kernel"],
+                    "same_answer_as_i8_digit_kernel": same["flat_fp4"], "same_answer_as_one_wave_per_simd_fp4_kernel": same["flat_fp4_w8"], "same_answer_as_tile_kernel": same["flat_tile_kernel"],
                     "same_answer_as_unfused_path": same["flat_unfused"]},
            "cpu_baseline": None, "parity_vs_oracle": None}
 

@@ -37,7 +37,9 @@ def main():
     ix.upload_vectors_device(X.data_ptr(), n, keepalive=X)
     Qh = Q.cpu().numpy()
     ref = None
-    for name, knobs in (("default", {}), ("w8", {"flat_fp4_w8": 1}), ("w8_even_deal", {"flat_fp4_w8": 2}), ("w8_even_deal_alternating", {"flat_fp4_w8": 3}), ("default_again", {}), ("w8_again", {"flat_fp4_w8": 1}), ("w8_even_deal_again", {"flat_fp4_w8": 2}), ("w8_even_deal_alternating_again", {"flat_fp4_w8": 3})):
+    variants = (("default", {}), ("w8", {"flat_fp4_w8": 1}), ("w8_even_deal", {"flat_fp4_w8": 2}), ("w8_even_deal_alternating", {"flat_fp4_w8": 3}),
+                ("w8_even_deal_alternating_128col", {"flat_fp4_w8": 4}))
+    for name, knobs in (variants + tuple((n_ + "_again", k_) for n_, k_ in variants)):
         with _lib.tuning(**knobs):
             ix.flat_search(Qh, 10)
             runs = []

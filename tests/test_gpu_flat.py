@@ -159,7 +159,7 @@ def test_flat_code_scan_fp4_two_waves_per_simd_adversarial_order_and_ragged_batc
     ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), storage_type=ca.StorageType(ca.StorageKind(O.STORAGE_SUBBYTE), 2))
     ix.upload_vectors(X)
     ref = ix.flat_search(Q, 10)
-    for v in (1, 2, 3):
+    for v in (1, 2, 3, 4):
         with _lib.tuning(flat_fp4_w8=v):
             got = ix.flat_search(Q, 10)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), v
@@ -181,7 +181,7 @@ def test_flat_code_scan_query_resident_kernel_equals_tile_kernel():
     ix.upload_vectors(X)
     ref = ix.flat_search(Q, k)
     from cosdata_amd import _lib
-    for env, val in (("flat_fp4", 0), ("flat_tile_kernel", 1), ("flat_unfused", 1), ("flat_fp4_w8", 1), ("flat_fp4_w8", 2), ("flat_fp4_w8", 3), ("flat_fp4_w8", 0)):
+    for env, val in (("flat_fp4", 0), ("flat_tile_kernel", 1), ("flat_unfused", 1), ("flat_fp4_w8", 1), ("flat_fp4_w8", 2), ("flat_fp4_w8", 3), ("flat_fp4_w8", 4), ("flat_fp4_w8", 0)):
         with _lib.tuning(**{env: val}):
             got = ix.flat_search(Q, k)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), env
