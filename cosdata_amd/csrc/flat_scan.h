@@ -28,6 +28,10 @@ hipError_t launch_flat_scan_expand_queries(const uint8_t *qcodes, u64 row_stride
 hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qdig, const float *qmags, u32 B, const uint8_t *codes,
                             const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo, bool fp4);
 
+// the same for u8 codes (flat_scan_u8_areg): qcodes = the queries' code rows [B][kdims], qsums / csums = code sums; rows must be exactly kdims bytes
+hipError_t launch_flat_scan_u8(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, const float *qmags, u32 B, const uint8_t *codes,
+                               const u32 *csums, const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo);
+
 // the walk's level table as a query-resident GEMM (kernels_scan.hip): tab[q][c] = (f32) exact integer dot; u8 or quaternary codes
 bool level_table_areg_supported(int eng, u64 row_stride);
 hipError_t launch_level_table_areg(int eng, u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, u32 B, const uint8_t *tcodes,

@@ -787,6 +787,8 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     // fused chunks of quaternary codes run on the query-resident kernel when K has an instantiation (tuning knob flat_tile_kernel = 1: never)
     const bool use_areg = ix->eng == ENG_Q2 && flat_scan_supported(kdims) && tune_or(TUNE_FLAT_TILE_KERNEL, 0) == 0;
     const bool use_fp4 = use_areg && tune_or(TUNE_FLAT_FP4, 1) != 0; // e2m1 digits on the scaled MFMA (kernels_scan.hip flat_scan_q2_fp4); 0 = i8 digits
+    // fused chunks of u8 codes too (round 6: flat_scan_u8_areg), when a row is exactly a supported number of 64-byte chunks
+    const bool use_u8q = ix->eng == ENG_U8 && ix->row_stride == (u64)kdims && kdims <= 768 && flat_scan_supported(kdims) && tune_or(TUNE_FLAT_TILE_KERNEL, 0) == 0; // (1024 dims: 256 AccVGPRs of fragments, the rest spills)
     int n_cus = 0;
     if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, ix->p.device) != hipSuccess || n_cus <= 0) n_cus = 256;
     constexpr u32 SEED = 16384, APP_CAP = 4096;
@@ -885,7 +887,7 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
             const bool use_fused = fused && n0 > 0;
             // chunk cap: the tile kernel's grid (and its event granularity) like 4 M; the query-resident kernel is persistent and
             // pays ~35 us of prologue per launch, so it takes everything that is left once the 8x rule allows it
-            u32 nc = use_fused ? (u32)std::min<u64>((u64)seen * 8, use_areg ? (1ull << 31) : (1ull << 22)) : first;
+            u32 nc = use_fused ? (u32)std::min<u64>((u64)seen * 8, use_areg || use_u8q ? (1ull << 31) : (1ull << 22)) : first;
             nc = std::min(nc, n - n0);
             dim3 grid((nc + CN - 1) / CN, (B + CM - 1) / CM);
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -898,6 +900,9 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
 #define FLAT_LAUNCH_PF(E, F) do { if (pf == 2) FLAT_LAUNCH(E, F, 2); else if (pf == 3) FLAT_LAUNCH(E, F, 3); else FLAT_LAUNCH(E, F, 1); } while (0)
             if (use_fused && use_areg) {
                 e = launch_flat_scan(kdims, (u32)n_cus, st, d_qdp, d_qm, B, ix->d_codes, ix->d_mags, ix->row_stride, n0, nc, ix->p.metric, fo, use_fp4);
+                if (e != hipSuccess) break;
+            } else if (use_fused && use_u8q) {
+                e = launch_flat_scan_u8(kdims, (u32)n_cus, st, d_qc, d_qs, d_qm, B, ix->d_codes, d_cs, ix->d_mags, ix->row_stride, n0, nc, ix->p.metric, fo);
                 if (e != hipSuccess) break;
             } else if (ix->eng == ENG_U8) {
                 if (use_fused) FLAT_LAUNCH_PF(ENG_U8, true); else FLAT_LAUNCH_PF(ENG_U8, false);

@@ -877,6 +877,144 @@ __global__ __launch_bounds__(256) void level_table_areg(const uint8_t *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Query-resident scan of u8 codes (round 6; the exhaustive mode of u8 storage ran the 256 x 128 tile kernel flat_codes_gemm_i8 until
+// now: every tile restages 256 query rows through LDS).  level_table_areg's loop — a workgroup is 4 waves, wave w keeps the recentred
+// (^ 0x80) MFMA A fragments of 64 query rows for the whole k range in AccVGPRs, column tiles of 64 code rows stream through
+// double-buffered LDS — with the fused scan's epilogue instead of a store: the exact integer dot (accumulator + 128 (sum q + sum c)
+// - 16384 K, kernels_flat.hip: the same correction), converted like the reference's `as f32` (x86_64.rs:22-66), screened per lane
+// against the 32 thresholds of its rows; the rare survivors are parked in LDS and get their exact quotient, key compare and global
+// append at the end of the kernel (areg_append: the value that is ranked is dot / (|q| |v|) exactly as the tile kernel forms it, so the
+// results are the tile kernel's bit for bit; tuning knob flat_tile_kernel = 1 keeps that one).
+// ------------------------------------------------------------------------------------------------
+template <int KC>
+__global__ __launch_bounds__(256) void flat_scan_u8_areg(const uint8_t *__restrict__ qcodes /*[B][64 KC]*/, const u32 *__restrict__ qsums,
+                                                         const float *__restrict__ qmags, u32 B, const uint8_t *__restrict__ codes,
+                                                         const u32 *__restrict__ csums, const float *__restrict__ mags, u64 row_stride, u32 n0,
+                                                         u32 n_chunk, u32 metric, const FusedOut fo) {
+    constexpr int K = KC * 64, KS = KC * 2, LDB = K + 16, PC = K / 16, NP = (64 * PC + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB] | survivors [AREG_STAGE][3] u32 | count
+    u32 *stage = (u32 *)(areg_lds + (size_t)2 * 64 * LDB), *stage_cnt = stage + 3 * AREG_STAGE;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const u32 row0 = blockIdx.y * 256 + w * 64;
+    const u32 n_tiles = (n_chunk + 63) / 64, G = gridDim.x;
+    u32 t = blockIdx.x;
+    if (t >= n_tiles) return; // uniform
+    if (tid == 0) *stage_cnt = 0; // published by the first barrier
+    i32x4 a[2][KS];
+    static_for<0, 2 * KS>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(Ic)::value / KS, s = decltype(Ic)::value % KS;
+        const u32 row = row0 + 32 * i + l31;
+        i32x4 v = *(const i32x4 *)(qcodes + (u64)(row < B ? row : B - 1) * K + 32 * s + 16 * half);
+        v = v ^ (int)0x80808080;
+        a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
+        asm volatile("" : "+a"(a[i][s]));
+    });
+    int rqs[2][16]; // 128 * sum(q) - 16384 K of this lane's 32 accumulator rows
+    float T[2][16]; // and their thresholds (flat_scan_q2_areg)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, rc = row < B ? row : B - 1;
+            rqs[i][r] = 128 * (int)qsums[rc] - 16384 * K;
+            const u64 k = fo.thr[rc];
+            const float qm = qmags[rc];
+            const float lo = k == 0ull ? -1.0f : simkey_inv((u32)(k >> 32)) * (1.0f - 4e-6f);
+            const float v = metric == 0u ? lo * qm : lo;
+            T[i][r] = row < B ? v : __builtin_inff();
+        }
+    uint4 raw[NP];
+    auto load_tile = [&](u32 tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const u32 g = (u32)p * 256u + (u32)tid, gg = g < 64u * PC ? g : 0u, c = gg / (u32)PC, pc = gg % (u32)PC;
+            const u32 col = tile * 64 + c, cc = col < n_chunk ? col : n_chunk - 1;
+            raw[p] = *(const uint4 *)(codes + (u64)(n0 + cc) * row_stride + (u64)pc * 16);
+        }
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const u32 g = (u32)p * 256u + (u32)tid, c = g / (u32)PC, pc = g % (u32)PC;
+            if (64 * PC % 256 != 0 && g >= 64u * PC) continue;
+            uint4 v = raw[p];
+            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+            *(uint4 *)(areg_lds + (size_t)buf * 64 * LDB + (size_t)c * LDB + (size_t)pc * 16) = v;
+        }
+    };
+    load_tile(t);
+    store_tile(0);
+    __syncthreads();
+    int P = 0;
+    while (true) {
+        const bool more = t + G < n_tiles; // uniform
+        if (more) load_tile(t + G);       // in flight while this tile is multiplied
+        const unsigned char *bt = areg_lds + (size_t)P * 64 * LDB + l31 * LDB + 16 * half;
+        i32x16 acc[2][2];
+        i32x4 bf[3][2];
+#pragma unroll
+        for (int s = 0; s < 2 && s < KS; s++) {
+            bf[s][0] = *(const i32x4 *)(bt + 32 * s);
+            bf[s][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * s);
+        }
+        static_for<0, KS>([&](auto Sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(Sc)::value;
+            if (s + 2 < KS) {
+                bf[(s + 2) % 3][0] = *(const i32x4 *)(bt + 32 * (s + 2));
+                bf[(s + 2) % 3][1] = *(const i32x4 *)(bt + 32 * LDB + 32 * (s + 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const i32x4 b0 = bf[s % 3][0], b1 = bf[s % 3][1];
+            areg_mfma<s == 0>(acc[0][0], a[0][s], b0);
+            areg_mfma<s == 0>(acc[0][1], a[0][s], b1);
+            areg_mfma<s == 0>(acc[1][0], a[1][s], b0);
+            areg_mfma<s == 0>(acc[1][1], a[1][s], b1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const u32 col = t * 64 + 32 * j + l31;
+            const bool cv = col < n_chunk;
+            const u32 gc = n0 + (cv ? col : n_chunk - 1);
+            const int cs = 128 * (int)csums[gc];
+            const float rx = metric == 0u ? __builtin_amdgcn_rcpf(mags[gc]) : 1.0f;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                float best = -__builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 16; r++) best = fmaxf(best, __builtin_fmaf((float)(u32)(acc[i][j][r] + rqs[i][r] + cs), rx, -T[i][r]));
+                if (best >= 0.0f && cv) {
+                    u32 rbase = row0 + 32 * i + 4 * half;
+                    asm volatile("" : "+v"(rbase));
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const u32 row = rbase + (r & 3) + 8 * (r >> 2);
+                        const u32 dot = (u32)(acc[i][j][r] + rqs[i][r] + cs);
+                        if (row < B && __builtin_fmaf((float)dot, rx, -T[i][r]) >= 0.0f) {
+                            const u32 sp = atomicAdd(stage_cnt, 1u);
+                            if (sp < AREG_STAGE) {
+                                stage[3 * sp] = col;
+                                stage[3 * sp + 1] = row;
+                                stage[3 * sp + 2] = dot;
+                            } else
+                                areg_append(fo, qmags, mags, metric, n0, col, row, dot); // staging full: append from here
+                        }
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        store_tile(P ^ 1); // the other buffer: every wave finished reading it before the last barrier
+        __syncthreads();
+        P ^= 1;
+        t += G;
+    }
+    __syncthreads();
+    const u32 staged = min(*stage_cnt, (u32)AREG_STAGE);
+    for (u32 e = tid; e < staged; e += 256) areg_append(fo, qmags, mags, metric, n0, stage[3 * e], stage[3 * e + 1], stage[3 * e + 2]);
+}
+
 } // namespace
 
 namespace cosdev {
@@ -942,6 +1080,28 @@ hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t 
 #undef AREG_CASE
 }
 
+
+template <int KC>
+static hipError_t launch_u8_kc(dim3 grid, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, const float *qmags, u32 B, const uint8_t *codes,
+                               const u32 *csums, const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
+    const size_t lds = (size_t)2 * 64 * (KC * 64 + 16) + (size_t)AREG_STAGE * 12 + 16;
+    hipError_t e = hipFuncSetAttribute((const void *)flat_scan_u8_areg<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((flat_scan_u8_areg<KC>), grid, dim3(256), lds, st, qcodes, qsums, qmags, B, codes, csums, mags, row_stride, n0, nc, metric, fo);
+    return hipGetLastError();
+}
+// fused chunk of u8 codes on the query-resident kernel (rows of exactly kdims = 64 KC bytes)
+hipError_t launch_flat_scan_u8(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, const float *qmags, u32 B, const uint8_t *codes,
+                               const u32 *csums, const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
+    const u32 n_tiles = (nc + 63) / 64;
+    dim3 grid(std::min(n_tiles, n_cus), (B + 255) / 256);
+#define U8_CASE(KC) case KC: return launch_u8_kc<KC>(grid, st, qcodes, qsums, qmags, B, codes, csums, mags, row_stride, n0, nc, metric, fo)
+    switch (kdims / 64) {
+        U8_CASE(2); U8_CASE(4); U8_CASE(6); U8_CASE(8); U8_CASE(12); U8_CASE(16);
+        default: return hipErrorInvalidValue;
+    }
+#undef U8_CASE
+}
 
 // level table as a query-resident GEMM: u8 codes whose rows are a whole number of 64-byte chunks with an instantiation, quaternary
 // codes whose rows (16 B per 64 dims) have one

@@ -202,3 +202,27 @@ def test_flat_code_scan_dot_product_metric_fused(storage, res):
     oix = O.OracleIndex(O.HNSWParams(dim=dim, metric=O.METRIC_DOT, storage=storage, resolution=res, num_layers=3)).set_vectors(X)
     oids, osc, ocnt = oix.flat_search_batch(Q, k, threads=8)
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+
+
+@pytest.mark.parametrize("dim,metric", [(768, "cosine"), (512, "cosine"), (128, "dot"), (384, "cosine")])
+def test_flat_u8_scan_query_resident_kernel_equals_oracle_and_tile_kernel(dim, metric):
+    """u8 fused chunks on flat_scan_u8_areg (round 6: rows of 128..768 dims that are whole 64-byte chunks); tuning knob flat_tile_kernel = 1
+    keeps the 256 x 128 tile kernel, flat_unfused = 1 the score-matrix path: three implementations and the oracle, one answer.  Ragged
+    shapes: n not a multiple of the 64-column tile, 261 queries (a second, almost empty row block)"""
+    import cosdata_amd as ca
+    from cosdata_amd import _lib
+    n, B, k = 70013, 261, 10
+    X = H.clustered_corpus(n, dim, n_centers=40, sigma=0.25, seed=51) * 0.9
+    Q = H.queries_from(X, B, noise=0.05, seed=12)
+    m = ca.DistanceMetric.Cosine if metric == "cosine" else ca.DistanceMetric.DotProduct
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), distance_metric=m, storage_type=ca.StorageType(ca.StorageKind(O.STORAGE_U8), 0))
+    ix.upload_vectors(X)
+    ref = ix.flat_search(Q, k)
+    for env in ("flat_tile_kernel", "flat_unfused"):
+        with _lib.tuning(**{env: 1}):
+            got = ix.flat_search(Q, k)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), env
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, metric=O.METRIC_COSINE if metric == "cosine" else O.METRIC_DOT, storage=O.STORAGE_U8, resolution=0,
+                                     num_layers=3)).set_vectors(X)
+    oids, osc, ocnt = oix.flat_search_batch(Q, k, threads=8)
+    assert np.array_equal(ref[2], ocnt) and np.array_equal(ref[0], oids) and np.array_equal(ref[1].view(np.uint32), osc.view(np.uint32))
