@@ -951,6 +951,16 @@ __global__ __launch_bounds__(256) void flat_scan_u8_areg(const uint8_t *__restri
         const bool more = t + G < n_tiles; // uniform
         if (more) load_tile(t + G);       // in flight while this tile is multiplied
         const unsigned char *bt = areg_lds + (size_t)P * 64 * LDB + l31 * LDB + 16 * half;
+        // the two column blocks' code sums and norms: requested HERE, in front of the k loop, used after it (asked for in the epilogue they
+        // cost a global-load latency per tile with nothing to cover it: a third of the kernel's wave time was s_waitcnt)
+        int csj[2];
+        float xmj[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const u32 col = t * 64 + 32 * j + l31, gc = n0 + (col < n_chunk ? col : n_chunk - 1);
+            csj[j] = (int)csums[gc];
+            xmj[j] = mags[gc];
+        }
         i32x16 acc[2][2];
         i32x4 bf[3][2];
 #pragma unroll
@@ -976,9 +986,8 @@ __global__ __launch_bounds__(256) void flat_scan_u8_areg(const uint8_t *__restri
         for (int j = 0; j < 2; j++) {
             const u32 col = t * 64 + 32 * j + l31;
             const bool cv = col < n_chunk;
-            const u32 gc = n0 + (cv ? col : n_chunk - 1);
-            const int cs = 128 * (int)csums[gc];
-            const float rx = metric == 0u ? __builtin_amdgcn_rcpf(mags[gc]) : 1.0f;
+            const int cs = 128 * csj[j];
+            const float rx = metric == 0u ? __builtin_amdgcn_rcpf(xmj[j]) : 1.0f;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 float best = -__builtin_inff();
