@@ -23,7 +23,7 @@ enum TuneKey : int {
     TUNE_WALK_TABLE_GEMM,     // 0 = the tile kernel (flat_codes_gemm_i8), 1 = the query-resident kernel (level_table_areg); default 1 where it exists
     TUNE_HOST_PIPELINE_MIN_B, // host calls of at least this many queries run as a chunk pipeline (default 8192; 0 = never)
     TUNE_FLAT_UNFUSED,        // 1 = exhaustive scans take the score-matrix path
-    TUNE_FLAT_TILE_KERNEL,    // 1 = quaternary scans take the 256 x 128 tile kernel instead of the query-resident one
+    TUNE_FLAT_TILE_KERNEL,    // 1 = quaternary and u8 scans take the 256 x 128 tile kernel instead of the query-resident ones
     TUNE_FLAT_PF,             // k panels prefetched by the tile kernel of cos_flat_search_batch (1..3; default 1 — the level table's tile GEMM is fixed at 2)
     TUNE_FLAT_FP4,            // 0 = quaternary scans multiply i8 digits, 1 = e2m1 digits on the f8f6f4 MFMA (default 1: the library is built for gfx950 only)
     TUNE_BM25_BLOCKS,         // workgroups of bm25_score_kernel (default 8192)
