@@ -204,7 +204,7 @@ def test_flat_code_scan_dot_product_metric_fused(storage, res):
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
 
 
-@pytest.mark.parametrize("dim,metric", [(768, "cosine"), (512, "cosine"), (128, "dot"), (384, "cosine")])
+@pytest.mark.parametrize("dim,metric", [(768, "cosine"), (512, "cosine"), (128, "dot"), (384, "cosine"), (768, "dot")])
 def test_flat_u8_scan_query_resident_kernel_equals_oracle_and_tile_kernel(dim, metric):
     """u8 fused chunks on flat_scan_u8_areg (round 6: rows of 128..768 dims that are whole 64-byte chunks); tuning knob flat_tile_kernel = 1
     keeps the 256 x 128 tile kernel, flat_unfused = 1 the score-matrix path: three implementations and the oracle, one answer.  Ragged
@@ -226,3 +226,23 @@ def test_flat_u8_scan_query_resident_kernel_equals_oracle_and_tile_kernel(dim, m
                                      num_layers=3)).set_vectors(X)
     oids, osc, ocnt = oix.flat_search_batch(Q, k, threads=8)
     assert np.array_equal(ref[2], ocnt) and np.array_equal(ref[0], oids) and np.array_equal(ref[1].view(np.uint32), osc.view(np.uint32))
+
+
+def test_flat_code_scan_fp4_two_waves_per_simd_dot_product_metric():
+    """DotProduct metric on flat_scan_q2_fp4_w8 (768-dim quaternary codes: scores are the raw integer dots, the screen's reciprocal is the
+    constant 4) against the oracle and the one-wave-per-SIMD kernel"""
+    import cosdata_amd as ca
+    from cosdata_amd import _lib
+    n, dim, B, k = 45011, 768, 70, 10
+    X = H.clustered_corpus(n, dim, n_centers=25, sigma=0.25, seed=37) * 0.8
+    Q = H.queries_from(X, B, noise=0.05, seed=5)
+    ix = ca.HNSWIndex(dim, ca.HNSWHyperParams(num_layers=3), distance_metric=ca.DistanceMetric.DotProduct,
+                      storage_type=ca.StorageType(ca.StorageKind(O.STORAGE_SUBBYTE), 2))
+    ix.upload_vectors(X)
+    ids, sc, cnt = ix.flat_search(Q, k)
+    with _lib.tuning(flat_fp4_w8=0):
+        got = ix.flat_search(Q, k)
+    assert np.array_equal(got[0], ids) and np.array_equal(got[1].view(np.uint32), sc.view(np.uint32)) and np.array_equal(got[2], cnt)
+    oix = O.OracleIndex(O.HNSWParams(dim=dim, metric=O.METRIC_DOT, storage=O.STORAGE_SUBBYTE, resolution=2, num_layers=3)).set_vectors(X)
+    oids, osc, ocnt = oix.flat_search_batch(Q, k, threads=8)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
