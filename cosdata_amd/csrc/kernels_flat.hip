@@ -788,7 +788,7 @@ extern "C" int32_t cos_flat_search_batch(cos_index *ix, const float *queries, ui
     const bool use_areg = ix->eng == ENG_Q2 && flat_scan_supported(kdims) && tune_or(TUNE_FLAT_TILE_KERNEL, 0) == 0;
     const bool use_fp4 = use_areg && tune_or(TUNE_FLAT_FP4, 1) != 0; // e2m1 digits on the scaled MFMA (kernels_scan.hip flat_scan_q2_fp4); 0 = i8 digits
     // fused chunks of u8 codes too (round 6: flat_scan_u8_areg), when a row is exactly a supported number of 64-byte chunks
-    const bool use_u8q = ix->eng == ENG_U8 && ix->row_stride == (u64)kdims && kdims <= 768 && flat_scan_supported(kdims) && tune_or(TUNE_FLAT_TILE_KERNEL, 0) == 0; // (1024 dims: 256 AccVGPRs of fragments, the rest spills)
+    const bool use_u8q = ix->eng == ENG_U8 && ix->row_stride == (u64)kdims && flat_scan_supported(kdims) && tune_or(TUNE_FLAT_TILE_KERNEL, 0) == 0; // (1024 dims: 32 query rows per wave instead of 64)
     int n_cus = 0;
     if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, ix->p.device) != hipSuccess || n_cus <= 0) n_cus = 256;
     constexpr u32 SEED = 16384, APP_CAP = 4096;

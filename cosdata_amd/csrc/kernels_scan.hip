@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void level_table_areg(const uint8_t *__restric
 // append at the end of the kernel (areg_append: the value that is ranked is dot / (|q| |v|) exactly as the tile kernel forms it, so the
 // results are the tile kernel's bit for bit; tuning knob flat_tile_kernel = 1 keeps that one).
 // ------------------------------------------------------------------------------------------------
-template <int KC>
+template <int KC, int RB /* row blocks of 32 queries per wave: 2 (K <= 768), 1 (K = 1024: 128 AccVGPRs of fragments) */>
 __global__ __launch_bounds__(256) void flat_scan_u8_areg(const uint8_t *__restrict__ qcodes /*[B][64 KC]*/, const u32 *__restrict__ qsums,
                                                          const float *__restrict__ qmags, u32 B, const uint8_t *__restrict__ codes,
                                                          const u32 *__restrict__ csums, const float *__restrict__ mags, u64 row_stride, u32 n0,
@@ -896,13 +896,13 @@ __global__ __launch_bounds__(256) void flat_scan_u8_areg(const uint8_t *__restri
     extern __shared__ __attribute__((aligned(16))) unsigned char areg_lds[]; // [2][64][LDB] | survivors [AREG_STAGE][3] u32 | count
     u32 *stage = (u32 *)(areg_lds + (size_t)2 * 64 * LDB), *stage_cnt = stage + 3 * AREG_STAGE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const u32 row0 = blockIdx.y * 256 + w * 64;
+    const u32 row0 = blockIdx.y * (128 * RB) + w * (32 * RB);
     const u32 n_tiles = (n_chunk + 63) / 64, G = gridDim.x;
     u32 t = blockIdx.x;
     if (t >= n_tiles) return; // uniform
     if (tid == 0) *stage_cnt = 0; // published by the first barrier
-    i32x4 a[2][KS];
-    static_for<0, 2 * KS>([&](auto Ic) __attribute__((always_inline)) {
+    i32x4 a[RB][KS];
+    static_for<0, RB * KS>([&](auto Ic) __attribute__((always_inline)) {
         constexpr int i = decltype(Ic)::value / KS, s = decltype(Ic)::value % KS;
         const u32 row = row0 + 32 * i + l31;
         i32x4 v = *(const i32x4 *)(qcodes + (u64)(row < B ? row : B - 1) * K + 32 * s + 16 * half);
@@ -910,10 +910,10 @@ __global__ __launch_bounds__(256) void flat_scan_u8_areg(const uint8_t *__restri
         a[i][s] = row < B ? v : i32x4{0, 0, 0, 0};
         asm volatile("" : "+a"(a[i][s]));
     });
-    int rqs[2][16]; // 128 * sum(q) - 16384 K of this lane's 32 accumulator rows
-    float T[2][16]; // and their thresholds (flat_scan_q2_areg)
+    int rqs[RB][16]; // 128 * sum(q) - 16384 K of this lane's 32 accumulator rows
+    float T[RB][16]; // and their thresholds (flat_scan_q2_areg)
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < RB; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const u32 row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, rc = row < B ? row : B - 1;
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256) void flat_scan_u8_areg(const uint8_t *__restri
             csj[j] = (int)csums[gc];
             xmj[j] = mags[gc];
         }
-        i32x16 acc[2][2];
+        i32x16 acc[RB][2];
         i32x4 bf[3][2];
 #pragma unroll
         for (int s = 0; s < 2 && s < KS; s++) {
@@ -978,8 +978,10 @@ __global__ __launch_bounds__(256) void flat_scan_u8_areg(const uint8_t *__restri
             const i32x4 b0 = bf[s % 3][0], b1 = bf[s % 3][1];
             areg_mfma<s == 0>(acc[0][0], a[0][s], b0);
             areg_mfma<s == 0>(acc[0][1], a[0][s], b1);
-            areg_mfma<s == 0>(acc[1][0], a[1][s], b0);
-            areg_mfma<s == 0>(acc[1][1], a[1][s], b1);
+            if constexpr (RB == 2) {
+                areg_mfma<s == 0>(acc[RB - 1][0], a[RB - 1][s], b0);
+                areg_mfma<s == 0>(acc[RB - 1][1], a[RB - 1][s], b1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
@@ -989,7 +991,7 @@ __global__ __launch_bounds__(256) void flat_scan_u8_areg(const uint8_t *__restri
             const int cs = 128 * csj[j];
             const float rx = metric == 0u ? __builtin_amdgcn_rcpf(xmj[j]) : 1.0f;
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < RB; i++) {
                 float best = -__builtin_inff();
 #pragma unroll
                 for (int r = 0; r < 16; r++) best = fmaxf(best, __builtin_fmaf((float)(u32)(acc[i][j][r] + rqs[i][r] + cs), rx, -T[i][r]));
@@ -1091,20 +1093,20 @@ hipError_t launch_flat_scan(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t 
 
 
 template <int KC>
-static hipError_t launch_u8_kc(dim3 grid, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, const float *qmags, u32 B, const uint8_t *codes,
+static hipError_t launch_u8_kc(u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, const float *qmags, u32 B, const uint8_t *codes,
                                const u32 *csums, const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
+    constexpr int RB = KC > 12 ? 1 : 2;
     const size_t lds = (size_t)2 * 64 * (KC * 64 + 16) + (size_t)AREG_STAGE * 12 + 16;
-    hipError_t e = hipFuncSetAttribute((const void *)flat_scan_u8_areg<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)flat_scan_u8_areg<KC, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((flat_scan_u8_areg<KC>), grid, dim3(256), lds, st, qcodes, qsums, qmags, B, codes, csums, mags, row_stride, n0, nc, metric, fo);
+    const dim3 grid(std::min((nc + 63) / 64, n_cus), (B + 128 * RB - 1) / (128 * RB));
+    hipLaunchKernelGGL((flat_scan_u8_areg<KC, RB>), grid, dim3(256), lds, st, qcodes, qsums, qmags, B, codes, csums, mags, row_stride, n0, nc, metric, fo);
     return hipGetLastError();
 }
 // fused chunk of u8 codes on the query-resident kernel (rows of exactly kdims = 64 KC bytes)
 hipError_t launch_flat_scan_u8(u32 kdims, u32 n_cus, hipStream_t st, const uint8_t *qcodes, const u32 *qsums, const float *qmags, u32 B, const uint8_t *codes,
                                const u32 *csums, const float *mags, u64 row_stride, u32 n0, u32 nc, u32 metric, const FusedOut &fo) {
-    const u32 n_tiles = (nc + 63) / 64;
-    dim3 grid(std::min(n_tiles, n_cus), (B + 255) / 256);
-#define U8_CASE(KC) case KC: return launch_u8_kc<KC>(grid, st, qcodes, qsums, qmags, B, codes, csums, mags, row_stride, n0, nc, metric, fo)
+#define U8_CASE(KC) case KC: return launch_u8_kc<KC>(n_cus, st, qcodes, qsums, qmags, B, codes, csums, mags, row_stride, n0, nc, metric, fo)
     switch (kdims / 64) {
         U8_CASE(2); U8_CASE(4); U8_CASE(6); U8_CASE(8); U8_CASE(12); U8_CASE(16);
         default: return hipErrorInvalidValue;

@@ -204,9 +204,9 @@ def test_flat_code_scan_dot_product_metric_fused(storage, res):
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
 
 
-@pytest.mark.parametrize("dim,metric", [(768, "cosine"), (512, "cosine"), (128, "dot"), (384, "cosine"), (768, "dot")])
+@pytest.mark.parametrize("dim,metric", [(768, "cosine"), (512, "cosine"), (128, "dot"), (384, "cosine"), (768, "dot"), (1024, "cosine"), (1024, "dot")])
 def test_flat_u8_scan_query_resident_kernel_equals_oracle_and_tile_kernel(dim, metric):
-    """u8 fused chunks on flat_scan_u8_areg (round 6: rows of 128..768 dims that are whole 64-byte chunks); tuning knob flat_tile_kernel = 1
+    """u8 fused chunks on flat_scan_u8_areg (round 6: rows of 128..1024 dims that are whole 64-byte chunks; 1024 dims: 32 query rows per wave); tuning knob flat_tile_kernel = 1
     keeps the 256 x 128 tile kernel, flat_unfused = 1 the score-matrix path: three implementations and the oracle, one answer.  Ragged
     shapes: n not a multiple of the 64-column tile, 261 queries (a second, almost empty row block)"""
     import cosdata_amd as ca
